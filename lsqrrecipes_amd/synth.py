@@ -1,0 +1,197 @@
+"""Seeded synthetic workloads for the five BASELINE.json configs.
+
+The distributions follow the reference's own generators:
+  plane   examples/planeEstimation.cxx:152-200
+  sphere  examples/sphereEstimation.cxx:136-184
+  dense   testing/DenseLinearEquationSystemParametersEstimatorTest.cxx:98-119,
+          examples/linearEquationSystemSolver.cxx:44-53,79-81
+  US      testing/SinglePointTargetUSCalibrationParametersEstimatorTest.cxx:556-666
+Generator: numpy Philox, fixed seeds (data only -- nothing here is on the hot path).
+"""
+import numpy as np
+
+SEEDS = {"plane": 0x5EED0001, "sphere": 0x5EED0002, "dense": 0x5EED0003, "us": 0x5EED0004,
+         "line": 0x5EED0005}
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
+
+
+def plane(n, outlier_frac, seed=SEEDS["plane"], dim=3, sigma=0.4, box=1000.0, outlier_dist=20.0):
+    """-> (points (n,dim) float64 shuffled, true params [n,a], is_inlier mask)."""
+    g = _rng(seed)
+    normal = g.uniform(0.0, 1.0, dim)
+    normal /= np.linalg.norm(normal)
+    a = g.uniform(-box, box, dim)
+    n_out = int(round(n * outlier_frac))
+    n_in = n - n_out
+    rp = g.uniform(-box, box, (n_in, dim))
+    noise = g.normal(0.0, sigma, (n_in, dim))
+    tmp = rp - a
+    inl = a + noise + (tmp - (tmp @ normal)[:, None] * normal)
+    out = np.empty((0, dim))
+    while out.shape[0] < n_out:
+        cand = g.uniform(-box, box, (max(n_out, 16), dim))
+        keep = np.abs((cand - a) @ normal) >= outlier_dist
+        out = np.vstack([out, cand[keep]])
+    out = out[:n_out]
+    pts = np.vstack([inl, out])
+    lab = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
+    perm = g.permutation(n)
+    return np.ascontiguousarray(pts[perm]), np.concatenate([normal, a]), lab[perm]
+
+
+def line(n, outlier_frac, seed=SEEDS["line"], dim=3, sigma=0.4, box=1000.0, outlier_dist=20.0):
+    g = _rng(seed)
+    d = g.uniform(0.0, 1.0, dim)
+    d /= np.linalg.norm(d)
+    a = g.uniform(-box, box, dim)
+    n_out = int(round(n * outlier_frac))
+    n_in = n - n_out
+    t = g.uniform(-box, box, n_in)
+    inl = a + t[:, None] * d + g.normal(0.0, sigma, (n_in, dim))
+    out = np.empty((0, dim))
+    while out.shape[0] < n_out:
+        cand = g.uniform(-box, box, (max(n_out, 16), dim))
+        v = cand - a
+        perp = v - (v @ d)[:, None] * d
+        out = np.vstack([out, cand[np.linalg.norm(perp, axis=1) >= outlier_dist]])
+    out = out[:n_out]
+    pts = np.vstack([inl, out])
+    lab = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
+    perm = g.permutation(n)
+    return np.ascontiguousarray(pts[perm]), np.concatenate([d, a]), lab[perm]
+
+
+def sphere(n, outlier_frac, seed=SEEDS["sphere"], dim=3, sigma=0.4, box=1000.0,
+           outlier_dist=20.0):
+    g = _rng(seed)
+    c = g.uniform(-box, box, dim)
+    r = g.uniform(0.0, box)
+    n_out = int(round(n * outlier_frac))
+    n_in = n - n_out
+    u = g.uniform(-1.0, 1.0, (n_in, dim))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    inl = c + r * u + g.normal(0.0, sigma, (n_in, dim))
+    out = np.empty((0, dim))
+    while out.shape[0] < n_out:
+        cand = g.uniform(-box, box, (max(n_out, 16), dim))
+        keep = np.abs(np.linalg.norm(cand - c, axis=1) - r) >= outlier_dist
+        out = np.vstack([out, cand[keep]])
+    out = out[:n_out]
+    pts = np.vstack([inl, out])
+    lab = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
+    perm = g.permutation(n)
+    return np.ascontiguousarray(pts[perm]), np.concatenate([c, [r]]), lab[perm]
+
+
+def dense(m, ncols, outlier_frac=0.05, seed=SEEDS["dense"], noise=0.05, outlier_scale=20.0):
+    """-> (augmented rows (m, ncols+1), true x, is_inlier)."""
+    g = _rng(seed)
+    A = g.uniform(-1.0, 1.0, (m, ncols))
+    x = g.uniform(-1.0, 1.0, ncols)
+    b = (A @ x) * (1.0 + g.uniform(-noise, noise, m))
+    n_out = int(round(m * outlier_frac))
+    lab = np.ones(m, bool)
+    if n_out:
+        idx = g.choice(m, n_out, replace=False)
+        b[idx] *= outlier_scale
+        lab[idx] = False
+    return np.ascontiguousarray(np.hstack([A, b[:, None]])), x, lab
+
+
+def euler_zyx(wz, wy, wx):
+    """R = Rz*Ry*Rx (common/Frame.cxx:87-113)."""
+    cz, sz, cy, sy, cx, sx = np.cos(wz), np.sin(wz), np.cos(wy), np.sin(wy), np.cos(wx), np.sin(wx)
+    return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                     [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                     [-sy, cy * sx, cy * cx]])
+
+
+def us_single(m, outlier_frac=0.0, seed=SEEDS["us"], pixel_sigma=1.0):
+    """Cross-wire phantom frames -> (records (m,15) float64, true 11-vector, is_inlier).
+    Record = Frame{rotation[3][3], translation[3], int outputFormat(+pad)} + Point2D (120 B)."""
+    g = _rng(seed)
+    mx, my = 0.143, 0.139
+    w3 = g.uniform(0.0, np.pi, 3)
+    t3 = g.uniform(-100.0, 100.0, 3)
+    t1 = g.uniform(-100.0, 100.0, 3)
+    R3 = euler_zyx(*w3)
+    rec = np.zeros((m, 15))
+    n_out = int(round(m * outlier_frac))
+    lab = np.ones(m, bool)
+    uv = np.stack([g.uniform(0.0, 640.0, m), g.uniform(0.0, 480.0, m)], axis=1)
+    w2 = g.uniform(0.0, np.pi, (m, 3))
+    for i in range(m):
+        R2 = euler_zyx(*w2[i])
+        q3 = R3 @ np.array([mx * uv[i, 0], my * uv[i, 1], 0.0]) + t3
+        t2 = t1 - R2 @ q3
+        rec[i, 0:9] = R2.reshape(9)
+        rec[i, 9:12] = t2
+    rec[:, 13:15] = uv + g.normal(0.0, pixel_sigma, (m, 2))
+    if n_out:
+        idx = g.choice(m, n_out, replace=False)
+        rec[idx, 9:12] = g.uniform(-100.0, 100.0, (n_out, 3))
+        lab[idx] = False
+    truth = np.concatenate([t1, t3, w3, [mx, my]])
+    return np.ascontiguousarray(rec), truth, lab
+
+
+def us_single_fast(m, outlier_frac=0.0, seed=SEEDS["us"], pixel_sigma=1.0):
+    """Vectorised us_single for m ~ 1e6 (same distributions, different stream order)."""
+    g = _rng(seed)
+    mx, my = 0.143, 0.139
+    w3 = g.uniform(0.0, np.pi, 3)
+    t3 = g.uniform(-100.0, 100.0, 3)
+    t1 = g.uniform(-100.0, 100.0, 3)
+    R3 = euler_zyx(*w3)
+    uv = np.stack([g.uniform(0.0, 640.0, m), g.uniform(0.0, 480.0, m)], axis=1)
+    w2 = g.uniform(0.0, np.pi, (m, 3))
+    cz, sz = np.cos(w2[:, 0]), np.sin(w2[:, 0])
+    cy, sy = np.cos(w2[:, 1]), np.sin(w2[:, 1])
+    cx, sx = np.cos(w2[:, 2]), np.sin(w2[:, 2])
+    R2 = np.empty((m, 3, 3))
+    R2[:, 0, 0] = cz * cy; R2[:, 0, 1] = cz * sy * sx - sz * cx; R2[:, 0, 2] = cz * sy * cx + sz * sx
+    R2[:, 1, 0] = sz * cy; R2[:, 1, 1] = sz * sy * sx + cz * cx; R2[:, 1, 2] = sz * sy * cx - cz * sx
+    R2[:, 2, 0] = -sy; R2[:, 2, 1] = cy * sx; R2[:, 2, 2] = cy * cx
+    q3 = (np.stack([mx * uv[:, 0], my * uv[:, 1], np.zeros(m)], axis=1) @ R3.T) + t3
+    t2 = t1 - np.einsum("mij,mj->mi", R2, q3)
+    rec = np.zeros((m, 15))
+    rec[:, 0:9] = R2.reshape(m, 9)
+    rec[:, 9:12] = t2
+    rec[:, 13:15] = uv + g.normal(0.0, pixel_sigma, (m, 2))
+    lab = np.ones(m, bool)
+    n_out = int(round(m * outlier_frac))
+    if n_out:
+        idx = g.choice(m, n_out, replace=False)
+        rec[idx, 9:12] = g.uniform(-100.0, 100.0, (n_out, 3))
+        lab[idx] = False
+    return np.ascontiguousarray(rec), np.concatenate([t1, t3, w3, [mx, my]]), lab
+
+
+def us_pointer(m, outlier_frac=0.0, seed=SEEDS["us"] + 1, pixel_sigma=1.0):
+    """Calibrated-pointer frames -> (records (m,18), true 8-vector, is_inlier)."""
+    g = _rng(seed)
+    mx, my = 0.143, 0.139
+    w3 = g.uniform(0.0, np.pi, 3)
+    t3 = g.uniform(-100.0, 100.0, 3)
+    R3 = euler_zyx(*w3)
+    rec = np.zeros((m, 18))
+    uv = np.stack([g.uniform(0.0, 640.0, m), g.uniform(0.0, 480.0, m)], axis=1)
+    w2 = g.uniform(0.0, np.pi, (m, 3))
+    t2 = g.uniform(-100.0, 100.0, (m, 3))
+    for i in range(m):
+        R2 = euler_zyx(*w2[i])
+        q3 = R3 @ np.array([mx * uv[i, 0], my * uv[i, 1], 0.0]) + t3
+        rec[i, 0:9] = R2.reshape(9)
+        rec[i, 9:12] = t2[i]
+        rec[i, 15:18] = R2 @ q3 + t2[i]
+    rec[:, 13:15] = uv + g.normal(0.0, pixel_sigma, (m, 2))
+    lab = np.ones(m, bool)
+    n_out = int(round(m * outlier_frac))
+    if n_out:
+        idx = g.choice(m, n_out, replace=False)
+        rec[idx, 15:18] = g.uniform(-100.0, 100.0, (n_out, 3))
+        lab[idx] = False
+    return np.ascontiguousarray(rec), np.concatenate([t3, w3, [mx, my]]), lab

@@ -1,0 +1,112 @@
+"""Generates the committed golden fixtures.  Run in the BUILD container only (needs
+/root/reference for the data files and for oracle/_ref, and scipy for the MINPACK cross-check):
+
+    python tests/golden/make_golden.py
+
+Outputs (all data, no reference source text):
+  ref_data/*.txt            data files the reference's own tests/examples hold
+                            (testing/Data/augmentedMatrix.txt, crossWirePhantom*.txt,
+                             examples/Data/augmentedMatrixWithOutliers.txt)
+  ransac_ref_vectors.npz    inputs + outputs of the REFERENCE RANSAC.hxx (oracle/_ref) on
+                            seeded data and seeded rand() streams
+  numerics_vectors.npz      NumPy/SciPy results (eigh, svd, lstsq, MINPACK lmder through
+                            scipy.optimize.leastsq) on seeded inputs
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import pyoracle as O  # noqa: E402
+from lsqrrecipes_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def copy_data():
+    for src in ("testing/Data/augmentedMatrix.txt", "testing/Data/crossWirePhantom2DPoints.txt",
+                "testing/Data/crossWirePhantomTransformations.txt",
+                "examples/Data/augmentedMatrixWithOutliers.txt"):
+        shutil.copy(os.path.join(REF, src), os.path.join(HERE, "ref_data", os.path.basename(src)))
+
+
+def ransac_vectors():
+    out = {}
+    cases = {
+        "plane": (O.cfg(O.PLANE, 3, 0.5), synth.plane(400, 0.3)[0]),
+        "sphere": (O.cfg(O.SPHERE, 3, 0.5, O.LS_GEOMETRIC), synth.sphere(400, 0.3)[0]),
+        "circle": (O.cfg(O.SPHERE, 2, 0.5, O.LS_ALGEBRAIC), synth.sphere(300, 0.25, dim=2)[0]),
+        "line": (O.cfg(O.LINE, 3, 0.5), synth.line(300, 0.3)[0]),
+        "dense": (O.cfg(O.DENSE, 5, 0.1), synth.dense(200, 5, 0.1)[0]),
+        "us": (O.cfg(O.US_SINGLE, 0, 3.0, 1), synth.us_single(60, 0.2)[0]),
+        "usp": (O.cfg(O.US_POINTER, 0, 3.0, 1), synth.us_pointer(60, 0.2)[0]),
+    }
+    for name, (c, data) in cases.items():
+        out[name + "_cfg"] = np.array([c.model, c.dim, c.delta, c.ls_type], dtype=np.float64)
+        out[name + "_data"] = data
+        for seed in (11, 12, 13):
+            r = O.ref_ransac(c, data, 0.99 if name in ("us", "usp", "dense") else 0.999,
+                             seed=seed, subsets_cap=1024)
+            key = "%s_s%d_" % (name, seed)
+            out[key + "fraction"] = np.array([r["fraction"]])
+            out[key + "params"] = r["params"]
+            out[key + "consensus"] = r["consensus"]
+            out[key + "subsets"] = r["subsets"]
+            out[key + "counts"] = np.array([r["estimate_calls"], r["agree_calls"], r["ls_calls"],
+                                            r["rand_calls"]], dtype=np.int64)
+    # exhaustive overload on a tiny set
+    c = O.cfg(O.PLANE, 3, 0.5)
+    data = synth.plane(14, 0.3, seed=77)[0]
+    r = O.ref_ransac(c, data, 0.0, exhaustive=True, subsets_cap=512)
+    out["exh_data"] = data
+    out["exh_fraction"] = np.array([r["fraction"]])
+    out["exh_params"] = r["params"]
+    out["exh_consensus"] = r["consensus"]
+    out["exh_subsets"] = r["subsets"]
+    np.savez_compressed(os.path.join(HERE, "ransac_ref_vectors.npz"), **out)
+
+
+def numerics_vectors():
+    from scipy.optimize import leastsq
+    g = np.random.default_rng(1234)
+    out = {}
+    for n in (3, 4, 12, 64):
+        A = g.normal(size=(n, n))
+        A = A + A.T
+        w, V = np.linalg.eigh(A)
+        out["eig%d_A" % n], out["eig%d_w" % n], out["eig%d_V" % n] = A, w, V
+    for (m, n) in ((12, 12), (40, 4), (64, 64), (300, 12)):
+        A = g.normal(size=(m, n))
+        b = g.normal(size=m)
+        out["svd%dx%d_A" % (m, n)] = A
+        out["svd%dx%d_b" % (m, n)] = b
+        out["svd%dx%d_s" % (m, n)] = np.linalg.svd(A, compute_uv=False)
+        out["svd%dx%d_x" % (m, n)] = np.linalg.lstsq(A, b, rcond=None)[0]
+    # sphere LM through MINPACK lmder (scipy) -- tolerances of SphereParametersEstimator.hxx:323-329
+    for dim, seed in ((3, 5), (2, 6)):
+        pts = synth.sphere(200, 0.0, seed=seed, dim=dim)[0]
+        init = O.sphere_algebraic(dim, pts)
+
+        def f(x, pts=pts, dim=dim):
+            return np.sqrt(((pts - x[:dim]) ** 2).sum(1)) - x[dim]
+
+        def J(x, pts=pts, dim=dim):
+            d = np.sqrt(((pts - x[:dim]) ** 2).sum(1))
+            return np.column_stack([(x[:dim] - pts) / d[:, None], -np.ones(len(pts))])
+        r = leastsq(f, init, Dfun=J, ftol=1e-10, xtol=1e-15, gtol=1e-15, maxfev=500,
+                    full_output=True)
+        out["lm_sphere%d_pts" % dim] = pts
+        out["lm_sphere%d_init" % dim] = init
+        out["lm_sphere%d_x" % dim] = r[0]
+        out["lm_sphere%d_nfev_ier" % dim] = np.array([r[2]["nfev"], r[4]])
+    np.savez_compressed(os.path.join(HERE, "numerics_vectors.npz"), **out)
+
+
+if __name__ == "__main__":
+    copy_data()
+    ransac_vectors()
+    numerics_vectors()
+    print("golden fixtures written to", HERE)

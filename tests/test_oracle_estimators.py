@@ -1,0 +1,188 @@
+"""Oracle estimators against the assertions of the reference's own test programs
+(testing/*Test.cxx), restated on seeded data."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from lsqrrecipes_amd import synth
+
+COS5 = 0.99619469809174553229501040247389  # testing/PlaneParametersEstimatorTest.cxx:129
+
+
+def test_plane_like_reference_test():
+    """testing/PlaneParametersEstimatorTest.cxx:71-158: delta 0.5, agree on/off plane, exact and
+    LS normals within 5 degrees, point-on-plane distance < delta."""
+    g = np.random.default_rng(7)
+    delta = 0.5
+    c = O.cfg(O.PLANE, 3, delta)
+    tri = g.uniform(-1000, 1000, (3, 3))
+    n = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+    n /= np.linalg.norm(n)
+    truth = np.concatenate([n, tri[0]])
+    exact = O.estimate(c, tri)
+    assert len(exact) == 6
+    assert abs(exact[:3] @ n) > COS5
+    assert abs((exact[3:] - tri[0]) @ n) < delta
+    # agree: on the plane, and 2*delta off it
+    assert O.agree(c, truth, tri[1])
+    assert not O.agree(c, truth, tri[1] + 2 * delta * n)
+    # 20 barycentric points + N(0,1) noise
+    w = g.uniform(0, 1, (20, 3))
+    w /= w.sum(1)[:, None]
+    pts = w @ tri + g.normal(0, 1.0, (20, 3))
+    ls = O.ls(c, pts)
+    assert abs(ls[:3] @ n) > COS5
+    assert abs((ls[3:] - tri[0]) @ n) < delta * 4  # noise sigma 1 => looser than the exact case
+    # degenerate: collinear points -> empty
+    col = np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]], float)
+    assert len(O.estimate(c, col)) == 0
+    # too few points
+    assert len(O.ls(c, pts[:2])) == 0
+
+
+@pytest.mark.parametrize("dim", [2, 3, 4])
+def test_sphere_like_reference_test(dim):
+    """testing/SphereParametersEstimatorTest.cxx:208-234,137-155,432-468,504-506: centre distance
+    and radius error <= 3 sigma for exact / algebraic / geometric."""
+    sigma = 1.0
+    pts, truth, _ = synth.sphere(50, 0.0, seed=100 + dim, dim=dim, sigma=sigma, box=50.0)
+    c = O.cfg(O.SPHERE, dim, 0.5, O.LS_GEOMETRIC)
+    clean = truth[:dim] + truth[dim] * np.eye(dim + 1, dim)  # axis points
+    clean[dim] = truth[:dim] - truth[dim] * np.eye(dim)[0]
+    ex = O.estimate(c, clean)
+    assert len(ex) == dim + 1
+    assert np.linalg.norm(ex[:dim] - truth[:dim]) < 1e-6 * max(1, truth[dim])
+    alg = O.sphere_algebraic(dim, pts)
+    geo = O.ls(c, pts)
+    for est in (alg, geo):
+        assert len(est) == dim + 1
+        assert np.linalg.norm(est[:dim] - truth[:dim]) <= 3 * sigma
+        assert abs(est[dim] - truth[dim]) <= 3 * sigma
+
+
+def test_sphere_agree_cases():
+    """testing/SphereParametersEstimatorTest.cxx:280-296: r = 2, delta = 0.5."""
+    c = O.cfg(O.SPHERE, 2, 0.5)
+    par = np.array([0.0, 0.0, 2.0])
+    assert O.agree(c, par, [2.0, 0.0])
+    assert O.agree(c, par, [2.4, 0.0])
+    assert O.agree(c, par, [1.6, 0.0])
+    assert not O.agree(c, par, [2.6, 0.0])
+    assert not O.agree(c, par, [1.4, 0.0])
+    assert not O.agree(c, par, [2.5, 0.0])  # strict <
+
+
+def test_sphere_degenerate():
+    c = O.cfg(O.SPHERE, 3, 0.5)
+    cop = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], float)  # coplanar
+    assert len(O.estimate(c, cop)) == 0
+    c2 = O.cfg(O.SPHERE, 2, 0.5)
+    assert len(O.estimate(c2, np.array([[0, 0], [1, 1], [2, 2]], float))) == 0
+
+
+def test_line_like_reference_test():
+    """testing/LineParametersEstimatorTest.cxx:98-213: delta 0.5, direction within 5 degrees."""
+    g = np.random.default_rng(3)
+    delta = 0.5
+    c = O.cfg(O.LINE, 2, delta)
+    a, b = g.uniform(-100, 100, 2), g.uniform(-100, 100, 2)
+    d = (a - b) / np.linalg.norm(a - b)
+    ex = O.estimate(c, np.stack([a, b]))
+    assert np.allclose(ex[:2], d) and np.allclose(ex[2:], a)
+    truth = np.concatenate([d, a])
+    nrm = np.array([-d[1], d[0]])
+    assert O.agree(c, truth, b)
+    assert not O.agree(c, truth, b + 2 * delta * nrm)
+    pts = a + g.uniform(-100, 100, 20)[:, None] * d + g.normal(0, 0.3, (20, 2))
+    ls = O.ls(c, pts)
+    assert abs(ls[:2] @ d) > COS5
+    assert abs((ls[2:] - a) @ nrm) < delta
+    # points closer than delta -> empty (LineParametersEstimator.hxx:33-35)
+    assert len(O.estimate(c, np.stack([a, a + 0.1 * d]))) == 0
+
+
+def test_dense_like_reference_test():
+    """testing/DenseLinear...Test.cxx:72-146: 5x5 exact to 1e-10; 200x5 with <=5% noise to 0.1."""
+    g = np.random.default_rng(5)
+    c = O.cfg(O.DENSE, 5, 0.1)
+    A = g.uniform(-1, 1, (5, 5))
+    x = g.uniform(-1, 1, 5)
+    rows = np.hstack([A, (A @ x)[:, None]])
+    assert np.allclose(O.estimate(c, rows), x, atol=1e-10)
+    rows2, x2, _ = synth.dense(200, 5, 0.0, seed=9)
+    assert np.allclose(O.ls(c, rows2), x2, atol=0.1)
+    # agree
+    assert O.agree(c, x, rows[0])
+    bad = rows[0].copy()
+    bad[5] += 0.2
+    assert not O.agree(c, x, bad)
+    # singular minimal set -> empty
+    sing = rows.copy()
+    sing[4] = sing[3]
+    assert len(O.estimate(c, sing)) == 0
+
+
+def _euler_close(a, b, tol):
+    d = np.abs((a - b + np.pi) % (2 * np.pi) - np.pi)
+    return np.all(d < tol)
+
+
+def test_us_single_like_reference_test():
+    """testing/SinglePointTargetUSCalibration...Test.cxx:179-220,466-552: delta 3; minimal-set
+    estimate from 4 clean frames agrees with clean data; iterative LS on noisy data within
+    1 mm (t3), 1 degree (one of two Euler solutions), scales within 1.0."""
+    c = O.cfg(O.US_SINGLE, 0, 3.0, 1)
+    clean, truth, _ = synth.us_single(50, 0.0, seed=21, pixel_sigma=0.0)
+    ex = O.estimate(c, clean[:4])
+    assert len(ex) == 20
+    assert O.agree(c, ex, clean[0]) and O.agree(c, ex, clean[30])
+    assert len(O.estimate(c, clean[:5])) == 0  # exactly 4 required (:21)
+    noisy, truth, _ = synth.us_single(50, 0.0, seed=21, pixel_sigma=1.0)
+    ls = O.ls(c, noisy)
+    assert len(ls) == 20
+    assert np.linalg.norm(ls[3:6] - truth[3:6]) < 1.0
+    wz, wy, wx = truth[6:9]
+    alt = np.array([wz + np.pi, np.pi - wy, wx + np.pi])
+    deg = np.pi / 180
+    assert _euler_close(ls[6:9], truth[6:9], deg) or _euler_close(ls[6:9], alt, deg)
+    assert abs(ls[9] - truth[9]) < 1.0 and abs(ls[10] - truth[10]) < 1.0
+    # the trailing 9 entries are the rotation products of the 11 (cxx:303-327)
+    R3 = synth.euler_zyx(*ls[6:9])
+    assert np.allclose(ls[11:14], ls[9] * R3[:, 0])
+    assert np.allclose(ls[14:17], ls[10] * R3[:, 1])
+    assert np.allclose(ls[17:20], R3[:, 2])
+
+
+def test_us_pointer_like_reference_test():
+    c = O.cfg(O.US_POINTER, 0, 3.0, 1)
+    clean, truth, _ = synth.us_pointer(50, 0.0, seed=22, pixel_sigma=0.0)
+    ex = O.estimate(c, clean[:3])
+    assert len(ex) == 17
+    assert O.agree(c, ex, clean[0]) and O.agree(c, ex, clean[40])
+    noisy, truth, _ = synth.us_pointer(50, 0.0, seed=22, pixel_sigma=1.0)
+    ls = O.ls(c, noisy)
+    assert len(ls) == 17
+    assert np.linalg.norm(ls[0:3] - truth[0:3]) < 1.0
+    assert abs(ls[6] - truth[6]) < 1.0 and abs(ls[7] - truth[7]) < 1.0
+
+
+def test_crosswire_experimental_data(golden_dir):
+    """testing/SinglePointTarget...Test.cxx:115-166 feeds testing/Data/crossWirePhantom*.txt and
+    only prints; here: the oracle must produce a calibration whose residuals are sane."""
+    T = np.loadtxt(os.path.join(golden_dir, "ref_data", "crossWirePhantomTransformations.txt"))
+    q = np.loadtxt(os.path.join(golden_dir, "ref_data", "crossWirePhantom2DPoints.txt"))
+    m = q.shape[0]
+    rec = np.zeros((m, 15))
+    T = T.reshape(m, 3, 4)
+    rec[:, 0:9] = T[:, :, :3].reshape(m, 9)
+    rec[:, 9:12] = T[:, :, 3]
+    rec[:, 13:15] = q
+    c = O.cfg(O.US_SINGLE, 0, 3.0, 1)
+    ls = O.ls(c, rec)
+    assert len(ls) == 20
+    st = O.stats(c, ls, rec)
+    assert st[2] < 3.0  # mean residual in mm
+    an = O.us_analytic(O.US_SINGLE, rec)
+    assert O.stats(c, ls, rec)[3] <= O.stats(c, an, rec)[3] + 1e-9  # LM does not worsen
