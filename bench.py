@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+  metric   RANSAC hypotheses/s (+ final-fit residual), plane, 10 M points, 50 % outliers
+  step     one pass of the hot path over one batch: sample H minimal subsets -> solve -> agree()
+           scan of all H hypotheses over all N observations -> first-max winner -> consensus mask
+           -> final least-squares fit.  Nothing is cached between steps (new subsets each step).
+  value    whole-job hypotheses/s = H * n_gpus * steps / wall time (observations already resident
+           in HBM when the timed region starts).
+  N > 1    one process per GPU (torch.distributed, RCCL): observations replicated, the hypothesis
+           stream sharded; all-reduce(MAX) picks the winner, all-reduce(SUM) of the moment block of
+           each rank's observation slice gives the final fit.  scaling = "weak" (H per GPU fixed).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--batch H] [--workload plane]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_GOPS = 39321.6  # 256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz: fp64 add/mul issue rate
+#                                (= the 78.6 TFLOP/s vector fp64 peak counting an FMA as one op;
+#                                the bit-exact agree() may not fuse, so this is its op roof)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--batch", type=int, default=4096, help="hypotheses per GPU per step")
+    ap.add_argument("--workload", default="plane", choices=["plane", "sphere", "line"])
+    ap.add_argument("--outliers", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=0, help="observations for the CPU leg "
+                    "(0 = same as --points)")
+    return ap.parse_args()
+
+
+def make_data(workload, n, outliers):
+    from lsqrrecipes_amd import synth
+    if workload == "plane":
+        return synth.plane(n, outliers)
+    if workload == "sphere":
+        return synth.sphere(n, outliers)
+    return synth.line(n, outliers)
+
+
+OPS_PER_PAIR = {"plane": 11, "sphere": 22, "line": 24}  # fp64 VALU instructions in agree()
+
+
+def cpu_baseline(workload, data, delta):
+    """Reference single-thread CPU path on the same workload, bounded to ~10-30 s: the
+    reference's own RANSAC.hxx (oracle/_ref, compiled from /root/reference in the build
+    container) driving the restated estimator; falls back to the oracle's C port of the loop."""
+    from oracle import pyoracle as O
+    model = {"plane": O.PLANE, "sphere": O.SPHERE, "line": O.LINE}[workload]
+    c = O.cfg(model, 3, delta, O.LS_ALGEBRAIC)
+    cores = 1
+    t0 = time.perf_counter()
+    if O.ref_available():
+        r = O.ref_ransac(c, data, 0.999, seed=20261003)
+        hyp = r["estimate_calls"]
+        kind = "reference"
+        what = ("reference RANSAC.hxx compiled unmodified (oracle/_ref) + restated %sParametersEstimator"
+                " (VNL absent), adaptive run p=0.999" % workload.capitalize())
+    else:
+        r = O.ransac(c, data, 0.999, sampler="ref", seed=20261003)
+        hyp = int((r["status"] != 1).sum())
+        kind = "port"
+        what = "oracle C port of RANSAC.hxx + estimator, adaptive run p=0.999"
+    dt = time.perf_counter() - t0
+    return {"value": hyp / dt, "unit": "hypotheses/s", "cores": cores, "kind": kind,
+            "sample": "%s; N=%d points; %d hypotheses in %.2f s; 1 thread" % (what, len(data), hyp, dt),
+            "fraction": r["fraction"]}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    dist = None
+    device = "cpu"
+    if a.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        device = "cuda:%d" % local
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    from lsqrrecipes_amd import _lib as L
+    from lsqrrecipes_amd.context import Context
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+
+    delta = 0.5
+    model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE}[a.workload]
+    ls_type = L.LS_GEOMETRIC
+    data, truth, lab = make_data(a.workload, a.points, a.outliers)
+    ctx = Context(local)
+    ctx.set_model(model, 3, delta, ls_type).upload(data)
+    comm = Comm(dist, device)
+    eng = ShardedRansac(ctx, comm)
+    H = a.batch
+    seed = 0xC0FFEE
+
+    def step(i):
+        votes, gidx, par = eng.batch(seed, i, H)
+        if gidx is None:
+            return None
+        if comm.world == 1:
+            # single GPU: mask + fit stay on the device end to end
+            _, cnt = ctx.mask(par, want_mask=False)
+            fit, info = ctx.ls_fit(use_mask=True)
+            return votes, fit, cnt
+        fit, cnt, info = eng.fit(par)
+        return votes, fit, cnt
+
+    def sync():
+        ctx.synchronize()
+        if a.gpus > 1:
+            import torch
+            torch.cuda.synchronize()
+        comm.barrier()
+
+    for i in range(a.warmup):
+        step(i)
+    ctx.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(a.steps):
+        last = step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    dt = comm.allreduce_max_f64(dt)
+    n_scan, ms_scan = ctx.profile_get("scan")
+    n_mask, ms_mask = ctx.profile_get("mask")
+    n_mom, ms_mom = ctx.profile_get("moments")
+    n_est, ms_est = ctx.profile_get("estimate")
+    ctx.profile(False)
+
+    if rank == 0:
+        total_hyp = H * a.gpus * a.steps
+        value = total_hyp / dt
+        votes, fit, cnt = last
+        res = ctx.stats(fit, use_mask=True) if comm.world == 1 else None
+        rec = data.shape[1] * 8
+        scan_ms = ms_scan / max(n_scan, 1)
+        alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis
+        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        pairs_per_s = float(H) * a.points / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                t = json.load(open(tfile))
+                key = "%s_%d_%d" % (a.workload, a.points, H)
+                traffic = t.get(key)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "RANSAC hypotheses/sec + final-fit residual, 10M pts",
+            "value": value, "unit": "hypotheses/s", "n_gpus": a.gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%sParametersEstimator + RANSAC, %d points, %d%% outliers, "
+                                   "delta=%.2f (BASELINE.json configs[1])" % (
+                                       a.workload.capitalize(), a.points, round(a.outliers * 100), delta)
+                       if a.workload == "plane" else "%s, %d points" % (a.workload, a.points),
+                       "points": a.points, "hypotheses_per_gpu_per_step": H,
+                       "record_bytes": rec, "parallelism": "hypotheses sharded over %d GPU(s), "
+                       "observations replicated" % a.gpus},
+            "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),
+                          "params": [float(x) for x in fit],
+                          "abs_dot_true_normal": float(abs(np.dot(fit[:3], truth[:3])))
+                          if a.workload != "sphere" else None,
+                          "residual_min_max_mean_sumsq": [float(x) for x in res] if res is not None else None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_scan<%s>" % a.workload,
+                         "launch_ms": scan_ms, "launches": int(n_scan),
+                         "note": "achieved = algorithmic bytes (H*N*%d B per launch, SURVEY 8d) / "
+                                 "launch time; the batched scan reads the observations once per "
+                                 "launch for all H hypotheses, so it is bound by fp64 VALU issue, "
+                                 "see valu_fp64" % rec,
+                         "valu_fp64": {"achieved_gops": pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9,
+                                       "peak_gops": FP64_VALU_PEAK_GOPS,
+                                       "frac": pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9 / FP64_VALU_PEAK_GOPS,
+                                       "ops_per_pair": OPS_PER_PAIR[a.workload]}},
+            "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
+                           "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1)},
+        }
+        if a.gpus == 1 and not a.no_cpu_baseline:
+            cp = a.cpu_points or a.points
+            out["cpu_baseline"] = cpu_baseline(a.workload, data[:cp], delta)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

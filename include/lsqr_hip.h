@@ -1,0 +1,213 @@
+/*
+ * lsqr_hip.h -- C ABI of the MI355X-native RANSAC + least-squares hot path
+ * (liblsqr_hip.so, built from lsqrrecipes_amd/csrc/ with hipcc --offload-arch=gfx950).
+ *
+ * This is the drop-in boundary for the one hot path of zivy/LSQRRecipes:
+ *     RANSAC<T,S>::compute()                      parametersEstimators/RANSAC.h:75-79,111-113
+ *       -> ParametersEstimator<T,S>::estimate()   parametersEstimators/ParametersEstimator.h:41-43
+ *       -> ParametersEstimator<T,S>::agree()      parametersEstimators/ParametersEstimator.h:55
+ *       -> ...::leastSquaresEstimate()            parametersEstimators/ParametersEstimator.h:51-53
+ * for the Plane / Sphere / Line / DenseLinearEquationSystem / SinglePointTargetUSCalibration
+ * estimators.  Plain C types only: no STL, no exceptions, no torch types cross this ABI.  Every
+ * entry point returns an lsqr_status; LSQR_OK == 0.  The reference's "empty parameters vector"
+ * failure convention (RANSAC.h:54-63) maps to LSQR_EMPTY (a normal outcome, not an error).
+ *
+ * The C++ header shim (lsqrrecipes_amd/include/RANSAC.h, ...Estimator.h) and the Python mirror
+ * (lsqrrecipes_amd/ python modules) are thin callers of exactly these functions.  There is no CPU
+ * fallback behind this ABI: without a usable HIP device lsqr_ctx_create fails with
+ * LSQR_ERR_NO_DEVICE.
+ *
+ * All records are fp64, array-of-structures, exactly as the reference lays them out:
+ *   Point<double,d>            d doubles                         common/Point.h:127
+ *   AugmentedRow<double,n>     n+1 doubles (aValues[n], bValue)  .../DenseLinear...Estimator.h:133-134
+ *   SingleUnknown DataType     15 slots = Frame{rotation[3][3], translation[3], int outputFormat
+ *                              (+4 B pad)} + Point2D             .../SinglePointTarget...h:45-48,
+ *                                                                common/Frame.h:30-31,41
+ *   CalibratedPointer DataType 18 slots (+ Point3D p)            .../SinglePointTarget...h:335-339
+ * A caller's std::vector<T> is passed as (pointer, count, stride in bytes) without repacking.
+ */
+#ifndef LSQR_HIP_H
+#define LSQR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define LSQR_API __attribute__((visibility("default")))
+#else
+#define LSQR_API
+#endif
+
+typedef enum {
+  LSQR_OK = 0,
+  LSQR_EMPTY = 1,          /* reference's empty-vector outcome: degenerate data / LS failed */
+  LSQR_ERR_INVALID = 2,    /* bad argument */
+  LSQR_ERR_NO_DEVICE = 3,  /* no HIP device / runtime unusable */
+  LSQR_ERR_HIP = 4,        /* a HIP call failed; see lsqr_last_error */
+  LSQR_ERR_STATE = 5       /* call order (no data uploaded, no hypotheses, ...) */
+} lsqr_status;
+
+typedef enum {
+  LSQR_MODEL_PLANE = 1,      /* PlaneParametersEstimator<dim>       params [n(dim), a(dim)]   */
+  LSQR_MODEL_SPHERE = 2,     /* SphereParametersEstimator<dim>      params [c(dim), r]        */
+  LSQR_MODEL_LINE = 3,       /* LineParametersEstimator<dim>        params [dir(dim), a(dim)] */
+  LSQR_MODEL_DENSE = 4,      /* DenseLinearEquationSystemParametersEstimator<double,n>, dim=n */
+  LSQR_MODEL_US_SINGLE = 5,  /* SingleUnknownPointTargetUSCalibrationParametersEstimator      */
+  LSQR_MODEL_US_POINTER = 6  /* CalibratedPointerTargetUSCalibrationParametersEstimator       */
+} lsqr_model;
+
+/* SphereParametersEstimator::LeastSquaresType (SphereParametersEstimator.h:28) and the US
+ * estimators' {ANALYTIC, ITERATIVE} (SinglePointTarget...h:57) */
+enum { LSQR_LS_ALGEBRAIC = 0, LSQR_LS_GEOMETRIC = 1, LSQR_LS_ANALYTIC = 0, LSQR_LS_ITERATIVE = 1 };
+
+/* What the reference passes to an estimator's constructor / setters. */
+typedef struct {
+  int32_t model;   /* lsqr_model */
+  int32_t dim;     /* point dimension (plane/sphere/line: 2 or 3), n for DENSE (1..64) */
+  double delta;    /* constructor argument, NOT squared (PlaneParametersEstimator.hxx:13-17) */
+  int32_t ls_type; /* sphere / US only */
+  int32_t reserved;
+} lsqr_model_cfg;
+
+typedef struct lsqr_ctx lsqr_ctx; /* owns a device, a stream and all device buffers */
+
+/* Result block of a final fit (leastSquaresEstimate). */
+typedef struct {
+  int32_t n_params;     /* 0 when status is LSQR_EMPTY */
+  int32_t lm_info;      /* MINPACK info code of the LM run (0 when no LM) */
+  int32_t lm_nfev;      /* LM function evaluations (= device passes) */
+  int32_t reserved;
+  uint64_t n_used;      /* observations that entered the fit */
+  double cost;          /* final sum of squared residuals where the model defines one, else 0 */
+} lsqr_fit_info;
+
+/* Outcome of RANSAC<T,S>::compute(). */
+typedef struct {
+  double fraction;        /* return value: |consensus| / N (RANSAC.hxx:144) */
+  uint64_t iterations;    /* loop iterations consumed, duplicates and degenerates included */
+  uint64_t evaluated;     /* hypotheses scanned on the device (>= the serial count) */
+  uint64_t best_index;    /* iteration index of the winner */
+  uint32_t best_votes;
+  int32_t n_params;       /* 0 -> parameters empty */
+  lsqr_fit_info fit;
+} lsqr_ransac_info;
+
+/* ---- library / device -------------------------------------------------------------------- */
+LSQR_API const char *lsqr_version(void);
+LSQR_API int lsqr_device_count(int *count);
+LSQR_API const char *lsqr_status_string(int status);
+
+/* ---- context ------------------------------------------------------------------------------ */
+LSQR_API int lsqr_ctx_create(int device, lsqr_ctx **out);
+LSQR_API void lsqr_ctx_destroy(lsqr_ctx *ctx);
+LSQR_API const char *lsqr_last_error(const lsqr_ctx *ctx);
+LSQR_API int lsqr_synchronize(lsqr_ctx *ctx);
+
+/* ---- model description (host only) -------------------------------------------------------- */
+LSQR_API int lsqr_min_subset(const lsqr_model_cfg *cfg);     /* numForEstimate() */
+LSQR_API int lsqr_num_params(const lsqr_model_cfg *cfg);     /* length of the parameters vector */
+LSQR_API int lsqr_record_doubles(const lsqr_model_cfg *cfg); /* tight record size in doubles */
+LSQR_API int lsqr_set_model(lsqr_ctx *ctx, const lsqr_model_cfg *cfg);
+
+/* ---- observations -------------------------------------------------------------------------- */
+/* Copies `count` host records (std::vector<T>::data(), stride sizeof(T)) to the device.
+ * Replaces: the `std::vector<T> &data` argument of RANSAC.h:75-79. */
+LSQR_API int lsqr_upload(lsqr_ctx *ctx, const void *host_records, size_t count,
+                         size_t stride_bytes);
+/* Adopts records already resident in device memory (no copy; caller keeps ownership). */
+LSQR_API int lsqr_attach(lsqr_ctx *ctx, const void *device_records, size_t count,
+                         size_t stride_bytes);
+LSQR_API size_t lsqr_count(const lsqr_ctx *ctx);
+
+/* ---- hypotheses: minimal-subset solve (estimate(), ParametersEstimator.h:41) ---------------- */
+/* Explicit subsets: H tuples of k record indices in DRAW order (RANSAC.hxx:65). */
+LSQR_API int lsqr_hypotheses_from_subsets(lsqr_ctx *ctx, const uint32_t *subsets, size_t H);
+/* Counter-based device sampler: hypothesis i uses stream element first_index + i of `seed`
+ * (replaces RANSAC.hxx:51-68; same "rank-th not yet chosen" selection rule, O(k^2) not O(N)).
+ * subsets_out (nullable) receives the H*k indices. */
+LSQR_API int lsqr_hypotheses_sample(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H,
+                                    uint32_t *subsets_out);
+/* ---- agree() scan over all observations (RANSAC.hxx:94-99, without the early exit) ---------- */
+LSQR_API int lsqr_scan(lsqr_ctx *ctx);
+/* Results of the current batch: any pointer may be NULL.  params: H*P doubles; valid: H bytes
+ * (0 = degenerate subset, estimate() returned an empty vector); votes: H counts. */
+LSQR_API int lsqr_get_hypotheses(lsqr_ctx *ctx, double *params, uint8_t *valid, uint32_t *votes);
+LSQR_API size_t lsqr_num_hypotheses(const lsqr_ctx *ctx);
+/* parameters (P doubles) and validity of one hypothesis of the current batch */
+LSQR_API int lsqr_get_hypothesis(lsqr_ctx *ctx, size_t hypothesis, double *params, uint8_t *valid);
+/* First-max winner of the current batch packed as (votes << 32) | (0xFFFFFFFF - index), so that a
+ * max-reduction over ranks (RCCL all-reduce) keeps the earliest best hypothesis (RANSAC.hxx:100). */
+LSQR_API int lsqr_best(lsqr_ctx *ctx, uint64_t *packed);
+
+/* ---- consensus mask (RANSAC.hxx:129-137) ----------------------------------------------------- */
+/* mask[i] = agree(params, data[i]) for i in [begin, end); kept on the device for lsqr_ls_fit.
+ * mask_out (nullable) receives end-begin bytes.  count_out (nullable) the number of inliers. */
+LSQR_API int lsqr_mask(lsqr_ctx *ctx, const double *params, size_t begin, size_t end,
+                       uint8_t *mask_out, uint64_t *count_out);
+LSQR_API int lsqr_mask_from_hypothesis(lsqr_ctx *ctx, size_t hypothesis, uint8_t *mask_out,
+                                       uint64_t *count_out);
+LSQR_API int lsqr_set_mask(lsqr_ctx *ctx, const uint8_t *mask); /* N bytes from the host */
+
+/* ---- final fit (leastSquaresEstimate(), ParametersEstimator.h:51) ---------------------------- */
+/* use_mask = 0 fits all observations, 1 only those in the device mask. */
+LSQR_API int lsqr_ls_fit(lsqr_ctx *ctx, int use_mask, double *params_out, lsqr_fit_info *info);
+/* Building blocks for multi-GPU fits: the normal-equation / moment block of [begin,end) and the
+ * small solve from a (summed) block.  lsqr_moments_len gives the block length in doubles. */
+LSQR_API int lsqr_moments_len(const lsqr_model_cfg *cfg, int phase);
+/* phase 0: the model's linear LS block about the origin x (ND doubles: any point near the model,
+ * identical on every rank); phase 1: the LM block {sum f^2, J^T J, J^T f} at the trial point x. */
+LSQR_API int lsqr_moments(lsqr_ctx *ctx, int use_mask, size_t begin, size_t end, int phase,
+                          const double *x, double *block_out);
+/* Small solve (on the device) from a summed phase-0 block taken about `origin`. */
+LSQR_API int lsqr_solve_moments(lsqr_ctx *ctx, const double *block, const double *origin,
+                                double *params_out, lsqr_fit_info *info);
+/* Levenberg-Marquardt over summed phase-1 blocks (MINPACK lmder control flow on the device):
+ *   lsqr_lm_begin(x0) -> x_trial;  repeat { block = sum over ranks of lsqr_moments(phase 1,
+ *   x_trial);  lsqr_lm_step(block) -> cont, x_trial }  until !cont.  On the last step params_out
+ *   receives the full parameter vector (status LSQR_EMPTY if LM did not converge). */
+LSQR_API int lsqr_lm_begin(lsqr_ctx *ctx, const double *x0, double *x_trial_out);
+LSQR_API int lsqr_lm_step(lsqr_ctx *ctx, const double *block, double *x_trial_out, int *cont,
+                          double *params_out, lsqr_fit_info *info);
+/* residual statistics as getDistanceStatistics() (SphereParametersEstimator.hxx:341-377):
+ * out = {min, max, mean, sum of squares} */
+LSQR_API int lsqr_stats(lsqr_ctx *ctx, const double *params, int use_mask, double out[4]);
+
+/* ---- whole path: RANSAC<T,S>::compute() ------------------------------------------------------ */
+/* Probabilistic overload (RANSAC.h:75-79).  Subsets come from `subsets` (n_subsets tuples, draw
+ * order) when non-NULL, else from the device sampler stream `seed`.  Hypotheses are evaluated in
+ * batches on the device and the serial loop of RANSAC.hxx:49-117 (duplicate filter, adaptive
+ * numTries, strict-> best update) is replayed over the batch results, so the outcome equals
+ * the serial reference's for the same subset stream.  params_out: lsqr_num_params doubles;
+ * consensus_out (nullable): N bytes.  Invalid input (N < k, p outside (0,1)) returns
+ * LSQR_ERR_INVALID with info->fraction = 0 and params_out untouched (RANSAC.hxx:16-19). */
+LSQR_API int lsqr_ransac(lsqr_ctx *ctx, double p, uint64_t seed, const uint32_t *subsets,
+                         size_t n_subsets, double *params_out, uint8_t *consensus_out,
+                         lsqr_ransac_info *info);
+/* Exhaustive overload (RANSAC.h:111-113): all C(N,k) subsets in lexicographic order. */
+LSQR_API int lsqr_ransac_exhaustive(lsqr_ctx *ctx, double *params_out, uint8_t *consensus_out,
+                                    lsqr_ransac_info *info);
+/* Host-side replay of RANSAC.hxx:79-112 over batch results (exposed for tests and for the
+ * multi-GPU driver).  state is 6 uint64: {i, numTries, best_votes, best_index, has_best, done};
+ * initialise with lsqr_replay_init.  Returns the number of batch entries consumed. */
+LSQR_API int lsqr_replay_init(size_t n, int k, double p, uint64_t state[6]);
+LSQR_API size_t lsqr_replay(size_t n, int k, double p, const uint32_t *subsets,
+                            const uint8_t *valid, const uint32_t *votes, size_t H,
+                            uint64_t base_index, void *dedup_set, uint64_t state[6]);
+LSQR_API void *lsqr_dedup_create(int k);
+LSQR_API void lsqr_dedup_destroy(void *set);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,
+ * 2 scan, 3 mask, 4 moments, 5 solve. */
+LSQR_API int lsqr_profile_enable(lsqr_ctx *ctx, int on);
+LSQR_API int lsqr_profile_get(lsqr_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);
+LSQR_API int lsqr_profile_reset(lsqr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQR_HIP_H */

@@ -1,0 +1,230 @@
+"""Context: object wrapper over one lsqr_ctx of the C ABI (one device, one stream)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Context:
+    def __init__(self, device=0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        st = self._lib.lsqr_ctx_create(int(device), C.byref(h))
+        if st != L.OK:
+            raise L.LsqrError(st, "lsqr_ctx_create(device=%d): %s" % (
+                device, self._lib.lsqr_status_string(st).decode()))
+        self._h = h
+        self.device = device
+        self.cfg = None
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsqr_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, st, allow_empty=False):
+        if st == L.OK or (allow_empty and st == L.EMPTY):
+            return st
+        raise L.LsqrError(st, "%s (%s)" % (self._lib.lsqr_status_string(st).decode(),
+                                           self._lib.lsqr_last_error(self._h).decode()))
+
+    # ---- model / data -------------------------------------------------------------------
+    def set_model(self, model, dim=3, delta=0.5, ls_type=L.LS_GEOMETRIC):
+        self.cfg = L.ModelCfg(int(model), int(dim), float(delta), int(ls_type), 0)
+        self._chk(self._lib.lsqr_set_model(self._h, C.byref(self.cfg)))
+        self.K = self._lib.lsqr_min_subset(C.byref(self.cfg))
+        self.P = self._lib.lsqr_num_params(C.byref(self.cfg))
+        self.ND = self._lib.lsqr_record_doubles(C.byref(self.cfg))
+        return self
+
+    def upload(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float64)
+        a = a.reshape(-1, a.shape[-1]) if a.ndim > 1 else a.reshape(-1, self.ND)
+        self._chk(self._lib.lsqr_upload(self._h, L.ptr(a), a.shape[0], a.shape[1] * 8))
+        self.n = a.shape[0]
+        return self
+
+    def attach(self, device_ptr, count, stride_bytes, keepalive=None):
+        self._keep = keepalive
+        self._chk(self._lib.lsqr_attach(self._h, C.c_void_p(device_ptr), count, stride_bytes))
+        self.n = count
+        return self
+
+    # ---- hypotheses ---------------------------------------------------------------------
+    def hypotheses_from_subsets(self, subsets):
+        s = np.ascontiguousarray(subsets, dtype=np.uint32).reshape(-1, self.K)
+        self._chk(self._lib.lsqr_hypotheses_from_subsets(self._h, L.ptr(s), s.shape[0]))
+        return s.shape[0]
+
+    def hypotheses_sample(self, seed, first, H, want_subsets=False):
+        out = np.zeros((H, self.K), dtype=np.uint32) if want_subsets else None
+        self._chk(self._lib.lsqr_hypotheses_sample(self._h, seed, first, H, L.ptr(out)))
+        return out
+
+    def scan(self):
+        self._chk(self._lib.lsqr_scan(self._h))
+
+    def hypotheses(self, params=True, valid=True, votes=True):
+        H = self._lib.lsqr_num_hypotheses(self._h)
+        p = np.zeros((H, self.P)) if params else None
+        v = np.zeros(H, dtype=np.uint8) if valid else None
+        c = np.zeros(H, dtype=np.uint32) if votes else None
+        self._chk(self._lib.lsqr_get_hypotheses(self._h, L.ptr(p), L.ptr(v), L.ptr(c)))
+        return p, v, c
+
+    def hypothesis(self, h):
+        p = np.zeros(self.P)
+        v = np.zeros(1, dtype=np.uint8)
+        self._chk(self._lib.lsqr_get_hypothesis(self._h, int(h), L.ptr(p), L.ptr(v)))
+        return p, bool(v[0])
+
+    def best(self):
+        packed = C.c_uint64(0)
+        self._chk(self._lib.lsqr_best(self._h, C.byref(packed)))
+        v = packed.value
+        return v, v >> 32, 0xFFFFFFFF - (v & 0xFFFFFFFF)
+
+    # ---- mask / fit ---------------------------------------------------------------------
+    def mask(self, params, begin=0, end=None, want_mask=True):
+        end = self.n if end is None else end
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        m = np.zeros(end - begin, dtype=np.uint8) if want_mask else None
+        cnt = C.c_uint64(0)
+        self._chk(self._lib.lsqr_mask(self._h, L.ptr(p), begin, end, L.ptr(m), C.byref(cnt)))
+        return m, cnt.value
+
+    def mask_from_hypothesis(self, h, want_mask=True):
+        m = np.zeros(self.n, dtype=np.uint8) if want_mask else None
+        cnt = C.c_uint64(0)
+        self._chk(self._lib.lsqr_mask_from_hypothesis(self._h, h, L.ptr(m), C.byref(cnt)))
+        return m, cnt.value
+
+    def set_mask(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape[0] == self.n
+        self._chk(self._lib.lsqr_set_mask(self._h, L.ptr(m)))
+
+    def ls_fit(self, use_mask=False):
+        """-> (params ndarray, possibly empty; FitInfo)"""
+        out = np.zeros(max(self.P, 32))
+        info = L.FitInfo()
+        st = self._chk(self._lib.lsqr_ls_fit(self._h, int(use_mask), L.ptr(out), C.byref(info)),
+                       allow_empty=True)
+        return (out[:info.n_params].copy() if st == L.OK else np.zeros(0)), info
+
+    def moments_len(self, phase):
+        return self._lib.lsqr_moments_len(C.byref(self.cfg), phase)
+
+    def moments(self, x, begin=0, end=None, phase=0, use_mask=False):
+        end = self.n if end is None else end
+        xv = np.zeros(32)
+        x = np.asarray(x, dtype=np.float64)
+        xv[:len(x)] = x
+        blk = np.zeros(self.moments_len(phase))
+        self._chk(self._lib.lsqr_moments(self._h, int(use_mask), begin, end, phase, L.ptr(xv),
+                                         L.ptr(blk)))
+        return blk
+
+    def solve_moments(self, block, origin):
+        b = np.ascontiguousarray(block, dtype=np.float64)
+        o = np.zeros(32)
+        o[:len(origin)] = origin
+        out = np.zeros(max(self.P, 32))
+        info = L.FitInfo()
+        st = self._chk(self._lib.lsqr_solve_moments(self._h, L.ptr(b), L.ptr(o), L.ptr(out),
+                                                    C.byref(info)), allow_empty=True)
+        return (out[:info.n_params].copy() if st == L.OK else np.zeros(0)), info
+
+    def lm_begin(self, x0):
+        x = np.zeros(32)
+        x[:len(x0)] = x0
+        xt = np.zeros(32)
+        self._chk(self._lib.lsqr_lm_begin(self._h, L.ptr(x), L.ptr(xt)))
+        return xt
+
+    def lm_step(self, block):
+        b = np.ascontiguousarray(block, dtype=np.float64)
+        xt = np.zeros(32)
+        out = np.zeros(32)
+        cont = C.c_int(0)
+        info = L.FitInfo()
+        st = self._chk(self._lib.lsqr_lm_step(self._h, L.ptr(b), L.ptr(xt), C.byref(cont),
+                                              L.ptr(out), C.byref(info)), allow_empty=True)
+        return bool(cont.value), xt, (out[:info.n_params].copy() if st == L.OK else np.zeros(0)), info
+
+    def stats(self, params, use_mask=False):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        out = np.zeros(4)
+        self._chk(self._lib.lsqr_stats(self._h, L.ptr(p), int(use_mask), L.ptr(out)))
+        return out
+
+    # ---- whole path ---------------------------------------------------------------------
+    def ransac(self, p, seed=1, subsets=None, want_consensus=True):
+        out = np.zeros(max(self.P, 32))
+        cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None
+        info = L.RansacInfo()
+        s = None
+        ns = 0
+        if subsets is not None:
+            s = np.ascontiguousarray(subsets, dtype=np.uint32).reshape(-1, self.K)
+            ns = s.shape[0]
+        st = self._lib.lsqr_ransac(self._h, float(p), seed, L.ptr(s), ns, L.ptr(out), L.ptr(cons),
+                                   C.byref(info))
+        if st == L.ERR_INVALID and info.iterations == 0 and info.fraction == 0:
+            return dict(status=st, fraction=0.0, params=None, consensus=None, info=info)
+        self._chk(st, allow_empty=True)
+        return dict(status=st, fraction=info.fraction,
+                    params=out[:info.n_params].copy() if st == L.OK else np.zeros(0),
+                    consensus=cons[:self.n] if (cons is not None and info.best_votes > 0) else None,
+                    info=info)
+
+    def ransac_exhaustive(self, want_consensus=True):
+        out = np.zeros(max(self.P, 32))
+        cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None
+        info = L.RansacInfo()
+        st = self._chk(self._lib.lsqr_ransac_exhaustive(self._h, L.ptr(out), L.ptr(cons),
+                                                        C.byref(info)), allow_empty=True)
+        return dict(status=st, fraction=info.fraction,
+                    params=out[:info.n_params].copy() if st == L.OK else np.zeros(0),
+                    consensus=cons[:self.n] if (cons is not None and info.best_votes > 0) else None,
+                    info=info)
+
+    # ---- measurement --------------------------------------------------------------------
+    def profile(self, on=True):
+        self._chk(self._lib.lsqr_profile_enable(self._h, int(on)))
+        self._chk(self._lib.lsqr_profile_reset(self._h))
+
+    def profile_get(self, name):
+        n = C.c_uint64(0)
+        ms = C.c_double(0)
+        self._chk(self._lib.lsqr_profile_get(self._h, L.KERNEL_IDS[name], C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def synchronize(self):
+        self._chk(self._lib.lsqr_synchronize(self._h))
+
+
+def replay(n, k, p, subsets, valid, votes, dedup=True):
+    """Host replay of RANSAC.hxx:49-117 over one batch (exposed for tests)."""
+    lib = L.load()
+    st = (C.c_uint64 * 6)()
+    lib.lsqr_replay_init(n, k, p, st)
+    s = np.ascontiguousarray(subsets, dtype=np.uint32)
+    v = np.ascontiguousarray(valid, dtype=np.uint8)
+    c = np.ascontiguousarray(votes, dtype=np.uint32)
+    d = lib.lsqr_dedup_create(k) if dedup else None
+    used = lib.lsqr_replay(n, k, p, L.ptr(s), L.ptr(v), L.ptr(c), len(c), 0, d, st)
+    if d:
+        lib.lsqr_dedup_destroy(d)
+    return dict(used=used, i=st[0], num_tries=st[1], best_votes=st[2], best_index=st[3],
+                has_best=bool(st[4]), done=bool(st[5]))

@@ -1,0 +1,314 @@
+// kernels.h -- the HIP kernels of the hot path (gfx950 / CDNA4, wave64).
+//
+//   k_sample     K0  counter-based minimal subsets, one lane per hypothesis
+//   k_estimate   K1  minimal-subset solve, one lane per hypothesis (small closed-form models)
+//   k_scan       K2  agree() count of H hypotheses over all observations.  Each lane keeps PPL
+//                    observations in registers and streams the hypotheses past them (their
+//                    parameters arrive through the scalar cache, uniform per wave); the per-
+//                    hypothesis inlier count of a wave is a ballot + s_bcnt1 (wavefront reduction),
+//                    accumulated per workgroup in LDS and flushed once with one global atomic per
+//                    hypothesis per workgroup.  One HBM pass over the observations serves the
+//                    whole batch: the kernel is bound by the fp64 VALU rate, not by HBM.
+//   k_mask       K3  consensus mask of one model + inlier count
+//   k_moments    K4  (masked) reduction of the observations to the model's moment block, fixed
+//                    reduction tree (lane-strided partial sums -> wave shuffle tree -> LDS ->
+//                    per-block partial) so results are run-to-run deterministic
+//   k_reduce / k_solve / k_lm_*  K5  fixed-order sum of the block partials and the small solves
+//                    (3x3 / 4x4 Jacobi eigen, LM step on n x n normal equations), single wave
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "models.h"
+#include "sampler.h"
+
+namespace lsqr {
+
+constexpr int kBlock = 256;       // 4 waves
+constexpr int kMaxPartials = 1024;  // blocks of the moment reduction
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t first, uint32_t H,
+                                                   uint64_t n, uint32_t *__restrict__ subsets) {
+  uint32_t h = blockIdx.x * kBlock + threadIdx.x;
+  if (h >= H) return;
+  uint32_t idx[K], sorted[K];
+  ctr_subset(seed, first + h, n, K, idx, sorted);
+  for (int l = 0; l < K; l++) subsets[(size_t)h * K + l] = idx[l];
+}
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_estimate(const double *__restrict__ data,
+                                                     size_t stride, size_t n,
+                                                     const uint32_t *__restrict__ subsets,
+                                                     uint32_t H, ModelConsts mc,
+                                                     double *__restrict__ hparams,
+                                                     uint8_t *__restrict__ valid) {
+  uint32_t h = blockIdx.x * kBlock + threadIdx.x;
+  if (h >= H) return;
+  double r[M::K][M::ND];
+  bool ok = true;
+  for (int l = 0; l < M::K; l++) {
+    size_t i = subsets[(size_t)h * M::K + l];
+    if (i >= n) {  // never index outside the observation buffer
+      ok = false;
+      i = 0;
+    }
+    for (int j = 0; j < M::ND; j++) r[l][j] = data[i * stride + j];
+  }
+  double par[M::P];
+  ok = ok && M::estimate(r, mc, par);
+  const double qnan = __builtin_nan("");
+  for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::P + j] = ok ? par[j] : qnan;
+  valid[h] = ok ? 1 : 0;
+}
+
+// K2.  grid-stride over tiles of kBlock*PPL observations; dynamic LDS = H counters.
+template <class M, int PPL>
+__global__ __launch_bounds__(kBlock) void k_scan(const double *__restrict__ data, size_t stride,
+                                                 size_t n, const double *__restrict__ sp,
+                                                 uint32_t H, ModelConsts mc,
+                                                 uint32_t *__restrict__ votes) {
+  extern __shared__ uint32_t s_cnt[];
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) s_cnt[h] = 0;
+  __syncthreads();
+  const size_t tile = (size_t)kBlock * PPL;
+  const double qnan = __builtin_nan("");
+  const bool leader = (threadIdx.x & 63) == 0;
+  for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
+    double rec[PPL][M::ND];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+      size_t i = base + (size_t)j * kBlock + threadIdx.x;
+      bool in = i < n;
+      const double *p = data + (in ? i : 0) * stride;
+#pragma unroll
+      for (int d = 0; d < M::ND; d++) rec[j][d] = in ? p[d] : qnan;  // NaN never agrees
+    }
+    for (uint32_t h = 0; h < H; h++) {
+      const double *hp = sp + (size_t)h * M::SP;  // wave-uniform -> scalar loads
+      uint32_t c = 0;
+#pragma unroll
+      for (int j = 0; j < PPL; j++)
+        c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
+      if (leader && c) atomicAdd(&s_cnt[h], c);
+    }
+  }
+  __syncthreads();
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
+  }
+}
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_mask(const double *__restrict__ data, size_t stride,
+                                                 size_t begin, size_t end,
+                                                 const double *__restrict__ par, ModelConsts mc,
+                                                 uint8_t *__restrict__ mask,
+                                                 unsigned long long *__restrict__ counter) {
+  __shared__ uint32_t s_c[kBlock / 64];
+  uint32_t local = 0;
+  for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < end;
+       i += (size_t)gridDim.x * kBlock) {
+    double x[M::ND];
+    const double *p = data + i * stride;
+#pragma unroll
+    for (int d = 0; d < M::ND; d++) x[d] = p[d];
+    bool a = M::agree(par, x, mc);
+    mask[i] = a ? 1 : 0;
+    local += a ? 1u : 0u;
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kBlock / 64; w++) t += s_c[w];
+    if (t) atomicAdd(counter, t);
+  }
+}
+
+// accumulate functors select the phase of a model's moment block
+template <class M>
+struct AccLs {
+  enum { N = M::NMOM };
+  static __device__ void acc(const double *x, const double *ctx, double *m) {
+    M::accumulate(x, ctx, m);
+  }
+};
+template <class M>
+struct AccLm {
+  enum { N = M::NMOM_LM };
+  static __device__ void acc(const double *x, const double *ctx, double *m) {
+    M::accumulate_lm(x, ctx, m);
+  }
+};
+
+// K4.  block b reduces the contiguous chunk [begin + b*chunk, begin + (b+1)*chunk) ∩ [begin,end).
+template <class M, class A, bool USE_MASK>
+__global__ __launch_bounds__(kBlock) void k_moments(const double *__restrict__ data,
+                                                    size_t stride, size_t begin, size_t end,
+                                                    size_t chunk,
+                                                    const uint8_t *__restrict__ mask,
+                                                    const double *__restrict__ ctxv,
+                                                    double *__restrict__ partials) {
+  __shared__ double s_m[kBlock / 64][A::N];
+  double acc[A::N];
+#pragma unroll
+  for (int k = 0; k < A::N; k++) acc[k] = 0.0;
+  double cv[M::P > M::ND ? M::P : M::ND];
+  for (int k = 0; k < (M::P > M::ND ? M::P : M::ND); k++) cv[k] = ctxv[k];
+  size_t lo = begin + (size_t)blockIdx.x * chunk;
+  size_t hi = lo + chunk < end ? lo + chunk : end;
+  for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    if (USE_MASK && !mask[i]) continue;
+    double x[M::ND];
+    const double *p = data + i * stride;
+#pragma unroll
+    for (int d = 0; d < M::ND; d++) x[d] = p[d];
+    A::acc(x, cv, acc);
+  }
+#pragma unroll
+  for (int k = 0; k < A::N; k++) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < A::N) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) t += s_m[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x] = t;
+  }
+}
+
+// fixed-order sum of the per-block partials -> mom[0..nmom)
+__global__ void k_reduce(const double *__restrict__ partials, int nblocks, int nmom,
+                         double *__restrict__ mom) {
+  int k = threadIdx.x;
+  if (k >= nmom) return;
+  double t = 0.0;
+  for (int b = 0; b < nblocks; b++) t += partials[(size_t)b * MOM_MAX + k];
+  mom[k] = t;
+}
+
+// result block written by the solve kernels: {status(1 ok / 0 empty), n_params, lm_info, lm_nfev,
+// continue flag}
+struct SolveOut {
+  int ok, n_params, lm_info, lm_nfev, cont, pad;
+  double cost;
+  double params[24];
+};
+
+template <class M>
+__global__ void k_solve(const double *__restrict__ mom, const double *__restrict__ org,
+                        ModelConsts mc, SolveOut *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double par[M::P];
+  bool ok = M::solve(mom, org, mc, par);
+  out->ok = ok ? 1 : 0;
+  out->n_params = ok ? M::P : 0;
+  out->lm_info = 0;
+  out->lm_nfev = 0;
+  out->cont = 0;
+  out->cost = 0.0;
+  for (int j = 0; j < M::P; j++) out->params[j] = ok ? par[j] : 0.0;
+}
+
+// LM: state lives in device memory; the trial point the next pass must evaluate is state->xtrial.
+__global__ void k_lm_init(LmState *st, const SolveOut *init, int n, double ftol, double xtol,
+                          double gtol, int maxfev, double factor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  lm_init(*st, n, init->params, ftol, xtol, gtol, maxfev, factor);
+}
+
+__global__ void k_lm_advance(LmState *st, const double *__restrict__ mom, SolveOut *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool cont = lm_advance(*st, mom);
+  out->cont = cont ? 1 : 0;
+  out->lm_info = st->info;
+  out->lm_nfev = st->nfev;
+  if (!cont) {
+    bool ok = st->info >= 1 && st->info <= 4;  // vnl_levenberg_marquardt::minimize -> true
+    out->ok = ok ? 1 : 0;
+    out->n_params = ok ? st->n : 0;
+    out->cost = st->fnorm * st->fnorm;
+    for (int j = 0; j < st->n; j++) out->params[j] = st->x[j];
+  }
+}
+
+// first-max winner of a vote array: (votes << 32) | (0xFFFFFFFF - index)
+__global__ __launch_bounds__(kBlock) void k_best(const uint32_t *__restrict__ votes,
+                                                 const uint8_t *__restrict__ valid, uint32_t H,
+                                                 unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long s_b[kBlock / 64];
+  unsigned long long best = 0;
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) {
+    if (!valid[h]) continue;
+    unsigned long long p = ((unsigned long long)votes[h] << 32) | (0xFFFFFFFFu - h);
+    best = p > best ? p : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_down(best, o);
+    best = other > best ? other : best;
+  }
+  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) best = s_b[w] > best ? s_b[w] : best;
+    *out = best;
+  }
+}
+
+// residual statistics {min, max, sum, sumsq, count} per block
+template <class M, bool USE_MASK>
+__global__ __launch_bounds__(kBlock) void k_stats(const double *__restrict__ data, size_t stride,
+                                                  size_t n, size_t chunk,
+                                                  const uint8_t *__restrict__ mask,
+                                                  const double *__restrict__ par,
+                                                  double *__restrict__ partials) {
+  __shared__ double s_m[kBlock / 64][5];
+  double mn = __builtin_inf(), mx = -__builtin_inf(), sum = 0, sq = 0, cnt = 0;
+  double pv[M::P];
+  for (int k = 0; k < M::P; k++) pv[k] = par[k];
+  size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    if (USE_MASK && !mask[i]) continue;
+    double x[M::ND];
+    const double *p = data + i * stride;
+    for (int d = 0; d < M::ND; d++) x[d] = p[d];
+    double r = M::residual(pv, x);
+    mn = r < mn ? r : mn;
+    mx = r > mx ? r : mx;
+    sum += r;
+    sq = fma(r, r, sq);
+    cnt += 1.0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    double a = __shfl_down(mn, o), b = __shfl_down(mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+    sum += __shfl_down(sum, o);
+    sq += __shfl_down(sq, o);
+    cnt += __shfl_down(cnt, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    double *s = s_m[threadIdx.x >> 6];
+    s[0] = mn; s[1] = mx; s[2] = sum; s[3] = sq; s[4] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      mn = s_m[w][0] < mn ? s_m[w][0] : mn;
+      mx = s_m[w][1] > mx ? s_m[w][1] : mx;
+      sum += s_m[w][2];
+      sq += s_m[w][3];
+      cnt += s_m[w][4];
+    }
+    double *o = partials + (size_t)blockIdx.x * 8;
+    o[0] = mn; o[1] = mx; o[2] = sum; o[3] = sq; o[4] = cnt;
+  }
+}
+
+}  // namespace lsqr

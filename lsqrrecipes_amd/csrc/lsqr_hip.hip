@@ -1,0 +1,1120 @@
+// lsqr_hip.hip -- C ABI (include/lsqr_hip.h) over the HIP kernels in kernels.h.
+// Host code here is plumbing: buffer ownership, launches on the context's stream, the serial
+// replay of RANSAC.hxx's adaptive loop over batch results.  No CPU implementation of the scan
+// or the fits exists in this library: without a device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <set>
+#include <vector>
+
+#include "../../include/lsqr_hip.h"
+#include "kernels.h"
+
+using namespace lsqr;
+
+// ------------------------------------------------------------------------------------------------
+struct lsqr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  lsqr_model_cfg cfg{};
+  ModelConsts mc{};
+  bool has_model = false;
+  int K = 0, P = 0, ND = 0;
+
+  const double *d_data = nullptr;  // observations (owned or attached)
+  double *d_data_owned = nullptr;
+  size_t data_cap = 0;  // doubles
+  size_t n = 0, stride = 0;  // stride in doubles
+
+  size_t H = 0, H_cap = 0;
+  uint32_t *d_subsets = nullptr;
+  double *d_hparams = nullptr;
+  uint8_t *d_valid = nullptr;
+  uint32_t *d_votes = nullptr;
+  bool scanned = false;
+
+  uint8_t *d_mask = nullptr;
+  size_t mask_cap = 0;
+  bool mask_valid = false;
+
+  double *d_partials = nullptr;  // kMaxPartials * MOM_MAX
+  double *d_mom = nullptr;       // MOM_MAX
+  double *d_vec = nullptr;       // 32 doubles: origin / parameter vector handed to kernels
+  double *d_par = nullptr;       // 32 doubles: model parameters for mask/stats
+  LmState *d_lm = nullptr;
+  SolveOut *d_out = nullptr;
+  unsigned long long *d_counter = nullptr;
+  bool origin_valid = false;
+
+  void *h_pin = nullptr;  // pinned staging (64 KiB)
+
+  bool prof = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint64_t launches[8] = {0};
+  double ms[8] = {0};
+
+  char err[512] = {0};
+};
+
+namespace {
+
+enum { KID_SAMPLE = 0, KID_ESTIMATE = 1, KID_SCAN = 2, KID_MASK = 3, KID_MOMENTS = 4, KID_SOLVE = 5 };
+
+int fail(lsqr_ctx *c, int status, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+  }
+  return status;
+}
+
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((c), LSQR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+struct ProfScope {
+  lsqr_ctx *c;
+  int id;
+  ProfScope(lsqr_ctx *c, int id) : c(c), id(id) {
+    if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+  }
+  ~ProfScope() {
+    if (c->prof) {
+      float t = 0;
+      (void)hipEventRecord(c->ev1, c->stream);
+      (void)hipEventSynchronize(c->ev1);
+      (void)hipEventElapsedTime(&t, c->ev0, c->ev1);
+      c->launches[id]++;
+      c->ms[id] += t;
+    }
+  }
+};
+
+template <class M>
+struct Tag {
+  typedef M type;
+};
+
+// model dispatch: f(Tag<Model>{}) -> int
+template <class F>
+int dispatch(const lsqr_model_cfg &cfg, F &&f) {
+  switch (cfg.model) {
+    case LSQR_MODEL_PLANE:
+      if (cfg.dim == 3) return f(Tag<PlaneModel<3>>{});
+      if (cfg.dim == 2) return f(Tag<PlaneModel<2>>{});
+      break;
+    case LSQR_MODEL_SPHERE:
+      if (cfg.dim == 3) return f(Tag<SphereModel<3>>{});
+      if (cfg.dim == 2) return f(Tag<SphereModel<2>>{});
+      break;
+    case LSQR_MODEL_LINE:
+      if (cfg.dim == 3) return f(Tag<LineModel<3>>{});
+      if (cfg.dim == 2) return f(Tag<LineModel<2>>{});
+      break;
+    default: break;
+  }
+  return LSQR_ERR_INVALID;
+}
+
+bool cfg_supported(const lsqr_model_cfg &cfg) {
+  return dispatch(cfg, [](auto) { return (int)LSQR_OK; }) == LSQR_OK;
+}
+
+template <class T>
+int ensure(lsqr_ctx *c, T **p, size_t *cap, size_t need) {
+  if (need <= *cap && *p) return LSQR_OK;
+  if (*p) HIPCHK(c, hipFree(*p));
+  *p = nullptr;
+  size_t ncap = std::max(need, *cap * 2);
+  HIPCHK(c, hipMalloc((void **)p, ncap * sizeof(T)));
+  *cap = ncap;
+  return LSQR_OK;
+}
+
+int ensure_hyp(lsqr_ctx *c, size_t H) {
+  if (H <= c->H_cap) return LSQR_OK;
+  size_t cap = std::max<size_t>(H, 4096);
+  if (c->d_subsets) (void)hipFree(c->d_subsets);
+  if (c->d_hparams) (void)hipFree(c->d_hparams);
+  if (c->d_valid) (void)hipFree(c->d_valid);
+  if (c->d_votes) (void)hipFree(c->d_votes);
+  c->d_subsets = nullptr; c->d_hparams = nullptr; c->d_valid = nullptr; c->d_votes = nullptr;
+  c->H_cap = 0;
+  HIPCHK(c, hipMalloc((void **)&c->d_subsets, cap * 64 * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc((void **)&c->d_hparams, cap * 64 * sizeof(double)));
+  HIPCHK(c, hipMalloc((void **)&c->d_valid, cap));
+  HIPCHK(c, hipMalloc((void **)&c->d_votes, cap * sizeof(uint32_t)));
+  c->H_cap = cap;
+  return LSQR_OK;
+}
+
+int need_ready(lsqr_ctx *c, bool need_data) {
+  if (!c) return LSQR_ERR_INVALID;
+  if (!c->has_model) return fail(c, LSQR_ERR_STATE, "lsqr_set_model has not been called");
+  if (need_data && (!c->d_data || c->n == 0))
+    return fail(c, LSQR_ERR_STATE, "no observations uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  return LSQR_OK;
+}
+
+int grid_for(size_t items, int per_block, int max_blocks) {
+  size_t b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (size_t)max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+// ---- hypotheses ---------------------------------------------------------------------------------
+int run_estimate(lsqr_ctx *c) {
+  return dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    ProfScope ps(c, KID_ESTIMATE);
+    int grid = (int)((c->H + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
+                       c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->mc, c->d_hparams,
+                       c->d_valid);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  });
+}
+
+constexpr uint32_t kScanChunk = 8192;  // hypotheses per scan launch (LDS counters: 32 KiB)
+
+int run_scan(lsqr_ctx *c) {
+  return dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    constexpr int PPL = 4;
+    HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+    size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
+    for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
+      uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
+      size_t lds = (size_t)hc * sizeof(uint32_t);
+      int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+      if (per_cu < 1) per_cu = 1;
+      size_t max_blocks = (size_t)256 * per_cu;
+      size_t tpb = (tiles + max_blocks - 1) / max_blocks;
+      int grid = (int)((tiles + tpb - 1) / tpb);
+      ProfScope ps(c, KID_SCAN);
+      hipLaunchKernelGGL((k_scan<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream, c->d_data,
+                         c->stride, c->n, c->d_hparams + h0 * M::P, hc, c->mc, c->d_votes + h0);
+      HIPCHK(c, hipGetLastError());
+    }
+    return LSQR_OK;
+  });
+}
+
+// ---- moments / solves ---------------------------------------------------------------------------
+// phase 0: the model's LS moment block about d_vec (origin); phase 1: LM block at d_vec (x trial)
+template <class M>
+int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase, int *nmom) {
+  size_t cnt = end - begin;
+  int nb = grid_for(cnt, kBlock * 16, kMaxPartials);
+  size_t chunk = (cnt + nb - 1) / nb;
+  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+  nb = (int)((cnt + chunk - 1) / chunk);
+  if (nb < 1) nb = 1;
+  {
+    ProfScope ps(c, KID_MOMENTS);
+    if (phase == 0) {
+      *nmom = M::NMOM;
+      if (use_mask)
+        hipLaunchKernelGGL((k_moments<M, AccLs<M>, true>), dim3(nb), dim3(kBlock), 0, c->stream,
+                           c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec,
+                           c->d_partials);
+      else
+        hipLaunchKernelGGL((k_moments<M, AccLs<M>, false>), dim3(nb), dim3(kBlock), 0, c->stream,
+                           c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec,
+                           c->d_partials);
+    } else {
+      if constexpr (requires { M::NMOM_LM; }) {
+        *nmom = M::NMOM_LM;
+        if (use_mask)
+          hipLaunchKernelGGL((k_moments<M, AccLm<M>, true>), dim3(nb), dim3(kBlock), 0, c->stream,
+                             c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec,
+                             c->d_partials);
+        else
+          hipLaunchKernelGGL((k_moments<M, AccLm<M>, false>), dim3(nb), dim3(kBlock), 0,
+                             c->stream, c->d_data, c->stride, begin, end, chunk, c->d_mask,
+                             c->d_vec, c->d_partials);
+      } else {
+        return fail(c, LSQR_ERR_INVALID, "model has no iterative phase");
+      }
+    }
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    ProfScope ps(c, KID_SOLVE);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(128), 0, c->stream, c->d_partials, nb, *nmom,
+                       c->d_mom);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LSQR_OK;
+}
+
+int read_out(lsqr_ctx *c, SolveOut *o) {
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_out, sizeof(SolveOut), hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(o, c->h_pin, sizeof(SolveOut));
+  return LSQR_OK;
+}
+
+bool wants_lm(const lsqr_model_cfg &cfg) {
+  return (cfg.model == LSQR_MODEL_SPHERE && cfg.ls_type == LSQR_LS_GEOMETRIC);
+}
+
+void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, double *gtol,
+                 int *maxfev) {
+  // SphereParametersEstimator.hxx:323-329: x and g tolerances 10e-16, 500 evaluations; ftol is
+  // vnl_nonlinear_minimizer's default xtol*0.01 = 1e-10.
+  *n = cfg.dim + 1;
+  *ftol = 1e-10;
+  *xtol = 10e-16;
+  *gtol = 10e-16;
+  *maxfev = 500;
+}
+
+// leastSquaresEstimate over [0,n) (single device).  Leaves the result in d_out.
+int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
+  return dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    int nmom = 0, st;
+    if (!c->origin_valid) {  // default origin: the first observation
+      HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND,
+                               hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (c->cfg.model == LSQR_MODEL_SPHERE ? 0 : M::ND),
+                               sizeof(double) * M::ND, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if ((st = launch_moments<M>(c, use_mask, 0, c->n, 0, &nmom)) != LSQR_OK) return st;
+    {
+      ProfScope ps(c, KID_SOLVE);
+      hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
+                         c->d_out);
+      HIPCHK(c, hipGetLastError());
+    }
+    if (!wants_lm(c->cfg)) return read_out(c, out);
+    if ((st = read_out(c, out)) != LSQR_OK) return st;
+    if (!out->ok) return LSQR_OK;  // algebraic initialiser failed -> empty (Sphere...hxx:231-232)
+    int n;
+    double ftol, xtol, gtol;
+    int maxfev;
+    lm_settings(c->cfg, &n, &ftol, &xtol, &gtol, &maxfev);
+    hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out, n, ftol,
+                       xtol, gtol, maxfev, 100.0);
+    HIPCHK(c, hipGetLastError());
+    for (;;) {
+      HIPCHK(c, hipMemcpyAsync(c->d_vec, (const char *)c->d_lm + offsetof(LmState, xtrial),
+                               sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+      if ((st = launch_moments<M>(c, use_mask, 0, c->n, 1, &nmom)) != LSQR_OK) return st;
+      {
+        ProfScope ps(c, KID_SOLVE);
+        hipLaunchKernelGGL(k_lm_advance, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_mom,
+                           c->d_out);
+        HIPCHK(c, hipGetLastError());
+      }
+      if ((st = read_out(c, out)) != LSQR_OK) return st;
+      if (!out->cont) break;
+    }
+    return LSQR_OK;
+  });
+}
+
+int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t *count_out) {
+  int st = ensure(c, &c->d_mask, &c->mask_cap, c->n);
+  if (st != LSQR_OK) return st;
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    ProfScope ps(c, KID_MASK);
+    int grid = grid_for(end - begin, kBlock * 8, 256 * 8);
+    hipLaunchKernelGGL((k_mask<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
+                       begin, end, c->d_par, c->mc, c->d_mask, c->d_counter);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  });
+  if (st != LSQR_OK) return st;
+  c->mask_valid = true;
+  c->origin_valid = true;
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));
+  if (mask_out)
+    HIPCHK(c, hipMemcpyAsync(mask_out, c->d_mask + begin, end - begin, hipMemcpyDeviceToHost,
+                             c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (count_out) *count_out = *(unsigned long long *)c->h_pin;
+  return LSQR_OK;
+}
+
+// ---- RANSAC.hxx replay --------------------------------------------------------------------------
+struct TupleLess {
+  bool operator()(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) const {
+    return a < b;  // lexicographic == RANSAC.h:135-149 SubSetIndexComparator
+  }
+};
+typedef std::set<std::vector<uint32_t>, TupleLess> DedupSet;
+
+// RANSAC.hxx:254-280
+unsigned int choose_sat(unsigned int n, unsigned int m) {
+  double denominatorEnd, numeratorStart, numerator, denominator, i, result;
+  if ((n - m) > m) {
+    numeratorStart = n - m + 1;
+    denominatorEnd = m;
+  } else {
+    numeratorStart = m + 1;
+    denominatorEnd = n - m;
+  }
+  for (i = numeratorStart, numerator = 1; i <= n; i++) numerator *= i;
+  for (i = 1, denominator = 1; i <= denominatorEnd; i++) denominator *= i;
+  result = numerator / denominator;
+  if (denominator > std::numeric_limits<double>::max() ||
+      numerator > std::numeric_limits<double>::max() ||
+      static_cast<double>(std::numeric_limits<unsigned int>::max()) < result)
+    return std::numeric_limits<unsigned int>::max();
+  return static_cast<unsigned int>(result);
+}
+
+// (int) cast at RANSAC.hxx:108 made explicit: out-of-range / NaN -> 0x80000000 as cvttsd2si does
+unsigned int cast_tries(double x) {
+  if (!(x > -2147483649.0 && x < 2147483648.0)) return 0x80000000u;
+  return (unsigned int)(int)x;
+}
+
+enum { RS_I = 0, RS_TRIES = 1, RS_BEST = 2, RS_BEST_IDX = 3, RS_HAS = 4, RS_DONE = 5 };
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *lsqr_version(void) { return "lsqrrecipes_amd 0.1 (gfx950)"; }
+
+const char *lsqr_status_string(int s) {
+  switch (s) {
+    case LSQR_OK: return "ok";
+    case LSQR_EMPTY: return "empty result (degenerate data or failed fit)";
+    case LSQR_ERR_INVALID: return "invalid argument";
+    case LSQR_ERR_NO_DEVICE: return "no usable HIP device";
+    case LSQR_ERR_HIP: return "HIP runtime error";
+    case LSQR_ERR_STATE: return "call order error";
+  }
+  return "unknown status";
+}
+
+int lsqr_device_count(int *count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (count) *count = (e == hipSuccess) ? n : 0;
+  return e == hipSuccess ? LSQR_OK : LSQR_ERR_NO_DEVICE;
+}
+
+int lsqr_ctx_create(int device, lsqr_ctx **out) {
+  if (!out) return LSQR_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return LSQR_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return LSQR_ERR_NO_DEVICE;
+  lsqr_ctx *c = new lsqr_ctx();
+  c->device = device;
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipMalloc((void **)&c->d_partials, sizeof(double) * kMaxPartials * MOM_MAX) == hipSuccess &&
+            hipMalloc((void **)&c->d_mom, sizeof(double) * 4096) == hipSuccess &&
+            hipMalloc((void **)&c->d_vec, sizeof(double) * 128) == hipSuccess &&
+            hipMalloc((void **)&c->d_par, sizeof(double) * 128) == hipSuccess &&
+            hipMalloc((void **)&c->d_lm, sizeof(LmState)) == hipSuccess &&
+            hipMalloc((void **)&c->d_out, sizeof(SolveOut)) == hipSuccess &&
+            hipMalloc((void **)&c->d_counter, 64) == hipSuccess &&
+            hipHostMalloc(&c->h_pin, 1 << 16) == hipSuccess;
+  if (!ok) {
+    lsqr_ctx_destroy(c);
+    return LSQR_ERR_HIP;
+  }
+  *out = c;
+  return LSQR_OK;
+}
+
+void lsqr_ctx_destroy(lsqr_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_valid, c->d_votes, c->d_mask,
+                  c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *lsqr_last_error(const lsqr_ctx *c) { return c ? c->err : "null context"; }
+
+int lsqr_synchronize(lsqr_ctx *c) {
+  if (!c) return LSQR_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LSQR_OK;
+}
+
+// ---- model description ---------------------------------------------------------------------------
+int lsqr_min_subset(const lsqr_model_cfg *cfg) {
+  if (!cfg) return 0;
+  switch (cfg->model) {
+    case LSQR_MODEL_PLANE: return cfg->dim;
+    case LSQR_MODEL_SPHERE: return cfg->dim + 1;
+    case LSQR_MODEL_LINE: return 2;
+    case LSQR_MODEL_DENSE: return cfg->dim;
+    case LSQR_MODEL_US_SINGLE: return 4;
+    case LSQR_MODEL_US_POINTER: return 3;
+  }
+  return 0;
+}
+int lsqr_num_params(const lsqr_model_cfg *cfg) {
+  if (!cfg) return 0;
+  switch (cfg->model) {
+    case LSQR_MODEL_PLANE:
+    case LSQR_MODEL_LINE: return 2 * cfg->dim;
+    case LSQR_MODEL_SPHERE: return cfg->dim + 1;
+    case LSQR_MODEL_DENSE: return cfg->dim;
+    case LSQR_MODEL_US_SINGLE: return 20;
+    case LSQR_MODEL_US_POINTER: return 17;
+  }
+  return 0;
+}
+int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
+  if (!cfg) return 0;
+  switch (cfg->model) {
+    case LSQR_MODEL_PLANE:
+    case LSQR_MODEL_SPHERE:
+    case LSQR_MODEL_LINE: return cfg->dim;
+    case LSQR_MODEL_DENSE: return cfg->dim + 1;
+    case LSQR_MODEL_US_SINGLE: return 15;
+    case LSQR_MODEL_US_POINTER: return 18;
+  }
+  return 0;
+}
+
+int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
+  if (!c || !cfg) return LSQR_ERR_INVALID;
+  if (!cfg_supported(*cfg))
+    return fail(c, LSQR_ERR_INVALID, "unsupported model %d / dim %d", cfg->model, cfg->dim);
+  if (cfg->model == LSQR_MODEL_SPHERE && cfg->ls_type != LSQR_LS_ALGEBRAIC &&
+      cfg->ls_type != LSQR_LS_GEOMETRIC)  // SphereParametersEstimator.hxx:17-18 throws
+    return fail(c, LSQR_ERR_INVALID, "invalid sphere least squares type %d", cfg->ls_type);
+  c->cfg = *cfg;
+  c->mc.delta = cfg->delta;
+  c->mc.delta_sq = cfg->delta * cfg->delta;
+  c->mc.dim = cfg->dim;
+  c->mc.ls_type = cfg->ls_type;
+  c->K = lsqr_min_subset(cfg);
+  c->P = lsqr_num_params(cfg);
+  c->ND = lsqr_record_doubles(cfg);
+  c->has_model = true;
+  c->H = 0;
+  c->scanned = false;
+  c->mask_valid = false;
+  c->origin_valid = false;
+  return LSQR_OK;
+}
+
+// ---- observations ----------------------------------------------------------------------------------
+static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
+  if (stride_bytes % sizeof(double) != 0 || stride_bytes / sizeof(double) < (size_t)c->ND)
+    return fail(c, LSQR_ERR_INVALID, "record stride %zu B does not hold %d doubles", stride_bytes,
+                c->ND);
+  if (count > 0xFFFFFFF0ull) return fail(c, LSQR_ERR_INVALID, "too many observations");
+  c->n = count;
+  c->stride = stride_bytes / sizeof(double);
+  c->H = 0;
+  c->scanned = false;
+  c->mask_valid = false;
+  c->origin_valid = false;
+  return LSQR_OK;
+}
+
+int lsqr_upload(lsqr_ctx *c, const void *host, size_t count, size_t stride_bytes) {
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  if (!host && count) return fail(c, LSQR_ERR_INVALID, "null records");
+  if ((st = set_data_common(c, count, stride_bytes)) != LSQR_OK) return st;
+  size_t doubles = std::max<size_t>(count * c->stride, 1);
+  if ((st = ensure(c, &c->d_data_owned, &c->data_cap, doubles)) != LSQR_OK) return st;
+  if (count)
+    HIPCHK(c, hipMemcpyAsync(c->d_data_owned, host, count * stride_bytes, hipMemcpyHostToDevice,
+                             c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->d_data = c->d_data_owned;
+  return LSQR_OK;
+}
+
+int lsqr_attach(lsqr_ctx *c, const void *dev, size_t count, size_t stride_bytes) {
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  if (!dev && count) return fail(c, LSQR_ERR_INVALID, "null records");
+  if ((st = set_data_common(c, count, stride_bytes)) != LSQR_OK) return st;
+  c->d_data = (const double *)dev;
+  return LSQR_OK;
+}
+
+size_t lsqr_count(const lsqr_ctx *c) { return c ? c->n : 0; }
+
+// ---- hypotheses ------------------------------------------------------------------------------------
+int lsqr_hypotheses_from_subsets(lsqr_ctx *c, const uint32_t *subsets, size_t H) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!subsets || H == 0 || H > (1u << 20)) return fail(c, LSQR_ERR_INVALID, "bad subset batch");
+  if (c->n < (size_t)c->K) return fail(c, LSQR_ERR_INVALID, "fewer observations than a subset");
+  if ((st = ensure_hyp(c, H)) != LSQR_OK) return st;
+  c->H = H;
+  c->scanned = false;
+  HIPCHK(c, hipMemcpyAsync(c->d_subsets, subsets, H * c->K * sizeof(uint32_t),
+                           hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may free `subsets` on return
+  return run_estimate(c);
+}
+
+int lsqr_hypotheses_sample(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
+                           uint32_t *subsets_out) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (H == 0 || H > (1u << 20)) return fail(c, LSQR_ERR_INVALID, "bad batch size");
+  if (c->n < (size_t)c->K) return fail(c, LSQR_ERR_INVALID, "fewer observations than a subset");
+  if ((st = ensure_hyp(c, H)) != LSQR_OK) return st;
+  c->H = H;
+  c->scanned = false;
+  {
+    ProfScope ps(c, KID_SAMPLE);
+    int grid = (int)((H + kBlock - 1) / kBlock);
+#define LSQR_SAMPLE_CASE(KK)                                                                   \
+  case KK:                                                                                     \
+    hipLaunchKernelGGL((k_sample<KK>), dim3(grid), dim3(kBlock), 0, c->stream, seed, first,    \
+                       (uint32_t)H, (uint64_t)c->n, c->d_subsets);                             \
+    break;
+    switch (c->K) {
+      LSQR_SAMPLE_CASE(2) LSQR_SAMPLE_CASE(3) LSQR_SAMPLE_CASE(4)
+      default: return fail(c, LSQR_ERR_INVALID, "sampler: unsupported subset size %d", c->K);
+    }
+#undef LSQR_SAMPLE_CASE
+    HIPCHK(c, hipGetLastError());
+  }
+  if ((st = run_estimate(c)) != LSQR_OK) return st;
+  if (subsets_out) {
+    HIPCHK(c, hipMemcpyAsync(subsets_out, c->d_subsets, H * c->K * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LSQR_OK;
+}
+
+int lsqr_scan(lsqr_ctx *c) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (c->H == 0) return fail(c, LSQR_ERR_STATE, "no hypotheses to scan");
+  if ((st = run_scan(c)) != LSQR_OK) return st;
+  c->scanned = true;
+  return LSQR_OK;
+}
+
+size_t lsqr_num_hypotheses(const lsqr_ctx *c) { return c ? c->H : 0; }
+
+int lsqr_get_hypotheses(lsqr_ctx *c, double *params, uint8_t *valid, uint32_t *votes) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (c->H == 0) return fail(c, LSQR_ERR_STATE, "no hypotheses");
+  if (votes && !c->scanned) return fail(c, LSQR_ERR_STATE, "lsqr_scan has not run");
+  if (params)
+    HIPCHK(c, hipMemcpyAsync(params, c->d_hparams, c->H * c->P * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+  if (valid)
+    HIPCHK(c, hipMemcpyAsync(valid, c->d_valid, c->H, hipMemcpyDeviceToHost, c->stream));
+  if (votes)
+    HIPCHK(c, hipMemcpyAsync(votes, c->d_votes, c->H * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LSQR_OK;
+}
+
+int lsqr_get_hypothesis(lsqr_ctx *c, size_t h, double *params, uint8_t *valid) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (h >= c->H) return fail(c, LSQR_ERR_INVALID, "hypothesis index out of range");
+  double *hp = (double *)c->h_pin;
+  HIPCHK(c, hipMemcpyAsync(hp, c->d_hparams + h * c->P, sizeof(double) * c->P,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hp + 64, c->d_valid + h, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (params) memcpy(params, hp, sizeof(double) * c->P);
+  if (valid) *valid = *(uint8_t *)(hp + 64);
+  return LSQR_OK;
+}
+
+int lsqr_best(lsqr_ctx *c, uint64_t *packed) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!packed || !c->scanned) return fail(c, LSQR_ERR_STATE, "lsqr_scan has not run");
+  hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
+                     (uint32_t)c->H, c->d_counter + 1);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 1, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *packed = *(unsigned long long *)c->h_pin;
+  return LSQR_OK;
+}
+
+// ---- mask ----------------------------------------------------------------------------------------
+int lsqr_mask(lsqr_ctx *c, const double *params, size_t begin, size_t end, uint8_t *mask_out,
+              uint64_t *count_out) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!params || begin > end || end > c->n) return fail(c, LSQR_ERR_INVALID, "bad mask range");
+  HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return run_mask(c, begin, end, mask_out, count_out);
+}
+
+int lsqr_mask_from_hypothesis(lsqr_ctx *c, size_t h, uint8_t *mask_out, uint64_t *count_out) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (h >= c->H) return fail(c, LSQR_ERR_INVALID, "hypothesis index out of range");
+  HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams + h * c->P, sizeof(double) * c->P,
+                           hipMemcpyDeviceToDevice, c->stream));
+  return run_mask(c, 0, c->n, mask_out, count_out);
+}
+
+int lsqr_set_mask(lsqr_ctx *c, const uint8_t *mask) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!mask) return fail(c, LSQR_ERR_INVALID, "null mask");
+  if ((st = ensure(c, &c->d_mask, &c->mask_cap, c->n)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->d_mask, mask, c->n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->mask_valid = true;
+  c->origin_valid = false;
+  return LSQR_OK;
+}
+
+// ---- final fit -------------------------------------------------------------------------------------
+int lsqr_ls_fit(lsqr_ctx *c, int use_mask, double *params_out, lsqr_fit_info *info) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (use_mask && !c->mask_valid) return fail(c, LSQR_ERR_STATE, "no mask on the device");
+  if (!use_mask) c->origin_valid = false;
+  SolveOut out;
+  memset(&out, 0, sizeof out);
+  if ((st = run_fit(c, use_mask, &out)) != LSQR_OK) return st;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->n_params = out.n_params;
+    info->lm_info = out.lm_info;
+    info->lm_nfev = out.lm_nfev;
+    info->cost = out.cost;
+  }
+  if (!out.ok) return LSQR_EMPTY;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+  return LSQR_OK;
+}
+
+int lsqr_moments_len(const lsqr_model_cfg *cfg, int phase) {
+  if (!cfg) return 0;
+  return dispatch(*cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if (phase == 0) return (int)M::NMOM;
+    if constexpr (requires { M::NMOM_LM; }) return (int)M::NMOM_LM;
+    return 0;
+  });
+}
+
+int lsqr_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase, const double *x,
+                 double *block_out) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (begin > end || end > c->n || !block_out) return fail(c, LSQR_ERR_INVALID, "bad range");
+  if (use_mask && !c->mask_valid) return fail(c, LSQR_ERR_STATE, "no mask on the device");
+  if (!x) return fail(c, LSQR_ERR_INVALID, "moments need an origin / evaluation point");
+  HIPCHK(c, hipMemcpyAsync(c->d_vec, x, sizeof(double) * 32, hipMemcpyHostToDevice, c->stream));
+  int nmom = 0;
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    return launch_moments<M>(c, use_mask, begin, end, phase, &nmom);
+  });
+  if (st != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(block_out, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LSQR_OK;
+}
+
+static void fill_info(const SolveOut &out, lsqr_fit_info *info) {
+  if (!info) return;
+  memset(info, 0, sizeof *info);
+  info->n_params = out.n_params;
+  info->lm_info = out.lm_info;
+  info->lm_nfev = out.lm_nfev;
+  info->cost = out.cost;
+}
+
+int lsqr_solve_moments(lsqr_ctx *c, const double *block, const double *origin, double *params_out,
+                       lsqr_fit_info *info) {
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  if (!block || !origin) return fail(c, LSQR_ERR_INVALID, "null argument");
+  int nmom = lsqr_moments_len(&c->cfg, 0);
+  HIPCHK(c, hipMemcpyAsync(c->d_mom, block, sizeof(double) * nmom, hipMemcpyHostToDevice,
+                           c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_vec, origin, sizeof(double) * c->ND, hipMemcpyHostToDevice,
+                           c->stream));
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    ProfScope ps(c, KID_SOLVE);
+    hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
+                       c->d_out);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  });
+  if (st != LSQR_OK) return st;
+  SolveOut out;
+  if ((st = read_out(c, &out)) != LSQR_OK) return st;
+  fill_info(out, info);
+  if (!out.ok) return LSQR_EMPTY;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+  return LSQR_OK;
+}
+
+int lsqr_lm_begin(lsqr_ctx *c, const double *x0, double *x_trial_out) {
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  if (!wants_lm(c->cfg)) return fail(c, LSQR_ERR_INVALID, "model/ls_type has no iterative fit");
+  if (!x0) return fail(c, LSQR_ERR_INVALID, "null x0");
+  int n, maxfev;
+  double ftol, xtol, gtol;
+  lm_settings(c->cfg, &n, &ftol, &xtol, &gtol, &maxfev);
+  SolveOut seed;
+  memset(&seed, 0, sizeof seed);
+  for (int j = 0; j < n; j++) seed.params[j] = x0[j];
+  memcpy(c->h_pin, &seed, sizeof seed);
+  HIPCHK(c, hipMemcpyAsync(c->d_out, c->h_pin, sizeof seed, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out, n, ftol, xtol,
+                     gtol, maxfev, 100.0);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (x_trial_out)
+    for (int j = 0; j < n; j++) x_trial_out[j] = x0[j];
+  return LSQR_OK;
+}
+
+int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *cont,
+                 double *params_out, lsqr_fit_info *info) {
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  if (!block || !cont) return fail(c, LSQR_ERR_INVALID, "null argument");
+  int nmom = lsqr_moments_len(&c->cfg, 1);
+  if (nmom <= 0) return fail(c, LSQR_ERR_INVALID, "model has no iterative phase");
+  HIPCHK(c, hipMemcpyAsync(c->d_mom, block, sizeof(double) * nmom, hipMemcpyHostToDevice,
+                           c->stream));
+  {
+    ProfScope ps(c, KID_SOLVE);
+    hipLaunchKernelGGL(k_lm_advance, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_mom, c->d_out);
+    HIPCHK(c, hipGetLastError());
+  }
+  SolveOut out;
+  if ((st = read_out(c, &out)) != LSQR_OK) return st;
+  *cont = out.cont;
+  fill_info(out, info);
+  if (out.cont) {
+    if (x_trial_out) {
+      HIPCHK(c, hipMemcpyAsync(c->h_pin, (const char *)c->d_lm + offsetof(LmState, xtrial),
+                               sizeof(double) * LM_NMAX, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      memcpy(x_trial_out, c->h_pin, sizeof(double) * c->P);
+    }
+    return LSQR_OK;
+  }
+  if (!out.ok) return LSQR_EMPTY;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+  return LSQR_OK;
+}
+
+int lsqr_stats(lsqr_ctx *c, const double *params, int use_mask, double out[4]) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!params || !out) return fail(c, LSQR_ERR_INVALID, "null argument");
+  if (use_mask && !c->mask_valid) return fail(c, LSQR_ERR_STATE, "no mask on the device");
+  HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice,
+                           c->stream));
+  int nb = grid_for(c->n, kBlock * 16, kMaxPartials);
+  size_t chunk = (c->n + nb - 1) / nb;
+  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+  nb = (int)((c->n + chunk - 1) / chunk);
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if (use_mask)
+      hipLaunchKernelGGL((k_stats<M, true>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
+                         c->stride, c->n, chunk, c->d_mask, c->d_par, c->d_partials);
+    else
+      hipLaunchKernelGGL((k_stats<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
+                         c->stride, c->n, chunk, c->d_mask, c->d_par, c->d_partials);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  });
+  if (st != LSQR_OK) return st;
+  std::vector<double> part((size_t)nb * 8);
+  HIPCHK(c, hipMemcpyAsync(part.data(), c->d_partials, part.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double mn = INFINITY, mx = -INFINITY, sum = 0, sq = 0, cnt = 0;
+  for (int b = 0; b < nb; b++) {  // fixed order
+    mn = std::min(mn, part[b * 8 + 0]);
+    mx = std::max(mx, part[b * 8 + 1]);
+    sum += part[b * 8 + 2];
+    sq += part[b * 8 + 3];
+    cnt += part[b * 8 + 4];
+  }
+  if (cnt == 0) return LSQR_EMPTY;
+  out[0] = mn;
+  out[1] = mx;
+  out[2] = sum / cnt;
+  out[3] = sq;
+  return LSQR_OK;
+}
+
+// ---- replay of the serial loop ------------------------------------------------------------------------
+void *lsqr_dedup_create(int) { return new DedupSet(); }
+void lsqr_dedup_destroy(void *s) { delete (DedupSet *)s; }
+
+int lsqr_replay_init(size_t n, int k, double, uint64_t st[6]) {
+  if (!st) return LSQR_ERR_INVALID;
+  st[RS_I] = 0;
+  st[RS_TRIES] = choose_sat((unsigned int)n, (unsigned int)k);  // RANSAC.hxx:41,47
+  st[RS_BEST] = 0;
+  st[RS_BEST_IDX] = 0;
+  st[RS_HAS] = 0;
+  st[RS_DONE] = (st[RS_TRIES] == 0);
+  return LSQR_OK;
+}
+
+// RANSAC.hxx:49-117 over the entries of one batch; base_index = loop index of entry 0.
+size_t lsqr_replay(size_t n, int k, double p, const uint32_t *subsets, const uint8_t *valid,
+                   const uint32_t *votes, size_t H, uint64_t base_index, void *dedup,
+                   uint64_t st[6]) {
+  DedupSet *set = (DedupSet *)dedup;
+  const unsigned int N = (unsigned int)n;
+  const unsigned int allTries = choose_sat(N, (unsigned int)k);
+  const double numerator = log(1.0 - p);
+  size_t e = 0;
+  std::vector<uint32_t> key((size_t)k);
+  for (; e < H && !st[RS_DONE]; e++) {
+    uint64_t i = base_index + e;
+    if (i >= st[RS_TRIES]) {
+      st[RS_DONE] = 1;
+      break;
+    }
+    st[RS_I] = i + 1;
+    bool fresh = true;
+    if (set) {
+      for (int l = 0; l < k; l++) key[l] = subsets[e * k + l] + 1;  // :71-76
+      std::sort(key.begin(), key.end());
+      fresh = set->insert(key).second;  // :79
+    }
+    if (fresh && valid[e]) {            // :84-88
+      unsigned int cur = votes[e];
+      if (cur > st[RS_BEST]) {          // :100 strict
+        st[RS_BEST] = cur;
+        st[RS_BEST_IDX] = i;
+        st[RS_HAS] = 1;
+        if (cur == N) {                 // :104-105
+          st[RS_DONE] = 1;
+          e++;
+          break;
+        }
+        double denominator = log(1.0 - pow((double)cur / (double)N, (double)k));
+        unsigned int t = cast_tries(numerator / denominator + 0.5);  // :108
+        st[RS_TRIES] = t < allTries ? t : allTries;                   // :110
+      }
+    }
+    if (i + 1 >= st[RS_TRIES]) {
+      st[RS_DONE] = 1;
+      e++;
+      break;
+    }
+  }
+  return e;
+}
+
+// ---- RANSAC<T,S>::compute ------------------------------------------------------------------------------
+static int finish_ransac(lsqr_ctx *c, bool has_best, const double *best_params, uint32_t best_votes,
+                         double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info) {
+  info->best_votes = best_votes;
+  info->fraction = (double)best_votes / (double)c->n;
+  info->n_params = 0;
+  if (!has_best || best_votes == 0) return LSQR_EMPTY;  // RANSAC.hxx:129: nothing written
+  uint64_t cnt = 0;
+  int st = lsqr_mask(c, best_params, 0, c->n, consensus_out, &cnt);
+  if (st != LSQR_OK) return st;
+  if (cnt != best_votes)
+    return fail(c, LSQR_ERR_HIP, "consensus mask count %llu != scan votes %u",
+                (unsigned long long)cnt, best_votes);
+  st = lsqr_ls_fit(c, 1, params_out, &info->fit);
+  info->fit.n_used = cnt;
+  if (st == LSQR_OK) info->n_params = info->fit.n_params;
+  return st;
+}
+
+int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, size_t n_subsets,
+                double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info) {
+  lsqr_ransac_info local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof *info);
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  const int k = c->K;
+  // RANSAC.hxx:16-19: return 0, parameters untouched
+  if (c->n < (size_t)k || !(p < 1.0) || !(p > 0.0)) return LSQR_ERR_INVALID;
+  if ((st = need_ready(c, true)) != LSQR_OK) return st;
+  uint64_t rs[6];
+  lsqr_replay_init(c->n, k, p, rs);
+  DedupSet dedup;
+  std::vector<uint32_t> sub, votes;
+  std::vector<uint8_t> valid;
+  std::vector<double> best_params((size_t)c->P, 0.0);
+  uint64_t base = 0;
+  size_t batch = 256;
+  while (!rs[RS_DONE]) {
+    size_t H = batch;
+    if (subsets) {
+      if (base >= n_subsets) break;  // caller's stream exhausted
+      H = std::min<size_t>(H, n_subsets - base);
+    }
+    uint64_t remaining = rs[RS_TRIES] - base;
+    if (remaining < H) H = (size_t)remaining;
+    if (H == 0) break;
+    sub.resize(H * k);
+    if (subsets) {
+      memcpy(sub.data(), subsets + base * k, H * k * sizeof(uint32_t));
+      st = lsqr_hypotheses_from_subsets(c, sub.data(), H);
+    } else {
+      st = lsqr_hypotheses_sample(c, seed, base, H, sub.data());
+    }
+    if (st != LSQR_OK) return st;
+    if ((st = lsqr_scan(c)) != LSQR_OK) return st;
+    votes.resize(H);
+    valid.resize(H);
+    if ((st = lsqr_get_hypotheses(c, nullptr, valid.data(), votes.data())) != LSQR_OK) return st;
+    uint64_t prev_best_idx = rs[RS_BEST_IDX];
+    bool had = rs[RS_HAS] != 0;
+    size_t used = lsqr_replay(c->n, k, p, sub.data(), valid.data(), votes.data(), H, base, &dedup,
+                              rs);
+    info->evaluated += H;
+    if (rs[RS_HAS] && (!had || rs[RS_BEST_IDX] != prev_best_idx)) {
+      size_t e = (size_t)(rs[RS_BEST_IDX] - base);
+      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + e * c->P,
+                               sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    base += used;
+    if (used < H) break;
+    batch = std::min<size_t>(batch * 4, 4096);
+  }
+  info->iterations = rs[RS_I];
+  info->best_index = rs[RS_BEST_IDX];
+  return finish_ransac(c, rs[RS_HAS] != 0, best_params.data(), (uint32_t)rs[RS_BEST], params_out,
+                       consensus_out, info);
+}
+
+int lsqr_ransac_exhaustive(lsqr_ctx *c, double *params_out, uint8_t *consensus_out,
+                           lsqr_ransac_info *info) {
+  lsqr_ransac_info local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof *info);
+  int st = need_ready(c, false);
+  if (st != LSQR_OK) return st;
+  const int k = c->K;
+  if (c->n < (size_t)k) return LSQR_EMPTY;  // RANSAC.hxx:165-169: cleared, returns 0
+  if ((st = need_ready(c, true)) != LSQR_OK) return st;
+  // all C(N,k) tuples in lexicographic order (RANSAC.hxx:197-213), in batches
+  std::vector<uint32_t> comb((size_t)k), sub, votes;
+  std::vector<uint8_t> valid;
+  std::vector<double> best_params((size_t)c->P, 0.0);
+  for (int l = 0; l < k; l++) comb[l] = (uint32_t)l;
+  bool more = true, has = false;
+  uint32_t best = 0;
+  uint64_t index = 0, best_idx = 0;
+  const size_t B = 4096;
+  while (more) {
+    sub.clear();
+    size_t H = 0;
+    while (more && H < B) {
+      sub.insert(sub.end(), comb.begin(), comb.end());
+      H++;
+      int l = k - 1;
+      while (l >= 0 && comb[l] == (uint32_t)(c->n - k + l)) l--;
+      if (l < 0) more = false;
+      else {
+        comb[l]++;
+        for (int j = l + 1; j < k; j++) comb[j] = comb[j - 1] + 1;
+      }
+    }
+    if ((st = lsqr_hypotheses_from_subsets(c, sub.data(), H)) != LSQR_OK) return st;
+    if ((st = lsqr_scan(c)) != LSQR_OK) return st;
+    votes.resize(H);
+    valid.resize(H);
+    if ((st = lsqr_get_hypotheses(c, nullptr, valid.data(), votes.data())) != LSQR_OK) return st;
+    long winner = -1;
+    for (size_t e = 0; e < H; e++)
+      if (valid[e] && votes[e] > best) {  // :245 strict
+        best = votes[e];
+        winner = (long)e;
+        best_idx = index + e;
+        has = true;
+      }
+    if (winner >= 0) {
+      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + (size_t)winner * c->P,
+                               sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    index += H;
+    info->evaluated += H;
+  }
+  info->iterations = index;
+  info->best_index = best_idx;
+  return finish_ransac(c, has, best_params.data(), best, params_out, consensus_out, info);
+}
+
+// ---- measurement ------------------------------------------------------------------------------------------
+int lsqr_profile_enable(lsqr_ctx *c, int on) {
+  if (!c) return LSQR_ERR_INVALID;
+  c->prof = on != 0;
+  return LSQR_OK;
+}
+int lsqr_profile_get(lsqr_ctx *c, int id, uint64_t *launches, double *total_ms) {
+  if (!c || id < 0 || id >= 8) return LSQR_ERR_INVALID;
+  if (launches) *launches = c->launches[id];
+  if (total_ms) *total_ms = c->ms[id];
+  return LSQR_OK;
+}
+int lsqr_profile_reset(lsqr_ctx *c) {
+  if (!c) return LSQR_ERR_INVALID;
+  memset(c->launches, 0, sizeof c->launches);
+  memset(c->ms, 0, sizeof c->ms);
+  return LSQR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// models.h -- per-model arithmetic of the hot path, written once as LSQR_HD so the device
+// kernels (lsqr_hip.hip) and the host-compiled unit tests (tests/host_math/) share it.
+//
+// Bit-exactness contract: estimate() and agree() of plane / sphere / line follow the reference's
+// operation order literally (file:line cited at each function) and this translation unit is
+// compiled with -ffp-contract=off, so on gfx950 (IEEE fp64 add/mul/div/sqrt, correctly rounded)
+// they produce the same bits as the reference's x86-64 build.  The final fits only owe 1e-6
+// relative agreement and use the most accurate formulation available (shifted moments, fma).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "lm_core.h"
+#include "small_linalg.h"
+
+namespace lsqr {
+
+struct ModelConsts {
+  double delta;     // constructor argument
+  double delta_sq;  // delta*delta as the reference stores it (PlaneParametersEstimator.hxx:16)
+  int dim;
+  int ls_type;
+};
+
+static const double kEPS = 2.220446049250313e-016;  // common/Epsilon.h:19
+static const double kSphereEPS = 1e-9;              // SphereParametersEstimator.hxx:11
+
+enum { MOM_MAX = 96 };  // largest moment block handled by the generic reduction
+
+// ------------------------------------------------------------------------------------ plane
+template <int D>
+struct PlaneModel {
+  enum { ND = D, K = D, P = 2 * D, SP = 2 * D };
+  enum { NMOM = 1 + D + D * (D + 1) / 2 };
+
+  // PlaneParametersEstimator.hxx:36-109 (D == 3: :48-69; point a = first drawn datum, :107-108).
+  // D == 2 takes the reference's SVD null-vector branch (:70-104), restated in closed form
+  // (normal = unit perpendicular of p1-p0; sign arbitrary as with any null vector).
+  static LSQR_HD bool estimate(const double (*r)[ND], const ModelConsts &, double *par) {
+    if constexpr (D == 3) {
+      double v1[3], v2[3];
+      v1[0] = r[1][0] - r[0][0];
+      v1[1] = r[1][1] - r[0][1];
+      v1[2] = r[1][2] - r[0][2];
+      v2[0] = r[2][0] - r[0][0];
+      v2[1] = r[2][1] - r[0][1];
+      v2[2] = r[2][2] - r[0][2];
+      double nx = v1[1] * v2[2] - v1[2] * v2[1];
+      double ny = v1[2] * v2[0] - v1[0] * v2[2];
+      double nz = v1[0] * v2[1] - v1[1] * v2[0];
+      double norm = sqrt(nx * nx + ny * ny + nz * nz);
+      if (norm < kEPS) return false;
+      par[0] = nx / norm;
+      par[1] = ny / norm;
+      par[2] = nz / norm;
+    } else {
+      double vx = r[1][0] - r[0][0], vy = r[1][1] - r[0][1];
+      double norm = sqrt(vx * vx + vy * vy);
+      if (norm < kEPS) return false;
+      par[0] = -vy / norm;
+      par[1] = vx / norm;
+    }
+    for (int i = 0; i < D; i++) par[D + i] = r[0][i];
+    return true;
+  }
+
+  // PlaneParametersEstimator.hxx:196-203
+  static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
+    double s = 0;
+    for (int i = 0; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
+    return (s * s) < c.delta_sq;
+  }
+  static LSQR_HD double residual(const double *sp, const double *x) {
+    double s = 0;
+    for (int i = 0; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
+    return fabs(s);
+  }
+
+  // moments about `org`: {N, sum x', sum x'x'^T (upper)}  (PlaneParametersEstimator.hxx:141-154
+  // accumulates the same sums un-shifted; shifting removes the cancellation at :160)
+  static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
+    double d[D];
+    for (int i = 0; i < D; i++) d[i] = x[i] - org[i];
+    m[0] += 1.0;
+    int q = 1 + D;
+    for (int i = 0; i < D; i++) {
+      m[1 + i] += d[i];
+      for (int j = i; j < D; j++, q++) m[q] = fma(d[i], d[j], m[q]);
+    }
+  }
+
+  // covariance eigenvector: smallest (plane, :163-171) or largest (line) eigenvalue
+  static LSQR_HD bool solve_cov(const double *m, const double *org, bool largest, int min_n,
+                                double *par) {
+    double N = m[0];
+    if (N < (double)min_n) return false;
+    double mean[D], cov[D * D], w[D], v[D * D];
+    for (int i = 0; i < D; i++) mean[i] = m[1 + i] / N;
+    int q = 1 + D;
+    for (int i = 0; i < D; i++)
+      for (int j = i; j < D; j++) {
+        double cij = m[q++] - N * mean[i] * mean[j];
+        cov[i * D + j] = cov[j * D + i] = cij;
+      }
+    sym_eig(D, cov, w, v);
+    int col = largest ? D - 1 : 0;
+    for (int i = 0; i < D; i++) par[i] = v[i * D + col];
+    for (int i = 0; i < D; i++) par[D + i] = mean[i] + org[i];
+    return true;
+  }
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &, double *par) {
+    return solve_cov(m, org, false, D, par);  // :133 needs >= D points
+  }
+};
+
+// ------------------------------------------------------------------------------------ line
+template <int D>
+struct LineModel {
+  enum { ND = D, K = 2, P = 2 * D, SP = 2 * D };
+  enum { NMOM = PlaneModel<D>::NMOM };
+
+  // LineParametersEstimator.hxx:23-48
+  static LSQR_HD bool estimate(const double (*r)[ND], const ModelConsts &c, double *par) {
+    // Point::distanceSquared = squared_magnitude of the difference (common/Point.h:97-99)
+    double dist = 0;
+    for (int i = 0; i < D; i++) dist += (r[0][i] - r[1][i]) * (r[0][i] - r[1][i]);
+    if (dist < c.delta_sq) return false;
+    double dirNorm = 0.0;
+    for (int i = 0; i < D; i++) {
+      par[i] = r[0][i] - r[1][i];
+      dirNorm += par[i] * par[i];
+      par[D + i] = r[0][i];
+    }
+    dirNorm = sqrt(dirNorm);
+    for (int i = 0; i < D; i++) par[i] /= dirNorm;
+    return true;
+  }
+
+  // LineParametersEstimator.hxx:135-150
+  static LSQR_HD double dist_sq(const double *sp, const double *x) {
+    double v[D], vDotN = 0.0;
+    for (int i = 0; i < D; i++) {
+      v[i] = x[i] - sp[D + i];
+      vDotN += v[i] * sp[i];
+    }
+    double d = 0.0;
+    for (int i = 0; i < D; i++) d += (v[i] - vDotN * sp[i]) * (v[i] - vDotN * sp[i]);
+    return d;
+  }
+  static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
+    return dist_sq(sp, x) < c.delta_sq;
+  }
+  static LSQR_HD double residual(const double *sp, const double *x) { return sqrt(dist_sq(sp, x)); }
+
+  static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
+    PlaneModel<D>::accumulate(x, org, m);
+  }
+  // LineParametersEstimator.hxx:68-111: largest eigenvector, needs >= 2 points
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &, double *par) {
+    return PlaneModel<D>::solve_cov(m, org, true, 2, par);
+  }
+};
+
+// ------------------------------------------------------------------------------------ sphere
+template <int D>
+struct SphereModel {
+  enum { ND = D, K = D + 1, P = D + 1, SP = D + 1 };
+  // algebraic phase: {N, sum x', sum x'x'^T upper, sum x'|x'|^2, sum |x'|^2, sum |x'|^4}
+  enum { NMOM = 1 + D + D * (D + 1) / 2 + D + 2 };
+  enum { NLM = D + 1, NMOM_LM = 1 + (D + 1) * (D + 2) / 2 + (D + 1) };
+
+  static LSQR_HD bool estimate(const double (*r)[ND], const ModelConsts &, double *par) {
+    if constexpr (D == 2) {  // SphereParametersEstimator.hxx:80-109
+      const double *p0 = r[0], *p1 = r[1], *p2 = r[2];
+      double A00 = p0[0] - p1[0], A01 = p0[1] - p1[1];
+      double A10 = p0[0] - p2[0], A11 = p0[1] - p2[1];
+      double detA = (A00 * A11 - A01 * A10);
+      if (fabs(detA) < kSphereEPS) return false;
+      detA *= 2.0;
+      double b0 = A00 * (p0[0] + p1[0]) + A01 * (p0[1] + p1[1]);
+      double b1 = A10 * (p0[0] + p2[0]) + A11 * (p0[1] + p2[1]);
+      par[0] = (A11 * b0 - A01 * b1) / detA;
+      par[1] = (A00 * b1 - A10 * b0) / detA;
+      par[2] = sqrt((p0[0] - par[0]) * (p0[0] - par[0]) + (p0[1] - par[1]) * (p0[1] - par[1]));
+      return true;
+    } else {  // SphereParametersEstimator.hxx:115-163
+      const double *p0 = r[0], *p1 = r[1], *p2 = r[2], *p3 = r[3];
+      double A00 = p0[0] - p1[0], A01 = p0[1] - p1[1], A02 = p0[2] - p1[2];
+      double A10 = p0[0] - p2[0], A11 = p0[1] - p2[1], A12 = p0[2] - p2[2];
+      double A20 = p0[0] - p3[0], A21 = p0[1] - p3[1], A22 = p0[2] - p3[2];
+      double CT00 = A11 * A22 - A12 * A21;
+      double CT10 = A12 * A20 - A10 * A22;
+      double CT20 = A10 * A21 - A11 * A20;
+      double detA = A00 * CT00 + A01 * CT10 + A02 * CT20;
+      if (fabs(detA) < kSphereEPS) return false;
+      detA *= 2;
+      double CT01 = A02 * A21 - A01 * A22;
+      double CT11 = A00 * A22 - A02 * A20;
+      double CT21 = A01 * A20 - A00 * A21;
+      double CT02 = A01 * A12 - A02 * A11;
+      double CT12 = A02 * A10 - A00 * A12;
+      double CT22 = A00 * A11 - A01 * A10;
+      double b0 = A00 * (p0[0] + p1[0]) + A01 * (p0[1] + p1[1]) + A02 * (p0[2] + p1[2]);
+      double b1 = A10 * (p0[0] + p2[0]) + A11 * (p0[1] + p2[1]) + A12 * (p0[2] + p2[2]);
+      double b2 = A20 * (p0[0] + p3[0]) + A21 * (p0[1] + p3[1]) + A22 * (p0[2] + p3[2]);
+      par[0] = (CT00 * b0 + CT01 * b1 + CT02 * b2) / detA;
+      par[1] = (CT10 * b0 + CT11 * b1 + CT12 * b2) / detA;
+      par[2] = (CT20 * b0 + CT21 * b1 + CT22 * b2) / detA;
+      par[3] = sqrt(((p0[0] - par[0]) * (p0[0] - par[0])) + ((p0[1] - par[1]) * (p0[1] - par[1])) +
+                    ((p0[2] - par[2]) * (p0[2] - par[2])));
+      return true;
+    }
+  }
+
+  // SphereParametersEstimator.hxx:255-264 (distance, not squared, against delta)
+  static LSQR_HD double residual(const double *sp, const double *x) {
+    double s = 0;
+    for (int i = 0; i < D; i++) s += ((x[i] - sp[i]) * (x[i] - sp[i]));
+    return fabs(sqrt(s) - sp[D]);
+  }
+  static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
+    return residual(sp, x) < c.delta;
+  }
+
+  // algebraic fit (SphereParametersEstimator.hxx:267-307): rows [-2x, 1], rhs -|x|^2, as
+  // (D+1)x(D+1) normal equations in coordinates shifted by `org` (the fit is translation
+  // equivariant; shifting keeps the normal equations well conditioned).
+  static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
+    double d[D], q = 0;
+    for (int i = 0; i < D; i++) {
+      d[i] = x[i] - org[i];
+      q = fma(d[i], d[i], q);
+    }
+    m[0] += 1.0;
+    int k = 1 + D;
+    for (int i = 0; i < D; i++) {
+      m[1 + i] += d[i];
+      for (int j = i; j < D; j++, k++) m[k] = fma(d[i], d[j], m[k]);
+    }
+    for (int i = 0; i < D; i++, k++) m[k] = fma(d[i], q, m[k]);
+    m[k] += q;
+    m[k + 1] = fma(q, q, m[k + 1]);
+  }
+
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &, double *par) {
+    const int n = D + 1;
+    if (m[0] < (double)n) return false;  // :271
+    // unknown y = [c', rho] with rho = |c'|^2 - r^2:  A = [-2x', 1], b = -|x'|^2
+    double G[n * n], rhs[n], x[n], work[2 * n * n + 3 * n];
+    int k = 1 + D;
+    for (int i = 0; i < D; i++)
+      for (int j = i; j < D; j++) {
+        double v = 4.0 * m[k++];
+        G[i * n + j] = G[j * n + i] = v;
+      }
+    for (int i = 0; i < D; i++) {
+      G[i * n + D] = G[D * n + i] = -2.0 * m[1 + i];
+      rhs[i] = 2.0 * m[k++];
+    }
+    G[D * n + D] = m[0];
+    rhs[D] = -m[k];
+    int rank = spd_solve_eig(n, G, rhs, 1e-14, x, work);
+    if (rank < n) return false;  // :295-296
+    double r2 = -x[D];
+    for (int i = 0; i < D; i++) r2 += x[i] * x[i];
+    if (!(r2 > 0)) return false;  // :303-306
+    for (int i = 0; i < D; i++) par[i] = x[i] + org[i];
+    par[D] = sqrt(r2);
+    return true;
+  }
+
+  // geometric fit pass (f: SphereParametersEstimator.hxx:394-409, gradf: :413-431):
+  // {sum f^2, J^T J upper, J^T f} at xk = [c, r]
+  static LSQR_HD void accumulate_lm(const double *x, const double *xk, double *m) {
+    double J[D + 1], sq = 0.0;
+    for (int j = 0; j < D; j++) sq += (x[j] - xk[j]) * (x[j] - xk[j]);
+    double s = sqrt(sq);
+    double f = s - xk[D];
+    for (int j = 0; j < D; j++) J[j] = (xk[j] - x[j]) / s;
+    J[D] = -1;
+    m[0] = fma(f, f, m[0]);
+    int k = 1;
+    for (int i = 0; i <= D; i++)
+      for (int j = i; j <= D; j++, k++) m[k] = fma(J[i], J[j], m[k]);
+    for (int i = 0; i <= D; i++, k++) m[k] = fma(J[i], f, m[k]);
+  }
+};
+
+}  // namespace lsqr

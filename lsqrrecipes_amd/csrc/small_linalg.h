@@ -1,0 +1,163 @@
+// small_linalg.h -- fixed-size dense kernels used by the minimal-subset solves and the final
+// fits: cyclic Jacobi symmetric eigen (what the reference takes from vnl_symmetric_eigensystem,
+// PlaneParametersEstimator.hxx:163), one-sided Jacobi SVD / pseudo-inverse solve (vnl_svd,
+// vnl_matrix_inverse + zero_out_absolute, DenseLinear...Estimator.hxx:38-45) and pivoted
+// Cholesky (normal equations of the LM step).  Everything is LSQR_HD so that the same source
+// runs in device kernels and in the host-compiled unit tests (tests/host_math/).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define LSQR_HD __host__ __device__ inline
+#else
+#define LSQR_HD inline
+#endif
+
+namespace lsqr {
+
+// Symmetric eigen decomposition, N <= 64.  a: n*n row-major (destroyed), w ascending,
+// v: columns are unit eigenvectors.
+LSQR_HD void sym_eig(int n, double *a, double *w, double *v) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0.0, dg = 0.0;
+    for (int i = 0; i < n; i++) {
+      dg += a[i * n + i] * a[i * n + i];
+      for (int j = i + 1; j < n; j++) off += a[i * n + j] * a[i * n + j];
+    }
+    if (off == 0.0 || off <= 1e-34 * dg) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        double apq = a[p * n + q];
+        if (apq == 0.0) continue;
+        double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; k++) {
+          double akp = a[k * n + p], akq = a[k * n + q];
+          a[k * n + p] = c * akp - s * akq;
+          a[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          double apk = a[p * n + k], aqk = a[q * n + k];
+          a[p * n + k] = c * apk - s * aqk;
+          a[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          double vkp = v[k * n + p], vkq = v[k * n + q];
+          v[k * n + p] = c * vkp - s * vkq;
+          v[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < n; i++) w[i] = a[i * n + i];
+  for (int i = 0; i < n - 1; i++) {
+    int m = i;
+    for (int j = i + 1; j < n; j++)
+      if (w[j] < w[m]) m = j;
+    if (m != i) {
+      double t = w[i];
+      w[i] = w[m];
+      w[m] = t;
+      for (int j = 0; j < n; j++) {
+        t = v[j * n + i];
+        v[j * n + i] = v[j * n + m];
+        v[j * n + m] = t;
+      }
+    }
+  }
+}
+
+// Serial one-sided Jacobi SVD of an m*n matrix (m >= n, row-major with leading dimension lda,
+// overwritten by U*diag(s) then normalised to U); s unsorted; v n*n.
+LSQR_HD void svd_jacobi(int m, int n, double *a, int lda, double *s, double *v) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+    for (int i = 0; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < m; k++) {
+          double ui = a[k * lda + i], uj = a[k * lda + j];
+          al += ui * ui;
+          be += uj * uj;
+          ga += ui * uj;
+        }
+        if (ga == 0.0 || fabs(ga) <= 1e-16 * sqrt(al * be)) continue;
+        rotated = true;
+        double zeta = (be - al) / (2.0 * ga);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        for (int k = 0; k < m; k++) {
+          double ui = a[k * lda + i], uj = a[k * lda + j];
+          a[k * lda + i] = c * ui - sn * uj;
+          a[k * lda + j] = sn * ui + c * uj;
+        }
+        for (int k = 0; k < n; k++) {
+          double vi = v[k * n + i], vj = v[k * n + j];
+          v[k * n + i] = c * vi - sn * vj;
+          v[k * n + j] = sn * vi + c * vj;
+        }
+      }
+    if (!rotated) break;
+  }
+  for (int j = 0; j < n; j++) {
+    double nrm = 0;
+    for (int k = 0; k < m; k++) nrm += a[k * lda + j] * a[k * lda + j];
+    nrm = sqrt(nrm);
+    s[j] = nrm;
+    if (nrm > 0)
+      for (int k = 0; k < m; k++) a[k * lda + j] /= nrm;
+  }
+}
+
+// x = pinv(A) b, singular values <= tol zeroed; returns the rank.  a (m*n, lda) is destroyed;
+// s (n) and v (n*n) are scratch.
+LSQR_HD int pinv_solve(int m, int n, double *a, int lda, const double *b, double tol, double *x,
+                       double *s, double *v) {
+  svd_jacobi(m, n, a, lda, s, v);
+  int rank = 0;
+  for (int k = 0; k < n; k++) x[k] = 0.0;
+  for (int j = 0; j < n; j++) {
+    if (!(s[j] > tol)) continue;
+    rank++;
+    double d = 0;
+    for (int k = 0; k < m; k++) d += a[k * lda + j] * b[k];
+    d /= s[j];
+    for (int k = 0; k < n; k++) x[k] += v[k * n + j] * d;
+  }
+  return rank;
+}
+
+// Symmetric positive (semi)definite solve through the eigen decomposition, with the diagonal
+// scaled to 1 first; eigenvalues <= rtol * max are treated as zero (rank deficiency).  g (n*n,
+// full symmetric, destroyed), rhs n -> x n.  Returns the rank.  work: 2*n*n + 3*n doubles.
+LSQR_HD int spd_solve_eig(int n, double *g, const double *rhs, double rtol, double *x,
+                          double *work) {
+  double *d = work, *w = d + n, *y = w + n, *v = y + n, *gs = v + n * n;
+  for (int i = 0; i < n; i++) d[i] = g[i * n + i] > 0 ? 1.0 / sqrt(g[i * n + i]) : 0.0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) gs[i * n + j] = g[i * n + j] * d[i] * d[j];
+  sym_eig(n, gs, w, v);
+  double wmax = w[n - 1];
+  int rank = 0;
+  for (int j = 0; j < n; j++) {
+    double t = 0;
+    for (int i = 0; i < n; i++) t += v[i * n + j] * (rhs[i] * d[i]);
+    if (w[j] > rtol * wmax && w[j] > 0) {
+      y[j] = t / w[j];
+      rank++;
+    } else
+      y[j] = 0;
+  }
+  for (int i = 0; i < n; i++) {
+    double t = 0;
+    for (int j = 0; j < n; j++) t += v[i * n + j] * y[j];
+    x[i] = t * d[i];
+  }
+  return rank;
+}
+
+}  // namespace lsqr

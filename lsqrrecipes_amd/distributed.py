@@ -1,0 +1,112 @@
+"""Multi-GPU RANSAC step: hypothesis ranges sharded over ranks, observations replicated.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  The path shards trivially: every rank scans its own slice of the
+hypothesis stream against its replica of the observations; the exchange steps are tiny and
+latency-bound:
+  C1  all-reduce(MAX) of one int64 = (votes << 32) | (0xFFFFFFFF - index in the global batch):
+      picks the earliest best hypothesis exactly as the strict '>' of RANSAC.hxx:100 does;
+      all-reduce(SUM) of the zero-padded winner parameters (x + 0 is exact) shares the model.
+  C2  all-reduce(SUM) of the fp64 moment block of each rank's observation slice for the final
+      fit (and of the {sum f^2, J^T J, J^T f} block per LM evaluation).
+`engine` is a lsqrrecipes_amd.context.Context (tests substitute an object with the same methods).
+"""
+import numpy as np
+
+
+class Comm:
+    """Minimal collective interface over torch.distributed (or a no-op for world size 1)."""
+
+    def __init__(self, dist=None, device="cpu"):
+        self.dist = dist
+        self.device = device
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+
+    def allreduce_max_i64(self, value):
+        if self.dist is None:
+            return int(value)
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def allreduce_sum_f64(self, arr):
+        if self.dist is None:
+            return np.asarray(arr, dtype=np.float64)
+        import torch
+        t = torch.tensor(np.asarray(arr, dtype=np.float64), dtype=torch.float64,
+                         device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allreduce_max_f64(self, value):
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+
+def slice_bounds(n, rank, world):
+    """Contiguous observation slice of a rank (fixed split => deterministic reduction order)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+class ShardedRansac:
+    def __init__(self, engine, comm):
+        self.e = engine
+        self.c = comm
+
+    def batch(self, seed, batch_index, H):
+        """One batch of world*H hypotheses: sample+solve+scan own slice, pick the global winner.
+        Returns (votes, global_index_in_stream, params) of the earliest best hypothesis, or
+        (0, None, None) when no hypothesis of the batch was valid."""
+        e, c = self.e, self.c
+        first = (batch_index * c.world + c.rank) * H
+        e.hypotheses_sample(seed, first, H)
+        e.scan()
+        packed, votes, idx = e.best()
+        mine = 0
+        if packed:
+            in_batch = c.rank * H + idx
+            mine = (int(votes) << 32) | (0xFFFFFFFF - in_batch)
+        win = c.allreduce_max_i64(mine)
+        if win == 0:
+            return 0, None, None
+        wvotes = win >> 32
+        in_batch = 0xFFFFFFFF - (win & 0xFFFFFFFF)
+        owner, lidx = divmod(in_batch, H)
+        par = np.zeros(e.P)
+        if owner == c.rank:
+            par, _ = e.hypothesis(lidx)
+        par = c.allreduce_sum_f64(par)  # zeros elsewhere: exact broadcast
+        return int(wvotes), batch_index * c.world * H + in_batch, par
+
+    def fit(self, params):
+        """Consensus mask of `params` + final least-squares fit, observation range sharded."""
+        e, c = self.e, self.c
+        import ctypes as C
+        from . import _lib as L
+        lo, hi = slice_bounds(e.n, c.rank, c.world)
+        _, cnt = e.mask(params, lo, hi, want_mask=False)
+        sphere = e.cfg.model == L.SPHERE
+        origin = params[:e.ND] if sphere else params[e.ND:2 * e.ND]
+        block = c.allreduce_sum_f64(e.moments(origin, lo, hi, phase=0, use_mask=True))
+        fit, info = e.solve_moments(block, origin)
+        nfev = 0
+        if len(fit) and sphere and e.cfg.ls_type == L.LS_GEOMETRIC:
+            xt = e.lm_begin(fit)
+            while True:
+                blk = c.allreduce_sum_f64(e.moments(xt[:e.P], lo, hi, phase=1, use_mask=True))
+                cont, xt, fit, info = e.lm_step(blk)
+                nfev += 1
+                if not cont:
+                    break
+        total = int(round(block[0]))
+        return fit, total, info

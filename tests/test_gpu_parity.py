@@ -1,0 +1,294 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.  Bars (BASELINE.json north_star): consensus
+masks, vote counts, minimal-subset models and sampler output BIT-EXACT; final-fit parameters within
+1e-6 relative (plane / line normals modulo sign, as the reference's own tests compare |dot|)."""
+import os
+
+import numpy as np
+import pytest
+
+from lsqrrecipes_amd import _lib as L
+from lsqrrecipes_amd import synth
+from lsqrrecipes_amd.context import Context
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6  # tolerance stated by BASELINE.json north_star for estimated parameters
+
+CASES = [(L.PLANE, 3), (L.PLANE, 2), (L.SPHERE, 3), (L.SPHERE, 2), (L.LINE, 3), (L.LINE, 2)]
+
+
+def _data(model, dim, n, seed, outliers=0.4):
+    if model == L.PLANE:
+        return synth.plane(n, outliers, seed=seed, dim=dim)[0]
+    if model == L.SPHERE:
+        return synth.sphere(n, outliers, seed=seed, dim=dim)[0]
+    return synth.line(n, outliers, seed=seed, dim=dim)[0]
+
+
+def _params_close(model, dim, got, want):
+    assert len(got) == len(want) and len(want) > 0
+    if model in (L.PLANE, L.LINE):
+        assert abs(abs(np.dot(got[:dim], want[:dim])) - 1.0) < REL
+        s = np.sign(np.dot(got[:dim], want[:dim]))
+        assert np.allclose(s * got[:dim], want[:dim], rtol=REL, atol=REL)
+        if model == L.PLANE:
+            # the point is only defined up to motion inside the plane: compare its offset along n
+            assert abs(np.dot(got[dim:] - want[dim:], want[:dim])) < REL * max(1.0, np.abs(want[dim:]).max())
+            assert np.allclose(got[dim:], want[dim:], rtol=REL, atol=1e-6)
+        else:
+            assert np.allclose(got[dim:], want[dim:], rtol=REL, atol=1e-6)
+    else:
+        assert np.allclose(got, want, rtol=REL, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("model,dim", CASES)
+@pytest.mark.parametrize("n", [1, 63, 1000, 4097, 50_003])
+def test_hypotheses_and_scan_bit_exact(ctx, model, dim, n):
+    oc = O.cfg(model, dim, 0.5)
+    k = O.lib().orc_min_subset(oc)
+    if n < k:
+        n = k
+    data = _data(model, dim, n, 1000 + n + model)
+    H = 96
+    subs = O.ctr_subsets(5, 0, H, n, k)
+    ctx.set_model(model, dim, 0.5).upload(data)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in range(H):
+        want = O.estimate(oc, data[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0)
+        if not valid[h]:
+            assert votes[h] == 0 and np.all(np.isnan(par[h]))
+            continue
+        if model == L.PLANE and dim == 2:   # SVD null-vector branch: sign arbitrary (unpinned)
+            assert abs(abs(par[h][:2] @ want[:2]) - 1) < 1e-12
+            want = par[h]
+        else:
+            assert np.array_equal(par[h], want), "minimal-subset model differs at h=%d" % h
+        cnt, _ = O.scan(oc, want, data)
+        assert votes[h] == cnt, "vote count differs at h=%d" % h
+    # winner (first max) and its mask
+    packed, bv, bi = ctx.best()
+    vv = np.where(valid > 0, votes, 0)
+    assert bv == vv.max() and bi == int(np.argmax(vv))
+    m, cnt = ctx.mask_from_hypothesis(bi)
+    wcnt, wmask = O.scan(oc, par[bi], data)
+    assert cnt == wcnt == bv and np.array_equal(m, wmask)
+
+
+@pytest.mark.parametrize("n,k_model", [(10, (L.PLANE, 3)), (1000, (L.SPHERE, 3)),
+                                       (10_000_000, (L.PLANE, 3)), (77, (L.LINE, 2))])
+def test_device_sampler_bit_exact(ctx, n, k_model):
+    model, dim = k_model
+    data = np.zeros((min(n, 1000), dim))
+    ctx.set_model(model, dim, 0.5)
+    if n > 1000:
+        data = np.zeros((n, dim))
+    ctx.upload(data)
+    subs = ctx.hypotheses_sample(1234, 10_000, 300, want_subsets=True)
+    want = O.ctr_subsets(1234, 10_000, 300, n, ctx.K)
+    assert np.array_equal(subs, want)
+
+
+@pytest.mark.parametrize("model,dim", CASES)
+def test_mask_and_fit_against_oracle(ctx, model, dim):
+    for ls_type in ((L.LS_ALGEBRAIC, L.LS_GEOMETRIC) if model == L.SPHERE else (0,)):
+        oc = O.cfg(model, dim, 0.5, ls_type)
+        n = 20_011
+        data = _data(model, dim, n, 555 + model + dim)
+        k = O.lib().orc_min_subset(oc)
+        ctx.set_model(model, dim, 0.5, ls_type).upload(data)
+        subs = O.ctr_subsets(9, 0, 64, n, k)
+        ctx.hypotheses_from_subsets(subs)
+        ctx.scan()
+        par, valid, votes = ctx.hypotheses()
+        _, bv, bi = ctx.best()
+        m, cnt = ctx.mask(par[bi])
+        wcnt, wmask = O.scan(oc, par[bi], data)
+        assert np.array_equal(m, wmask) and cnt == wcnt
+        got, info = ctx.ls_fit(use_mask=True)
+        want = O.ls(oc, data, wmask)
+        _params_close(model, dim, got, want)
+        # all-data fit (estimator.leastSquaresEstimate(data) without RANSAC)
+        clean = _data(model, dim, 5000, 99 + model, outliers=0.0)
+        ctx.upload(clean)
+        got, info = ctx.ls_fit(use_mask=False)
+        _params_close(model, dim, got, O.ls(oc, clean))
+        # residual statistics
+        st = ctx.stats(got)
+        wst = O.stats(oc, got, clean)
+        assert np.allclose(st, wst, rtol=1e-9, atol=1e-12)
+
+
+def test_sphere_lm_info_and_cost(ctx):
+    pts = synth.sphere(30_000, 0.0, seed=4242)[0]
+    ctx.set_model(L.SPHERE, 3, 0.5, L.LS_GEOMETRIC).upload(pts)
+    got, info = ctx.ls_fit()
+    init = O.sphere_algebraic(3, pts)
+    want, winfo, wnfev = O.sphere_geometric(3, pts, init)
+    assert 1 <= info.lm_info <= 4 and 1 <= winfo <= 4
+    assert abs(info.lm_nfev - wnfev) <= 3
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-8)
+    res = np.linalg.norm(pts - want[:3], axis=1) - want[3]
+    assert np.isclose(info.cost, (res ** 2).sum(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3), (L.SPHERE, 2)])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ransac_equals_serial_reference_loop(ctx, model, dim, seed):
+    """RANSAC<T,S>::compute through the C ABI == the serial loop (oracle, pinned against the
+    reference's RANSAC.hxx) for the same subset stream: iterations, winner, mask, fraction."""
+    ls_type = L.LS_GEOMETRIC
+    oc = O.cfg(model, dim, 0.5, ls_type)
+    n = 6000 + seed
+    data = _data(model, dim, n, 70 + seed + model, outliers=0.5)
+    ctx.set_model(model, dim, 0.5, ls_type).upload(data)
+    # (a) device sampler stream vs the oracle's restatement of it
+    r = ctx.ransac(0.999, seed=seed)
+    w = O.ransac(oc, data, 0.999, sampler="ctr", seed=seed, first=0)
+    assert r["info"].iterations == w["iters"]
+    assert r["info"].best_index == w["best_iter"] and r["info"].best_votes == w["best_votes"]
+    assert r["fraction"] == w["fraction"]
+    assert np.array_equal(r["consensus"], w["consensus"])
+    _params_close(model, dim, r["params"], w["params"])
+    # (b) an explicit subset stream with duplicates
+    subs = O.ctr_subsets(seed + 50, 0, 3000, n, ctx.K)
+    subs[5] = subs[1]
+    subs[9] = subs[4][::-1]
+    r = ctx.ransac(0.99, subsets=subs)
+    w = O.ransac(oc, data, 0.99, sampler="list", subsets=subs)
+    assert r["info"].iterations == w["iters"] and r["info"].best_index == w["best_iter"]
+    assert np.array_equal(r["consensus"], w["consensus"])
+    _params_close(model, dim, r["params"], w["params"])
+
+
+@pytest.mark.parametrize("name", ["plane", "sphere", "circle", "line"])
+def test_against_reference_golden_vectors(ctx, golden_dir, name):
+    """Outputs of the REFERENCE's RANSAC.hxx (tests/golden/ransac_ref_vectors.npz).  The recorded
+    subset list holds the non-duplicate draws of the reference run, in order; replaying it selects
+    the same first-max winner, so the mask must be bit-identical and the LS parameters within tol."""
+    rv = np.load(os.path.join(golden_dir, "ransac_ref_vectors.npz"))
+    cfgv = rv[name + "_cfg"]
+    model, dim, delta, ls_type = int(cfgv[0]), int(cfgv[1]), float(cfgv[2]), int(cfgv[3])
+    data = rv[name + "_data"]
+    ctx.set_model(model, dim, delta, ls_type).upload(data)
+    for seed in (11, 12, 13):
+        key = "%s_s%d_" % (name, seed)
+        r = ctx.ransac(0.999, subsets=rv[key + "subsets"])
+        assert r["fraction"] == rv[key + "fraction"][0]
+        assert np.array_equal(r["consensus"], rv[key + "consensus"])
+        _params_close(model, dim, r["params"], rv[key + "params"])
+
+
+def test_exhaustive_against_reference_golden(ctx, golden_dir):
+    rv = np.load(os.path.join(golden_dir, "ransac_ref_vectors.npz"))
+    ctx.set_model(L.PLANE, 3, 0.5).upload(rv["exh_data"])
+    r = ctx.ransac_exhaustive()
+    assert r["fraction"] == rv["exh_fraction"][0]
+    assert np.array_equal(r["consensus"], rv["exh_consensus"])
+    _params_close(L.PLANE, 3, r["params"], rv["exh_params"])
+    assert r["info"].iterations == 364
+
+
+def test_error_conventions(ctx):
+    data = synth.plane(100, 0.2)[0]
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    for p in (0.0, 1.0, -1.0, 2.0, float("nan")):
+        r = ctx.ransac(p)
+        assert r["status"] == L.ERR_INVALID and r["fraction"] == 0.0 and r["params"] is None
+    ctx.upload(data[:2])                       # fewer observations than a minimal subset
+    assert ctx.ransac(0.9)["status"] == L.ERR_INVALID
+    r = ctx.ransac_exhaustive()                # exhaustive overload: cleared, returns 0
+    assert r["status"] == L.EMPTY and len(r["params"]) == 0
+    # every subset degenerate -> no consensus, parameters empty, consensus not written
+    same = np.tile(np.array([[1.0, 2.0, 3.0]]), (20, 1))
+    ctx.upload(same)
+    r = ctx.ransac(0.9, subsets=O.ctr_subsets(1, 0, 50, 20, 3))
+    assert r["status"] == L.EMPTY and r["fraction"] == 0.0 and r["consensus"] is None
+    # too few points for a fit -> empty
+    ctx.upload(data[:2])
+    got, _ = ctx.ls_fit()
+    assert len(got) == 0
+    # unsupported model / stride errors are reported, not ignored
+    with pytest.raises(L.LsqrError):
+        ctx.set_model(L.PLANE, 7, 0.5)
+    with pytest.raises(L.LsqrError):
+        ctx.set_model(L.SPHERE, 3, 0.5, ls_type=5)
+
+
+def test_strided_records(ctx):
+    """std::vector<T> with sizeof(T) larger than the payload (stride in bytes is honoured)."""
+    data = synth.plane(3000, 0.3, seed=8)[0]
+    wide = np.zeros((3000, 5))
+    wide[:, :3] = data
+    wide[:, 3:] = 1e300
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    subs = O.ctr_subsets(2, 0, 32, 3000, 3)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(wide)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in range(32):
+        assert votes[h] == O.scan(oc, par[h], data)[0]
+
+
+def test_sphere_boundary_sqrt(ctx):
+    """agree() compares sqrt(d2)-r with delta (SphereParametersEstimator.hxx:261-263): points
+    within a few ulp of the decision boundary must classify exactly as on the CPU."""
+    g = np.random.default_rng(3)
+    c0 = np.array([10.5, -3.25, 7.125])
+    r, delta = 123.456, 0.5
+    u = g.normal(size=(40_000, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    rad = np.where(g.random(40_000) < 0.5, r + delta, r - delta) * (1 + g.integers(-8, 9, 40_000) * 2.2e-16)
+    pts = c0 + u * rad[:, None]
+    oc = O.cfg(O.SPHERE, 3, delta)
+    par = np.concatenate([c0, [r]])
+    ctx.set_model(L.SPHERE, 3, delta).upload(pts)
+    m, cnt = ctx.mask(par)
+    wcnt, wm = O.scan(oc, par, pts)
+    assert 0.2 < wcnt / len(pts) < 0.8
+    assert np.array_equal(m, wm)
+
+
+def test_full_size_plane_properties(ctx):
+    """BASELINE config 2 size (10M points, 50% outliers): size-independent properties plus a
+    bit-exact check of a few hypotheses against the oracle."""
+    n = 10_000_000
+    data, truth, lab = synth.plane(n, 0.5)
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    subs = ctx.hypotheses_sample(7, 0, 512, want_subsets=True)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    _, bv, bi = ctx.best()
+    assert bv == votes.max() and votes[bi] == bv and np.all(votes[:bi] < bv)
+    m, cnt = ctx.mask_from_hypothesis(bi)
+    assert cnt == bv == int(m.sum())                       # mask count == scan votes
+    for h in (0, bi, 511):                                 # oracle, full size, bit-exact
+        assert votes[h] == O.scan(oc, par[h], data)[0]
+    assert np.array_equal(m, O.scan(oc, par[bi], data)[1])
+    # a wider band can only gain votes
+    ctx.set_model(L.PLANE, 3, 1.0).upload(data)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    _, _, votes2 = ctx.hypotheses()
+    assert np.all(votes2 >= votes)
+    # end to end: the consensus is (almost) the true inlier set and the fit recovers the plane
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    r = ctx.ransac(0.999, seed=3)
+    assert abs(abs(r["params"][:3] @ truth[:3]) - 1) < 1e-7
+    assert abs((r["params"][3:] - truth[3:]) @ truth[:3]) < 0.01
+    assert (r["consensus"].astype(bool) & ~lab).sum() < 0.01 * n
+    want = O.ls(oc, data, r["consensus"])
+    _params_close(L.PLANE, 3, r["params"], want)
