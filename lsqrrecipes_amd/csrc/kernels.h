@@ -27,12 +27,13 @@ namespace lsqr {
 constexpr int kBlock = 256;       // 4 waves
 constexpr int kMaxPartials = 1024;  // blocks of the moment reduction
 
-template <int K>
+template <int KMAX>
 __global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t first, uint32_t H,
-                                                   uint64_t n, uint32_t *__restrict__ subsets) {
+                                                   uint64_t n, int K,
+                                                   uint32_t *__restrict__ subsets) {
   uint32_t h = blockIdx.x * kBlock + threadIdx.x;
   if (h >= H) return;
-  uint32_t idx[K], sorted[K];
+  uint32_t idx[KMAX], sorted[KMAX];
   ctr_subset(seed, first + h, n, K, idx, sorted);
   for (int l = 0; l < K; l++) subsets[(size_t)h * K + l] = idx[l];
 }
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void k_estimate(const double *__restrict__ 
   double par[M::P];
   ok = ok && M::estimate(r, mc, par);
   const double qnan = __builtin_nan("");
-  for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::P + j] = ok ? par[j] : qnan;
+  for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = ok ? par[j] : qnan;
+  for (int j = M::P; j < M::SP; j++) hparams[(size_t)h * M::SP + j] = 0.0;
   valid[h] = ok ? 1 : 0;
 }
 
@@ -76,14 +78,16 @@ __global__ __launch_bounds__(kBlock) void k_scan(const double *__restrict__ data
   const double qnan = __builtin_nan("");
   const bool leader = (threadIdx.x & 63) == 0;
   for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
-    double rec[PPL][M::ND];
+    double rec[PPL][M::REC];
 #pragma unroll
     for (int j = 0; j < PPL; j++) {
       size_t i = base + (size_t)j * kBlock + threadIdx.x;
       bool in = i < n;
-      const double *p = data + (in ? i : 0) * stride;
+      M::load(data + (in ? i : 0) * stride, mc, rec[j]);
+      if (!in) {
 #pragma unroll
-      for (int d = 0; d < M::ND; d++) rec[j][d] = in ? p[d] : qnan;  // NaN never agrees
+        for (int d = 0; d < M::REC; d++) rec[j][d] = qnan;  // NaN never agrees
+      }
     }
     for (uint32_t h = 0; h < H; h++) {
       const double *hp = sp + (size_t)h * M::SP;  // wave-uniform -> scalar loads
@@ -111,10 +115,8 @@ __global__ __launch_bounds__(kBlock) void k_mask(const double *__restrict__ data
   uint32_t local = 0;
   for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < end;
        i += (size_t)gridDim.x * kBlock) {
-    double x[M::ND];
-    const double *p = data + i * stride;
-#pragma unroll
-    for (int d = 0; d < M::ND; d++) x[d] = p[d];
+    double x[M::REC];
+    M::load(data + i * stride, mc, x);
     bool a = M::agree(par, x, mc);
     mask[i] = a ? 1 : 0;
     local += a ? 1u : 0u;
@@ -152,21 +154,20 @@ __global__ __launch_bounds__(kBlock) void k_moments(const double *__restrict__ d
                                                     size_t chunk,
                                                     const uint8_t *__restrict__ mask,
                                                     const double *__restrict__ ctxv,
+                                                    ModelConsts mc,
                                                     double *__restrict__ partials) {
   __shared__ double s_m[kBlock / 64][A::N];
   double acc[A::N];
 #pragma unroll
   for (int k = 0; k < A::N; k++) acc[k] = 0.0;
-  double cv[M::P > M::ND ? M::P : M::ND];
-  for (int k = 0; k < (M::P > M::ND ? M::P : M::ND); k++) cv[k] = ctxv[k];
+  double cv[M::P > M::REC ? M::P : M::REC];
+  for (int k = 0; k < (M::P > M::REC ? M::P : M::REC); k++) cv[k] = ctxv[k];
   size_t lo = begin + (size_t)blockIdx.x * chunk;
   size_t hi = lo + chunk < end ? lo + chunk : end;
   for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
     if (USE_MASK && !mask[i]) continue;
-    double x[M::ND];
-    const double *p = data + i * stride;
-#pragma unroll
-    for (int d = 0; d < M::ND; d++) x[d] = p[d];
+    double x[M::REC];
+    M::load(data + i * stride, mc, x);
     A::acc(x, cv, acc);
   }
 #pragma unroll
@@ -183,14 +184,16 @@ __global__ __launch_bounds__(kBlock) void k_moments(const double *__restrict__ d
   }
 }
 
-// fixed-order sum of the per-block partials -> mom[0..nmom)
-__global__ void k_reduce(const double *__restrict__ partials, int nblocks, int nmom,
-                         double *__restrict__ mom) {
-  int k = threadIdx.x;
+// fixed-order sum of the per-block partials -> mom[0..nmom): one wave per moment, lane-strided
+// partial sums then a shuffle tree (the order depends only on nblocks).
+__global__ __launch_bounds__(64) void k_reduce(const double *__restrict__ partials, int nblocks,
+                                               int pstride, int nmom, double *__restrict__ mom) {
+  int k = blockIdx.x;
   if (k >= nmom) return;
   double t = 0.0;
-  for (int b = 0; b < nblocks; b++) t += partials[(size_t)b * MOM_MAX + k];
-  mom[k] = t;
+  for (int b = threadIdx.x; b < nblocks; b += 64) t += partials[(size_t)b * pstride + k];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if (threadIdx.x == 0) mom[k] = t;
 }
 
 // result block written by the solve kernels: {status(1 ok / 0 empty), n_params, lm_info, lm_nfev,
@@ -198,7 +201,7 @@ __global__ void k_reduce(const double *__restrict__ partials, int nblocks, int n
 struct SolveOut {
   int ok, n_params, lm_info, lm_nfev, cont, pad;
   double cost;
-  double params[24];
+  double params[64];
 };
 
 template <class M>
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_stats(const double *__restrict__ dat
                                                   size_t n, size_t chunk,
                                                   const uint8_t *__restrict__ mask,
                                                   const double *__restrict__ par,
+                                                  ModelConsts mc,
                                                   double *__restrict__ partials) {
   __shared__ double s_m[kBlock / 64][5];
   double mn = __builtin_inf(), mx = -__builtin_inf(), sum = 0, sq = 0, cnt = 0;
@@ -275,10 +279,9 @@ __global__ __launch_bounds__(kBlock) void k_stats(const double *__restrict__ dat
   size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
   for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
     if (USE_MASK && !mask[i]) continue;
-    double x[M::ND];
-    const double *p = data + i * stride;
-    for (int d = 0; d < M::ND; d++) x[d] = p[d];
-    double r = M::residual(pv, x);
+    double x[M::REC];
+    M::load(data + i * stride, mc, x);
+    double r = M::residual(pv, x, mc);
     mn = r < mn ? r : mn;
     mx = r > mx ? r : mx;
     sum += r;

@@ -15,6 +15,7 @@
 
 #include "../../include/lsqr_hip.h"
 #include "kernels.h"
+#include "dense.h"
 
 using namespace lsqr;
 
@@ -25,7 +26,7 @@ struct lsqr_ctx {
   lsqr_model_cfg cfg{};
   ModelConsts mc{};
   bool has_model = false;
-  int K = 0, P = 0, ND = 0;
+  int K = 0, P = 0, ND = 0, HS = 0;  // HS: row stride (doubles) of d_hparams
 
   const double *d_data = nullptr;  // observations (owned or attached)
   double *d_data_owned = nullptr;
@@ -123,10 +124,21 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
       if (cfg.dim == 3) return f(Tag<LineModel<3>>{});
       if (cfg.dim == 2) return f(Tag<LineModel<2>>{});
       break;
+    case LSQR_MODEL_DENSE:
+      if (cfg.dim >= 1 && cfg.dim <= 8) return f(Tag<DenseModel<8>>{});
+      if (cfg.dim <= 16 && cfg.dim > 8) return f(Tag<DenseModel<16>>{});
+      if (cfg.dim <= 32 && cfg.dim > 16) return f(Tag<DenseModel<32>>{});
+      if (cfg.dim <= 64 && cfg.dim > 32) return f(Tag<DenseModel<64>>{});
+      break;
     default: break;
   }
   return LSQR_ERR_INVALID;
 }
+
+size_t dense_lds_bytes(int n) { return sizeof(double) * ((size_t)2 * n * (n | 1) + 3 * n); }
+int dense_ne(int n) { return (n + 1) * (n + 2) / 2; }
+constexpr int kDenseBlocks = 256;
+int dense_pstride(int n) { return (dense_ne(n) + 1 + 7) & ~7; }
 
 bool cfg_supported(const lsqr_model_cfg &cfg) {
   return dispatch(cfg, [](auto) { return (int)LSQR_OK; }) == LSQR_OK;
@@ -181,10 +193,17 @@ int run_estimate(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     ProfScope ps(c, KID_ESTIMATE);
-    int grid = (int)((c->H + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
-                       c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->mc, c->d_hparams,
-                       c->d_valid);
+    if constexpr (M::IS_DENSE) {
+      hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(64),
+                         dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
+                         c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP, c->d_hparams,
+                         c->d_valid);
+    } else {
+      int grid = (int)((c->H + kBlock - 1) / kBlock);
+      hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
+                         c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->mc, c->d_hparams,
+                         c->d_valid);
+    }
     HIPCHK(c, hipGetLastError());
     return LSQR_OK;
   });
@@ -195,7 +214,7 @@ constexpr uint32_t kScanChunk = 8192;  // hypotheses per scan launch (LDS counte
 int run_scan(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
-    constexpr int PPL = 4;
+    constexpr int PPL = M::PPL;
     HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
     size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
     for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
@@ -208,7 +227,7 @@ int run_scan(lsqr_ctx *c) {
       int grid = (int)((tiles + tpb - 1) / tpb);
       ProfScope ps(c, KID_SCAN);
       hipLaunchKernelGGL((k_scan<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream, c->d_data,
-                         c->stride, c->n, c->d_hparams + h0 * M::P, hc, c->mc, c->d_votes + h0);
+                         c->stride, c->n, c->d_hparams + h0 * M::SP, hc, c->mc, c->d_votes + h0);
       HIPCHK(c, hipGetLastError());
     }
     return LSQR_OK;
@@ -217,8 +236,45 @@ int run_scan(lsqr_ctx *c) {
 
 // ---- moments / solves ---------------------------------------------------------------------------
 // phase 0: the model's LS moment block about d_vec (origin); phase 1: LM block at d_vec (x trial)
+int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int *nmom) {
+  const int n = c->cfg.dim, ne = dense_ne(n), ps = dense_pstride(n);
+  size_t cnt = end - begin;
+  int nb = grid_for(cnt, kSyrkTile * 8, kDenseBlocks);
+  size_t chunk = (cnt + nb - 1) / nb;
+  chunk = (chunk + kSyrkTile - 1) / kSyrkTile * kSyrkTile;
+  nb = (int)((cnt + chunk - 1) / chunk);
+  if (nb < 1) nb = 1;
+  *nmom = ne + 1;
+  {
+    ProfScope ps_(c, KID_MOMENTS);
+    size_t lds = sizeof(double) * kSyrkTile * ((n + 1) | 1) + kSyrkTile;
+    hipLaunchKernelGGL(k_syrk_dense, dim3(nb), dim3(256), lds, c->stream, c->d_data, c->stride,
+                       begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    ProfScope ps_(c, KID_SOLVE);
+    hipLaunchKernelGGL(k_reduce, dim3(*nmom), dim3(64), 0, c->stream, c->d_partials, nb, ps, *nmom,
+                       c->d_mom);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LSQR_OK;
+}
+
+int launch_solve_dense(lsqr_ctx *c) {
+  ProfScope ps(c, KID_SOLVE);
+  hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(64), dense_lds_bytes(c->cfg.dim), c->stream,
+                     c->d_mom, (int)c->cfg.dim, c->d_out);
+  HIPCHK(c, hipGetLastError());
+  return LSQR_OK;
+}
+
 template <class M>
 int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase, int *nmom) {
+  if constexpr (M::IS_DENSE) {
+    if (phase != 0) return fail(c, LSQR_ERR_INVALID, "dense model has no iterative phase");
+    return launch_moments_dense(c, use_mask, begin, end, nmom);
+  } else {
   size_t cnt = end - begin;
   int nb = grid_for(cnt, kBlock * 16, kMaxPartials);
   size_t chunk = (cnt + nb - 1) / nb;
@@ -231,23 +287,23 @@ int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phas
       *nmom = M::NMOM;
       if (use_mask)
         hipLaunchKernelGGL((k_moments<M, AccLs<M>, true>), dim3(nb), dim3(kBlock), 0, c->stream,
-                           c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec,
+                           c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec, c->mc,
                            c->d_partials);
       else
         hipLaunchKernelGGL((k_moments<M, AccLs<M>, false>), dim3(nb), dim3(kBlock), 0, c->stream,
-                           c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec,
+                           c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec, c->mc,
                            c->d_partials);
     } else {
       if constexpr (requires { M::NMOM_LM; }) {
         *nmom = M::NMOM_LM;
         if (use_mask)
           hipLaunchKernelGGL((k_moments<M, AccLm<M>, true>), dim3(nb), dim3(kBlock), 0, c->stream,
-                             c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec,
+                             c->d_data, c->stride, begin, end, chunk, c->d_mask, c->d_vec, c->mc,
                              c->d_partials);
         else
           hipLaunchKernelGGL((k_moments<M, AccLm<M>, false>), dim3(nb), dim3(kBlock), 0,
                              c->stream, c->d_data, c->stride, begin, end, chunk, c->d_mask,
-                             c->d_vec, c->d_partials);
+                             c->d_vec, c->mc, c->d_partials);
       } else {
         return fail(c, LSQR_ERR_INVALID, "model has no iterative phase");
       }
@@ -256,11 +312,12 @@ int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phas
   }
   {
     ProfScope ps(c, KID_SOLVE);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(128), 0, c->stream, c->d_partials, nb, *nmom,
-                       c->d_mom);
+    hipLaunchKernelGGL(k_reduce, dim3(*nmom), dim3(64), 0, c->stream, c->d_partials, nb,
+                       (int)MOM_MAX, *nmom, c->d_mom);
     HIPCHK(c, hipGetLastError());
   }
   return LSQR_OK;
+  }
 }
 
 int read_out(lsqr_ctx *c, SolveOut *o) {
@@ -291,6 +348,11 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     int nmom = 0, st;
+    if constexpr (M::IS_DENSE) {
+      if ((st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
+      if ((st = launch_solve_dense(c)) != LSQR_OK) return st;
+      return read_out(c, out);
+    } else {
     if (!c->origin_valid) {  // default origin: the first observation
       HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND,
                                hipMemcpyDeviceToDevice, c->stream));
@@ -329,6 +391,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
       if (!out->cont) break;
     }
     return LSQR_OK;
+    }
   });
 }
 
@@ -431,7 +494,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
   c->device = device;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipMalloc((void **)&c->d_partials, sizeof(double) * kMaxPartials * MOM_MAX) == hipSuccess &&
+            hipMalloc((void **)&c->d_partials, sizeof(double) * kDenseBlocks * 2160) == hipSuccess &&
             hipMalloc((void **)&c->d_mom, sizeof(double) * 4096) == hipSuccess &&
             hipMalloc((void **)&c->d_vec, sizeof(double) * 128) == hipSuccess &&
             hipMalloc((void **)&c->d_par, sizeof(double) * 128) == hipSuccess &&
@@ -523,6 +586,7 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->K = lsqr_min_subset(cfg);
   c->P = lsqr_num_params(cfg);
   c->ND = lsqr_record_doubles(cfg);
+  c->HS = dispatch(*cfg, [](auto tag) { return (int)decltype(tag)::type::SP; });
   c->has_model = true;
   c->H = 0;
   c->scanned = false;
@@ -599,16 +663,12 @@ int lsqr_hypotheses_sample(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
   {
     ProfScope ps(c, KID_SAMPLE);
     int grid = (int)((H + kBlock - 1) / kBlock);
-#define LSQR_SAMPLE_CASE(KK)                                                                   \
-  case KK:                                                                                     \
-    hipLaunchKernelGGL((k_sample<KK>), dim3(grid), dim3(kBlock), 0, c->stream, seed, first,    \
-                       (uint32_t)H, (uint64_t)c->n, c->d_subsets);                             \
-    break;
-    switch (c->K) {
-      LSQR_SAMPLE_CASE(2) LSQR_SAMPLE_CASE(3) LSQR_SAMPLE_CASE(4)
-      default: return fail(c, LSQR_ERR_INVALID, "sampler: unsupported subset size %d", c->K);
-    }
-#undef LSQR_SAMPLE_CASE
+    if (c->K <= 4)
+      hipLaunchKernelGGL((k_sample<4>), dim3(grid), dim3(kBlock), 0, c->stream, seed, first,
+                         (uint32_t)H, (uint64_t)c->n, c->K, c->d_subsets);
+    else
+      hipLaunchKernelGGL((k_sample<64>), dim3(grid), dim3(kBlock), 0, c->stream, seed, first,
+                         (uint32_t)H, (uint64_t)c->n, c->K, c->d_subsets);
     HIPCHK(c, hipGetLastError());
   }
   if ((st = run_estimate(c)) != LSQR_OK) return st;
@@ -637,8 +697,9 @@ int lsqr_get_hypotheses(lsqr_ctx *c, double *params, uint8_t *valid, uint32_t *v
   if (c->H == 0) return fail(c, LSQR_ERR_STATE, "no hypotheses");
   if (votes && !c->scanned) return fail(c, LSQR_ERR_STATE, "lsqr_scan has not run");
   if (params)
-    HIPCHK(c, hipMemcpyAsync(params, c->d_hparams, c->H * c->P * sizeof(double),
-                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(params, c->P * sizeof(double), c->d_hparams,
+                               c->HS * sizeof(double), c->P * sizeof(double), c->H,
+                               hipMemcpyDeviceToHost, c->stream));
   if (valid)
     HIPCHK(c, hipMemcpyAsync(valid, c->d_valid, c->H, hipMemcpyDeviceToHost, c->stream));
   if (votes)
@@ -653,7 +714,7 @@ int lsqr_get_hypothesis(lsqr_ctx *c, size_t h, double *params, uint8_t *valid) {
   if (st != LSQR_OK) return st;
   if (h >= c->H) return fail(c, LSQR_ERR_INVALID, "hypothesis index out of range");
   double *hp = (double *)c->h_pin;
-  HIPCHK(c, hipMemcpyAsync(hp, c->d_hparams + h * c->P, sizeof(double) * c->P,
+  HIPCHK(c, hipMemcpyAsync(hp, c->d_hparams + h * c->HS, sizeof(double) * c->P,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(hp + 64, c->d_valid + h, 1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -682,6 +743,7 @@ int lsqr_mask(lsqr_ctx *c, const double *params, size_t begin, size_t end, uint8
   int st = need_ready(c, true);
   if (st != LSQR_OK) return st;
   if (!params || begin > end || end > c->n) return fail(c, LSQR_ERR_INVALID, "bad mask range");
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -692,7 +754,7 @@ int lsqr_mask_from_hypothesis(lsqr_ctx *c, size_t h, uint8_t *mask_out, uint64_t
   int st = need_ready(c, true);
   if (st != LSQR_OK) return st;
   if (h >= c->H) return fail(c, LSQR_ERR_INVALID, "hypothesis index out of range");
-  HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams + h * c->P, sizeof(double) * c->P,
+  HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams + h * c->HS, sizeof(double) * c->HS,
                            hipMemcpyDeviceToDevice, c->stream));
   return run_mask(c, 0, c->n, mask_out, count_out);
 }
@@ -735,9 +797,13 @@ int lsqr_moments_len(const lsqr_model_cfg *cfg, int phase) {
   if (!cfg) return 0;
   return dispatch(*cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
-    if (phase == 0) return (int)M::NMOM;
-    if constexpr (requires { M::NMOM_LM; }) return (int)M::NMOM_LM;
-    return 0;
+    if constexpr (M::IS_DENSE) {
+      return phase == 0 ? dense_ne(cfg->dim) + 1 : 0;
+    } else {
+      if (phase == 0) return (int)M::NMOM;
+      if constexpr (requires { M::NMOM_LM; }) return (int)M::NMOM_LM;
+      return 0;
+    }
   });
 }
 
@@ -778,15 +844,19 @@ int lsqr_solve_moments(lsqr_ctx *c, const double *block, const double *origin, d
   int nmom = lsqr_moments_len(&c->cfg, 0);
   HIPCHK(c, hipMemcpyAsync(c->d_mom, block, sizeof(double) * nmom, hipMemcpyHostToDevice,
                            c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_vec, origin, sizeof(double) * c->ND, hipMemcpyHostToDevice,
-                           c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_vec, origin, sizeof(double) * std::min(c->ND, 32),
+                           hipMemcpyHostToDevice, c->stream));
   st = dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
-    ProfScope ps(c, KID_SOLVE);
-    hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
-                       c->d_out);
-    HIPCHK(c, hipGetLastError());
-    return LSQR_OK;
+    if constexpr (M::IS_DENSE) {
+      return launch_solve_dense(c);
+    } else {
+      ProfScope ps(c, KID_SOLVE);
+      hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
+                         c->d_out);
+      HIPCHK(c, hipGetLastError());
+      return LSQR_OK;
+    }
   });
   if (st != LSQR_OK) return st;
   SolveOut out;
@@ -858,6 +928,7 @@ int lsqr_stats(lsqr_ctx *c, const double *params, int use_mask, double out[4]) {
   if (st != LSQR_OK) return st;
   if (!params || !out) return fail(c, LSQR_ERR_INVALID, "null argument");
   if (use_mask && !c->mask_valid) return fail(c, LSQR_ERR_STATE, "no mask on the device");
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice,
                            c->stream));
   int nb = grid_for(c->n, kBlock * 16, kMaxPartials);
@@ -868,10 +939,10 @@ int lsqr_stats(lsqr_ctx *c, const double *params, int use_mask, double out[4]) {
     typedef typename decltype(tag)::type M;
     if (use_mask)
       hipLaunchKernelGGL((k_stats<M, true>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
-                         c->stride, c->n, chunk, c->d_mask, c->d_par, c->d_partials);
+                         c->stride, c->n, chunk, c->d_mask, c->d_par, c->mc, c->d_partials);
     else
       hipLaunchKernelGGL((k_stats<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
-                         c->stride, c->n, chunk, c->d_mask, c->d_par, c->d_partials);
+                         c->stride, c->n, chunk, c->d_mask, c->d_par, c->mc, c->d_partials);
     HIPCHK(c, hipGetLastError());
     return LSQR_OK;
   });
@@ -1025,7 +1096,7 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     info->evaluated += H;
     if (rs[RS_HAS] && (!had || rs[RS_BEST_IDX] != prev_best_idx)) {
       size_t e = (size_t)(rs[RS_BEST_IDX] - base);
-      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + e * c->P,
+      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + e * c->HS,
                                sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -1086,7 +1157,7 @@ int lsqr_ransac_exhaustive(lsqr_ctx *c, double *params_out, uint8_t *consensus_o
         has = true;
       }
     if (winner >= 0) {
-      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + (size_t)winner * c->P,
+      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + (size_t)winner * c->HS,
                                sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }

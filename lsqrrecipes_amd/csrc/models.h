@@ -30,8 +30,11 @@ enum { MOM_MAX = 96 };  // largest moment block handled by the generic reduction
 // ------------------------------------------------------------------------------------ plane
 template <int D>
 struct PlaneModel {
-  enum { ND = D, K = D, P = 2 * D, SP = 2 * D };
+  enum { ND = D, K = D, P = 2 * D, SP = 2 * D, REC = D, PPL = 4, IS_DENSE = 0 };
   enum { NMOM = 1 + D + D * (D + 1) / 2 };
+  static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
+    for (int i = 0; i < D; i++) rec[i] = p[i];
+  }
 
   // PlaneParametersEstimator.hxx:36-109 (D == 3: :48-69; point a = first drawn datum, :107-108).
   // D == 2 takes the reference's SVD null-vector branch (:70-104), restated in closed form
@@ -70,7 +73,7 @@ struct PlaneModel {
     for (int i = 0; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
     return (s * s) < c.delta_sq;
   }
-  static LSQR_HD double residual(const double *sp, const double *x) {
+  static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) {
     double s = 0;
     for (int i = 0; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
     return fabs(s);
@@ -116,8 +119,11 @@ struct PlaneModel {
 // ------------------------------------------------------------------------------------ line
 template <int D>
 struct LineModel {
-  enum { ND = D, K = 2, P = 2 * D, SP = 2 * D };
+  enum { ND = D, K = 2, P = 2 * D, SP = 2 * D, REC = D, PPL = 4, IS_DENSE = 0 };
   enum { NMOM = PlaneModel<D>::NMOM };
+  static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
+    for (int i = 0; i < D; i++) rec[i] = p[i];
+  }
 
   // LineParametersEstimator.hxx:23-48
   static LSQR_HD bool estimate(const double (*r)[ND], const ModelConsts &c, double *par) {
@@ -150,7 +156,7 @@ struct LineModel {
   static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
     return dist_sq(sp, x) < c.delta_sq;
   }
-  static LSQR_HD double residual(const double *sp, const double *x) { return sqrt(dist_sq(sp, x)); }
+  static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) { return sqrt(dist_sq(sp, x)); }
 
   static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
     PlaneModel<D>::accumulate(x, org, m);
@@ -164,7 +170,10 @@ struct LineModel {
 // ------------------------------------------------------------------------------------ sphere
 template <int D>
 struct SphereModel {
-  enum { ND = D, K = D + 1, P = D + 1, SP = D + 1 };
+  enum { ND = D, K = D + 1, P = D + 1, SP = D + 1, REC = D, PPL = 4, IS_DENSE = 0 };
+  static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
+    for (int i = 0; i < D; i++) rec[i] = p[i];
+  }
   // algebraic phase: {N, sum x', sum x'x'^T upper, sum x'|x'|^2, sum |x'|^2, sum |x'|^4}
   enum { NMOM = 1 + D + D * (D + 1) / 2 + D + 2 };
   enum { NLM = D + 1, NMOM_LM = 1 + (D + 1) * (D + 2) / 2 + (D + 1) };
@@ -213,13 +222,13 @@ struct SphereModel {
   }
 
   // SphereParametersEstimator.hxx:255-264 (distance, not squared, against delta)
-  static LSQR_HD double residual(const double *sp, const double *x) {
+  static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) {
     double s = 0;
     for (int i = 0; i < D; i++) s += ((x[i] - sp[i]) * (x[i] - sp[i]));
     return fabs(sqrt(s) - sp[D]);
   }
   static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
-    return residual(sp, x) < c.delta;
+    return residual(sp, x, c) < c.delta;
   }
 
   // algebraic fit (SphereParametersEstimator.hxx:267-307): rows [-2x, 1], rhs -|x|^2, as

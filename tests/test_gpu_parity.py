@@ -292,3 +292,106 @@ def test_full_size_plane_properties(ctx):
     assert (r["consensus"].astype(bool) & ~lab).sum() < 0.01 * n
     want = O.ls(oc, data, r["consensus"])
     _params_close(L.PLANE, 3, r["params"], want)
+
+
+# ------------------------------------------------------------------------------------- dense Ax=b
+def _dense_close(got, want, tol=REL):
+    assert len(got) == len(want) and len(want) > 0
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol * scale
+
+
+@pytest.mark.parametrize("ncol,m", [(5, 200), (6, 1443), (17, 900), (64, 3000)])
+def test_dense_hypotheses_scan_mask(ctx, ncol, m):
+    """Minimal n x n solves go through a different SVD (one-sided Jacobi, wave-parallel) than the
+    oracle's, so models agree to rounding (1e-9), not bitwise; the agree() scan is then checked
+    BIT-EXACT against the oracle evaluated on the device's own models."""
+    rows = synth.dense(m, ncol, 0.1, seed=40 + ncol)[0]
+    oc = O.cfg(O.DENSE, ncol, 0.1)
+    ctx.set_model(L.DENSE, ncol, 0.1).upload(rows)
+    H = 48
+    subs = O.ctr_subsets(3, 0, H, m, ncol)
+    subs[5] = np.roll(subs[4], 1)
+    subs[7][1] = subs[7][0]          # repeated row -> singular system -> invalid
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in range(H):
+        want = O.estimate(oc, rows[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0), h
+        if not valid[h]:
+            assert votes[h] == 0
+            continue
+        _dense_close(par[h], want, 1e-8)
+        cnt, wm = O.scan(oc, par[h], rows)
+        assert votes[h] == cnt
+    assert not valid[7]
+    _, bv, bi = ctx.best()
+    m_dev, cnt = ctx.mask_from_hypothesis(bi)
+    wcnt, wmask = O.scan(oc, par[bi], rows)
+    assert cnt == wcnt == bv and np.array_equal(m_dev, wmask)
+    got, info = ctx.ls_fit(use_mask=True)
+    _dense_close(got, O.ls(oc, rows, wmask))
+    st = ctx.stats(got, use_mask=True)
+    assert np.allclose(st, O.stats(oc, got, rows, wmask), rtol=1e-9, atol=1e-12)
+
+
+def test_dense_known_answer_fixture(ctx, golden_dir):
+    """testing/Data/augmentedMatrix.txt (1443 x 7) against the solution hard-coded at
+    testing/DenseLinearEquationSystemParametersEstimatorTest.cxx:162-164 (tolerance 0.5 there)."""
+    M = np.loadtxt(os.path.join(golden_dir, "ref_data", "augmentedMatrix.txt"))
+    known = np.array([-1.777985584409468e+001, 1.111302171667757e+000, -1.568653413096010e+002,
+                      1.469013927556186e+002, -6.296891425314718e+001, -1.042139650090033e+003])
+    ctx.set_model(L.DENSE, 6, 0.5).upload(M)
+    got, info = ctx.ls_fit()
+    assert np.abs(got - known).max() < 1e-6 * 1042
+    # examples/linearEquationSystemSolver.cxx:160-200: the outlier-contaminated file, delta sqrt(1/3)
+    W = np.loadtxt(os.path.join(golden_dir, "ref_data", "augmentedMatrixWithOutliers.txt"))
+    ctx.set_model(L.DENSE, 6, np.sqrt(1.0 / 3.0)).upload(W)
+    r = ctx.ransac(0.999, seed=5)
+    approx = np.array([-17, 1, -157, 147, -63, -1042.0])   # examples/linear...cxx:180-181
+    assert np.abs(r["params"] - approx).max() < 1.5
+    oc = O.cfg(O.DENSE, 6, np.sqrt(1.0 / 3.0))
+    _dense_close(r["params"], O.ls(oc, W, r["consensus"]))
+
+
+def test_dense_rank_deficient_fit_is_empty(ctx):
+    g = np.random.default_rng(0)
+    A = g.uniform(-1, 1, (100, 5))
+    A[:, 4] = A[:, 0] + A[:, 1]       # rank 4
+    rows = np.hstack([A, g.uniform(-1, 1, (100, 1))])
+    ctx.set_model(L.DENSE, 5, 0.1).upload(rows)
+    got, _ = ctx.ls_fit()
+    assert len(got) == 0
+    assert len(O.ls(O.cfg(O.DENSE, 5, 0.1), rows)) == 0
+
+
+@pytest.mark.parametrize("ncol,m", [(5, 2000), (64, 20_000)])
+def test_dense_ransac_end_to_end(ctx, ncol, m):
+    rows, x_true, lab = synth.dense(m, ncol, 0.05 if ncol == 64 else 0.2, seed=7 + ncol,
+                                    noise=0.0005)
+    delta = 0.02
+    oc = O.cfg(O.DENSE, ncol, delta)
+    ctx.set_model(L.DENSE, ncol, delta).upload(rows)
+    subs = O.ctr_subsets(21, 0, 600, m, ncol)
+    r = ctx.ransac(0.99, subsets=subs)
+    assert r["status"] == L.OK
+    info = r["info"]
+    # winner: mask and votes consistent with the oracle evaluated on the device's winner model
+    ctx.hypotheses_from_subsets(subs[info.best_index:info.best_index + 1])
+    wpar, _ = ctx.hypothesis(0)
+    wcnt, wmask = O.scan(oc, wpar, rows)
+    assert wcnt == info.best_votes and np.array_equal(r["consensus"], wmask)
+    _dense_close(r["params"], O.ls(oc, rows, wmask))
+    assert np.abs(r["params"] - x_true).max() < 1e-2
+    # serial oracle on the same subset stream: same iteration count and winner
+    w = O.ransac(oc, rows, 0.99, sampler="list", subsets=subs)
+    assert info.iterations == w["iters"] and info.best_index == w["best_iter"]
+    assert abs(int(info.best_votes) - int(w["best_votes"])) <= 2
+
+
+def test_dense_sampler_k64(ctx):
+    rows = np.zeros((500, 65))
+    ctx.set_model(L.DENSE, 64, 0.1).upload(rows)
+    subs = ctx.hypotheses_sample(77, 5, 40, want_subsets=True)
+    assert np.array_equal(subs, O.ctr_subsets(77, 5, 40, 500, 64))
