@@ -13,7 +13,7 @@ namespace lsqr {
 
 template <int NRp>
 struct DenseModel {
-  enum { NR = NRp, REC = NRp + 1, SP = NRp, P = NRp, PPL = 1, IS_DENSE = 1 };
+  enum { NR = NRp, REC = NRp + 1, SP = NRp, P = NRp, PPL = 1, IS_DENSE = 1, IS_US = 0 };
 
   static LSQR_HD void load(const double *p, const ModelConsts &c, double *rec) {
     const int n = c.dim;

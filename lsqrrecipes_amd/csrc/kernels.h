@@ -226,6 +226,7 @@ __global__ void k_lm_init(LmState *st, const SolveOut *init, int n, double ftol,
   lm_init(*st, n, init->params, ftol, xtol, gtol, maxfev, factor);
 }
 
+template <class M>
 __global__ void k_lm_advance(LmState *st, const double *__restrict__ mom, SolveOut *out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   bool cont = lm_advance(*st, mom);
@@ -235,9 +236,9 @@ __global__ void k_lm_advance(LmState *st, const double *__restrict__ mom, SolveO
   if (!cont) {
     bool ok = st->info >= 1 && st->info <= 4;  // vnl_levenberg_marquardt::minimize -> true
     out->ok = ok ? 1 : 0;
-    out->n_params = ok ? st->n : 0;
     out->cost = st->fnorm * st->fnorm;
-    for (int j = 0; j < st->n; j++) out->params[j] = st->x[j];
+    int np = M::lm_finalize(st->x, out->params);
+    out->n_params = ok ? np : 0;
   }
 }
 

@@ -16,6 +16,7 @@
 #include "../../include/lsqr_hip.h"
 #include "kernels.h"
 #include "dense.h"
+#include "us_kernels.h"
 
 using namespace lsqr;
 
@@ -124,6 +125,8 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
       if (cfg.dim == 3) return f(Tag<LineModel<3>>{});
       if (cfg.dim == 2) return f(Tag<LineModel<2>>{});
       break;
+    case LSQR_MODEL_US_SINGLE: return f(Tag<USModel<true>>{});
+    case LSQR_MODEL_US_POINTER: return f(Tag<USModel<false>>{});
     case LSQR_MODEL_DENSE:
       if (cfg.dim >= 1 && cfg.dim <= 8) return f(Tag<DenseModel<8>>{});
       if (cfg.dim <= 16 && cfg.dim > 8) return f(Tag<DenseModel<16>>{});
@@ -198,6 +201,10 @@ int run_estimate(lsqr_ctx *c) {
                          dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
                          c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP, c->d_hparams,
                          c->d_valid);
+    } else if constexpr (M::IS_US) {
+      hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
+                         c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
+                         c->d_hparams, c->d_valid);
     } else {
       int grid = (int)((c->H + kBlock - 1) / kBlock);
       hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
@@ -329,7 +336,9 @@ int read_out(lsqr_ctx *c, SolveOut *o) {
 }
 
 bool wants_lm(const lsqr_model_cfg &cfg) {
-  return (cfg.model == LSQR_MODEL_SPHERE && cfg.ls_type == LSQR_LS_GEOMETRIC);
+  return (cfg.model == LSQR_MODEL_SPHERE && cfg.ls_type == LSQR_LS_GEOMETRIC) ||
+         ((cfg.model == LSQR_MODEL_US_SINGLE || cfg.model == LSQR_MODEL_US_POINTER) &&
+          cfg.ls_type == LSQR_LS_ITERATIVE);
 }
 
 void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, double *gtol,
@@ -341,6 +350,15 @@ void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, 
   *xtol = 10e-16;
   *gtol = 10e-16;
   *maxfev = 500;
+  if (cfg.model == LSQR_MODEL_US_SINGLE) {  // SinglePointTarget...Estimator.cxx:287-295
+    *n = 11;
+    *ftol = *xtol = *gtol = 10e-16;
+    *maxfev = 5000;
+  } else if (cfg.model == LSQR_MODEL_US_POINTER) {  // :931-939
+    *n = 8;
+    *ftol = *xtol = *gtol = 10e-8;
+    *maxfev = 5000;
+  }
 }
 
 // leastSquaresEstimate over [0,n) (single device).  Leaves the result in d_out.
@@ -383,8 +401,9 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
       if ((st = launch_moments<M>(c, use_mask, 0, c->n, 1, &nmom)) != LSQR_OK) return st;
       {
         ProfScope ps(c, KID_SOLVE);
-        hipLaunchKernelGGL(k_lm_advance, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_mom,
-                           c->d_out);
+        if constexpr (requires { M::NMOM_LM; })
+          hipLaunchKernelGGL((k_lm_advance<M>), dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_mom,
+                             c->d_out);
         HIPCHK(c, hipGetLastError());
       }
       if ((st = read_out(c, out)) != LSQR_OK) return st;
@@ -899,11 +918,19 @@ int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *con
   if (nmom <= 0) return fail(c, LSQR_ERR_INVALID, "model has no iterative phase");
   HIPCHK(c, hipMemcpyAsync(c->d_mom, block, sizeof(double) * nmom, hipMemcpyHostToDevice,
                            c->stream));
-  {
-    ProfScope ps(c, KID_SOLVE);
-    hipLaunchKernelGGL(k_lm_advance, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_mom, c->d_out);
-    HIPCHK(c, hipGetLastError());
-  }
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if constexpr (requires { M::NMOM_LM; }) {
+      ProfScope ps(c, KID_SOLVE);
+      hipLaunchKernelGGL((k_lm_advance<M>), dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_mom,
+                         c->d_out);
+      HIPCHK(c, hipGetLastError());
+      return LSQR_OK;
+    } else {
+      return LSQR_ERR_INVALID;
+    }
+  });
+  if (st != LSQR_OK) return st;
   SolveOut out;
   if ((st = read_out(c, &out)) != LSQR_OK) return st;
   *cont = out.cont;

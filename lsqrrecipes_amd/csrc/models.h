@@ -30,7 +30,7 @@ enum { MOM_MAX = 96 };  // largest moment block handled by the generic reduction
 // ------------------------------------------------------------------------------------ plane
 template <int D>
 struct PlaneModel {
-  enum { ND = D, K = D, P = 2 * D, SP = 2 * D, REC = D, PPL = 4, IS_DENSE = 0 };
+  enum { ND = D, K = D, P = 2 * D, SP = 2 * D, REC = D, PPL = 4, IS_DENSE = 0, IS_US = 0 };
   enum { NMOM = 1 + D + D * (D + 1) / 2 };
   static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
     for (int i = 0; i < D; i++) rec[i] = p[i];
@@ -119,7 +119,7 @@ struct PlaneModel {
 // ------------------------------------------------------------------------------------ line
 template <int D>
 struct LineModel {
-  enum { ND = D, K = 2, P = 2 * D, SP = 2 * D, REC = D, PPL = 4, IS_DENSE = 0 };
+  enum { ND = D, K = 2, P = 2 * D, SP = 2 * D, REC = D, PPL = 4, IS_DENSE = 0, IS_US = 0 };
   enum { NMOM = PlaneModel<D>::NMOM };
   static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
     for (int i = 0; i < D; i++) rec[i] = p[i];
@@ -170,7 +170,7 @@ struct LineModel {
 // ------------------------------------------------------------------------------------ sphere
 template <int D>
 struct SphereModel {
-  enum { ND = D, K = D + 1, P = D + 1, SP = D + 1, REC = D, PPL = 4, IS_DENSE = 0 };
+  enum { ND = D, K = D + 1, P = D + 1, SP = D + 1, REC = D, PPL = 4, IS_DENSE = 0, IS_US = 0 };
   static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
     for (int i = 0; i < D; i++) rec[i] = p[i];
   }
@@ -276,6 +276,11 @@ struct SphereModel {
     for (int i = 0; i < D; i++) par[i] = x[i] + org[i];
     par[D] = sqrt(r2);
     return true;
+  }
+
+  static LSQR_HD int lm_finalize(const double *x, double *par) {
+    for (int i = 0; i <= D; i++) par[i] = x[i];
+    return D + 1;
   }
 
   // geometric fit pass (f: SphereParametersEstimator.hxx:394-409, gradf: :413-431):

@@ -1,0 +1,298 @@
+// us.h -- SingleUnknownPointTarget / CalibratedPointerTarget ultrasound calibration estimators
+// (parametersEstimators/SinglePointTargetUSCalibrationParametersEstimator.{h,cxx}) on the device.
+//
+// Record layout (doubles): Frame::rotation[3][3] 0..8 (row-major), Frame::translation 9..11,
+// slot 12 = Frame::outputFormat (int) + padding (never read), Point2D q 13..14, and for the
+// calibrated-pointer variant Point3D p 15..17  (common/Frame.h:30-31,41; ...Estimator.h:45-48,
+// 335-339).  Parameter vectors: SINGLE 20 = [t1(3), t3(3), wz, wy, wx, mx, my, mx*R3(:,1),
+// my*R3(:,2), R3(:,3)]; POINTER 17 = the same without t1.
+#pragma once
+#include <math.h>
+
+#include "lm_core.h"
+#include "models.h"
+#include "small_linalg.h"
+
+namespace lsqr {
+
+static const double kUsSvEps = 1.192092896e-07;  // ...Estimator.cxx:196,843 (FLT_EPSILON)
+
+template <bool SINGLE>
+struct USModel {
+  enum {
+    ND = SINGLE ? 15 : 18, REC = ND, K = SINGLE ? 4 : 3, P = SINGLE ? 20 : 17, SP = P, PPL = 2,
+    IS_DENSE = 0, IS_US = 1,
+    NC = SINGLE ? 12 : 9,                       // unknowns of the analytic system
+    NMOM = 1 + NC * (NC + 1) / 2 + NC,          // {N, A^T A upper, A^T b}
+    NLM = SINGLE ? 11 : 8, NMOM_LM = 1 + NLM * (NLM + 1) / 2 + NLM,
+    T3C = SINGLE ? 11 : 8, T3T = SINGLE ? 3 : 0  // offsets of the T3 columns / translation
+  };
+
+  static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) rec[i] = (i == 12) ? 0.0 : p[i];
+  }
+
+  // q' = T2*T3*[u,v,0,1] (...Estimator.cxx:74-107 / :728-766).  The reference forms the 4x4
+  // product T2*T3 and then multiplies by q with vnl's running sums from 0.  The terms dropped here
+  // are products with the exact constants 0 and 1 of the homogeneous rows/entries (x*0 = 0,
+  // s+0 = s, x*1 = x for finite x), so the remaining roundings are the reference's.
+  static LSQR_HD void map(const double *par, const double *x, double q[3]) {
+    const double u = x[13], v = x[14];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double r0 = x[3 * i], r1 = x[3 * i + 1], r2 = x[3 * i + 2];
+      double m0 = r0 * par[T3C + 0];
+      m0 += r1 * par[T3C + 1];
+      m0 += r2 * par[T3C + 2];
+      double m1 = r0 * par[T3C + 3];
+      m1 += r1 * par[T3C + 4];
+      m1 += r2 * par[T3C + 5];
+      double m3 = r0 * par[T3T + 0];
+      m3 += r1 * par[T3T + 1];
+      m3 += r2 * par[T3T + 2];
+      m3 += x[9 + i];
+      double s = m0 * u;
+      s += m1 * v;
+      s += m3;
+      q[i] = s;
+    }
+  }
+  static LSQR_HD double dist_sq(const double *par, const double *x) {
+    double q[3];
+    map(par, x, q);
+    double ex, ey, ez;
+    if (SINGLE) {
+      ex = q[0] - par[0];
+      ey = q[1] - par[1];
+      ez = q[2] - par[2];
+    } else {
+      ex = q[0] - x[15];
+      ey = q[1] - x[16];
+      ez = q[2] - x[17];
+    }
+    return ex * ex + ey * ey + ez * ez;
+  }
+  static LSQR_HD bool agree(const double *par, const double *x, const ModelConsts &c) {
+    return dist_sq(par, x) < c.delta_sq;
+  }
+  static LSQR_HD double residual(const double *par, const double *x, const ModelConsts &) {
+    return sqrt(dist_sq(par, x));
+  }
+
+  // one row (j = 0..2) of the analytic system [u*R2 v*R2 R2 (-I)] x = rhs
+  // (...Estimator.cxx:137-190 / :800-836)
+  static LSQR_HD double row(const double *x, int j, double *a) {
+    const double u = x[13], v = x[14];
+    for (int k = 0; k < 3; k++) {
+      a[k] = x[3 * j + k] * u;
+      a[3 + k] = x[3 * j + k] * v;
+      a[6 + k] = x[3 * j + k];
+    }
+    if (SINGLE) {
+      a[9] = a[10] = a[11] = 0.0;
+      a[9 + j] = -1.0;
+      return -x[9 + j];
+    }
+    return x[15 + j] - x[9 + j];
+  }
+
+  static LSQR_HD void accumulate(const double *x, const double *, double *m) {
+    m[0] += 1.0;
+    for (int j = 0; j < 3; j++) {
+      double a[NC];
+      double b = row(x, j, a);
+      int k = 1;
+      for (int p = 0; p < NC; p++)
+        for (int q = p; q < NC; q++, k++) m[k] = fma(a[p], a[q], m[k]);
+      for (int p = 0; p < NC; p++, k++) m[k] = fma(a[p], b, m[k]);
+    }
+  }
+
+  // scale factors, closest rotation, Euler angles -> parameter vector
+  // (...Estimator.cxx:204-269 / :851-916)
+  static LSQR_HD void finish(const double *x, double *par) {
+    double r1[3], r2[3], r3[3], R3[9], s[3], V[9];
+    for (int j = 0; j < 3; j++) {
+      r1[j] = x[j];
+      r2[j] = x[3 + j];
+    }
+    double m_x = sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+    double m_y = sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+    for (int j = 0; j < 3; j++) {
+      r1[j] /= m_x;
+      r2[j] /= m_y;
+    }
+    r3[0] = r1[1] * r2[2] - r1[2] * r2[1];
+    r3[1] = r1[2] * r2[0] - r1[0] * r2[2];
+    r3[2] = r1[0] * r2[1] - r1[1] * r2[0];
+    for (int j = 0; j < 3; j++) {
+      R3[3 * j + 0] = r1[j];
+      R3[3 * j + 1] = r2[j];
+      R3[3 * j + 2] = r3[j];
+    }
+    svd_jacobi(3, 3, R3, 3, s, V);  // R3 <- U
+    double Rn[9];
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++) {
+        double t = 0;
+        for (int l = 0; l < 3; l++) t += R3[3 * j + l] * V[3 * k + l];
+        Rn[3 * j + k] = t;
+      }
+    const double smallAngle = 0.008726535498373935, halfPI = 1.5707963267948966192313216916398;
+    double omega_z, omega_x;
+    double omega_y = atan2(-Rn[6], sqrt(Rn[0] * Rn[0] + Rn[3] * Rn[3]));
+    if (fabs(omega_y - halfPI) > smallAngle && fabs(omega_y + halfPI) > smallAngle) {
+      double cy = cos(omega_y);
+      omega_z = atan2(Rn[3] / cy, Rn[0] / cy);
+      omega_x = atan2(Rn[7] / cy, Rn[8] / cy);
+    } else {
+      omega_z = 0;
+      omega_x = atan2(Rn[1], Rn[4]);
+    }
+    int k = 0;
+    if (SINGLE) {
+      par[k++] = x[9];
+      par[k++] = x[10];
+      par[k++] = x[11];
+    }
+    par[k++] = x[6];
+    par[k++] = x[7];
+    par[k++] = x[8];
+    par[k++] = omega_z;
+    par[k++] = omega_y;
+    par[k++] = omega_x;
+    par[k++] = m_x;
+    par[k++] = m_y;
+    par[k++] = m_x * Rn[0];
+    par[k++] = m_x * Rn[3];
+    par[k++] = m_x * Rn[6];
+    par[k++] = m_y * Rn[1];
+    par[k++] = m_y * Rn[4];
+    par[k++] = m_y * Rn[7];
+    par[k++] = Rn[2];
+    par[k++] = Rn[5];
+    par[k++] = Rn[8];
+  }
+
+  // analytic least squares from the normal equations (...Estimator.cxx:120-270 / :775-917).
+  // The reference thresholds the singular values of A at FLT_EPSILON; on the normal equations
+  // rank deficiency shows as eigenvalues at the rounding floor of the (scaled) Gram matrix.
+  static LSQR_HD bool solve(const double *m, const double *, const ModelConsts &, double *par) {
+    if (m[0] < (double)K) return false;
+    double G[NC * NC], rhs[NC], x[NC], work[2 * NC * NC + 3 * NC];
+    int k = 1;
+    for (int p = 0; p < NC; p++)
+      for (int q = p; q < NC; q++, k++) G[p * NC + q] = G[q * NC + p] = m[k];
+    for (int p = 0; p < NC; p++, k++) rhs[p] = m[k];
+    int rank = spd_solve_eig(NC, G, rhs, 1e-13, x, work);
+    if (rank < NC) return false;
+    finish(x, par);
+    return true;
+  }
+
+  // f (...Estimator.cxx:415-509 / :1059-1146) and gradf (:512-658 / :1149-1286) of one frame,
+  // reduced to {sum f^2, J^T J upper, J^T f}
+  static LSQR_HD void accumulate_lm(const double *rec, const double *xk, double *m) {
+    const int o = SINGLE ? 3 : 0;
+    double t_1x = 0, t_1y = 0, t_1z = 0;
+    if (SINGLE) {
+      t_1x = xk[0];
+      t_1y = xk[1];
+      t_1z = xk[2];
+    }
+    const double t_3x = xk[o + 0], t_3y = xk[o + 1], t_3z = xk[o + 2];
+    const double sz = sin(xk[o + 3]), cz = cos(xk[o + 3]);
+    const double sy = sin(xk[o + 4]), cy = cos(xk[o + 4]);
+    const double sx = sin(xk[o + 5]), cx = cos(xk[o + 5]);
+    const double m_x = xk[o + 6], m_y = xk[o + 7];
+    const double R3_11 = cz * cy, R3_21 = sz * cy, R3_31 = -sy;
+    const double R3_12 = cz * sy * sx - sz * cx, R3_22 = sz * sy * sx + cz * cx, R3_32 = cy * sx;
+    const double *R2 = rec, *t2 = rec + 9;
+    const double u = rec[13], v = rec[14];
+    double A1[9], A2[9], A3[9];  // A_i1..A_i9 of the reference, per row i
+    for (int k = 0; k < 3; k++) {
+      A1[k] = u * R2[k];     A1[3 + k] = v * R2[k];     A1[6 + k] = R2[k];
+      A2[k] = u * R2[3 + k]; A2[3 + k] = v * R2[3 + k]; A2[6 + k] = R2[3 + k];
+      A3[k] = u * R2[6 + k]; A3[3 + k] = v * R2[6 + k]; A3[6 + k] = R2[6 + k];
+    }
+    double b_1, b_2, b_3;
+    if (SINGLE) {
+      b_1 = -t2[0]; b_2 = -t2[1]; b_3 = -t2[2];
+    } else {
+      b_1 = rec[15] - t2[0]; b_2 = rec[16] - t2[1]; b_3 = rec[17] - t2[2];
+    }
+#define LSQR_US_EXPR(A, t1, b)                                                                  \
+  (A[0] * m_x * R3_11 + A[1] * m_x * R3_21 + A[2] * m_x * R3_31 + A[3] * m_y * R3_12 +           \
+   A[4] * m_y * R3_22 + A[5] * m_y * R3_32 + A[6] * t_3x + A[7] * t_3y + A[8] * t_3z - (t1) - (b))
+    const double expr1 = LSQR_US_EXPR(A1, t_1x, b_1);
+    const double expr2 = LSQR_US_EXPR(A2, t_1y, b_2);
+    const double expr3 = LSQR_US_EXPR(A3, t_1z, b_3);
+#undef LSQR_US_EXPR
+    const double delta_i = sqrt(expr1 * expr1 + expr2 * expr2 + expr3 * expr3);
+    double J[NLM];
+    if (SINGLE) {
+      J[0] = -expr1 / delta_i;
+      J[1] = -expr2 / delta_i;
+      J[2] = -expr3 / delta_i;
+    }
+    J[o + 0] = (A1[6] * expr1 + A2[6] * expr2 + A3[6] * expr3) / delta_i;
+    J[o + 1] = (A1[7] * expr1 + A2[7] * expr2 + A3[7] * expr3) / delta_i;
+    J[o + 2] = (A1[8] * expr1 + A2[8] * expr2 + A3[8] * expr3) / delta_i;
+    double v1 = -m_x * sz * cy, v2 = m_x * cz * cy, v3 = -m_y * (sz * sy * sx + cz * cx),
+           v4 = m_y * (cz * sy * sx - sz * cx), v5, v6;
+    J[o + 3] = ((A1[0] * v1 + A1[1] * v2 + A1[3] * v3 + A1[4] * v4) * expr1 +
+                (A2[0] * v1 + A2[1] * v2 + A2[3] * v3 + A2[4] * v4) * expr2 +
+                (A3[0] * v1 + A3[1] * v2 + A3[3] * v3 + A3[4] * v4) * expr3) / delta_i;
+    v1 = -m_x * sy * cz;
+    v2 = -m_x * sy * sz;
+    v3 = -m_x * cy;
+    v4 = m_y * sx * cy * cz;
+    v5 = m_y * sx * cy * sz;
+    v6 = -m_y * sx * sy;
+    J[o + 4] = ((A1[0] * v1 + A1[1] * v2 + A1[2] * v3 + A1[3] * v4 + A1[4] * v5 + A1[5] * v6) * expr1 +
+                (A2[0] * v1 + A2[1] * v2 + A2[2] * v3 + A2[3] * v4 + A2[4] * v5 + A2[5] * v6) * expr2 +
+                (A3[0] * v1 + A3[1] * v2 + A3[2] * v3 + A3[3] * v4 + A3[4] * v5 + A3[5] * v6) * expr3) /
+               delta_i;
+    v1 = m_y * (cz * sy * cx + sz * sx);
+    v2 = m_y * (sz * sy * cx - cz * sx);
+    v3 = m_y * cy * cx;
+    J[o + 5] = ((A1[3] * v1 + A1[4] * v2 + A1[5] * v3) * expr1 +
+                (A2[3] * v1 + A2[4] * v2 + A2[5] * v3) * expr2 +
+                (A3[3] * v1 + A3[4] * v2 + A3[5] * v3) * expr3) / delta_i;
+    J[o + 6] = ((A1[0] * R3_11 + A1[1] * R3_21 + A1[2] * R3_31) * expr1 +
+                (A2[0] * R3_11 + A2[1] * R3_21 + A2[2] * R3_31) * expr2 +
+                (A3[0] * R3_11 + A3[1] * R3_21 + A3[2] * R3_31) * expr3) / delta_i;
+    J[o + 7] = ((A1[3] * R3_12 + A1[4] * R3_22 + A1[5] * R3_32) * expr1 +
+                (A2[3] * R3_12 + A2[4] * R3_22 + A2[5] * R3_32) * expr2 +
+                (A3[3] * R3_12 + A3[4] * R3_22 + A3[5] * R3_32) * expr3) / delta_i;
+    m[0] = fma(delta_i, delta_i, m[0]);
+    int k = 1;
+    for (int p = 0; p < NLM; p++)
+      for (int q = p; q < NLM; q++, k++) m[k] = fma(J[p], J[q], m[k]);
+    for (int p = 0; p < NLM; p++, k++) m[k] = fma(J[p], delta_i, m[k]);
+  }
+
+  // ...Estimator.cxx:300-327 / :944-971: append the rotation products to the LM solution
+  static LSQR_HD int lm_finalize(const double *x, double *par) {
+    const int o = SINGLE ? 3 : 0;
+    for (int i = 0; i < NLM; i++) par[i] = x[i];
+    const double cz = cos(x[o + 3]), sz = sin(x[o + 3]);
+    const double cy = cos(x[o + 4]), sy = sin(x[o + 4]);
+    const double cx = cos(x[o + 5]), sx = sin(x[o + 5]);
+    const double mx = x[o + 6], my = x[o + 7];
+    int k = NLM;
+    par[k++] = mx * cz * cy;
+    par[k++] = mx * sz * cy;
+    par[k++] = -mx * sy;
+    par[k++] = my * (cz * sy * sx - sz * cx);
+    par[k++] = my * (sz * sy * sx + cz * cx);
+    par[k++] = my * cy * sx;
+    par[k++] = cz * sy * cx + sz * sx;
+    par[k++] = sz * sy * cx - cz * sx;
+    par[k++] = cy * cx;
+    return k;
+  }
+};
+
+}  // namespace lsqr

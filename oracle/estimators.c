@@ -659,7 +659,8 @@ int orc_us_iterative(int model, const double *const *recs, size_t n, const doubl
   info = orc_lmder(us_lm_fcn, &c, (int)n, np, x, tol, tol, tol, 5000, 100.0, &nfev, NULL, NULL);
   if (info_out) *info_out = info;
   if (nfev_out) *nfev_out = nfev;
-  if (info < 1 || info > 4) return 0;
+  /* `out` always receives the last iterate (diagnostics); the return value carries the
+   * reference's ok flag: 0 == empty vector unless MINPACK info is 1..4 */
   for (i = 0; i < np; i++) out[i] = x[i];
   cz = cos(x[o + 3]); sz = sin(x[o + 3]);
   cy = cos(x[o + 4]); sy = sin(x[o + 4]);
@@ -676,6 +677,7 @@ int orc_us_iterative(int model, const double *const *recs, size_t n, const doubl
   out[k++] = cz * sy * cx + sz * sx;
   out[k++] = sz * sy * cx - cz * sx;
   out[k++] = cy * cx;
+  if (info < 1 || info > 4) return 0;
   return k;
 }
 

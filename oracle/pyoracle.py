@@ -336,6 +336,7 @@ def us_iterative(model, recs, init):
     init = np.ascontiguousarray(init, dtype=np.float64)
     out = np.zeros(20)
     info, nfev = C.c_int(0), C.c_int(0)
-    n = lib().orc_us_iterative(model, _ptrs(rows), len(rows), _d(init), _d(out),
-                               C.byref(info), C.byref(nfev))
-    return out[:n].copy(), info.value, nfev.value
+    lib().orc_us_iterative(model, _ptrs(rows), len(rows), _d(init), _d(out),
+                           C.byref(info), C.byref(nfev))
+    # the last iterate is returned even when the reference would report failure (info not in 1..4)
+    return out[:(20 if model == US_SINGLE else 17)].copy(), info.value, nfev.value

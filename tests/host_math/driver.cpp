@@ -9,15 +9,20 @@
 
 #include "models.h"
 #include "sampler.h"
+#include "us.h"
 
 using namespace lsqr;
 
 template <class M>
 static int t_estimate(const double *recs, const ModelConsts &mc, double *par) {
+  if constexpr (M::IS_US) {
+    return -1;  // K1 of the US models is a wave kernel (device only)
+  } else {
   double r[M::K][M::ND];
   for (int l = 0; l < M::K; l++)
     for (int j = 0; j < M::ND; j++) r[l][j] = recs[l * M::ND + j];
   return M::estimate(r, mc, par) ? M::P : 0;
+  }
 }
 
 template <class M>
@@ -54,6 +59,8 @@ static int t_lm(const double *data, size_t n, const double *x0, double ftol, dou
     case 22: { typedef SphereModel<2> M; CALL; } break;              \
     case 33: { typedef LineModel<3> M; CALL; } break;                \
     case 32: { typedef LineModel<2> M; CALL; } break;                \
+    case 50: { typedef USModel<true> M; CALL; } break;               \
+    case 60: { typedef USModel<false> M; CALL; } break;              \
     default: break;                                                  \
   }
 
@@ -91,6 +98,20 @@ int hm_ls(int model, int dim, double delta, const double *data, size_t n, const 
   ModelConsts mc = consts(dim, delta, 0);
   int r = -1;
   DISPATCH(model, dim, r = t_ls<M>(data, n, mask, org, mc, par, mom_out));
+  return r;
+}
+
+int hm_us_lm(int single, const double *data, size_t n, const double *x0, double tol, int maxfev,
+             double *par, int *info, int *nfev) {
+  double x[11];
+  int r;
+  if (single) {
+    r = t_lm<USModel<true>>(data, n, x0, tol, tol, tol, maxfev, x, info, nfev);
+    if (r) r = USModel<true>::lm_finalize(x, par);
+  } else {
+    r = t_lm<USModel<false>>(data, n, x0, tol, tol, tol, maxfev, x, info, nfev);
+    if (r) r = USModel<false>::lm_finalize(x, par);
+  }
   return r;
 }
 
