@@ -1,0 +1,149 @@
+// LsqrDevice.h -- C++ glue between the header-level API of the drop-in and the C ABI
+// (include/lsqr_hip.h).  One lsqr_ctx per host thread (the reference is single threaded and not
+// thread safe, RANSAC.hxx:44,59; here each thread simply gets its own context and stream).
+// Errors of the device layer are never swallowed: anything other than LSQR_OK / LSQR_EMPTY throws
+// std::runtime_error; there is no CPU path to fall back to.
+#ifndef _LSQR_DEVICE_H_
+#define _LSQR_DEVICE_H_
+
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lsqr_hip.h"
+
+namespace lsqrRecipes {
+namespace detail {
+
+class Device {
+ public:
+  static Device &instance() {
+    static thread_local Device d;
+    return d;
+  }
+  lsqr_ctx *ctx() {
+    if (!h) {
+      int dev = 0;
+      if (const char *e = std::getenv("LSQR_DEVICE")) dev = std::atoi(e);
+      int st = lsqr_ctx_create(dev, &h);
+      if (st != LSQR_OK)
+        throw std::runtime_error(std::string("lsqrRecipes: cannot create a device context: ") +
+                                 lsqr_status_string(st));
+    }
+    return h;
+  }
+  // returns true for LSQR_OK, false for LSQR_EMPTY, throws otherwise
+  bool check(int st) {
+    if (st == LSQR_OK) return true;
+    if (st == LSQR_EMPTY) return false;
+    throw std::runtime_error(std::string("lsqrRecipes device error: ") + lsqr_status_string(st) +
+                             " (" + (h ? lsqr_last_error(h) : "") + ")");
+  }
+  void model(const lsqr_model_cfg &cfg) { check(lsqr_set_model(ctx(), &cfg)); }
+  ~Device() {
+    if (h) lsqr_ctx_destroy(h);
+  }
+
+ private:
+  Device() : h(0) {}
+  lsqr_ctx *h;
+};
+
+// contiguous copy of the records behind a vector of pointers (the reference passes
+// std::vector<T*> to estimate() / leastSquaresEstimate())
+template <class T>
+inline void gather(const std::vector<T *> &ptrs, std::vector<T> &out) {
+  out.clear();
+  out.reserve(ptrs.size());
+  for (size_t i = 0; i < ptrs.size(); i++) out.push_back(*ptrs[i]);
+}
+
+// estimate(): minimal-subset solve of exactly k records, in the given (draw) order
+template <class T>
+inline void exactFit(const lsqr_model_cfg &cfg, const T *recs, size_t count,
+                     std::vector<double> &parameters) {
+  parameters.clear();
+  Device &d = Device::instance();
+  d.model(cfg);
+  const int k = lsqr_min_subset(&cfg), P = lsqr_num_params(&cfg);
+  if (count < (size_t)k) return;
+  d.check(lsqr_upload(d.ctx(), recs, count, sizeof(T)));
+  std::vector<uint32_t> idx((size_t)k);
+  for (int i = 0; i < k; i++) idx[i] = (uint32_t)i;
+  d.check(lsqr_hypotheses_from_subsets(d.ctx(), &idx[0], 1));
+  std::vector<double> p((size_t)P);
+  uint8_t valid = 0;
+  d.check(lsqr_get_hypothesis(d.ctx(), 0, &p[0], &valid));
+  if (valid) parameters.assign(p.begin(), p.end());
+}
+
+// leastSquaresEstimate() over all given records
+template <class T>
+inline void lsFit(const lsqr_model_cfg &cfg, const T *recs, size_t count,
+                  std::vector<double> &parameters, lsqr_fit_info *info = 0) {
+  parameters.clear();
+  if (count == 0) return;
+  Device &d = Device::instance();
+  d.model(cfg);
+  d.check(lsqr_upload(d.ctx(), recs, count, sizeof(T)));
+  std::vector<double> p(64);
+  lsqr_fit_info fi;
+  if (d.check(lsqr_ls_fit(d.ctx(), 0, &p[0], &fi))) parameters.assign(p.begin(), p.begin() + fi.n_params);
+  if (info) *info = fi;
+}
+
+template <class T>
+inline bool agreeOne(const lsqr_model_cfg &cfg, const std::vector<double> &parameters, const T &rec) {
+  Device &d = Device::instance();
+  d.model(cfg);
+  if ((int)parameters.size() < lsqr_num_params(&cfg))
+    throw std::out_of_range("lsqrRecipes: parameters vector too short for agree()");
+  d.check(lsqr_upload(d.ctx(), &rec, 1, sizeof(T)));
+  uint8_t m = 0;
+  d.check(lsqr_mask(d.ctx(), &parameters[0], 0, 1, &m, 0));
+  return m != 0;
+}
+
+// getDistanceStatistics(): min / max / mean of the model's residual over the data
+template <class T>
+inline void distanceStats(const lsqr_model_cfg &cfg, const std::vector<double> &parameters,
+                          const T *recs, size_t count, double &mn, double &mx, double &mean) {
+  Device &d = Device::instance();
+  d.model(cfg);
+  d.check(lsqr_upload(d.ctx(), recs, count, sizeof(T)));
+  double out[4];
+  d.check(lsqr_stats(d.ctx(), &parameters[0], 0, out));
+  mn = out[0];
+  mx = out[1];
+  mean = out[2];
+}
+
+// iterative refinement from a caller-supplied start (Sphere::geometricLeastSquaresEstimate,
+// US::iterativeLeastSquaresEstimate): MINPACK control flow on the device, one pass per evaluation
+template <class T>
+inline void lmFit(const lsqr_model_cfg &cfg, const T *recs, size_t count,
+                  const std::vector<double> &initial, std::vector<double> &final_) {
+  final_.clear();
+  Device &d = Device::instance();
+  d.model(cfg);
+  d.check(lsqr_upload(d.ctx(), recs, count, sizeof(T)));
+  const int nmom = lsqr_moments_len(&cfg, 1);
+  std::vector<double> block((size_t)nmom), xt(64, 0.0), x0(64, 0.0), out(64, 0.0);
+  for (size_t i = 0; i < initial.size() && i < 64; i++) x0[i] = initial[i];
+  d.check(lsqr_lm_begin(d.ctx(), &x0[0], &xt[0]));
+  for (;;) {
+    int cont = 0;
+    lsqr_fit_info fi;
+    d.check(lsqr_moments(d.ctx(), 0, 0, count, 1, &xt[0], &block[0]));
+    bool ok = d.check(lsqr_lm_step(d.ctx(), &block[0], &xt[0], &cont, &out[0], &fi));
+    if (!cont) {
+      if (ok) final_.assign(out.begin(), out.begin() + fi.n_params);
+      return;
+    }
+  }
+}
+
+}  // namespace detail
+}  // namespace lsqrRecipes
+#endif

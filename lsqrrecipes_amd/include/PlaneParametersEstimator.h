@@ -1,0 +1,60 @@
+// PlaneParametersEstimator.h -- drop-in for parametersEstimators/PlaneParametersEstimator.{h,hxx}:
+// (hyper)plane [n, a], dot(n, p - a) = 0.  Same constructor / setDelta / virtuals; every method
+// runs on the device through the C ABI.  Device models exist for dimension 2 and 3.
+#ifndef _PLANE_PARAMETERS_ESTIMATOR_H_
+#define _PLANE_PARAMETERS_ESTIMATOR_H_
+
+#include "LsqrDevice.h"
+#include "ParametersEstimator.h"
+#include "Point.h"
+
+namespace lsqrRecipes {
+
+template <unsigned int dimension>
+class PlaneParametersEstimator : public ParametersEstimator<Point<double, dimension>, double> {
+  typedef Point<double, dimension> PointT;
+
+ public:
+  PlaneParametersEstimator(double delta)
+      : ParametersEstimator<PointT, double>(dimension), delta(delta) {}
+
+  virtual void estimate(std::vector<PointT *> &data, std::vector<double> &parameters) {
+    std::vector<PointT> tmp;
+    detail::gather(data, tmp);
+    estimate(tmp, parameters);
+  }
+  virtual void estimate(std::vector<PointT> &data, std::vector<double> &parameters) {
+    parameters.clear();
+    if (this->minForEstimate == 0 || data.size() < this->minForEstimate) return;
+    detail::exactFit(cfg(), &data[0], data.size(), parameters);
+  }
+  virtual void leastSquaresEstimate(std::vector<PointT *> &data, std::vector<double> &parameters) {
+    std::vector<PointT> tmp;
+    detail::gather(data, tmp);
+    leastSquaresEstimate(tmp, parameters);
+  }
+  virtual void leastSquaresEstimate(std::vector<PointT> &data, std::vector<double> &parameters) {
+    parameters.clear();
+    if (data.size() < this->minForEstimate) return;
+    detail::lsFit(cfg(), &data[0], data.size(), parameters);
+  }
+  virtual bool agree(std::vector<double> &parameters, PointT &data) {
+    return detail::agreeOne(cfg(), parameters, data);
+  }
+  void setDelta(double d) { this->delta = d; }
+
+  virtual bool deviceModel(lsqr_model_cfg &c) const {
+    c = cfg();
+    return dimension == 2 || dimension == 3;
+  }
+
+ private:
+  lsqr_model_cfg cfg() const {
+    lsqr_model_cfg c = {LSQR_MODEL_PLANE, (int32_t)dimension, delta, 0, 0};
+    return c;
+  }
+  double delta;  // the reference stores delta*delta; the device layer squares it the same way
+};
+
+}  // namespace lsqrRecipes
+#endif

@@ -1,0 +1,351 @@
+// estimatorTests -- the assertions of the reference's ctest programs for the hot-path estimators
+// (testing/PlaneParametersEstimatorTest.cxx, SphereParametersEstimatorTest.cxx,
+// LineParametersEstimatorTest.cxx, DenseLinearEquationSystemParametersEstimatorTest.cxx,
+// SinglePointTargetUSCalibrationParametersEstimatorTest.cxx) re-written against the drop-in
+// headers, plus RANSAC-level checks (the reference has none).  Runs on the GPU through the C++
+// API exactly as a user of the reference would call it.  Exit code 0 == all passed.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "DenseLinearEquationSystemParametersEstimator.h"
+#include "LineParametersEstimator.h"
+#include "PlaneParametersEstimator.h"
+#include "RANSAC.h"
+#include "SinglePointTargetUSCalibrationParametersEstimator.h"
+#include "SphereParametersEstimator.h"
+
+using namespace lsqrRecipes;
+
+static int failures = 0;
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+      failures++;                                                          \
+    }                                                                      \
+  } while (0)
+
+static std::mt19937_64 gen(12345);
+static double U(double a, double b) { return std::uniform_real_distribution<double>(a, b)(gen); }
+static double N(double s) { return std::normal_distribution<double>(0.0, s)(gen); }
+static const double COS5 = 0.99619469809174553229501040247389;
+
+static void planeTest() {  // testing/PlaneParametersEstimatorTest.cxx:71-158
+  typedef Point<double, 3> P;
+  const double delta = 0.5;
+  PlaneParametersEstimator<3> est(delta);
+  std::vector<P> minimal(3), noisy;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) minimal[i][j] = U(-1000, 1000);
+  double v1[3], v2[3], n[3];
+  for (int j = 0; j < 3; j++) {
+    v1[j] = minimal[1][j] - minimal[0][j];
+    v2[j] = minimal[2][j] - minimal[0][j];
+  }
+  n[0] = v1[1] * v2[2] - v1[2] * v2[1];
+  n[1] = v1[2] * v2[0] - v1[0] * v2[2];
+  n[2] = v1[0] * v2[1] - v1[1] * v2[0];
+  double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  for (int j = 0; j < 3; j++) n[j] /= nn;
+  std::vector<double> truth(n, n + 3), params;
+  for (int j = 0; j < 3; j++) truth.push_back(minimal[0][j]);
+  P on = minimal[1], off = minimal[1];
+  for (int j = 0; j < 3; j++) off[j] += 2 * delta * n[j];
+  CHECK(est.agree(truth, on));
+  CHECK(!est.agree(truth, off));
+  est.estimate(minimal, params);
+  CHECK(params.size() == 6);
+  if (params.size() == 6) {
+    double dot = params[0] * n[0] + params[1] * n[1] + params[2] * n[2], d = 0;
+    for (int j = 0; j < 3; j++) d += (params[3 + j] - minimal[0][j]) * n[j];
+    CHECK(std::fabs(dot) > COS5);
+    CHECK(std::fabs(d) < delta);
+  }
+  for (int i = 0; i < 20; i++) {  // barycentric combinations + noise
+    double w[3] = {U(0, 1), U(0, 1), U(0, 1)}, s = w[0] + w[1] + w[2];
+    P p;
+    for (int j = 0; j < 3; j++)
+      p[j] = (w[0] * minimal[0][j] + w[1] * minimal[1][j] + w[2] * minimal[2][j]) / s + N(0.1);
+    noisy.push_back(p);
+  }
+  est.leastSquaresEstimate(noisy, params);
+  CHECK(params.size() == 6);
+  if (params.size() == 6) {
+    double dot = params[0] * n[0] + params[1] * n[1] + params[2] * n[2], d = 0;
+    for (int j = 0; j < 3; j++) d += (params[3 + j] - minimal[0][j]) * n[j];
+    CHECK(std::fabs(dot) > COS5);
+    CHECK(std::fabs(d) < delta);
+  }
+  std::vector<P> collinear(3);  // degenerate minimal set -> empty
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) collinear[i][j] = i;
+  est.estimate(collinear, params);
+  CHECK(params.empty());
+  std::vector<P *> ptrs;  // pointer overloads
+  for (size_t i = 0; i < noisy.size(); i++) ptrs.push_back(&noisy[i]);
+  est.leastSquaresEstimate(ptrs, params);
+  CHECK(params.size() == 6);
+}
+
+static void sphereTest() {  // testing/SphereParametersEstimatorTest.cxx:280-296,504-506
+  typedef Point<double, 2> P2;
+  SphereParametersEstimator<2> circ(0.5);
+  std::vector<double> truth = {0.0, 0.0, 2.0}, params;
+  P2 p;
+  p[1] = 0;
+  p[0] = 2.0; CHECK(circ.agree(truth, p));
+  p[0] = 2.4; CHECK(circ.agree(truth, p));
+  p[0] = 2.6; CHECK(!circ.agree(truth, p));
+  p[0] = 1.4; CHECK(!circ.agree(truth, p));
+  // Gander, Golub, Strebel circle (test :313-324): geometric fit (4.7398, 2.9835, 4.7142)
+  double g[6][2] = {{1, 7}, {2, 6}, {5, 8}, {7, 7}, {9, 5}, {3, 7}};
+  std::vector<P2> pts;
+  for (auto &r : g) {
+    P2 q;
+    q[0] = r[0];
+    q[1] = r[1];
+    pts.push_back(q);
+  }
+  circ.setLeastSquaresType(SphereParametersEstimator<2>::GEOMETRIC);
+  circ.leastSquaresEstimate(pts, params);
+  CHECK(params.size() == 3);
+  if (params.size() == 3) {
+    CHECK(std::fabs(params[0] - 4.7398) < 1e-4);
+    CHECK(std::fabs(params[1] - 2.9835) < 1e-4);
+    CHECK(std::fabs(params[2] - 4.7142) < 1e-4);
+  }
+  typedef Point<double, 3> P3;
+  SphereParametersEstimator<3> sph(0.5);
+  double c[3] = {U(-50, 50), U(-50, 50), U(-50, 50)}, r = U(10, 50), sigma = 1.0;
+  std::vector<P3> data;
+  for (int i = 0; i < 20; i++) {
+    double u[3] = {U(-1, 1), U(-1, 1), U(-1, 1)}, nu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    P3 q;
+    for (int j = 0; j < 3; j++) q[j] = c[j] + r * u[j] / nu + N(sigma) / 3;
+    data.push_back(q);
+  }
+  std::vector<P3 *> ptrs;
+  for (auto &q : data) ptrs.push_back(&q);
+  std::vector<double> alg, geo;
+  sph.algebraicLeastSquaresEstimate(ptrs, alg);
+  CHECK(alg.size() == 4);
+  sph.geometricLeastSquaresEstimate(ptrs, alg, geo);
+  CHECK(geo.size() == 4);
+  for (auto *est : {&alg, &geo})
+    if (est->size() == 4) {
+      double dc = 0;
+      for (int j = 0; j < 3; j++) dc += ((*est)[j] - c[j]) * ((*est)[j] - c[j]);
+      CHECK(std::sqrt(dc) <= 3 * sigma);
+      CHECK(std::fabs((*est)[3] - r) <= 3 * sigma);
+    }
+  bool threw = false;
+  try {
+    SphereParametersEstimator<3> bad(0.5, (SphereParametersEstimator<3>::LeastSquaresType)7);
+  } catch (std::exception &) {
+    threw = true;
+  }
+  CHECK(threw);  // SphereParametersEstimator.hxx:17-18
+}
+
+static void lineTest() {  // testing/LineParametersEstimatorTest.cxx:98-213
+  typedef Point<double, 2> P;
+  LineParametersEstimator<2> est(0.5);
+  std::vector<P> two(2), noisy;
+  two[0][0] = 10; two[0][1] = -4; two[1][0] = -70; two[1][1] = 55;
+  std::vector<double> params;
+  est.estimate(two, params);
+  CHECK(params.size() == 4);
+  double d[2] = {two[0][0] - two[1][0], two[0][1] - two[1][1]}, nd = std::sqrt(d[0] * d[0] + d[1] * d[1]);
+  d[0] /= nd; d[1] /= nd;
+  if (params.size() == 4) CHECK(std::fabs(params[0] * d[0] + params[1] * d[1]) > COS5);
+  P off = two[1];
+  off[0] += -d[1];
+  off[1] += d[0];
+  CHECK(est.agree(params, two[1]));
+  CHECK(!est.agree(params, off));
+  for (int i = 0; i < 20; i++) {
+    double t = U(-100, 100);
+    P p;
+    p[0] = two[0][0] + t * d[0] + N(0.2);
+    p[1] = two[0][1] + t * d[1] + N(0.2);
+    noisy.push_back(p);
+  }
+  est.leastSquaresEstimate(noisy, params);
+  CHECK(params.size() == 4 && std::fabs(params[0] * d[0] + params[1] * d[1]) > COS5);
+}
+
+static void denseTest(const char *matrixFile) {  // testing/DenseLinear...Test.cxx:72-209
+  const unsigned int n = 5;
+  typedef AugmentedRow<double, n> Row;
+  DenseLinearEquationSystemParametersEstimator<double, n> est(0.1);
+  std::vector<double> x(n), params;
+  for (auto &v : x) v = U(-1, 1);
+  std::vector<Row> exact, noisy;
+  for (unsigned i = 0; i < 200; i++) {
+    double a[n + 1], b = 0;
+    for (unsigned j = 0; j < n; j++) {
+      a[j] = U(-1, 1);
+      b += a[j] * x[j];
+    }
+    a[n] = b;
+    if (i < n) exact.push_back(Row(a));
+    a[n] = b * (1 + U(-0.05, 0.05));
+    noisy.push_back(Row(a));
+  }
+  est.estimate(exact, params);
+  CHECK(params.size() == n);
+  for (unsigned j = 0; j < params.size(); j++) CHECK(std::fabs(params[j] - x[j]) < 1e-10);
+  est.leastSquaresEstimate(noisy, params);
+  CHECK(params.size() == n);
+  for (unsigned j = 0; j < params.size(); j++) CHECK(std::fabs(params[j] - x[j]) < 0.1);
+  CHECK(est.agree(x, exact[0]));
+  if (matrixFile) {  // known-answer fixture, test :162-164, tolerance :183
+    const double known[6] = {-1.777985584409468e+001, 1.111302171667757e+000, -1.568653413096010e+002,
+                             1.469013927556186e+002,  -6.296891425314718e+001, -1.042139650090033e+003};
+    typedef AugmentedRow<double, 6> Row6;
+    std::ifstream in(matrixFile);
+    std::vector<Row6> rows;
+    double v[7];
+    while (in >> v[0] >> v[1] >> v[2] >> v[3] >> v[4] >> v[5] >> v[6]) rows.push_back(Row6(v));
+    CHECK(rows.size() == 1443);
+    DenseLinearEquationSystemParametersEstimator<double, 6> est6(0.5);
+    est6.leastSquaresEstimate(rows, params);
+    CHECK(params.size() == 6);
+    for (unsigned j = 0; j < params.size(); j++) CHECK(std::fabs(params[j] - known[j]) < 0.5);
+    for (unsigned j = 0; j < params.size(); j++) CHECK(std::fabs(params[j] - known[j]) < 1e-6 * 1042);
+  }
+}
+
+static void usTest() {  // testing/SinglePointTargetUSCalibration...Test.cxx:179-220,466-552
+  typedef SingleUnknownPointTargetUSCalibrationParametersEstimator Est;
+  typedef Est::DataType D;
+  const double PI = 3.14159265358979323846, mx = 0.143, my = 0.139;
+  Frame T3;
+  double w3[3] = {U(0, PI), U(0, PI), U(0, PI)}, t3[3] = {U(-100, 100), U(-100, 100), U(-100, 100)};
+  T3.setRotationEulerAngles(w3[2], w3[1], w3[0]);
+  T3.setTranslation(t3);
+  double t1[3] = {U(-100, 100), U(-100, 100), U(-100, 100)};
+  std::vector<D> clean, noisy;
+  for (int i = 0; i < 50; i++) {
+    D d;
+    double u = U(0, 640), v = U(0, 480), q[3] = {mx * u, my * v, 0}, q3[3], rq[3];
+    d.T2.setRotationEulerAngles(U(0, PI), U(0, PI), U(0, PI));
+    T3.apply(q, q3);
+    d.T2.apply(q3, rq);
+    d.T2.setTranslation(t1[0] - rq[0], t1[1] - rq[1], t1[2] - rq[2]);
+    d.q[0] = u;
+    d.q[1] = v;
+    clean.push_back(d);
+    d.q[0] += N(1.0);
+    d.q[1] += N(1.0);
+    noisy.push_back(d);
+  }
+  Est est(3.0);
+  std::vector<D> minimal(clean.begin(), clean.begin() + 4);
+  std::vector<double> params;
+  est.estimate(minimal, params);
+  CHECK(params.size() == 20);
+  if (params.size() == 20) CHECK(est.agree(params, clean[0]));
+  std::vector<D> five(clean.begin(), clean.begin() + 5);
+  est.estimate(five, params);
+  CHECK(params.empty());  // exactly four elements required
+  est.setLeastSquaresType(Est::ANALYTIC);
+  est.leastSquaresEstimate(noisy, params);
+  CHECK(params.size() == 20);
+  if (params.size() == 20) {
+    double dt = 0;
+    for (int j = 0; j < 3; j++) dt += (params[3 + j] - t3[j]) * (params[3 + j] - t3[j]);
+    CHECK(std::sqrt(dt) < 1.0);
+    CHECK(std::fabs(params[9] - mx) < 1.0 && std::fabs(params[10] - my) < 1.0);
+  }
+  est.setLeastSquaresType(Est::ITERATIVE);
+  est.leastSquaresEstimate(noisy, params);  // "iterative LS on noisy data must pass" (:213-220)
+  CHECK(params.size() == 20);
+  double mn, mxd, mean;
+  if (params.size() == 20) {
+    Est::getDistanceStatistics(params, noisy, mn, mxd, mean);
+    CHECK(mean < 3.0);
+  }
+}
+
+static void ransacTest() {
+  typedef Point<double, 3> P;
+  std::vector<P> data;
+  double n[3] = {0.6, 0.0, 0.8}, a[3] = {10, 20, 30};
+  for (int i = 0; i < 2000; i++) {
+    P p;
+    double d = 0;
+    for (int j = 0; j < 3; j++) {
+      p[j] = U(-1000, 1000);
+      d += (p[j] - a[j]) * n[j];
+    }
+    if (i % 2 == 0)
+      for (int j = 0; j < 3; j++) p[j] += -d * n[j] + N(0.2);
+    data.push_back(p);
+  }
+  PlaneParametersEstimator<3> est(0.5);
+  std::vector<double> params(3, 42.0);
+  std::vector<bool> consensus;
+  // invalid input: returns 0 and leaves parameters untouched (RANSAC.hxx:16-19)
+  CHECK((RANSAC<P, double>::compute(params, &est, data, 1.0) == 0));
+  CHECK(params.size() == 3 && params[0] == 42.0);
+  std::vector<P> tooFew(data.begin(), data.begin() + 2);
+  CHECK((RANSAC<P, double>::compute(params, &est, tooFew, 0.9) == 0));
+  CHECK(params.size() == 3);
+  CHECK((RANSAC<P, double>::compute(params, &est, tooFew) == 0));  // exhaustive: cleared
+  CHECK(params.empty());
+  double frac = RANSAC<P, double>::compute(params, &est, data, 0.999, &consensus);
+  CHECK(params.size() == 6 && consensus.size() == data.size());
+  CHECK(frac > 0.45 && frac < 0.55);
+  if (params.size() == 6) CHECK(std::fabs(std::fabs(params[0] * n[0] + params[1] * n[1] + params[2] * n[2]) - 1) < 1e-6);
+  size_t cnt = 0;
+  for (size_t i = 0; i < consensus.size(); i++) cnt += consensus[i];
+  CHECK(std::fabs((double)cnt / data.size() - frac) < 1e-12);
+  // reproducible for a fixed seed, different stream for another
+  std::vector<double> again;
+  double frac2 = RANSAC<P, double>::compute(again, &est, data, 0.999);
+  CHECK(frac2 == frac && again == params);
+  // exhaustive overload on a small set
+  std::vector<P> small(data.begin(), data.begin() + 16);
+  double fe = RANSAC<P, double>::compute(params, &est, small, &consensus);
+  CHECK(fe >= 3.0 / 16 && params.size() == 6);
+  CHECK((RANSAC<P, double>::lastInfo().iterations == 560));  // C(16,3)
+  // an estimator without a device model is refused loudly
+  struct Foreign : public ParametersEstimator<P, double> {
+    Foreign() : ParametersEstimator<P, double>(3) {}
+    void estimate(std::vector<P *> &, std::vector<double> &) {}
+    void estimate(std::vector<P> &, std::vector<double> &) {}
+    void leastSquaresEstimate(std::vector<P *> &, std::vector<double> &) {}
+    void leastSquaresEstimate(std::vector<P> &, std::vector<double> &) {}
+    bool agree(std::vector<double> &, P &) { return false; }
+  } foreign;
+  bool threw = false;
+  try {
+    RANSAC<P, double>::compute(params, &foreign, data, 0.9);
+  } catch (std::runtime_error &) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
+int main(int argc, char *argv[]) {
+  try {
+    planeTest();
+    sphereTest();
+    lineTest();
+    denseTest(argc > 1 ? argv[1] : 0);
+    usTest();
+    ransacTest();
+  } catch (std::exception &e) {
+    std::printf("EXCEPTION: %s\n", e.what());
+    return EXIT_FAILURE;
+  }
+  std::printf(failures ? "%d check(s) FAILED\n" : "all checks passed (%d failures)\n", failures);
+  return failures ? EXIT_FAILURE : EXIT_SUCCESS;
+}
