@@ -1,0 +1,143 @@
+"""Multi-GPU step logic (lsqrrecipes_amd/distributed.py) on CPU: world_size 2 over gloo.
+
+The collective pattern (all-reduce MAX of the packed winner, all-reduce SUM of zero-padded
+parameters and of the moment blocks) is exercised with a stand-in engine that answers the Context
+calls from the CPU oracle -- test infrastructure only; on the GPU the engine is the real Context
+(covered by bench.py --gpus N on the driver's 8-GPU node)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleEngine:
+    """Implements the subset of the Context interface ShardedRansac uses, on the CPU oracle."""
+
+    def __init__(self, data, delta=0.5):
+        from lsqrrecipes_amd import _lib as L
+        from oracle import pyoracle as O
+        self.O, self.L = O, L
+        self.data = data
+        self.n = len(data)
+        self.oc = O.cfg(O.PLANE, 3, delta)
+        self.cfg = L.ModelCfg(L.PLANE, 3, delta, 0, 0)
+        self.K, self.P, self.ND = 3, 6, 3
+        self._mask = np.zeros(self.n, dtype=np.uint8)
+
+    def hypotheses_sample(self, seed, first, H):
+        O = self.O
+        self.subs = O.ctr_subsets(seed, first, H, self.n, self.K)
+        self.par = [O.estimate(self.oc, self.data[s]) for s in self.subs]
+
+    def scan(self):
+        self.votes = np.array([self.O.scan(self.oc, p, self.data)[0] if len(p) else 0
+                               for p in self.par], dtype=np.int64)
+
+    def best(self):
+        if self.votes.max() == 0:
+            return 0, 0, 0
+        i = int(np.argmax(self.votes))
+        return (int(self.votes[i]) << 32) | (0xFFFFFFFF - i), int(self.votes[i]), i
+
+    def hypothesis(self, h):
+        return self.par[h], True
+
+    def mask(self, params, begin, end, want_mask=False):
+        cnt, m = self.O.scan(self.oc, params, self.data[begin:end])
+        self._mask[begin:end] = m
+        return None, cnt
+
+    def moments(self, origin, begin, end, phase=0, use_mask=True):
+        x = self.data[begin:end][self._mask[begin:end].astype(bool)] - origin
+        blk = [float(len(x))] + list(x.sum(0))
+        for i in range(3):
+            for j in range(i, 3):
+                blk.append(float((x[:, i] * x[:, j]).sum()))
+        return np.array(blk)
+
+    def solve_moments(self, block, origin):
+        N = block[0]
+        mean = block[1:4] / N
+        C = np.zeros((3, 3))
+        k = 4
+        for i in range(3):
+            for j in range(i, 3):
+                C[i, j] = C[j, i] = block[k] - N * mean[i] * mean[j]
+                k += 1
+        w, V = np.linalg.eigh(C)
+        return np.concatenate([V[:, 0], mean + origin]), None
+
+
+def _worker(rank, world, port, data, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+    eng = OracleEngine(data)
+    sr = ShardedRansac(eng, Comm(dist, "cpu"))
+    votes, gidx, par = sr.batch(seed=5, batch_index=0, H=24)
+    fit, cnt, _ = sr.fit(par)
+    votes2, gidx2, par2 = sr.batch(seed=5, batch_index=1, H=24)
+    if rank == 0:
+        out.put((votes, gidx, par, fit, cnt, votes2, gidx2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_ransac_world2_matches_single_process():
+    from lsqrrecipes_amd import synth
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac, slice_bounds
+    from oracle import pyoracle as O
+    data = synth.plane(1500, 0.4, seed=321)[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, data, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    votes, gidx, par, fit, cnt, votes2, gidx2 = res
+    # single process over the same 48-hypothesis global batch: same first-max winner
+    eng = OracleEngine(data)
+    sr = ShardedRansac(eng, Comm(None))
+    v1, g1, p1 = sr.batch(seed=5, batch_index=0, H=48)
+    assert (votes, gidx) == (v1, g1) and np.array_equal(par, p1)
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    wcnt, wmask = O.scan(oc, par, data)
+    assert cnt == wcnt == votes
+    want = O.ls(oc, data, wmask)
+    assert abs(abs(fit[:3] @ want[:3]) - 1) < 1e-9
+    assert abs((fit[3:] - want[3:]) @ want[:3]) < 1e-7
+    # second batch continues the global stream at index 48
+    v2, g2, _ = sr.batch(seed=5, batch_index=1, H=48)
+    assert (votes2, gidx2) == (v2, g2) and 48 <= gidx2 < 96
+    # observation slices tile [0, n) exactly
+    b = [slice_bounds(1501, r, 4) for r in range(4)]
+    assert b[0][0] == 0 and b[-1][1] == 1501 and all(b[i][1] == b[i + 1][0] for i in range(3))
+
+
+def test_comm_world1_is_identity():
+    from lsqrrecipes_amd.distributed import Comm
+    c = Comm(None)
+    assert c.allreduce_max_i64(7) == 7 and c.world == 1
+    assert np.array_equal(c.allreduce_sum_f64([1.0, 2.0]), [1.0, 2.0])
