@@ -58,6 +58,6 @@ int main() {
   std::cout << "\tDifference between real and computed radius: " << params[DIM] - r << "\n";
   std::cout << "\tPercentage of points which were used for final estimate: " << used << "\n";
   std::cout << "\tResidual over all data: min " << mn << " max " << mx << " mean " << mean << "\n";
-  return (std::sqrt(dc) < 1.0 && std::fabs(params[DIM] - r) < 1.0 && used > 0.8) ? EXIT_SUCCESS
+  return (std::sqrt(dc) < 1.0 && std::fabs(params[DIM] - r) < 1.0 && used > 0.5) ? EXIT_SUCCESS
                                                                                   : EXIT_FAILURE;
 }
