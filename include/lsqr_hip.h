@@ -200,6 +200,12 @@ LSQR_API size_t lsqr_replay(size_t n, int k, double p, const uint32_t *subsets,
 LSQR_API void *lsqr_dedup_create(int k);
 LSQR_API void lsqr_dedup_destroy(void *set);
 
+/* ---- tuning knobs (A/B measurements inside one process; defaults are the tuned values) --------- */
+/* "scan_ppl": observations per lane in k_scan (2, 4 or 8; 0 = model default);
+ * "scan_filter": 1 = fp32 pre-filter + exact fp64 re-evaluation of ambiguous observations
+ *                (bit-identical votes), 0 = plain fp64 scan. */
+LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,
  * 2 scan, 3 mask, 4 moments, 5 solve. */

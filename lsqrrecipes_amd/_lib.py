@@ -89,6 +89,7 @@ SIGNATURES = {
                                  C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, _u64p]),
     "lsqr_dedup_create": (C.c_void_p, [C.c_int]),
     "lsqr_dedup_destroy": (None, [C.c_void_p]),
+    "lsqr_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
     "lsqr_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "lsqr_profile_get": (C.c_int, [_ctx, C.c_int, _u64p, _dp]),
     "lsqr_profile_reset": (C.c_int, [_ctx]),

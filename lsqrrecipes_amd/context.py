@@ -199,6 +199,9 @@ class Context:
                     consensus=cons[:self.n] if (cons is not None and info.best_votes > 0) else None,
                     info=info)
 
+    def set_option(self, name, value):
+        self._chk(self._lib.lsqr_set_option(self._h, name.encode(), int(value)))
+
     # ---- measurement --------------------------------------------------------------------
     def profile(self, on=True):
         self._chk(self._lib.lsqr_profile_enable(self._h, int(on)))

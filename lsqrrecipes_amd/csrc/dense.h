@@ -35,6 +35,7 @@ struct DenseModel {
   static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) {
     return fabs(signed_res(sp, x));
   }
+  static LSQR_HD void prepare(double *, const ModelConsts &) {}
 };
 
 // K1 dense: one wave per hypothesis; n x n system in LDS; x = pinv(A) b, singular if any

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_estimate(const double *__restrict__ 
                                                      const uint32_t *__restrict__ subsets,
                                                      uint32_t H, ModelConsts mc,
                                                      double *__restrict__ hparams,
+                                                     float *__restrict__ hparams_f32,
                                                      uint8_t *__restrict__ valid) {
   uint32_t h = blockIdx.x * kBlock + threadIdx.x;
   if (h >= H) return;
@@ -60,8 +61,16 @@ __global__ __launch_bounds__(kBlock) void k_estimate(const double *__restrict__ 
   double par[M::P];
   ok = ok && M::estimate(r, mc, par);
   const double qnan = __builtin_nan("");
-  for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = ok ? par[j] : qnan;
-  for (int j = M::P; j < M::SP; j++) hparams[(size_t)h * M::SP + j] = 0.0;
+  double sp[M::SP];
+  for (int j = 0; j < M::P; j++) sp[j] = ok ? par[j] : qnan;
+  for (int j = M::P; j < M::SP; j++) sp[j] = 0.0;
+  M::prepare(sp, mc);
+  for (int j = 0; j < M::SP; j++) hparams[(size_t)h * M::SP + j] = sp[j];
+  if constexpr (requires { M::SPF; }) {
+    float f[M::SPF];
+    M::prepare_f32(sp, mc, f);
+    for (int j = 0; j < M::SPF; j++) hparams_f32[(size_t)h * M::SPF + j] = f[j];
+  }
   valid[h] = ok ? 1 : 0;
 }
 
@@ -92,9 +101,23 @@ __global__ __launch_bounds__(kBlock) void k_scan(const double *__restrict__ data
     for (uint32_t h = 0; h < H; h++) {
       const double *hp = sp + (size_t)h * M::SP;  // wave-uniform -> scalar loads
       uint32_t c = 0;
+      if constexpr (requires { M::use_literal(hp); }) {
+        // two formulations of the same predicate; the choice is per hypothesis, so branch on a
+        // scalar instead of letting the compiler evaluate both
+        if (__builtin_amdgcn_readfirstlane((int)M::use_literal(hp))) {
 #pragma unroll
-      for (int j = 0; j < PPL; j++)
-        c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
+          for (int j = 0; j < PPL; j++)
+            c += (uint32_t)__builtin_popcountll(__ballot(M::agree_literal(hp, rec[j], mc)));
+        } else {
+#pragma unroll
+          for (int j = 0; j < PPL; j++)
+            c += (uint32_t)__builtin_popcountll(__ballot(M::agree_interval(hp, rec[j])));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PPL; j++)
+          c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
+      }
       if (leader && c) atomicAdd(&s_cnt[h], c);
     }
   }
@@ -105,6 +128,121 @@ __global__ __launch_bounds__(kBlock) void k_scan(const double *__restrict__ data
   }
 }
 
+// derive the scan parameters (M::SP doubles) of one model in place
+template <class M>
+__global__ void k_prepare(double *par, ModelConsts mc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sp[M::SP];
+  for (int j = 0; j < M::SP; j++) sp[j] = j < M::P ? par[j] : 0.0;
+  M::prepare(sp, mc);
+  for (int j = M::P; j < M::SP; j++) par[j] = sp[j];
+}
+
+// K2 for the plane with an fp32 pre-filter: the packed-fp32 evaluation (two observations per
+// v_pk_* instruction) classifies every observation as certain inlier / certain outlier / ambiguous
+// (PlaneModel::prepare_f32 states the error bound); a wave whose tile holds an ambiguous observation
+// for the current hypothesis re-evaluates that tile with the exact fp64 predicate, so the votes are
+// bit-identical to k_scan's.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int D, int PPL>
+__global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restrict__ data,
+                                                           size_t stride, size_t n,
+                                                           const double *__restrict__ sp,
+                                                           const float *__restrict__ spf,
+                                                           uint32_t H, ModelConsts mc,
+                                                           uint32_t *__restrict__ votes) {
+  typedef PlaneModel<D> M;
+  static_assert(PPL % 2 == 0, "observations are processed in packed pairs");
+  extern __shared__ uint32_t s_cnt[];
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) s_cnt[h] = 0;
+  __syncthreads();
+  const size_t tile = (size_t)kBlock * PPL;
+  const bool leader = (threadIdx.x & 63) == 0;
+  const float fnan = __builtin_nanf("");
+  for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
+    // only the fp32 copies stay in registers; the rare exact path re-reads the fp64 records
+    v2f xs[PPL / 2][3];
+#pragma unroll
+    for (int q = 0; q < PPL / 2; q++) {
+      size_t i0 = base + (size_t)(2 * q) * kBlock + threadIdx.x, i1 = i0 + kBlock;
+      const double *p0 = data + (i0 < n ? i0 : 0) * stride, *p1 = data + (i1 < n ? i1 : 0) * stride;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        xs[q][d].x = d < D ? (i0 < n ? (float)p0[d] : fnan) : 0.0f;  // NaN never passes a '<'
+        xs[q][d].y = d < D ? (i1 < n ? (float)p1[d] : fnan) : 0.0f;
+      }
+    }
+    for (uint32_t h = 0; h < H; h++) {
+      const v2f *f = (const v2f *)(spf + (size_t)h * M::SPF);  // wave-uniform -> scalar loads
+      const v2f n0 = f[0], n1 = f[1], n2 = f[2], cneg = f[3];
+      const float tin = f[4].x, tout = f[4].y;
+      v2f a[PPL / 2];
+      unsigned long long any = 0;
+#pragma unroll
+      for (int q = 0; q < PPL / 2; q++) {
+        v2f s = cneg;
+        if (D == 3) s = __builtin_elementwise_fma(xs[q][2], n2, s);
+        s = __builtin_elementwise_fma(xs[q][1], n1, s);
+        s = __builtin_elementwise_fma(xs[q][0], n0, s);
+        a[q] = s;
+        any |= __ballot(__builtin_fabsf(s.x) < tout) | __ballot(__builtin_fabsf(s.y) < tout);
+      }
+      if (any == 0) continue;  // wave-uniform: no observation of this tile is near the plane
+      uint32_t c = 0;
+      unsigned long long amb = 0;
+#pragma unroll
+      for (int q = 0; q < PPL / 2; q++) {
+        float s0 = __builtin_fabsf(a[q].x), s1 = __builtin_fabsf(a[q].y);
+        unsigned long long in0 = __ballot(s0 < tin), in1 = __ballot(s1 < tin);
+        unsigned long long may0 = __ballot(s0 < tout), may1 = __ballot(s1 < tout);
+        c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
+        amb |= (in0 ^ may0) | (in1 ^ may1);
+      }
+      if (amb) {  // rare, wave-uniform: exact fp64 predicate for this tile and hypothesis
+        const double *hp = sp + (size_t)h * M::SP;
+        c = 0;
+        for (int j = 0; j < PPL; j++) {
+          size_t i = base + (size_t)j * kBlock + threadIdx.x;
+          bool in = i < n;
+          double x[D];
+          const double *p = data + (in ? i : 0) * stride;
+          for (int d = 0; d < D; d++) x[d] = p[d];
+          c += (uint32_t)__builtin_popcountll(__ballot(in && M::agree(hp, x, mc)));
+        }
+      }
+      if (leader && c) atomicAdd(&s_cnt[h], c);
+    }
+  }
+  __syncthreads();
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
+  }
+}
+
+// max |x| over the first nd doubles of every record (bit patterns of non-negative doubles are
+// ordered like the values, so an integer atomicMax works)
+__global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ data, size_t stride,
+                                                   size_t n, int nd,
+                                                   unsigned long long *__restrict__ out) {
+  unsigned long long m = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock)
+    for (int d = 0; d < nd; d++) {
+      double v = fabs(data[i * stride + d]);
+      unsigned long long b;
+      if (!(v == v)) v = __builtin_inf();  // NaN observation: disables the filter
+      __builtin_memcpy(&b, &v, 8);
+      m = b > m ? b : m;
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_down(m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_mask(const double *__restrict__ data, size_t stride,
                                                  size_t begin, size_t end,
@@ -113,11 +251,13 @@ __global__ __launch_bounds__(kBlock) void k_mask(const double *__restrict__ data
                                                  unsigned long long *__restrict__ counter) {
   __shared__ uint32_t s_c[kBlock / 64];
   uint32_t local = 0;
+  double sp[M::SP];
+  for (int j = 0; j < M::SP; j++) sp[j] = par[j];  // prepared by k_prepare
   for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < end;
        i += (size_t)gridDim.x * kBlock) {
     double x[M::REC];
     M::load(data + i * stride, mc, x);
-    bool a = M::agree(par, x, mc);
+    bool a = M::agree(sp, x, mc);
     mask[i] = a ? 1 : 0;
     local += a ? 1u : 0u;
   }

@@ -37,6 +37,8 @@ struct lsqr_ctx {
   size_t H = 0, H_cap = 0;
   uint32_t *d_subsets = nullptr;
   double *d_hparams = nullptr;
+  float *d_hparams_f32 = nullptr;
+  bool absmax_valid = false;
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   bool scanned = false;
@@ -53,6 +55,7 @@ struct lsqr_ctx {
   SolveOut *d_out = nullptr;
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
+  int opt_ppl = 0, opt_filter = 1;
 
   void *h_pin = nullptr;  // pinned staging (64 KiB)
 
@@ -163,12 +166,15 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   size_t cap = std::max<size_t>(H, 4096);
   if (c->d_subsets) (void)hipFree(c->d_subsets);
   if (c->d_hparams) (void)hipFree(c->d_hparams);
+  if (c->d_hparams_f32) (void)hipFree(c->d_hparams_f32);
+  c->d_hparams_f32 = nullptr;
   if (c->d_valid) (void)hipFree(c->d_valid);
   if (c->d_votes) (void)hipFree(c->d_votes);
   c->d_subsets = nullptr; c->d_hparams = nullptr; c->d_valid = nullptr; c->d_votes = nullptr;
   c->H_cap = 0;
   HIPCHK(c, hipMalloc((void **)&c->d_subsets, cap * 64 * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc((void **)&c->d_hparams, cap * 64 * sizeof(double)));
+  HIPCHK(c, hipMalloc((void **)&c->d_hparams_f32, cap * 16 * sizeof(float)));
   HIPCHK(c, hipMalloc((void **)&c->d_valid, cap));
   HIPCHK(c, hipMalloc((void **)&c->d_votes, cap * sizeof(uint32_t)));
   c->H_cap = cap;
@@ -192,9 +198,28 @@ int grid_for(size_t items, int per_block, int max_blocks) {
 }
 
 // ---- hypotheses ---------------------------------------------------------------------------------
+int ensure_absmax(lsqr_ctx *c) {
+  if (c->absmax_valid) return LSQR_OK;
+  HIPCHK(c, hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
+  int grid = grid_for(c->n, kBlock * 8, 2048);
+  hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
+                     c->ND, c->d_counter + 2);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 2, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(&c->mc.absmax, c->h_pin, sizeof(double));
+  c->absmax_valid = true;
+  return LSQR_OK;
+}
+
 int run_estimate(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
+    if constexpr (requires { M::SPF; }) {
+      int st = ensure_absmax(c);
+      if (st != LSQR_OK) return st;
+    }
     ProfScope ps(c, KID_ESTIMATE);
     if constexpr (M::IS_DENSE) {
       hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(64),
@@ -209,7 +234,7 @@ int run_estimate(lsqr_ctx *c) {
       int grid = (int)((c->H + kBlock - 1) / kBlock);
       hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
                          c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->mc, c->d_hparams,
-                         c->d_valid);
+                         c->d_hparams_f32, c->d_valid);
     }
     HIPCHK(c, hipGetLastError());
     return LSQR_OK;
@@ -218,26 +243,67 @@ int run_estimate(lsqr_ctx *c) {
 
 constexpr uint32_t kScanChunk = 8192;  // hypotheses per scan launch (LDS counters: 32 KiB)
 
+template <class M, int PPL>
+int run_scan_ppl(lsqr_ctx *c) {
+  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+  size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
+  for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
+    uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
+    size_t lds = (size_t)hc * sizeof(uint32_t);
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    size_t max_blocks = (size_t)256 * per_cu;
+    size_t tpb = (tiles + max_blocks - 1) / max_blocks;
+    int grid = (int)((tiles + tpb - 1) / tpb);
+    ProfScope ps(c, KID_SCAN);
+    hipLaunchKernelGGL((k_scan<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream, c->d_data,
+                       c->stride, c->n, c->d_hparams + h0 * M::SP, hc, c->mc, c->d_votes + h0);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LSQR_OK;
+}
+
+template <int D, int PPL>
+int run_scan_plane_f32(lsqr_ctx *c) {
+  typedef PlaneModel<D> M;
+  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+  size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
+  for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
+    uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
+    size_t lds = (size_t)hc * sizeof(uint32_t);
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    size_t max_blocks = (size_t)256 * per_cu;
+    size_t tpb = (tiles + max_blocks - 1) / max_blocks;
+    int grid = (int)((tiles + tpb - 1) / tpb);
+    ProfScope ps(c, KID_SCAN);
+    hipLaunchKernelGGL((k_scan_plane_f32<D, PPL>), dim3(grid), dim3(kBlock), lds, c->stream,
+                       c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
+                       c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LSQR_OK;
+}
+
 int run_scan(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
-    constexpr int PPL = M::PPL;
-    HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
-    size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
-    for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
-      uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
-      size_t lds = (size_t)hc * sizeof(uint32_t);
-      int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
-      if (per_cu < 1) per_cu = 1;
-      size_t max_blocks = (size_t)256 * per_cu;
-      size_t tpb = (tiles + max_blocks - 1) / max_blocks;
-      int grid = (int)((tiles + tpb - 1) / tpb);
-      ProfScope ps(c, KID_SCAN);
-      hipLaunchKernelGGL((k_scan<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream, c->d_data,
-                         c->stride, c->n, c->d_hparams + h0 * M::SP, hc, c->mc, c->d_votes + h0);
-      HIPCHK(c, hipGetLastError());
+    if constexpr (requires { M::SPF; }) {  // plane: fp32 pre-filter + exact re-evaluation
+      if (c->opt_filter) {
+        int ppl = c->opt_ppl ? c->opt_ppl : 4;  // measured best (tools/ab_scan.py)
+        if (ppl == 8) return run_scan_plane_f32<M::ND, 8>(c);
+        if (ppl == 16) return run_scan_plane_f32<M::ND, 16>(c);
+        return run_scan_plane_f32<M::ND, 4>(c);
+      }
     }
-    return LSQR_OK;
+    if constexpr (M::REC <= 3) {  // point models: PPL is tunable
+      int ppl = c->opt_ppl ? c->opt_ppl : 8;
+      if (ppl == 2) return run_scan_ppl<M, 2>(c);
+      if (ppl == 8) return run_scan_ppl<M, 8>(c);
+      return run_scan_ppl<M, 4>(c);
+    } else {
+      return run_scan_ppl<M, M::PPL>(c);
+    }
   });
 }
 
@@ -420,6 +486,10 @@ int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t 
   st = dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    if constexpr (M::SP > M::P && !M::IS_DENSE) {
+      hipLaunchKernelGGL((k_prepare<M>), dim3(1), dim3(64), 0, c->stream, c->d_par, c->mc);
+      HIPCHK(c, hipGetLastError());
+    }
     ProfScope ps(c, KID_MASK);
     int grid = grid_for(end - begin, kBlock * 8, 256 * 8);
     hipLaunchKernelGGL((k_mask<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
@@ -533,7 +603,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_valid, c->d_votes, c->d_mask,
+  void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_valid, c->d_votes, c->d_mask,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -602,6 +672,8 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->mc.delta_sq = cfg->delta * cfg->delta;
   c->mc.dim = cfg->dim;
   c->mc.ls_type = cfg->ls_type;
+  c->mc.thr = square_threshold(c->mc.delta_sq);
+  c->mc.absmax = 0.0;
   c->K = lsqr_min_subset(cfg);
   c->P = lsqr_num_params(cfg);
   c->ND = lsqr_record_doubles(cfg);
@@ -621,6 +693,7 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
                 c->ND);
   if (count > 0xFFFFFFF0ull) return fail(c, LSQR_ERR_INVALID, "too many observations");
   c->n = count;
+  c->absmax_valid = false;
   c->stride = stride_bytes / sizeof(double);
   c->H = 0;
   c->scanned = false;
@@ -1194,6 +1267,21 @@ int lsqr_ransac_exhaustive(lsqr_ctx *c, double *params_out, uint8_t *consensus_o
   info->iterations = index;
   info->best_index = best_idx;
   return finish_ransac(c, has, best_params.data(), best, params_out, consensus_out, info);
+}
+
+int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
+  if (!c || !name) return LSQR_ERR_INVALID;
+  if (!strcmp(name, "scan_ppl")) {
+    if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16)
+      return fail(c, LSQR_ERR_INVALID, "scan_ppl must be 0, 2, 4, 8 or 16");
+    c->opt_ppl = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_filter")) {
+    c->opt_filter = value != 0;
+    return LSQR_OK;
+  }
+  return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);
 }
 
 // ---- measurement ------------------------------------------------------------------------------------------

@@ -20,6 +20,79 @@ struct ModelConsts {
   double delta_sq;  // delta*delta as the reference stores it (PlaneParametersEstimator.hxx:16)
   int dim;
   int ls_type;
+  double thr;     // plane: smallest T >= 0 with fl(T*T) >= delta_sq, so that s*s < delta_sq <=> |s| < T
+  double absmax;  // max |coordinate| over the uploaded observations (error band of the fp32 filter)
+};
+
+// Exact restatement of "x*x < q" as "|x| < T" (fl(x*x) is monotone in |x|).
+LSQR_HD double square_threshold(double q) {
+  if (!(q > 0.0)) return 0.0;  // x*x < q is never true for q <= 0 (and for NaN)
+  // smallest non-negative double T with fl(T*T) >= q: bisection over the bit patterns of the
+  // non-negative doubles (their order is the order of their bit patterns)
+  unsigned long long lo = 0ULL, hi = 0x7FEFFFFFFFFFFFFFULL;  // 0.0 (false) .. DBL_MAX
+  double th;
+  __builtin_memcpy(&th, &hi, 8);
+  if (!(th * th >= q)) return INFINITY;  // unreachable for finite q
+  while (hi - lo > 1) {
+    unsigned long long mid = lo + (hi - lo) / 2;
+    double t;
+    __builtin_memcpy(&t, &mid, 8);
+    if (t * t >= q) hi = mid;
+    else lo = mid;
+  }
+  __builtin_memcpy(&th, &hi, 8);
+  return th;
+}
+
+// Bisection over the bit patterns of the non-negative doubles for a monotone predicate.
+LSQR_HD double bits_to_double(unsigned long long b) {
+  double d;
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+}
+// smallest non-negative finite double with pred true (pred: false ... false true ... true);
+// returns +inf when pred(DBL_MAX) is false
+template <class Pred>
+LSQR_HD double first_true(const Pred &pred) {
+  unsigned long long lo = 0ULL, hi = 0x7FEFFFFFFFFFFFFFULL;
+  if (pred(0.0)) return 0.0;
+  if (!pred(bits_to_double(hi))) return INFINITY;
+  while (hi - lo > 1) {
+    unsigned long long mid = lo + (hi - lo) / 2;
+    if (pred(bits_to_double(mid))) hi = mid;
+    else lo = mid;
+  }
+  return bits_to_double(hi);
+}
+// largest non-negative finite double with pred true (pred: true ... true false ... false);
+// returns -1 when pred(0) is false
+template <class Pred>
+LSQR_HD double last_true(const Pred &pred) {
+  unsigned long long lo = 0ULL, hi = 0x7FEFFFFFFFFFFFFFULL;
+  if (!pred(0.0)) return -1.0;
+  if (pred(bits_to_double(hi))) return bits_to_double(hi);
+  while (hi - lo > 1) {
+    unsigned long long mid = lo + (hi - lo) / 2;
+    if (pred(bits_to_double(mid))) lo = mid;
+    else hi = mid;
+  }
+  return bits_to_double(lo);
+}
+struct PredSubLt {  // fl(s - r) < d
+  double r, d;
+  LSQR_HD bool operator()(double s) const { return (s - r) < d; }
+};
+struct PredSubGt {  // fl(s - r) > d
+  double r, d;
+  LSQR_HD bool operator()(double s) const { return (s - r) > d; }
+};
+struct PredSqrtLe {  // fl(sqrt(x)) <= v
+  double v;
+  LSQR_HD bool operator()(double x) const { return sqrt(x) <= v; }
+};
+struct PredSqrtGe {  // fl(sqrt(x)) >= v
+  double v;
+  LSQR_HD bool operator()(double x) const { return sqrt(x) >= v; }
 };
 
 static const double kEPS = 2.220446049250313e-016;  // common/Epsilon.h:19
@@ -68,15 +141,56 @@ struct PlaneModel {
   }
 
   // PlaneParametersEstimator.hxx:196-203
+  // The reference accumulates from 0.0 (0.0 + x == x) and tests s*s < delta^2; |s| < c.thr is the
+  // same predicate (square_threshold) with two fp64 operations fewer per observation.
+  static LSQR_HD double signed_dist(const double *sp, const double *x) {
+    double s = sp[0] * (x[0] - sp[D]);
+    for (int i = 1; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
+    return s;
+  }
   static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
-    double s = 0;
-    for (int i = 0; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
-    return (s * s) < c.delta_sq;
+    return fabs(signed_dist(sp, x)) < c.thr;
   }
   static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) {
-    double s = 0;
-    for (int i = 0; i < D; i++) s += sp[i] * (x[i] - sp[D + i]);
-    return fabs(s);
+    return fabs(signed_dist(sp, x));
+  }
+  static LSQR_HD void prepare(double *, const ModelConsts &) {}
+
+  // ---- fp32 pre-filter (k_scan_plane_f32) ------------------------------------------------------
+  // The filter evaluates s32 = fma(x0,n0, fma(x1,n1, fma(x2,n2, -c))) with c = n.a, all inputs rounded to
+  // fp32.  With u = 2^-24, X = max |coordinate| over the observations, |n_i| <= 1, |a_i| <= X and every
+  // fp32 operation correctly rounded:  |c32 - n.a| <= 2uX;  the innermost fma is off by <= 4uX before and
+  // 7uX after rounding, the next two add (2+4)uX and (2+5)uX  =>  |s32 - n.(x-a)| <= 20uX, and the
+  // reference's fp64 s is within 1e-14 X of n.(x-a).  With E = 2.5e-6 X (> 20uX = 1.2e-6 X):
+  //     |s32| <  T - E  =>  |s| < T   (certainly agrees)
+  //     |s32| >= T + E  =>  |s| >= T  (certainly does not)
+  // and only observations in the band in between are re-evaluated with the exact fp64 formula.
+  enum { SPF = 12 };  // (n0,n0) (n1,n1) (n2,n2) (-c,-c) tin tout 0 0: pairs feed v_pk_* directly
+  static LSQR_HD float round_down_f32(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = nextafterf(f, -INFINITY);
+    return f;
+  }
+  static LSQR_HD float round_up_f32(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = nextafterf(f, INFINITY);
+    return f;
+  }
+  static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
+    const double X = c.absmax;
+    const double E = 2.5e-6 * X;
+    bool ok = X >= 1e-10 && X <= 1e15 && c.thr - E > 1e-30;
+    double cc = 0.0;
+    for (int i = 0; i < 12; i++) f[i] = 0.0f;
+    for (int i = 0; i < D; i++) {
+      ok = ok && fabs(sp[i]) <= 1.0000001 && fabs(sp[D + i]) <= X;
+      f[2 * i] = f[2 * i + 1] = (float)sp[i];
+      cc += sp[i] * sp[D + i];
+    }
+    f[6] = f[7] = -(float)cc;
+    f[8] = ok ? round_down_f32(c.thr - E) : -INFINITY;  // |s32| below: certain inlier
+    f[9] = ok ? round_up_f32(c.thr + E) : INFINITY;     // |s32| at or above: certain outlier
+    if (!(sp[0] == sp[0])) f[8] = f[9] = __builtin_nanf("");  // NaN model: nothing agrees
   }
 
   // moments about `org`: {N, sum x', sum x'x'^T (upper)}  (PlaneParametersEstimator.hxx:141-154
@@ -156,6 +270,7 @@ struct LineModel {
   static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
     return dist_sq(sp, x) < c.delta_sq;
   }
+  static LSQR_HD void prepare(double *, const ModelConsts &) {}
   static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) { return sqrt(dist_sq(sp, x)); }
 
   static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
@@ -170,7 +285,7 @@ struct LineModel {
 // ------------------------------------------------------------------------------------ sphere
 template <int D>
 struct SphereModel {
-  enum { ND = D, K = D + 1, P = D + 1, SP = D + 1, REC = D, PPL = 4, IS_DENSE = 0, IS_US = 0 };
+  enum { ND = D, K = D + 1, P = D + 1, SP = D + 3, REC = D, PPL = 4, IS_DENSE = 0, IS_US = 0 };
   static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
     for (int i = 0; i < D; i++) rec[i] = p[i];
   }
@@ -222,13 +337,57 @@ struct SphereModel {
   }
 
   // SphereParametersEstimator.hxx:255-264 (distance, not squared, against delta)
+  static LSQR_HD double dist_sq(const double *sp, const double *x) {
+    double s = ((x[0] - sp[0]) * (x[0] - sp[0]));
+    for (int i = 1; i < D; i++) s += ((x[i] - sp[i]) * (x[i] - sp[i]));
+    return s;
+  }
   static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) {
-    double s = 0;
-    for (int i = 0; i < D; i++) s += ((x[i] - sp[i]) * (x[i] - sp[i]));
-    return fabs(sqrt(s) - sp[D]);
+    return fabs(sqrt(dist_sq(sp, x)) - sp[D]);
+  }
+  static LSQR_HD bool agree_literal(const double *sp, const double *x, const ModelConsts &c) {
+    return residual(sp, x, c) < c.delta;
+  }
+  // |fl(fl(sqrt(d2)) - r)| < delta holds exactly for d2 in a closed interval [sp[D+1], sp[D+2]] of
+  // doubles (sqrt and s - r are monotone and correctly rounded): prepare() finds its end points
+  // with the same sqrt and subtraction, agree() then needs no sqrt.  sp[D+1] < 0 marks "interval
+  // search did not settle" and selects the literal formula.
+  static LSQR_HD void prepare(double *sp, const ModelConsts &c) {
+    const double r = sp[D], delta = c.delta;
+    sp[D + 1] = -1.0;
+    sp[D + 2] = 0.0;
+    if (!(r == r)) {  // NaN model: never agrees
+      sp[D + 1] = r;
+      sp[D + 2] = r;
+      return;
+    }
+    if (!(delta > 0.0) || !(r >= 0.0) || !(r < 1e300)) return;  // literal formula
+    PredSubLt below = {r, delta};
+    PredSubGt above = {r, -delta};
+    const double shi = last_true(below);   // largest s with fl(s-r) <  delta
+    const double slo = first_true(above);  // smallest s with fl(s-r) > -delta
+    if (shi < 0.0 || !(slo <= shi)) {      // empty set: a NaN interval never agrees
+      sp[D + 1] = sp[D + 2] = __builtin_nan("");
+      return;
+    }
+    PredSqrtLe le = {shi};
+    PredSqrtGe ge = {slo};
+    const double dhi = last_true(le);   // largest d2 with fl(sqrt(d2)) <= shi
+    const double dlo = first_true(ge);  // smallest d2 with fl(sqrt(d2)) >= slo
+    if (dhi < 0.0 || !(dlo <= dhi)) {
+      sp[D + 1] = sp[D + 2] = __builtin_nan("");
+      return;
+    }
+    sp[D + 1] = dlo;
+    sp[D + 2] = dhi;
+  }
+  static LSQR_HD bool use_literal(const double *sp) { return sp[D + 1] < 0.0; }  // per hypothesis
+  static LSQR_HD bool agree_interval(const double *sp, const double *x) {
+    double d2 = dist_sq(sp, x);
+    return (d2 >= sp[D + 1]) & (d2 <= sp[D + 2]);  // no short circuit: both are one v_cmp
   }
   static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
-    return residual(sp, x, c) < c.delta;
+    return use_literal(sp) ? agree_literal(sp, x, c) : agree_interval(sp, x);
   }
 
   // algebraic fit (SphereParametersEstimator.hxx:267-307): rows [-2x, 1], rhs -|x|^2, as

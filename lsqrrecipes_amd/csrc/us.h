@@ -79,6 +79,7 @@ struct USModel {
   static LSQR_HD double residual(const double *par, const double *x, const ModelConsts &) {
     return sqrt(dist_sq(par, x));
   }
+  static LSQR_HD void prepare(double *, const ModelConsts &) {}
 
   // one row (j = 0..2) of the analytic system [u*R2 v*R2 R2 (-I)] x = rhs
   // (...Estimator.cxx:137-190 / :800-836)

@@ -70,6 +70,8 @@ static ModelConsts consts(int dim, double delta, int ls) {
   mc.delta_sq = delta * delta;
   mc.dim = dim;
   mc.ls_type = ls;
+  mc.thr = square_threshold(mc.delta_sq);
+  mc.absmax = 0.0;
   return mc;
 }
 
@@ -88,7 +90,10 @@ int hm_agree(int model, int dim, double delta, const double *par, const double *
   int ok = 0;
   DISPATCH(model, dim, {
     ok = 1;
-    for (size_t i = 0; i < n; i++) mask[i] = M::agree(par, data + i * M::ND, mc) ? 1 : 0;
+    double sp[M::SP];
+    for (int j = 0; j < M::SP; j++) sp[j] = j < M::P ? par[j] : 0.0;
+    M::prepare(sp, mc);
+    for (size_t i = 0; i < n; i++) mask[i] = M::agree(sp, data + i * M::ND, mc) ? 1 : 0;
   });
   return ok;
 }
@@ -120,6 +125,18 @@ int hm_sphere_lm(int dim, const double *data, size_t n, const double *x0, double
   if (dim == 3) return t_lm<SphereModel<3>>(data, n, x0, ftol, xtol, gtol, maxfev, x, info, nfev);
   if (dim == 2) return t_lm<SphereModel<2>>(data, n, x0, ftol, xtol, gtol, maxfev, x, info, nfev);
   return -1;
+}
+
+double hm_square_threshold(double q) { return square_threshold(q); }
+
+// sphere interval thresholds: out = {dlo, dhi}
+void hm_sphere_prepare(int dim, double r, double delta, double *out) {
+  ModelConsts mc = consts(dim, delta, 0);
+  double sp[8] = {0};
+  sp[dim] = r;
+  if (dim == 3) SphereModel<3>::prepare(sp, mc); else SphereModel<2>::prepare(sp, mc);
+  out[0] = sp[dim + 1];
+  out[1] = sp[dim + 2];
 }
 
 void hm_ctr_subset(uint64_t seed, uint64_t h, uint64_t n, int k, uint32_t *idx) {

@@ -217,3 +217,51 @@ def test_us_agree_bit_exact_and_fits(hm, model):
                     C.c_double(tol), 5000, _p(got_it), C.byref(info), C.byref(nfev))
     assert 1 <= iw2 <= 4 and n == len(want) and 1 <= info.value <= 4
     assert np.allclose(got_it, w2, rtol=1e-6, atol=1e-6)
+
+
+def test_square_threshold_is_exact(hm):
+    """|s| < T  <=>  fl(s*s) < q for every double s (checked around the threshold and at random)."""
+    hm.hm_square_threshold.restype = C.c_double
+    g = np.random.default_rng(0)
+    for q in [0.25, 0.5 ** 2, 0.1, 1e-300, 3.0, 1e300, 2.0 ** -1074, 7.3e-310, 0.0, -1.0] + list(g.uniform(0, 10, 50)):
+        T = hm.hm_square_threshold(C.c_double(q))
+        cand = [T]
+        x = T
+        for _ in range(40):
+            x = np.nextafter(x, 0.0)
+            cand.append(x)
+        x = T
+        for _ in range(40):
+            x = np.nextafter(x, np.inf)
+            cand.append(x)
+        cand += list(g.uniform(0, 2 * max(T, 1e-3), 200))
+        for s in cand:
+            with np.errstate(over="ignore", under="ignore"):
+                assert (np.float64(s) * np.float64(s) < q) == (abs(s) < T), (q, s, T)
+
+
+def test_sphere_interval_thresholds_are_exact(hm):
+    """d2 in [dlo, dhi]  <=>  |sqrt(d2) - r| < delta, for doubles around both ends and at random."""
+    g = np.random.default_rng(1)
+    cases = [(2.0, 0.5), (123.456, 0.5), (0.3, 0.5), (1e6, 1e-3), (1e-3, 1e-9), (777.7, 20.0),
+             (5.0, 5.0), (0.0, 0.5)] + [(float(r), float(d)) for r, d in zip(g.uniform(0, 2000, 60), g.uniform(1e-3, 3, 60))]
+    for r, delta in cases:
+        out = np.zeros(2)
+        hm.hm_sphere_prepare(3, C.c_double(r), C.c_double(delta), _p(out))
+        dlo, dhi = out
+        assert dlo >= 0, (r, delta)   # interval search settled
+        cand = []
+        for e in (dlo, dhi):
+            x = e
+            for _ in range(30):
+                cand.append(x)
+                x = np.nextafter(x, np.inf)
+            x = e
+            for _ in range(30):
+                x = np.nextafter(x, -np.inf)
+                if x >= 0:
+                    cand.append(x)
+        cand += list(g.uniform(0, (r + 3 * delta) ** 2, 300))
+        for d2 in cand:
+            lit = abs(np.sqrt(np.float64(d2)) - r) < delta
+            assert lit == (dlo <= d2 <= dhi), (r, delta, d2, dlo, dhi)

@@ -1,0 +1,74 @@
+// microbench.hip -- issue rate of the VALU instructions the scan kernels are made of, measured on
+// the whole chip (every SIMD busy) so the numbers are directly comparable with k_scan's op roof.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip ; run on the GPU box
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define ITERS 4096
+template <int OP>
+__global__ __launch_bounds__(256) void bench(double *out, double a, double b, float fa, float fb) {
+  double x0 = threadIdx.x * 1e-3, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  float f0 = threadIdx.x * 1e-3f, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3, f4 = f0 + 4, f5 = f0 + 5, f6 = f0 + 6, f7 = f0 + 7;
+  v2f p0 = {f0, f1}, p1 = {f2, f3}, p2 = {f4, f5}, p3 = {f6, f7}, p4 = p0 + 1.f, p5 = p1 + 1.f, p6 = p2 + 1.f, p7 = p3 + 1.f;
+  unsigned cnt = 0;
+  for (int i = 0; i < ITERS; i++) {
+    if (OP == 0) { asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a)); }
+    if (OP == 1) { asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(b)); }
+    if (OP == 2) { asm volatile("v_fma_f64 %0, %0, %8, %0\n v_fma_f64 %1, %1, %8, %1\n v_fma_f64 %2, %2, %8, %2\n v_fma_f64 %3, %3, %8, %3\n v_fma_f64 %4, %4, %8, %4\n v_fma_f64 %5, %5, %8, %5\n v_fma_f64 %6, %6, %8, %6\n v_fma_f64 %7, %7, %8, %7" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(b)); }
+    if (OP == 3) { asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "s"(fa)); }
+    if (OP == 4) { asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "s"(fb)); }
+    if (OP == 5) { asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(a)); }
+    if (OP == 6) { asm volatile("v_pk_fma_f32 %0, %0, %8, %0\n v_pk_fma_f32 %1, %1, %8, %1\n v_pk_fma_f32 %2, %2, %8, %2\n v_pk_fma_f32 %3, %3, %8, %3\n v_pk_fma_f32 %4, %4, %8, %4\n v_pk_fma_f32 %5, %5, %8, %5\n v_pk_fma_f32 %6, %6, %8, %6\n v_pk_fma_f32 %7, %7, %8, %7" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(b)); }
+    if (OP == 7) { unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+      asm volatile("v_cmp_lt_f64 %0, %8, %16\n v_cmp_lt_f64 %1, %9, %16\n v_cmp_lt_f64 %2, %10, %16\n v_cmp_lt_f64 %3, %11, %16\n v_cmp_lt_f64 %4, %12, %16\n v_cmp_lt_f64 %5, %13, %16\n v_cmp_lt_f64 %6, %14, %16\n v_cmp_lt_f64 %7, %15, %16" : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3), "=s"(m4), "=s"(m5), "=s"(m6), "=s"(m7) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "s"(a));
+      cnt += __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3) + __builtin_popcountll(m4) + __builtin_popcountll(m5) + __builtin_popcountll(m6) + __builtin_popcountll(m7); }
+    if (OP == 8) { unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+      asm volatile("v_cmp_lt_f32 %0, %8, %16\n v_cmp_lt_f32 %1, %9, %16\n v_cmp_lt_f32 %2, %10, %16\n v_cmp_lt_f32 %3, %11, %16\n v_cmp_lt_f32 %4, %12, %16\n v_cmp_lt_f32 %5, %13, %16\n v_cmp_lt_f32 %6, %14, %16\n v_cmp_lt_f32 %7, %15, %16" : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3), "=s"(m4), "=s"(m5), "=s"(m6), "=s"(m7) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7), "s"(fa));
+      cnt += __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3) + __builtin_popcountll(m4) + __builtin_popcountll(m5) + __builtin_popcountll(m6) + __builtin_popcountll(m7); }
+    if (OP == 10) { unsigned c0;
+      asm volatile("v_cmp_lt_f64 vcc, %1, %9\n s_bcnt1_i32_b64 %0, vcc\n v_cmp_lt_f64 vcc, %2, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f64 vcc, %3, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f64 vcc, %4, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f64 vcc, %5, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f64 vcc, %6, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f64 vcc, %7, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f64 vcc, %8, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60" : "=s"(c0) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "s"(a) : "vcc", "s60", "scc");
+      cnt += c0; }
+    if (OP == 11) { unsigned c0;
+      asm volatile("v_cmp_lt_f32 vcc, %1, %9\n s_bcnt1_i32_b64 %0, vcc\n v_cmp_lt_f32 vcc, %2, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f32 vcc, %3, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f32 vcc, %4, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f32 vcc, %5, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f32 vcc, %6, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f32 vcc, %7, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60\n v_cmp_lt_f32 vcc, %8, %9\n s_bcnt1_i32_b64 s60, vcc\n s_add_u32 %0, %0, s60" : "=s"(c0) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7), "s"(fa) : "vcc", "s60", "scc");
+      cnt += c0; }
+    if (OP == 12) { unsigned c0 = 0, t;
+      asm volatile("v_add_co_u32 %1, vcc, %2, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %3, %3\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %4, %4\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %5, %5\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %6, %6\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %7, %7\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %8, %8\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_add_co_u32 %1, vcc, %9, %9\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(c0), "=&v"(t) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7) : "vcc");
+      cnt += c0; }
+    if (OP == 13) { // 4 independent arithmetic ops between compares: is the compare cost hidden?
+      unsigned long long m0, m1;
+      asm volatile("v_cmp_lt_f64 %0, %2, %10\n v_add_f64 %2, %2, %10\n v_add_f64 %3, %3, %10\n v_add_f64 %4, %4, %10\n v_add_f64 %5, %5, %10\n v_cmp_lt_f64 %1, %6, %10\n v_add_f64 %6, %6, %10\n v_add_f64 %7, %7, %10\n v_add_f64 %8, %8, %10\n v_add_f64 %9, %9, %10" : "=s"(m0), "=s"(m1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a));
+      cnt += __builtin_popcountll(m0) + __builtin_popcountll(m1); }
+    if (OP == 9) { asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(b)); }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y + cnt;
+}
+template <int OP>
+void run(const char *name, int lanes_per_inst, double *d, int blocks_per_cu) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  int grid = 256 * blocks_per_cu;
+  bench<OP><<<grid, 256>>>(d, 1e-9, 1.0000001, 1e-9f, 1.0000001f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < 5; r++) bench<OP><<<grid, 256>>>(d, 1e-9, 1.0000001, 1e-9f, 1.0000001f);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  double inst = (double)grid * 4 /*waves*/ * ITERS * 8;              // wave-instructions
+  double per_simd_cycles = ms * 1e-3 * 2.4e9 / (inst / 1024.0);       // cycles at 2.4 GHz nominal per wave-instruction per SIMD
+  printf("%-14s blocks/CU %d: %.3f ms  %.2f Tinst-lanes/s  (%.2f nominal cycles per wave-instruction per SIMD)\n", name, blocks_per_cu, ms, inst * 64 * (lanes_per_inst / 64.0) / (ms * 1e-3) / 1e12, per_simd_cycles);
+}
+int main() {
+  double *d; hipMalloc(&d, sizeof(double) * 256 * 256 * 8);
+  for (int b : {8, 2}) {
+    run<0>("v_add_f64", 64, d, b); run<1>("v_mul_f64", 64, d, b); run<2>("v_fma_f64", 64, d, b);
+    run<3>("v_add_f32", 64, d, b); run<4>("v_fma_f32", 64, d, b);
+    run<5>("v_pk_add_f32", 128, d, b); run<9>("v_pk_mul_f32", 128, d, b); run<6>("v_pk_fma_f32", 128, d, b);
+    run<7>("v_cmp_lt_f64", 64, d, b); run<8>("v_cmp_lt_f32", 64, d, b);
+    run<10>("cmp64vcc+bcnt", 64, d, b); run<11>("cmp32vcc+bcnt", 64, d, b); run<12>("addco+addc x8", 128, d, b);
+    run<13>("2cmp+8add f64", 80, d, b);
+    printf("\n");
+  }
+  return 0;
+}
