@@ -29,6 +29,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_GOPS = 39321.6  # 256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz: fp64 add/mul issue rate
 #                                (= the 78.6 TFLOP/s vector fp64 peak counting an FMA as one op;
 #                                the bit-exact agree() may not fuse, so this is its op roof)
+FP64_VALU_MEASURED_GOPS = 33000.0  # tools/microbench.hip on this pool: v_add_f64 / v_mul_f64 with
+#                                    every SIMD busy (4.8 nominal cycles per wave instruction)
 
 
 def parse():
@@ -38,7 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=4096, help="hypotheses per GPU per step")
-    ap.add_argument("--workload", default="plane", choices=["plane", "sphere", "line"])
+    ap.add_argument("--workload", default="plane",
+                    choices=["plane", "sphere", "line", "dense", "us"])
+    ap.add_argument("--no-filter", action="store_true", help="plain fp64 scan (no fp32 pre-filter)")
     ap.add_argument("--outliers", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="observations for the CPU leg "
@@ -52,10 +56,15 @@ def make_data(workload, n, outliers):
         return synth.plane(n, outliers)
     if workload == "sphere":
         return synth.sphere(n, outliers)
-    return synth.line(n, outliers)
+    if workload == "line":
+        return synth.line(n, outliers)
+    if workload == "dense":
+        return synth.dense(n, 64, 0.05)
+    return synth.us_single_fast(n, outliers)
 
 
-OPS_PER_PAIR = {"plane": 11, "sphere": 22, "line": 24}  # fp64 VALU instructions in agree()
+# fp64 VALU instructions of the exact agree() per (hypothesis, observation) pair: arithmetic + compares
+OPS_PER_PAIR = {"plane": 9, "sphere": 10, "line": 20, "dense": 130, "us": 69}
 
 
 def cpu_baseline(workload, data, delta):
@@ -63,8 +72,9 @@ def cpu_baseline(workload, data, delta):
     reference's own RANSAC.hxx (oracle/_ref, compiled from /root/reference in the build
     container) driving the restated estimator; falls back to the oracle's C port of the loop."""
     from oracle import pyoracle as O
-    model = {"plane": O.PLANE, "sphere": O.SPHERE, "line": O.LINE}[workload]
-    c = O.cfg(model, 3, delta, O.LS_ALGEBRAIC)
+    model = {"plane": O.PLANE, "sphere": O.SPHERE, "line": O.LINE, "dense": O.DENSE,
+             "us": O.US_SINGLE}[workload]
+    c = O.cfg(model, 64 if workload == "dense" else 3, delta, O.LS_ALGEBRAIC)
     cores = 1
     t0 = time.perf_counter()
     if O.ref_available():
@@ -103,12 +113,15 @@ def main():
     from lsqrrecipes_amd.context import Context
     from lsqrrecipes_amd.distributed import Comm, ShardedRansac
 
-    delta = 0.5
-    model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE}[a.workload]
-    ls_type = L.LS_GEOMETRIC
+    delta = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0}[a.workload]
+    model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE, "dense": L.DENSE,
+             "us": L.US_SINGLE}[a.workload]
+    ls_type = L.LS_ANALYTIC if a.workload == "us" else L.LS_GEOMETRIC
     data, truth, lab = make_data(a.workload, a.points, a.outliers)
     ctx = Context(local)
-    ctx.set_model(model, 3, delta, ls_type).upload(data)
+    ctx.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
+    if a.no_filter:
+        ctx.set_option("scan_filter", 0)
     comm = Comm(dist, device)
     eng = ShardedRansac(ctx, comm)
     H = a.batch
@@ -160,6 +173,8 @@ def main():
         alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs_per_s = float(H) * a.points / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
+        filtered = a.workload == "plane" and not a.no_filter
+        eq_gops = pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tfile):
@@ -177,27 +192,36 @@ def main():
             "config": {"workload": "%sParametersEstimator + RANSAC, %d points, %d%% outliers, "
                                    "delta=%.2f (BASELINE.json configs[1])" % (
                                        a.workload.capitalize(), a.points, round(a.outliers * 100), delta)
-                       if a.workload == "plane" else "%s, %d points" % (a.workload, a.points),
+                       if a.workload == "plane" else "%s estimator + RANSAC, %d observations" % (
+                           a.workload, a.points),
                        "points": a.points, "hypotheses_per_gpu_per_step": H,
                        "record_bytes": rec, "parallelism": "hypotheses sharded over %d GPU(s), "
                        "observations replicated" % a.gpus},
             "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),
                           "params": [float(x) for x in fit],
                           "abs_dot_true_normal": float(abs(np.dot(fit[:3], truth[:3])))
-                          if a.workload != "sphere" else None,
+                          if a.workload in ("plane", "line") else None,
                           "residual_min_max_mean_sumsq": [float(x) for x in res] if res is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_scan<%s>" % a.workload,
+                         "kernel": ("k_scan_plane_f32 (fp32 pre-filter + exact fp64 re-check)"
+                                    if filtered else "k_scan<%s> (exact fp64)" % a.workload),
                          "launch_ms": scan_ms, "launches": int(n_scan),
                          "note": "achieved = algorithmic bytes (H*N*%d B per launch, SURVEY 8d) / "
                                  "launch time; the batched scan reads the observations once per "
-                                 "launch for all H hypotheses, so it is bound by fp64 VALU issue, "
-                                 "see valu_fp64" % rec,
-                         "valu_fp64": {"achieved_gops": pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9,
-                                       "peak_gops": FP64_VALU_PEAK_GOPS,
-                                       "frac": pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9 / FP64_VALU_PEAK_GOPS,
-                                       "ops_per_pair": OPS_PER_PAIR[a.workload]}},
+                                 "launch for all H hypotheses, so it is bound by VALU issue, not "
+                                 "HBM: see valu" % rec,
+                         "valu": {"pairs_per_s": pairs_per_s,
+                                  "exact_fp64_ops_per_pair": OPS_PER_PAIR[a.workload],
+                                  "exact_equivalent_gops": eq_gops,
+                                  "fp64_issue_peak_gops": FP64_VALU_PEAK_GOPS,
+                                  "fp64_issue_measured_gops": FP64_VALU_MEASURED_GOPS,
+                                  "frac_of_peak": eq_gops / FP64_VALU_PEAK_GOPS,
+                                  "frac_of_measured_issue_rate": eq_gops / FP64_VALU_MEASURED_GOPS,
+                                  "note": ("the fp32 pre-filter decides most pairs without the "
+                                           "exact fp64 formula, so the exact-equivalent rate may "
+                                           "exceed the fp64 issue roof") if filtered else
+                                          "exact fp64 path: fraction of the fp64 add/mul issue rate"}},
             "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
                            "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1)},
         }

@@ -159,20 +159,24 @@ __global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restr
   __syncthreads();
   const size_t tile = (size_t)kBlock * PPL;
   const bool leader = (threadIdx.x & 63) == 0;
-  const float fnan = __builtin_nanf("");
   for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
-    // only the fp32 copies stay in registers; the rare exact path re-reads the fp64 records
+    // fp64 records (exact re-check) and their fp32 copies (filter) both stay in registers
+    double rec[PPL][D];
     v2f xs[PPL / 2][3];
 #pragma unroll
-    for (int q = 0; q < PPL / 2; q++) {
-      size_t i0 = base + (size_t)(2 * q) * kBlock + threadIdx.x, i1 = i0 + kBlock;
-      const double *p0 = data + (i0 < n ? i0 : 0) * stride, *p1 = data + (i1 < n ? i1 : 0) * stride;
+    for (int j = 0; j < PPL; j++) {
+      size_t i = base + (size_t)j * kBlock + threadIdx.x;
+      const double *p = data + (i < n ? i : 0) * stride;
+#pragma unroll
+      for (int d = 0; d < D; d++) rec[j][d] = i < n ? p[d] : __builtin_nan("");  // never agrees
+    }
+#pragma unroll
+    for (int q = 0; q < PPL / 2; q++)
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        xs[q][d].x = d < D ? (i0 < n ? (float)p0[d] : fnan) : 0.0f;  // NaN never passes a '<'
-        xs[q][d].y = d < D ? (i1 < n ? (float)p1[d] : fnan) : 0.0f;
+        xs[q][d].x = d < D ? (float)rec[2 * q][d] : 0.0f;  // NaN stays NaN: never passes a '<'
+        xs[q][d].y = d < D ? (float)rec[2 * q + 1][d] : 0.0f;
       }
-    }
     for (uint32_t h = 0; h < H; h++) {
       const v2f *f = (const v2f *)(spf + (size_t)h * M::SPF);  // wave-uniform -> scalar loads
       const v2f n0 = f[0], n1 = f[1], n2 = f[2], cneg = f[3];
@@ -202,14 +206,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restr
       if (amb) {  // rare, wave-uniform: exact fp64 predicate for this tile and hypothesis
         const double *hp = sp + (size_t)h * M::SP;
         c = 0;
-        for (int j = 0; j < PPL; j++) {
-          size_t i = base + (size_t)j * kBlock + threadIdx.x;
-          bool in = i < n;
-          double x[D];
-          const double *p = data + (in ? i : 0) * stride;
-          for (int d = 0; d < D; d++) x[d] = p[d];
-          c += (uint32_t)__builtin_popcountll(__ballot(in && M::agree(hp, x, mc)));
-        }
+#pragma unroll
+        for (int j = 0; j < PPL; j++)
+          c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
       }
       if (leader && c) atomicAdd(&s_cnt[h], c);
     }

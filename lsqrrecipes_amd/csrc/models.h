@@ -157,11 +157,13 @@ struct PlaneModel {
   static LSQR_HD void prepare(double *, const ModelConsts &) {}
 
   // ---- fp32 pre-filter (k_scan_plane_f32) ------------------------------------------------------
-  // The filter evaluates s32 = fma(x0,n0, fma(x1,n1, fma(x2,n2, -c))) with c = n.a, all inputs rounded to
-  // fp32.  With u = 2^-24, X = max |coordinate| over the observations, |n_i| <= 1, |a_i| <= X and every
-  // fp32 operation correctly rounded:  |c32 - n.a| <= 2uX;  the innermost fma is off by <= 4uX before and
-  // 7uX after rounding, the next two add (2+4)uX and (2+5)uX  =>  |s32 - n.(x-a)| <= 20uX, and the
-  // reference's fp64 s is within 1e-14 X of n.(x-a).  With E = 2.5e-6 X (> 20uX = 1.2e-6 X):
+  // The filter evaluates s32 = fma(x0,n0, fma(x1,n1, fma(x2,n2, -c))) with c = n.a, all inputs rounded
+  // to fp32 (u = 2^-24, every fp32 operation correctly rounded, X = max |coordinate| over the
+  // observations, so |x_i| <= X).  Per hypothesis:
+  //   inputs   |x32_i n32_i - x_i n_i| <= 2u|n_i|X (+u^2),  |c32 - c| <= u|c|
+  //   roundings of the three fma results: u(X|n2| + |c|), u(X(|n1|+|n2|) + |c|), u|s32| (negligible)
+  //   =>  |s32 - n.(x-a)| <= u [ X (2 sum|n_i| + |n1| + 2|n2|) + 3|c| ] =: B
+  // and the reference's fp64 s is within 1e-14 X of n.(x-a).  With E = 1.01 B + 1e-12 X:
   //     |s32| <  T - E  =>  |s| < T   (certainly agrees)
   //     |s32| >= T + E  =>  |s| >= T  (certainly does not)
   // and only observations in the band in between are re-evaluated with the exact fp64 formula.
@@ -177,16 +179,20 @@ struct PlaneModel {
     return f;
   }
   static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
-    const double X = c.absmax;
-    const double E = 2.5e-6 * X;
-    bool ok = X >= 1e-10 && X <= 1e15 && c.thr - E > 1e-30;
-    double cc = 0.0;
+    const double X = c.absmax, u = 5.9604644775390625e-08;
+    double cc = 0.0, s1 = 0.0;
     for (int i = 0; i < 12; i++) f[i] = 0.0f;
+    bool ok = X >= 1e-10 && X <= 1e15;
     for (int i = 0; i < D; i++) {
       ok = ok && fabs(sp[i]) <= 1.0000001 && fabs(sp[D + i]) <= X;
       f[2 * i] = f[2 * i + 1] = (float)sp[i];
       cc += sp[i] * sp[D + i];
+      s1 += fabs(sp[i]);
     }
+    const double n1 = fabs(sp[1]), n2 = D == 3 ? fabs(sp[D - 1]) : 0.0;
+    const double B = u * (X * (2.0 * s1 + (D == 3 ? n1 + 2.0 * n2 : n1)) + 3.0 * fabs(cc));
+    const double E = 1.01 * B + 1e-12 * X;
+    ok = ok && c.thr - E > 1e-30;
     f[6] = f[7] = -(float)cc;
     f[8] = ok ? round_down_f32(c.thr - E) : -INFINITY;  // |s32| below: certain inlier
     f[9] = ok ? round_up_f32(c.thr + E) : INFINITY;     // |s32| at or above: certain outlier

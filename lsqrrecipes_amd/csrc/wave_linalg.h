@@ -70,7 +70,9 @@ __device__ inline int wave_pinv_solve(int m, int n, double *A, int lda, double *
       al += __shfl_xor(al, 1);
       be += __shfl_xor(be, 1);
       ga += __shfl_xor(ga, 1);
-      bool rot = active && ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be);
+      // columns count as orthogonal once their cosine is at the rounding floor of an m-term dot
+      // product (a tighter bound only re-rotates noise until the sweep limit)
+      bool rot = active && ga != 0.0 && fabs(ga) > 4e-15 * sqrt(al * be);
       if (rot) {
         double zeta = (be - al) / (2.0 * ga);
         double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

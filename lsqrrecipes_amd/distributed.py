@@ -91,22 +91,26 @@ class ShardedRansac:
     def fit(self, params):
         """Consensus mask of `params` + final least-squares fit, observation range sharded."""
         e, c = self.e, self.c
-        import ctypes as C
         from . import _lib as L
         lo, hi = slice_bounds(e.n, c.rank, c.world)
         _, cnt = e.mask(params, lo, hi, want_mask=False)
-        sphere = e.cfg.model == L.SPHERE
-        origin = params[:e.ND] if sphere else params[e.ND:2 * e.ND]
+        model = e.cfg.model
+        if model == L.SPHERE:
+            origin = np.asarray(params[:e.ND])
+        elif model in (L.PLANE, L.LINE):
+            origin = np.asarray(params[e.ND:2 * e.ND])
+        else:
+            origin = np.zeros(3)  # dense / US blocks are not taken about an origin
         block = c.allreduce_sum_f64(e.moments(origin, lo, hi, phase=0, use_mask=True))
         fit, info = e.solve_moments(block, origin)
-        nfev = 0
-        if len(fit) and sphere and e.cfg.ls_type == L.LS_GEOMETRIC:
+        iterative = (model == L.SPHERE and e.cfg.ls_type == L.LS_GEOMETRIC) or (
+            model in (L.US_SINGLE, L.US_POINTER) and e.cfg.ls_type == L.LS_ITERATIVE)
+        if len(fit) and iterative:
             xt = e.lm_begin(fit)
             while True:
                 blk = c.allreduce_sum_f64(e.moments(xt[:e.P], lo, hi, phase=1, use_mask=True))
                 cont, xt, fit, info = e.lm_step(blk)
-                nfev += 1
                 if not cont:
                     break
-        total = int(round(block[0]))
+        total = int(round(c.allreduce_sum_f64([float(cnt)])[0]))
         return fit, total, info
