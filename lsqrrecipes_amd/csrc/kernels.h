@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restr
       const v2f n0 = f[0], n1 = f[1], n2 = f[2], cneg = f[3];
       const float tin = f[4].x, tout = f[4].y;
       v2f a[PPL / 2];
-      unsigned long long any = 0;
+      unsigned long long may[PPL], any = 0;
 #pragma unroll
       for (int q = 0; q < PPL / 2; q++) {
         v2f s = cneg;
@@ -190,18 +190,19 @@ __global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restr
         s = __builtin_elementwise_fma(xs[q][1], n1, s);
         s = __builtin_elementwise_fma(xs[q][0], n0, s);
         a[q] = s;
-        any |= __ballot(__builtin_fabsf(s.x) < tout) | __ballot(__builtin_fabsf(s.y) < tout);
+        may[2 * q] = __ballot(__builtin_fabsf(s.x) < tout);
+        may[2 * q + 1] = __ballot(__builtin_fabsf(s.y) < tout);
+        any |= may[2 * q] | may[2 * q + 1];
       }
       if (any == 0) continue;  // wave-uniform: no observation of this tile is near the plane
       uint32_t c = 0;
       unsigned long long amb = 0;
 #pragma unroll
       for (int q = 0; q < PPL / 2; q++) {
-        float s0 = __builtin_fabsf(a[q].x), s1 = __builtin_fabsf(a[q].y);
-        unsigned long long in0 = __ballot(s0 < tin), in1 = __ballot(s1 < tin);
-        unsigned long long may0 = __ballot(s0 < tout), may1 = __ballot(s1 < tout);
+        unsigned long long in0 = __ballot(__builtin_fabsf(a[q].x) < tin);
+        unsigned long long in1 = __ballot(__builtin_fabsf(a[q].y) < tin);
         c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
-        amb |= (in0 ^ may0) | (in1 ^ may1);
+        amb |= (in0 ^ may[2 * q]) | (in1 ^ may[2 * q + 1]);
       }
       if (amb) {  // rare, wave-uniform: exact fp64 predicate for this tile and hypothesis
         const double *hp = sp + (size_t)h * M::SP;
