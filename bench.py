@@ -103,7 +103,8 @@ def main():
         a.gpus = world
     dist = None
     device = "cpu"
-    if a.gpus > 1:
+    force_dist = os.environ.get("LSQR_FORCE_DIST") == "1"  # exercise the RCCL path at world size 1
+    if a.gpus > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -131,7 +132,7 @@ def main():
         votes, gidx, par = eng.batch(seed, i, H)
         if gidx is None:
             return None
-        if comm.world == 1:
+        if comm.world == 1 and not force_dist:
             # single GPU: mask + fit stay on the device end to end
             _, cnt = ctx.mask(par, want_mask=False)
             fit, info = ctx.ls_fit(use_mask=True)
@@ -141,7 +142,7 @@ def main():
 
     def sync():
         ctx.synchronize()
-        if a.gpus > 1:
+        if dist is not None:
             import torch
             torch.cuda.synchronize()
         comm.barrier()
@@ -167,7 +168,7 @@ def main():
         total_hyp = H * a.gpus * a.steps
         value = total_hyp / dt
         votes, fit, cnt = last
-        res = ctx.stats(fit, use_mask=True) if comm.world == 1 else None
+        res = ctx.stats(fit, use_mask=True) if (comm.world == 1 and not force_dist) else None
         rec = data.shape[1] * 8
         scan_ms = ms_scan / max(n_scan, 1)
         alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis

@@ -521,3 +521,148 @@ def test_crosswire_experimental_data_on_device(ctx, golden_dir):
     want = O.ls(O.cfg(O.US_SINGLE, 0, 3.0, 1), rec)
     if len(want) and len(got):
         assert np.allclose(got, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+# ------------------------------------------------------------------------------- edge cases / ABI
+def test_large_batch_is_chunked(ctx):
+    """H larger than one scan launch's LDS counter block (8192): votes must be identical to
+    per-chunk evaluation, and H = 1 works."""
+    data = synth.plane(30_000, 0.5, seed=17)[0]
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    H = 20_000
+    subs = ctx.hypotheses_sample(3, 0, H, want_subsets=True)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in (0, 8191, 8192, 16383, 16384, H - 1):
+        assert votes[h] == O.scan(oc, par[h], data)[0]
+    _, bv, bi = ctx.best()
+    assert bv == votes.max() and bi == int(np.argmax(votes))
+    ctx.hypotheses_from_subsets(subs[123:124])
+    ctx.scan()
+    _, _, v1 = ctx.hypotheses()
+    assert v1[0] == votes[123]
+
+
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3)])
+def test_filter_and_plain_scan_agree(ctx, model, dim):
+    """the fp32 pre-filter (plane) and every observations-per-lane variant give identical votes"""
+    data = _data(model, dim, 200_003, 4321, outliers=0.5)
+    ctx.set_model(model, dim, 0.5).upload(data)
+    ctx.hypotheses_sample(11, 0, 700)
+    ref = None
+    for ppl, filt in ((0, 1), (4, 0), (8, 0), (2, 0), (8, 1), (16, 1)):
+        ctx.set_option("scan_ppl", ppl)
+        ctx.set_option("scan_filter", filt)
+        ctx.scan()
+        _, _, votes = ctx.hypotheses(params=False)
+        if ref is None:
+            ref = votes.copy()
+        assert np.array_equal(votes, ref), (ppl, filt)
+    ctx.set_option("scan_ppl", 0)
+    ctx.set_option("scan_filter", 1)
+    oc = O.cfg(model, dim, 0.5)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in range(0, 700, 97):
+        assert ref[h] == O.scan(oc, par[h], data)[0]
+
+
+def test_filter_boundary_stress(ctx):
+    """observations placed within a few fp32 ulps of the plane band edge (|s| ~ delta) and huge
+    coordinates: the filter must route them to the exact path, votes stay bit-exact."""
+    g = np.random.default_rng(5)
+    n0 = np.array([0.36, 0.48, 0.8])
+    a0 = np.array([900.0, -700.0, 650.0])
+    base = g.uniform(-1000, 1000, (60_000, 3))
+    base -= ((base - a0) @ n0)[:, None] * n0            # on the plane
+    off = np.where(g.random(60_000) < 0.5, 0.5, -0.5) * (1 + g.integers(-40, 41, 60_000) * 1e-7)
+    pts = np.ascontiguousarray(base + off[:, None] * n0)
+    pts[:3] = [a0, a0 + np.array([1.0, 0, -0.45]) * 300, a0 + np.array([0, 1.0, -0.6]) * 300]
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(pts)
+    subs = np.vstack([[0, 1, 2], O.ctr_subsets(4, 0, 63, len(pts), 3)]).astype(np.uint32)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    assert abs(abs(par[0][:3] @ n0) - 1) < 1e-9
+    for h in range(64):
+        if valid[h]:
+            assert votes[h] == O.scan(oc, par[h], pts)[0]
+    assert 0.2 < votes[0] / len(pts) < 0.8
+    # coordinates beyond the filter's validated range: it must switch itself off, not misclassify
+    big = pts * 1e16
+    ctx.set_model(L.PLANE, 3, 0.5e16).upload(big)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    ocb = O.cfg(O.PLANE, 3, 0.5e16)
+    for h in (0, 5, 9):
+        if valid[h]:
+            assert votes[h] == O.scan(ocb, par[h], big)[0]
+
+
+ATTACH_SCRIPT = r"""
+import sys, numpy as np, torch
+torch.cuda.init()                      # torch's HIP runtime must come up before the library's
+sys.path.insert(0, %r)
+from lsqrrecipes_amd import _lib as L, synth
+from lsqrrecipes_amd.context import Context
+from oracle import pyoracle as O
+data = synth.sphere(50_000, 0.4, seed=9)[0]
+t = torch.from_numpy(data).to("cuda:0")
+oc = O.cfg(O.SPHERE, 3, 0.5, O.LS_ALGEBRAIC)
+with Context(0) as c1, Context(0) as c2:
+    c1.set_model(L.SPHERE, 3, 0.5, L.LS_ALGEBRAIC).attach(t.data_ptr(), len(data), 24, keepalive=t)
+    c2.set_model(L.PLANE, 3, 0.5).upload(synth.plane(10_000, 0.3, seed=1)[0])
+    r1 = c1.ransac(0.99, seed=4)
+    r2 = c2.ransac(0.99, seed=4)
+    w1 = O.ransac(oc, data, 0.99, sampler="ctr", seed=4)
+    assert np.array_equal(r1["consensus"], w1["consensus"]) and r1["info"].iterations == w1["iters"]
+    assert len(r2["params"]) == 6
+print("attach ok")
+"""
+
+
+def test_attach_device_memory_and_two_contexts():
+    """lsqr_attach adopts a device pointer (a torch tensor's storage); contexts are independent.
+    Runs in its own process: torch bundles its own HIP runtime, which has to initialise first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", ATTACH_SCRIPT % root], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "attach ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_call_order_errors(ctx):
+    with Context(0) as c:
+        with pytest.raises(L.LsqrError) as e:
+            c.upload(np.zeros((4, 3)))           # no model yet
+        assert e.value.status == L.ERR_STATE
+        c.set_model(L.PLANE, 3, 0.5)
+        with pytest.raises(L.LsqrError):
+            c.n = 0
+            c.scan()                              # no data
+        c.upload(synth.plane(100, 0.1)[0])
+        with pytest.raises(L.LsqrError):
+            c.scan()                              # no hypotheses
+        with pytest.raises(L.LsqrError):
+            c.ls_fit(use_mask=True)               # no mask
+        with pytest.raises(L.LsqrError):
+            c._chk(c._lib.lsqr_upload(c._h, None, 10, 20))   # stride not a multiple of 8 / too small
+        with pytest.raises(L.LsqrError):
+            c.set_option("no_such_option", 1)
+
+
+def test_profile_counters(ctx):
+    data = synth.plane(100_000, 0.5, seed=2)[0]
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    ctx.profile(True)
+    ctx.hypotheses_sample(1, 0, 256)
+    ctx.scan()
+    ctx.scan()
+    n, ms = ctx.profile_get("scan")
+    assert n == 2 and ms > 0
+    n, ms = ctx.profile_get("estimate")
+    assert n == 1
+    ctx.profile(False)
