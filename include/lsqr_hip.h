@@ -203,7 +203,9 @@ LSQR_API void lsqr_dedup_destroy(void *set);
 /* ---- tuning knobs (A/B measurements inside one process; defaults are the tuned values) --------- */
 /* "scan_ppl": observations per lane in k_scan (2, 4 or 8; 0 = model default);
  * "scan_filter": 1 = fp32 pre-filter + exact fp64 re-evaluation of ambiguous observations
- *                (bit-identical votes), 0 = plain fp64 scan. */
+ *                (bit-identical votes), 0 = plain fp64 scan;
+ * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS
+ *                (k_scan_dense_t), 0 = rows in registers, hypotheses through the scalar cache. */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -75,6 +75,72 @@ __global__ __launch_bounds__(64) void k_estimate_dense(const double *__restrict_
   if (lane == 0) valid[h] = ok ? 1 : 0;
 }
 
+// K2 dense, transposed: one hypothesis per LANE (its x in VGPRs, its own vote counter), the rows of
+// a tile staged once per workgroup in LDS (coalesced 16-byte loads) and broadcast to every lane with
+// uniform-address ds_read_b128.  No scalar loads, ballots or per-hypothesis atomics in the loop; the
+// per-pair arithmetic is the reference's (running sum of a_i*x_i from 0, minus b, |.| < delta).
+constexpr int kDenseTile = 32;  // rows per LDS tile
+
+template <int NR>
+__global__ __launch_bounds__(256) void k_scan_dense_t(const double *__restrict__ data,
+                                                      size_t stride, size_t m, size_t rows_per_block,
+                                                      const double *__restrict__ sp, uint32_t H, int n,
+                                                      double delta, uint32_t *__restrict__ votes) {
+  constexpr int LDW = NR + 2;  // 16-byte aligned row pitch in LDS; slot NR holds b
+  __shared__ __attribute__((aligned(16))) double tile[kDenseTile * LDW];
+  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+  double x[NR];
+  {
+    const double *hp = sp + (size_t)(h < H ? h : 0) * NR;
+    const double qnan = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < NR; i++) x[i] = h < H ? hp[i] : qnan;
+  }
+  uint32_t cnt = 0;
+  size_t lo = (size_t)blockIdx.y * rows_per_block;
+  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
+  for (size_t base = lo; base < hi; base += kDenseTile) {
+    int rows = (int)((hi - base) < (size_t)kDenseTile ? (hi - base) : (size_t)kDenseTile);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * LDW; idx += 256) {
+      int r = idx / LDW, c = idx % LDW;
+      double v = 0.0;
+      if (c < n) v = data[(base + r) * stride + c];
+      else if (c == NR) v = data[(base + r) * stride + n];
+      tile[idx] = v;
+    }
+    __syncthreads();
+    // RU rows at a time: RU independent running sums per lane, so that a dependent v_add_f64 is
+    // RU*2 instructions behind its producer (one row alone stalls on the fp64 pipeline latency)
+    constexpr int RU = 4;
+    int r = 0;
+    for (; r + RU <= rows; r += RU) {
+      double sum[RU];
+#pragma unroll
+      for (int u = 0; u < RU; u++) sum[u] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+#pragma unroll
+        for (int u = 0; u < RU; u++) sum[u] += tile[(r + u) * LDW + i] * x[i];
+      }
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        double t = sum[u] - tile[(r + u) * LDW + NR];
+        cnt += (fabs(t) < delta) ? 1u : 0u;
+      }
+    }
+    for (; r < rows; r++) {
+      const double *row = tile + r * LDW;
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < NR; i++) sum += row[i] * x[i];
+      sum -= row[NR];
+      cnt += (fabs(sum) < delta) ? 1u : 0u;
+    }
+  }
+  if (h < H && cnt) atomicAdd(&votes[h], cnt);
+}
+
 // K4 dense: upper triangle of sum z z^T, z = [a, b] (n+1 entries) -> normal equations A^T A,
 // A^T b (+ b^T b, + count).  Rows are staged through LDS in tiles; each thread owns a fixed set
 // of matrix entries; per-block partial sums are reduced later in a fixed order.

@@ -55,7 +55,7 @@ struct lsqr_ctx {
   SolveOut *d_out = nullptr;
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
-  int opt_ppl = 0, opt_filter = 1;
+  int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0;
 
   void *h_pin = nullptr;  // pinned staging (64 KiB)
 
@@ -288,6 +288,22 @@ int run_scan_plane_f32(lsqr_ctx *c) {
 int run_scan(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
+    if constexpr (M::IS_DENSE) {  // hypotheses in lanes, rows broadcast from LDS (A/B variant)
+      if (c->opt_dense_t) {
+        HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+        unsigned hb = (unsigned)((c->H + 255) / 256);
+        size_t chunks = std::max<size_t>(1, 512 / hb);
+        size_t rpb = (c->n + chunks - 1) / chunks;
+        rpb = (rpb + kDenseTile - 1) / kDenseTile * kDenseTile;
+        chunks = (c->n + rpb - 1) / rpb;
+        ProfScope ps(c, KID_SCAN);
+        hipLaunchKernelGGL((k_scan_dense_t<M::NR>), dim3(hb, (unsigned)chunks), dim3(256), 0,
+                           c->stream, c->d_data, c->stride, c->n, rpb, c->d_hparams,
+                           (uint32_t)c->H, (int)c->cfg.dim, c->mc.delta, c->d_votes);
+        HIPCHK(c, hipGetLastError());
+        return LSQR_OK;
+      }
+    }
     if constexpr (requires { M::SPF; }) {  // plane: fp32 pre-filter + exact re-evaluation
       if (c->opt_filter) {
         int ppl = c->opt_ppl ? c->opt_ppl : 4;  // measured best (tools/ab_scan.py)
@@ -1279,6 +1295,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_filter")) {
     c->opt_filter = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_transposed")) {
+    c->opt_dense_t = value != 0;
     return LSQR_OK;
   }
   return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);

@@ -40,6 +40,11 @@ __global__ __launch_bounds__(256) void bench(double *out, double a, double b, fl
       unsigned long long m0, m1;
       asm volatile("v_cmp_lt_f64 %0, %2, %10\n v_add_f64 %2, %2, %10\n v_add_f64 %3, %3, %10\n v_add_f64 %4, %4, %10\n v_add_f64 %5, %5, %10\n v_cmp_lt_f64 %1, %6, %10\n v_add_f64 %6, %6, %10\n v_add_f64 %7, %7, %10\n v_add_f64 %8, %8, %10\n v_add_f64 %9, %9, %10" : "=s"(m0), "=s"(m1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a));
       cnt += __builtin_popcountll(m0) + __builtin_popcountll(m1); }
+    if (OP == 14) { // one dependent chain: t = x_k * s ; acc += t   (8 pairs, the dense agree() pattern)
+      asm volatile("v_mul_f64 %1, %2, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %3, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %4, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %5, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %6, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %7, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %8, %10\n v_add_f64 %0, %0, %1\n v_mul_f64 %1, %9, %10\n v_add_f64 %0, %0, %1" : "+v"(x0), "=&v"(x1) : "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x2), "v"(x3), "s"(b)); }
+    if (OP == 15) { // two interleaved chains with separate temporaries
+      double t0, t1;
+      asm volatile("v_mul_f64 %2, %4, %8\n v_mul_f64 %3, %5, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3\n v_mul_f64 %2, %6, %8\n v_mul_f64 %3, %7, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3\n v_mul_f64 %2, %4, %8\n v_mul_f64 %3, %5, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3\n v_mul_f64 %2, %6, %8\n v_mul_f64 %3, %7, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3" : "+v"(x0), "+v"(x1), "=&v"(t0), "=&v"(t1) : "v"(x2), "v"(x3), "v"(x4), "v"(x5), "s"(b)); }
     if (OP == 9) { asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(b)); }
   }
   out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y + cnt;
@@ -61,13 +66,14 @@ void run(const char *name, int lanes_per_inst, double *d, int blocks_per_cu) {
 }
 int main() {
   double *d; hipMalloc(&d, sizeof(double) * 256 * 256 * 8);
-  for (int b : {8, 2}) {
+  for (int b : {8, 4, 3, 2, 1}) {
     run<0>("v_add_f64", 64, d, b); run<1>("v_mul_f64", 64, d, b); run<2>("v_fma_f64", 64, d, b);
     run<3>("v_add_f32", 64, d, b); run<4>("v_fma_f32", 64, d, b);
     run<5>("v_pk_add_f32", 128, d, b); run<9>("v_pk_mul_f32", 128, d, b); run<6>("v_pk_fma_f32", 128, d, b);
     run<7>("v_cmp_lt_f64", 64, d, b); run<8>("v_cmp_lt_f32", 64, d, b);
     run<10>("cmp64vcc+bcnt", 64, d, b); run<11>("cmp32vcc+bcnt", 64, d, b); run<12>("addco+addc x8", 128, d, b);
     run<13>("2cmp+8add f64", 80, d, b);
+    run<14>("dep mul->add", 128, d, b); run<15>("2 chains", 128, d, b);
     printf("\n");
   }
   return 0;
