@@ -226,6 +226,19 @@ def main():
             "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
                            "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1)},
         }
+        if a.gpus == 1 and dist is None:
+            # the whole RANSAC<T,S>::compute() (adaptive termination, p = 0.999) on the resident data
+            ctx.ransac(0.999, seed=7, want_consensus=False)
+            t1 = time.perf_counter()
+            reps = 5
+            for r_ in range(reps):
+                rr = ctx.ransac(0.999, seed=100 + r_, want_consensus=False)
+            out["compute_end_to_end"] = {
+                "ms": (time.perf_counter() - t1) / reps * 1e3, "p": 0.999,
+                "iterations": int(rr["info"].iterations), "scanned": int(rr["info"].evaluated),
+                "fraction": rr["fraction"],
+                "note": "RANSAC<T,S>::compute(): batches of 256/1024/4096 hypotheses + serial replay + "
+                        "mask + final fit, observations resident"}
         if a.gpus == 1 and not a.no_cpu_baseline:
             cp = a.cpu_points or a.points
             out["cpu_baseline"] = cpu_baseline(a.workload, data[:cp], delta)

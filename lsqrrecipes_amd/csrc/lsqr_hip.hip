@@ -1219,6 +1219,9 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     base += used;
     if (used < H) break;
     batch = std::min<size_t>(batch * 4, 4096);
+    // Safety stop (deviation from the reference, which would keep drawing up to C(N,k) subsets):
+    // if 2^22 consecutive iterations produced no model at all the data are degenerate.
+    if (!rs[RS_HAS] && base >= (1ull << 22)) break;
   }
   info->iterations = rs[RS_I];
   info->best_index = rs[RS_BEST_IDX];
