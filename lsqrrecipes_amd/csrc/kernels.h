@@ -138,21 +138,19 @@ __global__ void k_prepare(double *par, ModelConsts mc) {
   for (int j = M::P; j < M::SP; j++) par[j] = sp[j];
 }
 
-// K2 for the plane with an fp32 pre-filter: the packed-fp32 evaluation (two observations per
+// K2 with an fp32 pre-filter (plane, sphere): the packed-fp32 evaluation (two observations per
 // v_pk_* instruction) classifies every observation as certain inlier / certain outlier / ambiguous
-// (PlaneModel::prepare_f32 states the error bound); a wave whose tile holds an ambiguous observation
-// for the current hypothesis re-evaluates that tile with the exact fp64 predicate, so the votes are
+// (M::prepare_f32 states the error bound); a wave whose tile holds an ambiguous observation for the
+// current hypothesis re-evaluates that tile with the exact fp64 predicate, so the votes are
 // bit-identical to k_scan's.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int D, int PPL>
-__global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restrict__ data,
+template <class M, int PPL>
+__global__ __launch_bounds__(kBlock) void k_scan_f32(const double *__restrict__ data,
                                                            size_t stride, size_t n,
                                                            const double *__restrict__ sp,
                                                            const float *__restrict__ spf,
                                                            uint32_t H, ModelConsts mc,
                                                            uint32_t *__restrict__ votes) {
-  typedef PlaneModel<D> M;
+  constexpr int D = M::ND;
   static_assert(PPL % 2 == 0, "observations are processed in packed pairs");
   extern __shared__ uint32_t s_cnt[];
   for (uint32_t h = threadIdx.x; h < H; h += kBlock) s_cnt[h] = 0;
@@ -179,22 +177,19 @@ __global__ __launch_bounds__(kBlock) void k_scan_plane_f32(const double *__restr
       }
     for (uint32_t h = 0; h < H; h++) {
       const v2f *f = (const v2f *)(spf + (size_t)h * M::SPF);  // wave-uniform -> scalar loads
-      const v2f n0 = f[0], n1 = f[1], n2 = f[2], cneg = f[3];
+      const v2f fp[4] = {f[0], f[1], f[2], f[3]};
       const float tin = f[4].x, tout = f[4].y;
       v2f a[PPL / 2];
       unsigned long long may[PPL], any = 0;
 #pragma unroll
       for (int q = 0; q < PPL / 2; q++) {
-        v2f s = cneg;
-        if (D == 3) s = __builtin_elementwise_fma(xs[q][2], n2, s);
-        s = __builtin_elementwise_fma(xs[q][1], n1, s);
-        s = __builtin_elementwise_fma(xs[q][0], n0, s);
+        v2f s = M::filter_value(xs[q], fp);
         a[q] = s;
         may[2 * q] = __ballot(__builtin_fabsf(s.x) < tout);
         may[2 * q + 1] = __ballot(__builtin_fabsf(s.y) < tout);
         any |= may[2 * q] | may[2 * q + 1];
       }
-      if (any == 0) continue;  // wave-uniform: no observation of this tile is near the plane
+      if (any == 0) continue;  // wave-uniform: no observation of this tile is near the model
       uint32_t c = 0;
       unsigned long long amb = 0;
 #pragma unroll

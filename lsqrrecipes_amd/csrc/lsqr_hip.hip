@@ -263,9 +263,8 @@ int run_scan_ppl(lsqr_ctx *c) {
   return LSQR_OK;
 }
 
-template <int D, int PPL>
-int run_scan_plane_f32(lsqr_ctx *c) {
-  typedef PlaneModel<D> M;
+template <class M, int PPL>
+int run_scan_f32(lsqr_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
   size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
   for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
@@ -277,7 +276,7 @@ int run_scan_plane_f32(lsqr_ctx *c) {
     size_t tpb = (tiles + max_blocks - 1) / max_blocks;
     int grid = (int)((tiles + tpb - 1) / tpb);
     ProfScope ps(c, KID_SCAN);
-    hipLaunchKernelGGL((k_scan_plane_f32<D, PPL>), dim3(grid), dim3(kBlock), lds, c->stream,
+    hipLaunchKernelGGL((k_scan_f32<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream,
                        c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
                        c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
     HIPCHK(c, hipGetLastError());
@@ -304,12 +303,12 @@ int run_scan(lsqr_ctx *c) {
         return LSQR_OK;
       }
     }
-    if constexpr (requires { M::SPF; }) {  // plane: fp32 pre-filter + exact re-evaluation
+    if constexpr (requires { M::SPF; }) {  // plane, sphere: fp32 pre-filter + exact re-evaluation
       if (c->opt_filter) {
         int ppl = c->opt_ppl ? c->opt_ppl : 4;  // measured best (tools/ab_scan.py)
-        if (ppl == 8) return run_scan_plane_f32<M::ND, 8>(c);
-        if (ppl == 16) return run_scan_plane_f32<M::ND, 16>(c);
-        return run_scan_plane_f32<M::ND, 4>(c);
+        if (ppl == 8) return run_scan_f32<M, 8>(c);
+        if (ppl == 16) return run_scan_f32<M, 16>(c);
+        return run_scan_f32<M, 4>(c);
       }
     }
     if constexpr (M::REC <= 3) {  // point models: PPL is tunable

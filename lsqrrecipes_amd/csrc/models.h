@@ -15,6 +15,8 @@
 
 namespace lsqr {
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // two observations per packed fp32 op
+
 struct ModelConsts {
   double delta;     // constructor argument
   double delta_sq;  // delta*delta as the reference stores it (PlaneParametersEstimator.hxx:16)
@@ -198,6 +200,17 @@ struct PlaneModel {
     f[9] = ok ? round_up_f32(c.thr + E) : INFINITY;     // |s32| at or above: certain outlier
     if (!(sp[0] == sp[0])) f[8] = f[9] = __builtin_nanf("");  // NaN model: nothing agrees
   }
+#if defined(__HIPCC__)
+  // filter measure of two observations (xs[d] = coordinate d of both): |value| is compared with
+  // f[4].x (certain inlier below) and f[4].y (certain outlier at or above)
+  static __device__ inline v2f filter_value(const v2f *xs, const v2f *f) {
+    v2f s = f[3];
+    if (D == 3) s = __builtin_elementwise_fma(xs[2], f[2], s);
+    s = __builtin_elementwise_fma(xs[1], f[1], s);
+    s = __builtin_elementwise_fma(xs[0], f[0], s);
+    return s;
+  }
+#endif
 
   // moments about `org`: {N, sum x', sum x'x'^T (upper)}  (PlaneParametersEstimator.hxx:141-154
   // accumulates the same sums un-shifted; shifting removes the cancellation at :160)
@@ -387,6 +400,54 @@ struct SphereModel {
     sp[D + 1] = dlo;
     sp[D + 2] = dhi;
   }
+  // ---- fp32 pre-filter (k_scan_f32) --------------------------------------------------------------
+  // d32 = sum (x32_i - c32_i)^2 (fma chain), value t = d32 - mid with [Dlo, Dhi] = mid -+ half the exact
+  // squared-radius interval of prepare().  u = 2^-24, X = max |coordinate| of the observations,
+  // C = max |c_i|, D* = sum (x_i - c_i)^2:
+  //   |d32_i - (x_i - c_i)| <= e := 2u(X + C)(1 + u)        (two input roundings + the subtraction)
+  //   |d32 - D*| <= 2 sqrt(3) e sqrt(D*) + 3 e^2 + 3u D* =: E(D*)   (squares + three roundings)
+  // E is increasing; for every observation with D* <= Dcap := 2 Dhi + 1 the error is <= E(Dcap), and
+  // (when E(Dcap) <= Dhi/4, checked) an observation with D* > Dcap has d32 > Dhi + E(Dcap), i.e. lies
+  // outside the candidate band anyway.  Ecap = 1.01 E(Dcap) + 3u Dcap (the subtraction of mid and
+  // its rounding) + 1e-12 Dcap (fp64 vs exact):
+  //   |t| <  half - Ecap  =>  D_ref in [Dlo, Dhi]  (certainly agrees)
+  //   |t| >= half + Ecap  =>  certainly does not;   in between: exact fp64 predicate.
+  enum { SPF = 12 };
+  static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
+    const double X = c.absmax, u = 5.9604644775390625e-08;
+    for (int i = 0; i < 12; i++) f[i] = 0.0f;
+    double C = 0.0;
+    for (int i = 0; i < D; i++) {
+      f[2 * i] = f[2 * i + 1] = -(float)sp[i];  // x + (-c)
+      C = fabs(sp[i]) > C ? fabs(sp[i]) : C;
+    }
+    const double dlo = sp[D + 1], dhi = sp[D + 2];
+    bool ok = X >= 1e-10 && X <= 1e15 && C <= 1e15 && dlo >= 0.0 && dhi >= dlo && dhi <= 1e30;
+    const double dcap = 2.0 * dhi + 1.0;
+    const double e = 2.0 * u * (X + C) * (1.0 + u);
+    const double E = 2.0 * 1.7320508075688774 * e * sqrt(dcap) + 3.0 * e * e + 3.0 * u * dcap;
+    const double Ecap = 1.01 * E + 3.0 * u * dcap + 1e-12 * dcap;
+    ok = ok && Ecap <= 0.25 * dhi;
+    const double mid = 0.5 * (dlo + dhi), half = 0.5 * (dhi - dlo);
+    f[6] = f[7] = -(float)mid;
+    const double slack = Ecap + 2.0 * u * mid;  // mid itself is rounded to fp32
+    f[8] = (ok && half - slack > 0.0) ? PlaneModel<3>::round_down_f32(half - slack) : -INFINITY;
+    f[9] = ok ? PlaneModel<3>::round_up_f32(half + slack) : INFINITY;
+    if (!(sp[0] == sp[0]) || (dlo != dlo)) f[8] = f[9] = __builtin_nanf("");  // never agrees
+  }
+#if defined(__HIPCC__)
+  static __device__ inline v2f filter_value(const v2f *xs, const v2f *f) {
+    v2f d0 = xs[0] + f[0], d1 = xs[1] + f[1];
+    v2f s = d0 * d0;
+    s = __builtin_elementwise_fma(d1, d1, s);
+    if (D == 3) {
+      v2f d2 = xs[2] + f[2];
+      s = __builtin_elementwise_fma(d2, d2, s);
+    }
+    return s + f[3];
+  }
+#endif
+
   static LSQR_HD bool use_literal(const double *sp) { return sp[D + 1] < 0.0; }  // per hypothesis
   static LSQR_HD bool agree_interval(const double *sp, const double *x) {
     double d2 = dist_sq(sp, x);

@@ -666,3 +666,32 @@ def test_profile_counters(ctx):
     n, ms = ctx.profile_get("estimate")
     assert n == 1
     ctx.profile(False)
+
+
+def test_sphere_filter_boundary_stress(ctx):
+    """observations within a few fp32 ulps of both edges of the sphere band, scanned through the
+    fp32 pre-filter: votes must equal the oracle's exact count for every hypothesis."""
+    g = np.random.default_rng(8)
+    c0 = np.array([310.5, -420.25, 97.125])
+    r, delta = 512.0, 0.5
+    u = g.normal(size=(80_000, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    edge = np.where(g.random(80_000) < 0.5, r + delta, r - delta)
+    rad = edge * (1 + g.integers(-60, 61, 80_000) * 1e-8)
+    pts = np.ascontiguousarray(c0 + u * rad[:, None])
+    # four exact points of the sphere first, so that hypothesis 0 is (almost) the true sphere
+    pts[:4] = c0 + r * np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]], float)
+    oc = O.cfg(O.SPHERE, 3, delta)
+    ctx.set_model(L.SPHERE, 3, delta).upload(pts)
+    subs = np.vstack([[0, 1, 2, 3], O.ctr_subsets(6, 0, 63, len(pts), 4)]).astype(np.uint32)
+    for filt in (1, 0):
+        ctx.set_option("scan_filter", filt)
+        ctx.hypotheses_from_subsets(subs)
+        ctx.scan()
+        par, valid, votes = ctx.hypotheses()
+        assert np.allclose(par[0], np.concatenate([c0, [r]]), atol=1e-9)
+        for h in range(64):
+            if valid[h]:
+                assert votes[h] == O.scan(oc, par[h], pts)[0], (filt, h)
+        assert 0.2 < votes[0] / len(pts) < 0.8
+    ctx.set_option("scan_filter", 1)
