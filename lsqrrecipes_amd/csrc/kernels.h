@@ -340,11 +340,18 @@ struct SolveOut {
 };
 
 template <class M>
-__global__ void k_solve(const double *__restrict__ mom, const double *__restrict__ org,
-                        ModelConsts mc, SolveOut *__restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_solve(const double *__restrict__ mom,
+                                              const double *__restrict__ org, ModelConsts mc,
+                                              SolveOut *__restrict__ out) {
+  __shared__ double m[MOM_MAX];
+  __shared__ double ws[M::NMOM > 40 ? 512 : 8];  // workspace for the larger normal-equation solves
+  for (int i = threadIdx.x; i < (int)M::NMOM; i += 64) m[i] = mom[i];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   double par[M::P];
-  bool ok = M::solve(mom, org, mc, par);
+  bool ok;
+  if constexpr (requires { M::solve_ws(m, org, mc, par, ws); }) ok = M::solve_ws(m, org, mc, par, ws);
+  else ok = M::solve(m, org, mc, par);
   out->ok = ok ? 1 : 0;
   out->n_params = ok ? M::P : 0;
   out->lm_info = 0;
@@ -361,19 +368,40 @@ __global__ void k_lm_init(LmState *st, const SolveOut *init, int n, double ftol,
   lm_init(*st, n, init->params, ftol, xtol, gtol, maxfev, factor);
 }
 
+// The step runs on one lane; its state and the moment block are staged in LDS (the state machine
+// indexes small matrices dynamically -- from global memory every access would cost an L2 round trip).
 template <class M>
-__global__ void k_lm_advance(LmState *st, const double *__restrict__ mom, SolveOut *out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  bool cont = lm_advance(*st, mom);
-  out->cont = cont ? 1 : 0;
-  out->lm_info = st->info;
-  out->lm_nfev = st->nfev;
-  if (!cont) {
-    bool ok = st->info >= 1 && st->info <= 4;  // vnl_levenberg_marquardt::minimize -> true
-    out->ok = ok ? 1 : 0;
-    out->cost = st->fnorm * st->fnorm;
-    int np = M::lm_finalize(st->x, out->params);
-    out->n_params = ok ? np : 0;
+__global__ __launch_bounds__(64) void k_lm_advance(LmState *st, const double *__restrict__ mom,
+                                                   SolveOut *out) {
+  __shared__ LmState s;
+  __shared__ double m[LM_MOM_MAX];
+  {
+    const int nw = (int)(sizeof(LmState) / sizeof(int));
+    const int *src = (const int *)st;
+    int *dst = (int *)&s;
+    for (int i = threadIdx.x; i < nw; i += 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)M::NMOM_LM; i += 64) m[i] = mom[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool cont = lm_advance(s, m);
+    out->cont = cont ? 1 : 0;
+    out->lm_info = s.info;
+    out->lm_nfev = s.nfev;
+    if (!cont) {
+      bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
+      out->ok = ok ? 1 : 0;
+      out->cost = s.fnorm * s.fnorm;
+      int np = M::lm_finalize(s.x, out->params);
+      out->n_params = ok ? np : 0;
+    }
+  }
+  __syncthreads();
+  {
+    const int nw = (int)(sizeof(LmState) / sizeof(int));
+    const int *src = (const int *)&s;
+    int *dst = (int *)st;
+    for (int i = threadIdx.x; i < nw; i += 64) dst[i] = src[i];
   }
 }
 

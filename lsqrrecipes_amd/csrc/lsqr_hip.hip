@@ -55,7 +55,8 @@ struct lsqr_ctx {
   SolveOut *d_out = nullptr;
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
-  int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0;
+  int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1;
+  LmState h_lm;  // host copy of the LM state (opt_lm_host)
 
   void *h_pin = nullptr;  // pinned staging (64 KiB)
 
@@ -473,6 +474,34 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
     double ftol, xtol, gtol;
     int maxfev;
     lm_settings(c->cfg, &n, &ftol, &xtol, &gtol, &maxfev);
+    if constexpr (requires { M::NMOM_LM; }) {
+      if (c->opt_lm_host) {
+        // MINPACK's control flow between device passes runs on the host (like the RANSAC replay):
+        // a few hundred flops per evaluation; every N-scale operation stays a device pass.
+        LmState &s = c->h_lm;
+        lm_init(s, n, out->params, ftol, xtol, gtol, maxfev, 100.0);
+        double *pin = (double *)c->h_pin;
+        for (;;) {
+          for (int j = 0; j < n; j++) pin[j] = s.xtrial[j];
+          HIPCHK(c, hipMemcpyAsync(c->d_vec, pin, sizeof(double) * n, hipMemcpyHostToDevice,
+                                   c->stream));
+          if ((st = launch_moments<M>(c, use_mask, 0, c->n, 1, &nmom)) != LSQR_OK) return st;
+          HIPCHK(c, hipMemcpyAsync(pin + 64, c->d_mom, sizeof(double) * nmom,
+                                   hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          if (!lm_advance(s, pin + 64)) break;
+        }
+        bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
+        out->ok = ok ? 1 : 0;
+        out->cont = 0;
+        out->lm_info = s.info;
+        out->lm_nfev = s.nfev;
+        out->cost = s.fnorm * s.fnorm;
+        int np = M::lm_finalize(s.x, out->params);
+        out->n_params = ok ? np : 0;
+        return LSQR_OK;
+      }
+    }
     hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out, n, ftol,
                        xtol, gtol, maxfev, 100.0);
     HIPCHK(c, hipGetLastError());
@@ -983,6 +1012,12 @@ int lsqr_lm_begin(lsqr_ctx *c, const double *x0, double *x_trial_out) {
   int n, maxfev;
   double ftol, xtol, gtol;
   lm_settings(c->cfg, &n, &ftol, &xtol, &gtol, &maxfev);
+  if (c->opt_lm_host) {
+    lm_init(c->h_lm, n, x0, ftol, xtol, gtol, maxfev, 100.0);
+    if (x_trial_out)
+      for (int j = 0; j < n; j++) x_trial_out[j] = x0[j];
+    return LSQR_OK;
+  }
   SolveOut seed;
   memset(&seed, 0, sizeof seed);
   for (int j = 0; j < n; j++) seed.params[j] = x0[j];
@@ -1004,6 +1039,35 @@ int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *con
   if (!block || !cont) return fail(c, LSQR_ERR_INVALID, "null argument");
   int nmom = lsqr_moments_len(&c->cfg, 1);
   if (nmom <= 0) return fail(c, LSQR_ERR_INVALID, "model has no iterative phase");
+  if (c->opt_lm_host) {
+    LmState &s = c->h_lm;
+    bool go = lm_advance(s, block);
+    *cont = go ? 1 : 0;
+    lsqr_fit_info fi;
+    memset(&fi, 0, sizeof fi);
+    fi.lm_info = s.info;
+    fi.lm_nfev = s.nfev;
+    fi.cost = s.fnorm * s.fnorm;
+    if (go) {
+      if (x_trial_out)
+        for (int j = 0; j < s.n; j++) x_trial_out[j] = s.xtrial[j];
+      if (info) *info = fi;
+      return LSQR_OK;
+    }
+    bool ok = s.info >= 1 && s.info <= 4;
+    double par[64];
+    int np = dispatch(c->cfg, [&](auto tag) -> int {
+      typedef typename decltype(tag)::type M;
+      if constexpr (requires { M::NMOM_LM; }) return M::lm_finalize(s.x, par);
+      else return 0;
+    });
+    fi.n_params = ok ? np : 0;
+    if (info) *info = fi;
+    if (!ok) return LSQR_EMPTY;
+    if (params_out)
+      for (int j = 0; j < np; j++) params_out[j] = par[j];
+    return LSQR_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_mom, block, sizeof(double) * nmom, hipMemcpyHostToDevice,
                            c->stream));
   st = dispatch(c->cfg, [&](auto tag) -> int {
@@ -1297,6 +1361,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_filter")) {
     c->opt_filter = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_host")) {
+    c->opt_lm_host = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_transposed")) {

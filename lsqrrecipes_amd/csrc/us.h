@@ -179,9 +179,11 @@ struct USModel {
   // analytic least squares from the normal equations (...Estimator.cxx:120-270 / :775-917).
   // The reference thresholds the singular values of A at FLT_EPSILON; on the normal equations
   // rank deficiency shows as eigenvalues at the rounding floor of the (scaled) Gram matrix.
-  static LSQR_HD bool solve(const double *m, const double *, const ModelConsts &, double *par) {
+  // ws: 2*NC*NC + 5*NC doubles (LDS on the device: the eigen solver indexes its matrices dynamically)
+  static LSQR_HD bool solve_ws(const double *m, const double *, const ModelConsts &, double *par,
+                               double *ws) {
     if (m[0] < (double)K) return false;
-    double G[NC * NC], rhs[NC], x[NC], work[2 * NC * NC + 3 * NC];
+    double *G = ws, *rhs = G + NC * NC, *x = rhs + NC, *work = x + NC;  // work: NC*NC + 3*NC ... see below
     int k = 1;
     for (int p = 0; p < NC; p++)
       for (int q = p; q < NC; q++, k++) G[p * NC + q] = G[q * NC + p] = m[k];
@@ -190,6 +192,10 @@ struct USModel {
     if (rank < NC) return false;
     finish(x, par);
     return true;
+  }
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &c, double *par) {
+    double ws[3 * NC * NC + 5 * NC];
+    return solve_ws(m, org, c, par, ws);
   }
 
   // f (...Estimator.cxx:415-509 / :1059-1146) and gradf (:512-658 / :1149-1286) of one frame,

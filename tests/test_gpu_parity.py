@@ -695,3 +695,24 @@ def test_sphere_filter_boundary_stress(ctx):
                 assert votes[h] == O.scan(oc, par[h], pts)[0], (filt, h)
         assert 0.2 < votes[0] / len(pts) < 0.8
     ctx.set_option("scan_filter", 1)
+
+
+def test_lm_host_and_device_stepping_agree(ctx):
+    """the LM control flow (lm_core.h) runs on the host by default and in a device kernel with
+    lm_host=0: same code, same iterates."""
+    pts = synth.sphere(40_000, 0.0, seed=11)[0]
+    res = []
+    for host in (1, 0):
+        ctx.set_option("lm_host", host)
+        ctx.set_model(L.SPHERE, 3, 0.5, L.LS_GEOMETRIC).upload(pts)
+        fit, info = ctx.ls_fit()
+        res.append((fit, info.lm_info, info.lm_nfev))
+        small = synth.us_single(50, 0.0, seed=21, pixel_sigma=1.0)[0]
+        ctx.set_model(L.US_SINGLE, 0, 3.0, L.LS_ITERATIVE).upload(small)
+        fit, info = ctx.ls_fit()
+        res.append((fit, info.lm_info, info.lm_nfev))
+    ctx.set_option("lm_host", 1)
+    assert res[0][1] == res[2][1] and res[0][2] == res[2][2]
+    assert np.allclose(res[0][0], res[2][0], rtol=1e-12, atol=1e-12)
+    assert len(res[1][0]) == len(res[3][0]) == 20
+    assert np.allclose(res[1][0], res[3][0], rtol=1e-6, atol=1e-6)
