@@ -202,6 +202,109 @@ __global__ __launch_bounds__(256) void k_syrk_dense(const double *__restrict__ d
   if (threadIdx.x == 0) out[ne] = cnt;
 }
 
+// K4 dense on the matrix cores: the same block of sums as k_syrk_dense with v_mfma_f64_16x16x4_f64.
+// z = [a, b] is padded to 80 = 5 x 16 columns; for 4 rows at a time lane l holds z_k[16 b + (l & 15)],
+// k = l >> 4, for b = 0..4 -- which is at once the A operand (A[i][k]) of block-row b and the B operand
+// (B[k][j]) of block-column b, so the 15 upper 16x16 blocks of sum z z^T need 5 loads and 15 MFMAs per
+// 4 rows and no LDS traffic in the loop.  (fp64 MFMA peaks at the vector FMA rate on MI355X; what it
+// buys here is operand reuse.)  The four waves of a workgroup fold their accumulators in wave order
+// through LDS, so the per-block partial is deterministic.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int VAR>
+__global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ data, size_t stride,
+                                                   size_t begin, size_t end, size_t chunk, int n,
+                                                   const uint8_t *__restrict__ mask, int use_mask,
+                                                   int pstride, double *__restrict__ partials) {
+  __shared__ double fold[15 * 256];
+  __shared__ unsigned s_rows[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane >> 4, c16 = lane & 15;
+  const int nz = n + 1;
+  d4 acc[15];
+#pragma unroll
+  for (int t = 0; t < 15; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  unsigned rows_used = 0;
+  size_t lo = begin + (size_t)blockIdx.x * chunk;
+  size_t hi = lo + chunk < end ? lo + chunk : end;
+  // software pipeline: the loads of the next 4-row group are issued before the 15 MFMAs of the
+  // current one (one wave per SIMD: nothing else would cover the HBM latency)
+  constexpr int PF = 4;  // groups in flight
+  double z[PF][5];
+  unsigned char mk[PF];
+  // Loop-invariant column offsets (columns past the row are read from column 0 and zeroed below);
+  // loads never depend on the mask byte (a dependent load would drain the whole ring with vmcnt(0)).
+  int off[5];
+  bool colok[5];
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    colok[b] = 16 * b + c16 < nz;
+    off[b] = colok[b] ? 16 * b + c16 : 0;
+  }
+  const size_t last = hi > lo ? hi - 1 : lo;
+  auto fetch = [&](size_t g, double *zz, unsigned char &m) {
+    size_t row = g + k;
+    bool in = row < hi;
+    const double *rp = data + (in ? row : last) * stride;
+    m = in ? (use_mask ? mask[row] : (unsigned char)1) : (unsigned char)0;
+#pragma unroll
+    for (int b = 0; b < 5; b++) zz[b] = rp[off[b]];
+  };
+  size_t g = lo + (size_t)wave * 4;
+#pragma unroll
+  for (int p = 0; p < PF; p++) fetch(g + (size_t)p * 16, z[p], mk[p]);
+  for (; g < hi; g += 16 * PF) {
+#pragma unroll
+    for (int p = 0; p < PF; p++) {
+      double zc[5];
+      bool vc = mk[p] != 0;
+#pragma unroll
+      for (int b = 0; b < 5; b++) zc[b] = (vc && colok[b]) ? z[p][b] : 0.0;
+      if (VAR != 2) fetch(g + (size_t)(p + PF) * 16, z[p], mk[p]);  // refill this slot for the next round
+      rows_used += (unsigned)__builtin_popcountll(__ballot(vc && c16 == 0));
+      if (VAR == 1) {  // diagnostic: loads only
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc[b][0] += zc[b];
+      } else {
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < 5; bi++)
+#pragma unroll
+          for (int bj = bi; bj < 5; bj++, t++)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[bi], zc[bj], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // fold the four waves in order 0,1,2,3; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 15; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          int pos = t * 256 + (k + 4 * rg) * 16 + c16;
+          fold[pos] = (w == 0 ? 0.0 : fold[pos]) + acc[t][rg];
+        }
+      if (lane == 0) s_rows[w] = rows_used;
+    }
+    __syncthreads();
+  }
+  double *out = partials + (size_t)blockIdx.x * pstride;
+  const int ne = nz * (nz + 1) / 2;
+  for (int pos = threadIdx.x; pos < 15 * 256; pos += 256) {
+    int t = pos >> 8, r = (pos >> 4) & 15, cc = pos & 15;
+    int bi = 0, rem = t;  // t -> (bi, bj) of the upper block triangle
+    while (rem >= 5 - bi) {
+      rem -= 5 - bi;
+      bi++;
+    }
+    int bj = bi + rem;
+    int i = 16 * bi + r, j = 16 * bj + cc;
+    if (i <= j && j < nz) out[i * nz - i * (i - 1) / 2 + (j - i)] = fold[pos];
+  }
+  if (threadIdx.x == 0) out[ne] = (double)(s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3]);
+}
+
 // K5 dense: x = pinv(A) b from the normal equations block (DenseLinear...Estimator.hxx:64-96:
 // rank(A) < n -> empty).  One wave; G = A^T A (n x n) in LDS.
 __global__ __launch_bounds__(64) void k_solve_dense(const double *__restrict__ mom, int n,

@@ -55,7 +55,7 @@ struct lsqr_ctx {
   SolveOut *d_out = nullptr;
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
-  int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1;
+  int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1, opt_syrk_diag = 0;
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
 
   void *h_pin = nullptr;  // pinned staging (64 KiB)
@@ -336,9 +336,21 @@ int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, in
   *nmom = ne + 1;
   {
     ProfScope ps_(c, KID_MOMENTS);
-    size_t lds = sizeof(double) * kSyrkTile * ((n + 1) | 1) + kSyrkTile;
-    hipLaunchKernelGGL(k_syrk_dense, dim3(nb), dim3(256), lds, c->stream, c->d_data, c->stride,
-                       begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+    if (c->opt_filter) {  // default: matrix-core SYRK
+      if (c->opt_syrk_diag == 1)  // diagnostics (tools/syrk_ab.py): loads only / MFMAs only
+        hipLaunchKernelGGL(k_syrk_mfma<1>, dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride,
+                           begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+      else if (c->opt_syrk_diag == 2)
+        hipLaunchKernelGGL(k_syrk_mfma<2>, dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride,
+                           begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+      else
+        hipLaunchKernelGGL(k_syrk_mfma<0>, dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride,
+                           begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+    } else {
+      size_t lds = sizeof(double) * kSyrkTile * ((n + 1) | 1) + kSyrkTile;
+      hipLaunchKernelGGL(k_syrk_dense, dim3(nb), dim3(256), lds, c->stream, c->d_data, c->stride,
+                         begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+    }
     HIPCHK(c, hipGetLastError());
   }
   {
@@ -1361,6 +1373,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_filter")) {
     c->opt_filter = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "syrk_diag")) {  // 1: loads only, 2: MFMAs only (timing diagnostics, wrong sums)
+    c->opt_syrk_diag = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "lm_host")) {

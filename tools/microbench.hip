@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
 #define ITERS 4096
 template <int OP>
 __global__ __launch_bounds__(256) void bench(double *out, double a, double b, float fa, float fb) {
@@ -13,6 +14,7 @@ __global__ __launch_bounds__(256) void bench(double *out, double a, double b, fl
   float f0 = threadIdx.x * 1e-3f, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3, f4 = f0 + 4, f5 = f0 + 5, f6 = f0 + 6, f7 = f0 + 7;
   v2f p0 = {f0, f1}, p1 = {f2, f3}, p2 = {f4, f5}, p3 = {f6, f7}, p4 = p0 + 1.f, p5 = p1 + 1.f, p6 = p2 + 1.f, p7 = p3 + 1.f;
   unsigned cnt = 0;
+  d4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0, m6 = m0, m7 = m0;
   for (int i = 0; i < ITERS; i++) {
     if (OP == 0) { asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a)); }
     if (OP == 1) { asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(b)); }
@@ -45,9 +47,15 @@ __global__ __launch_bounds__(256) void bench(double *out, double a, double b, fl
     if (OP == 15) { // two interleaved chains with separate temporaries
       double t0, t1;
       asm volatile("v_mul_f64 %2, %4, %8\n v_mul_f64 %3, %5, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3\n v_mul_f64 %2, %6, %8\n v_mul_f64 %3, %7, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3\n v_mul_f64 %2, %4, %8\n v_mul_f64 %3, %5, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3\n v_mul_f64 %2, %6, %8\n v_mul_f64 %3, %7, %8\n v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3" : "+v"(x0), "+v"(x1), "=&v"(t0), "=&v"(t1) : "v"(x2), "v"(x3), "v"(x4), "v"(x5), "s"(b)); }
+    if (OP == 16) { // 8 independent fp64 MFMAs 16x16x4 (2048 flop each)
+      static_assert(true, "");
+      m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, m0, 0, 0, 0); m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x2, m1, 0, 0, 0);
+      m2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, x3, m2, 0, 0, 0); m3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, x4, m3, 0, 0, 0);
+      m4 = __builtin_amdgcn_mfma_f64_16x16x4f64(x4, x5, m4, 0, 0, 0); m5 = __builtin_amdgcn_mfma_f64_16x16x4f64(x5, x6, m5, 0, 0, 0);
+      m6 = __builtin_amdgcn_mfma_f64_16x16x4f64(x6, x7, m6, 0, 0, 0); m7 = __builtin_amdgcn_mfma_f64_16x16x4f64(x7, x0, m7, 0, 0, 0); }
     if (OP == 9) { asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(b)); }
   }
-  out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y + cnt;
+  out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y + cnt + m0[0] + m1[1] + m2[2] + m3[3] + m4[0] + m5[1] + m6[2] + m7[3];
 }
 template <int OP>
 void run(const char *name, int lanes_per_inst, double *d, int blocks_per_cu) {
@@ -66,13 +74,14 @@ void run(const char *name, int lanes_per_inst, double *d, int blocks_per_cu) {
 }
 int main() {
   double *d; hipMalloc(&d, sizeof(double) * 256 * 256 * 8);
-  for (int b : {8, 4, 3, 2, 1}) {
+  for (int b : {2, 1}) {
     run<0>("v_add_f64", 64, d, b); run<1>("v_mul_f64", 64, d, b); run<2>("v_fma_f64", 64, d, b);
     run<3>("v_add_f32", 64, d, b); run<4>("v_fma_f32", 64, d, b);
     run<5>("v_pk_add_f32", 128, d, b); run<9>("v_pk_mul_f32", 128, d, b); run<6>("v_pk_fma_f32", 128, d, b);
     run<7>("v_cmp_lt_f64", 64, d, b); run<8>("v_cmp_lt_f32", 64, d, b);
     run<10>("cmp64vcc+bcnt", 64, d, b); run<11>("cmp32vcc+bcnt", 64, d, b); run<12>("addco+addc x8", 128, d, b);
     run<13>("2cmp+8add f64", 80, d, b);
+    run<16>("mfma_f64_16x16x4", 64, d, b);
     run<14>("dep mul->add", 128, d, b); run<15>("2 chains", 128, d, b);
     printf("\n");
   }
