@@ -226,7 +226,8 @@ def main():
             "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
                            "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1)},
         }
-        if a.gpus == 1 and dist is None:
+        if a.gpus == 1 and dist is None and a.workload in ("plane", "sphere", "line"):
+            ctx.set_option("max_iterations", 100000)
             # the whole RANSAC<T,S>::compute() (adaptive termination, p = 0.999) on the resident data
             ctx.ransac(0.999, seed=7, want_consensus=False)
             t1 = time.perf_counter()

@@ -204,6 +204,8 @@ LSQR_API void lsqr_dedup_destroy(void *set);
 /* "scan_ppl": observations per lane in k_scan (2, 4 or 8; 0 = model default);
  * "scan_filter": 1 = fp32 pre-filter + exact fp64 re-evaluation of ambiguous observations
  *                (bit-identical votes), 0 = plain fp64 scan;
+ * "max_iterations": stop lsqr_ransac after this many loop iterations even if the adaptive bound
+ *                asks for more (0 = the reference's behaviour: up to C(N,k));
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the
  *                host, 0 = in a single-lane device kernel (same lm_core.h code either way);
  * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS

@@ -40,19 +40,21 @@ struct DenseModel {
 
 // K1 dense: one wave per hypothesis; n x n system in LDS; x = pinv(A) b, singular if any
 // sigma <= EPS (DenseLinear...Estimator.hxx:17-49)
-__global__ __launch_bounds__(64) void k_estimate_dense(const double *__restrict__ data,
+__global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict__ data,
                                                        size_t stride, size_t nobs,
                                                        const uint32_t *__restrict__ subsets,
                                                        uint32_t H, int n, int sp_stride,
                                                        double *__restrict__ hparams,
                                                        uint8_t *__restrict__ valid) {
   extern __shared__ double sm[];
+  __shared__ int s_bad;
   const int lane = threadIdx.x;
   const uint32_t h = blockIdx.x;
   const int lda = n | 1;
   double *A = sm, *V = A + n * lda, *b = V + n * lda, *cw = b + n, *x = cw + n;
   bool in_range = true;
-  for (int idx = lane; idx < n * n; idx += 64) {
+  if (lane == 0) s_bad = 0;
+  for (int idx = lane; idx < n * n; idx += 256) {
     int l = idx / n, c = idx % n;
     size_t i = subsets[(size_t)h * n + l];
     if (i >= nobs) {
@@ -61,16 +63,17 @@ __global__ __launch_bounds__(64) void k_estimate_dense(const double *__restrict_
     }
     A[c * lda + l] = data[i * stride + c];
   }
-  for (int l = lane; l < n; l += 64) {
+  for (int l = lane; l < n; l += 256) {
     size_t i = subsets[(size_t)h * n + l];
     if (i >= nobs) i = 0;
     b[l] = data[i * stride + n];
   }
   __syncthreads();
-  int rank = wave_pinv_solve(n, n, A, lda, V, lda, b, kEPS, 0.0, x, cw);
-  bool ok = (rank == n) && !__any(!in_range);
+  if (!in_range) s_bad = 1;
+  int rank = block_pinv_solve<256>(n, n, A, lda, V, lda, b, kEPS, 0.0, x, cw);
+  bool ok = (rank == n) && !s_bad;
   const double qnan = __builtin_nan("");
-  for (int j = lane; j < sp_stride; j += 64)
+  for (int j = lane; j < sp_stride; j += 256)
     hparams[(size_t)h * sp_stride + j] = j < n ? (ok ? x[j] : qnan) : 0.0;
   if (lane == 0) valid[h] = ok ? 1 : 0;
 }
@@ -307,19 +310,19 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
 
 // K5 dense: x = pinv(A) b from the normal equations block (DenseLinear...Estimator.hxx:64-96:
 // rank(A) < n -> empty).  One wave; G = A^T A (n x n) in LDS.
-__global__ __launch_bounds__(64) void k_solve_dense(const double *__restrict__ mom, int n,
-                                                    SolveOut *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_solve_dense(const double *__restrict__ mom, int n,
+                                                     SolveOut *__restrict__ out) {
   extern __shared__ double sm[];
-  const int lane = threadIdx.x, nz = n + 1, lda = n | 1;
+  const int tid = threadIdx.x, nz = n + 1, lda = n | 1;
   const int ne = nz * (nz + 1) / 2;
   double *G = sm, *V = G + n * lda, *rhs = V + n * lda, *cw = rhs + n, *x = cw + n;
-  for (int idx = lane; idx < n * n; idx += 64) {
+  for (int idx = tid; idx < n * n; idx += 256) {
     int i = idx / n, j = idx % n;
     int a = i < j ? i : j, bb = i < j ? j : i;
     int e = a * nz - a * (a - 1) / 2 + (bb - a);
     G[j * lda + i] = mom[e];
   }
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += 256) {
     int e = i * nz - i * (i - 1) / 2 + (n - i);
     rhs[i] = mom[e];
   }
@@ -327,9 +330,9 @@ __global__ __launch_bounds__(64) void k_solve_dense(const double *__restrict__ m
   double count = mom[ne];
   // sigma(A)^2 are the singular values of G: rank test relative to the largest one (the
   // reference's absolute sigma <= 2.2e-16 test only ever fires for exactly singular systems)
-  int rank = wave_pinv_solve(n, n, G, lda, V, lda, rhs, 0.0, 1e-13, x, cw);
+  int rank = block_pinv_solve<256>(n, n, G, lda, V, lda, rhs, 0.0, 1e-13, x, cw);
   bool ok = rank == n && count >= (double)n;
-  if (lane == 0) {
+  if (tid == 0) {
     out->ok = ok ? 1 : 0;
     out->n_params = ok ? n : 0;
     out->lm_info = 0;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64) void k_solve_dense(const double *__restrict__ m
     out->cont = 0;
     out->cost = 0.0;
   }
-  for (int j = lane; j < n; j += 64) out->params[j] = ok ? x[j] : 0.0;
+  for (int j = tid; j < n; j += 256) out->params[j] = ok ? x[j] : 0.0;
 }
 
 }  // namespace lsqr

@@ -56,6 +56,7 @@ struct lsqr_ctx {
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
   int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1, opt_syrk_diag = 0;
+  long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
 
   void *h_pin = nullptr;  // pinned staging (64 KiB)
@@ -223,7 +224,7 @@ int run_estimate(lsqr_ctx *c) {
     }
     ProfScope ps(c, KID_ESTIMATE);
     if constexpr (M::IS_DENSE) {
-      hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(64),
+      hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256),
                          dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
                          c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP, c->d_hparams,
                          c->d_valid);
@@ -364,7 +365,7 @@ int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, in
 
 int launch_solve_dense(lsqr_ctx *c) {
   ProfScope ps(c, KID_SOLVE);
-  hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(64), dense_lds_bytes(c->cfg.dim), c->stream,
+  hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(256), dense_lds_bytes(c->cfg.dim), c->stream,
                      c->d_mom, (int)c->cfg.dim, c->d_out);
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
@@ -1297,6 +1298,7 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     // Safety stop (deviation from the reference, which would keep drawing up to C(N,k) subsets):
     // if 2^22 consecutive iterations produced no model at all the data are degenerate.
     if (!rs[RS_HAS] && base >= (1ull << 22)) break;
+    if (c->opt_max_iter > 0 && base >= (uint64_t)c->opt_max_iter) break;  // caller's budget
   }
   info->iterations = rs[RS_I];
   info->best_index = rs[RS_BEST_IDX];
@@ -1373,6 +1375,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_filter")) {
     c->opt_filter = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "max_iterations")) {  // budget for lsqr_ransac (0 = reference behaviour)
+    c->opt_max_iter = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "syrk_diag")) {  // 1: loads only, 2: MFMAs only (timing diagnostics, wrong sums)
