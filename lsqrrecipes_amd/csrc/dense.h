@@ -144,6 +144,162 @@ __global__ __launch_bounds__(256) void k_scan_dense_t(const double *__restrict__
   if (h < H && cnt) atomicAdd(&votes[h], cnt);
 }
 
+// K2 dense on the matrix cores.  The residuals of a block of rows against a block of hypotheses are
+// a GEMM; v_mfma_f64_16x16x4 evaluates it with fused multiply-adds, which round differently from the
+// reference's separate multiply and add -- so the MFMA result is used as a FILTER with a rigorous
+// band, exactly like the fp32 pre-filter of the point models:
+//   both the reference's running sum and any fma-ordered evaluation of a.x - b are within
+//   g = gamma_{n+1} (sum |a_i||x_i| + |b|) <= gamma_{n+1} Amax (||x||_1 + 1) of the exact value
+//   (gamma_k = k u / (1 - k u), u = 2^-53, Amax = max |entry| of the uploaded rows), hence within
+//   E_h = 2.02 g of each other.  |res| < delta - E_h => agrees; |res| >= delta + E_h => does not;
+//   pairs in between (probability ~1e-13) go to a worklist and are decided by the exact formula
+//   (k_dense_recheck).  Votes are therefore bit-identical to k_scan<DenseModel>.
+// Tiling: workgroup = 64 rows x 64 hypotheses, both staged in LDS with a 66-double pitch (the
+// 16 x 4 fragment reads of a wave hit 32 distinct 8-byte slots); wave w owns rows 16w..16w+15 and
+// four 16 x 16 accumulator tiles; each lane counts the inliers of its own hypothesis columns.
+constexpr int kDmPitch = 66;
+constexpr unsigned kAmbCap = 1u << 20;
+constexpr int kDmHypChunk = 2048;  // hypotheses per launch (LDS vote counters: 8 KiB)
+
+// per hypothesis thresholds {delta - E_h, delta + E_h} of the MFMA filter ({-1,-1}: never agrees)
+__global__ void k_dense_thresholds(const double *__restrict__ sp, uint32_t H, int n, int nr,
+                                   double delta, double amax, double *__restrict__ thr) {
+  uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  double l1 = 0.0;
+  for (int k = 0; k < n; k++) l1 += fabs(sp[(size_t)h * nr + k]);
+  const double u = 1.1102230246251565e-16, kg = (double)(n + 1) * u;
+  const double E = 2.02 * (kg / (1.0 - kg)) * amax * (l1 + 1.0);
+  bool live = l1 == l1 && l1 < 1e300;  // NaN / non-finite model: never agrees
+  thr[2 * (size_t)h] = live ? delta - E : -1.0;
+  thr[2 * (size_t)h + 1] = live ? delta + E : -1.0;
+}
+
+// Each workgroup owns a range of rows: a 64-row tile stays in LDS while all hypothesis blocks
+// (64 each, L2 resident) stream past it, so the rows are read from HBM once per launch.
+template <int NR>
+__global__ __launch_bounds__(256) void k_scan_dense_mfma(
+    const double *__restrict__ data, size_t stride, size_t m, size_t rows_per_block,
+    const double *__restrict__ sp, const double *__restrict__ thr, uint32_t H, int n,
+    uint32_t *__restrict__ votes, unsigned long long *__restrict__ amb_list,
+    unsigned int *__restrict__ amb_count, uint32_t hyp_base) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  extern __shared__ double sm[];
+  double *At = sm;                      // 64 rows x pitch
+  double *Bt = At + 64 * kDmPitch;      // 64 hypotheses x pitch
+  double *bv = Bt + 64 * kDmPitch;      // 64 right-hand sides
+  double *tin = bv + 64, *tout = tin + 64;  // thresholds of the current hypothesis block
+  uint32_t *s_cnt = (uint32_t *)(tout + 64);  // H counters
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, k4 = lane >> 4;
+  const uint32_t nhb = (H + 63) / 64;
+  for (uint32_t h = tid; h < H; h += 256) s_cnt[h] = 0;
+  size_t lo = (size_t)blockIdx.x * rows_per_block;
+  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
+  // hypothesis tiles are fetched into registers one block ahead of their use
+  double nb[16], nti = -1.0, nto = -1.0;
+  auto fetch_hyp = [&](uint32_t hb) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      int idx = tid + q * 256, hh = idx >> 6, kk = idx & 63;
+      uint32_t h = hb * 64 + hh;
+      nb[q] = (h < H && kk < n) ? sp[(size_t)h * NR + kk] : 0.0;
+    }
+    if (tid < 64) {
+      uint32_t h = hb * 64 + tid;
+      nti = h < H ? thr[2 * (size_t)h] : -1.0;
+      nto = h < H ? thr[2 * (size_t)h + 1] : -1.0;
+    }
+  };
+  if (lo < hi) fetch_hyp(0);
+  for (size_t base = lo; base < hi; base += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      int r = idx >> 6, kk = idx & 63;
+      size_t row = base + r;
+      At[r * kDmPitch + kk] = (row < hi && kk < n) ? data[row * stride + kk] : 0.0;
+    }
+    if (tid < 64) {
+      size_t row = base + tid;
+      bv[tid] = row < hi ? data[row * stride + n] : __builtin_nan("");  // NaN: row never counts
+    }
+    for (uint32_t hb = 0; hb < nhb; hb++) {
+      __syncthreads();  // previous block's fragment reads are done
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        int idx = tid + q * 256;
+        Bt[(idx >> 6) * kDmPitch + (idx & 63)] = nb[q];
+      }
+      if (tid < 64) {
+        tin[tid] = nti;
+        tout[tid] = nto;
+      }
+      __syncthreads();
+      fetch_hyp(hb + 1 < nhb ? hb + 1 : 0);  // next block (or block 0 for the next row tile)
+      d4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double *ap = At + (wave * 16 + c16) * kDmPitch + k4;
+      const double *bp = Bt + c16 * kDmPitch + k4;
+#pragma unroll 4
+      for (int s4 = 0; s4 < 64; s4 += 4) {
+        double a = ap[s4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[t * 16 * kDmPitch + s4], acc[t], 0, 0, 0);
+      }
+      // D layout: column (hypothesis) = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int hh = t * 16 + c16;
+        const double ti = tin[hh], to = tout[hh];
+        uint32_t c = 0;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int r = wave * 16 + k4 + 4 * rg;
+          const double res = fabs(acc[t][rg] - bv[r]);
+          c += res < ti ? 1u : 0u;
+          if (res >= ti && res < to) {  // ambiguous: decided exactly by k_dense_recheck
+            unsigned slot = atomicAdd(amb_count, 1u);
+            if (slot < kAmbCap)
+              amb_list[slot] = ((unsigned long long)(base + r) << 32) |
+                               (unsigned long long)(hyp_base + hb * 64 + hh);
+          }
+        }
+        c += __shfl_xor(c, 16);  // lanes l, l^16, l^32, l^48 hold the same hypothesis column
+        c += __shfl_xor(c, 32);
+        if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + hh], c);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t h = tid; h < H; h += 256) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
+  }
+}
+
+// exact decision of the pairs the MFMA filter could not classify
+template <int NR>
+__global__ __launch_bounds__(256) void k_dense_recheck(const double *__restrict__ data,
+                                                       size_t stride, const double *__restrict__ sp,
+                                                       ModelConsts mc,
+                                                       const unsigned long long *__restrict__ amb_list,
+                                                       const unsigned int *__restrict__ amb_count,
+                                                       uint32_t *__restrict__ votes) {
+  typedef DenseModel<NR> M;
+  unsigned total = *amb_count;
+  if (total > kAmbCap) total = kAmbCap;
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    unsigned long long v = amb_list[e];
+    size_t row = (size_t)(v >> 32);
+    uint32_t h = (uint32_t)(v & 0xffffffffu);
+    double x[M::REC];
+    M::load(data + row * stride, mc, x);
+    if (M::agree(sp + (size_t)h * NR, x, mc)) atomicAdd(&votes[h], 1u);
+  }
+}
+
 // K4 dense: upper triangle of sum z z^T, z = [a, b] (n+1 entries) -> normal equations A^T A,
 // A^T b (+ b^T b, + count).  Rows are staged through LDS in tiles; each thread owns a fixed set
 // of matrix entries; per-block partial sums are reduced later in a fixed order.

@@ -38,6 +38,7 @@ struct lsqr_ctx {
   uint32_t *d_subsets = nullptr;
   double *d_hparams = nullptr;
   float *d_hparams_f32 = nullptr;
+  unsigned long long *d_amb = nullptr;  // worklist of the dense MFMA filter
   bool absmax_valid = false;
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
@@ -289,6 +290,49 @@ int run_scan_f32(lsqr_ctx *c) {
 int run_scan(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
+    if constexpr (M::IS_DENSE) {  // default: MFMA filter + exact recheck of ambiguous pairs
+      if (c->opt_filter && !c->opt_dense_t) {
+        int st = ensure_absmax(c);
+        if (st != LSQR_OK) return st;
+        if (!c->d_amb) HIPCHK(c, hipMalloc((void **)&c->d_amb, sizeof(unsigned long long) * kAmbCap));
+        if (c->mc.absmax <= 1e100) {  // finite, sane magnitudes: the filter's bound applies
+          HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+          HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+          double *d_thr = c->d_partials;  // scratch: 2 doubles per hypothesis (H <= 2^20 checked)
+          if (c->H * 2 > (size_t)kDenseBlocks * 2160) return fail(c, LSQR_ERR_INVALID, "batch too large");
+          size_t tiles = (c->n + 63) / 64;
+          size_t nblk = std::min<size_t>(tiles, 512);
+          size_t rpb = (tiles + nblk - 1) / nblk * 64;
+          nblk = (c->n + rpb - 1) / rpb;
+          {
+            ProfScope ps(c, KID_SCAN);
+            hipLaunchKernelGGL(k_dense_thresholds, dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0,
+                               c->stream, c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, (int)M::NR,
+                               c->mc.delta, c->mc.absmax, d_thr);
+            HIPCHK(c, hipGetLastError());
+            for (size_t h0 = 0; h0 < c->H; h0 += kDmHypChunk) {
+              uint32_t hc = (uint32_t)std::min<size_t>(kDmHypChunk, c->H - h0);
+              size_t lds = sizeof(double) * (2 * 64 * kDmPitch + 3 * 64) + sizeof(uint32_t) * hc;
+              hipLaunchKernelGGL((k_scan_dense_mfma<M::NR>), dim3((unsigned)nblk), dim3(256), lds,
+                                 c->stream, c->d_data, c->stride, c->n, rpb,
+                                 c->d_hparams + h0 * M::NR, d_thr + 2 * h0, hc, (int)c->cfg.dim,
+                                 c->d_votes + h0, c->d_amb, (unsigned int *)(c->d_counter + 3),
+                                 (uint32_t)h0);
+              HIPCHK(c, hipGetLastError());
+            }
+            hipLaunchKernelGGL((k_dense_recheck<M::NR>), dim3(64), dim3(256), 0, c->stream, c->d_data,
+                               c->stride, c->d_hparams, c->mc, c->d_amb,
+                               (const unsigned int *)(c->d_counter + 3), c->d_votes);
+            HIPCHK(c, hipGetLastError());
+          }
+          // worklist overflow (never seen: ~1e-13 of the pairs are ambiguous) -> exact kernel
+          HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          if (*(unsigned int *)c->h_pin <= kAmbCap) return LSQR_OK;
+        }
+      }
+    }
     if constexpr (M::IS_DENSE) {  // hypotheses in lanes, rows broadcast from LDS (A/B variant)
       if (c->opt_dense_t) {
         HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
@@ -660,7 +704,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_valid, c->d_votes, c->d_mask,
+  void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);

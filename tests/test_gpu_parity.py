@@ -716,3 +716,42 @@ def test_lm_host_and_device_stepping_agree(ctx):
     assert np.allclose(res[0][0], res[2][0], rtol=1e-12, atol=1e-12)
     assert len(res[1][0]) == len(res[3][0]) == 20
     assert np.allclose(res[1][0], res[3][0], rtol=1e-6, atol=1e-6)
+
+
+def test_dense_mfma_filter_is_exact(ctx):
+    """the dense scan evaluates residuals with fp64 MFMAs (fused multiply-adds) and only decides
+    pairs whose residual is clear of delta by the rigorous band; pairs inside the band go through the
+    exact formula.  delta is placed exactly on one row's reference residual (and one ulp above) so
+    that this row is forced through the worklist; every variant must give the oracle's votes."""
+    ncol, m = 64, 5000
+    rows = synth.dense(m, ncol, 0.1, seed=123, noise=0.01)[0]
+    subs = O.ctr_subsets(9, 0, 80, m, ncol)
+    ctx.set_model(L.DENSE, ncol, 0.1).upload(rows)
+    ctx.hypotheses_from_subsets(subs)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    h = int(np.argmax(valid))
+    x = par[h]
+    # reference residual of row 777 for hypothesis h, computed in the reference's operation order
+    s = 0.0
+    for i in range(ncol):
+        s += rows[777, i] * x[i]
+    rho = abs(s - rows[777, ncol])
+    assert rho > 0
+    for delta in (rho, np.nextafter(rho, np.inf), np.nextafter(rho, 0.0), 0.1):
+        oc = O.cfg(O.DENSE, ncol, delta)
+        want = None
+        for variant in ("mfma", "plain", "transposed"):
+            ctx.set_option("scan_filter", 0 if variant == "plain" else 1)
+            ctx.set_option("dense_transposed", 1 if variant == "transposed" else 0)
+            ctx.set_model(L.DENSE, ncol, delta).upload(rows)
+            ctx.hypotheses_from_subsets(subs)
+            ctx.scan()
+            p2, v2, votes = ctx.hypotheses()
+            assert np.array_equal(p2[valid > 0], par[valid > 0])
+            if want is None:
+                want = np.array([O.scan(oc, p2[i], rows)[0] if v2[i] else 0 for i in range(80)])
+            assert np.array_equal(votes, want), (delta, variant)
+        # the boundary row itself: strict '<'
+        assert O.agree(oc, x, rows[777]) == (rho < delta)
+    ctx.set_option("scan_filter", 1)
+    ctx.set_option("dense_transposed", 0)
