@@ -174,7 +174,10 @@ def main():
         alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs_per_s = float(H) * a.points / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
-        filtered = a.workload == "plane" and not a.no_filter
+        filtered = a.workload in ("plane", "sphere", "us") and not a.no_filter
+        kname = {"plane": "k_scan_f32<plane> (fp32 pre-filter + exact fp64 re-check)",
+                 "sphere": "k_scan_f32<sphere> (fp32 pre-filter + exact fp64 re-check)",
+                 "us": "k_scan<us> (fused fp64 pre-filter + exact fp64 re-check)"}.get(a.workload)
         eq_gops = pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "scan_traffic.json")
@@ -205,8 +208,7 @@ def main():
                           "residual_min_max_mean_sumsq": [float(x) for x in res] if res is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("k_scan_plane_f32 (fp32 pre-filter + exact fp64 re-check)"
-                                    if filtered else "k_scan<%s> (exact fp64)" % a.workload),
+                         "kernel": kname if filtered else "k_scan<%s> (exact fp64)" % a.workload,
                          "launch_ms": scan_ms, "launches": int(n_scan),
                          "note": "achieved = algorithmic bytes (H*N*%d B per launch, SURVEY 8d) / "
                                  "launch time; the batched scan reads the observations once per "
@@ -219,7 +221,7 @@ def main():
                                   "fp64_issue_measured_gops": FP64_VALU_MEASURED_GOPS,
                                   "frac_of_peak": eq_gops / FP64_VALU_PEAK_GOPS,
                                   "frac_of_measured_issue_rate": eq_gops / FP64_VALU_MEASURED_GOPS,
-                                  "note": ("the fp32 pre-filter decides most pairs without the "
+                                  "note": ("the pre-filter decides most pairs without the "
                                            "exact fp64 formula, so the exact-equivalent rate may "
                                            "exceed the fp64 issue roof") if filtered else
                                           "exact fp64 path: fraction of the fp64 add/mul issue rate"}},

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_estimate(const double *__restrict__ 
 }
 
 // K2.  grid-stride over tiles of kBlock*PPL observations; dynamic LDS = H counters.
-template <class M, int PPL>
+template <class M, int PPL, bool FILT = true>
 __global__ __launch_bounds__(kBlock) void k_scan(const double *__restrict__ data, size_t stride,
                                                  size_t n, const double *__restrict__ sp,
                                                  uint32_t H, ModelConsts mc,
@@ -112,6 +112,24 @@ __global__ __launch_bounds__(kBlock) void k_scan(const double *__restrict__ data
 #pragma unroll
           for (int j = 0; j < PPL; j++)
             c += (uint32_t)__builtin_popcountll(__ballot(M::agree_interval(hp, rec[j])));
+        }
+      } else if constexpr (FILT && requires { M::filter_value(hp, rec[0]); }) {
+        // fused / re-associated fp64 filter with a rigorous band (M::prepare); ambiguous tiles are
+        // re-evaluated with the exact predicate
+        const double tin = hp[M::P], tout = hp[M::P + 1];
+        unsigned long long amb = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+          double v = M::filter_value(hp, rec[j]);
+          unsigned long long in = __ballot(v < tin), may = __ballot(v < tout);
+          c += (uint32_t)__builtin_popcountll(in);
+          amb |= in ^ may;
+        }
+        if (amb) {
+          c = 0;
+#pragma unroll
+          for (int j = 0; j < PPL; j++)
+            c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
         }
       } else {
 #pragma unroll
@@ -219,12 +237,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_f32(const double *__restrict__ 
 // max |x| over the first nd doubles of every record (bit patterns of non-negative doubles are
 // ordered like the values, so an integer atomicMax works)
 __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ data, size_t stride,
-                                                   size_t n, int nd,
+                                                   size_t n, int nd, int skip,
                                                    unsigned long long *__restrict__ out) {
   unsigned long long m = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock)
     for (int d = 0; d < nd; d++) {
+      if (d == skip) continue;  // US records: slot 12 holds an int + padding, not a double
       double v = fabs(data[i * stride + d]);
       unsigned long long b;
       if (!(v == v)) v = __builtin_inf();  // NaN observation: disables the filter

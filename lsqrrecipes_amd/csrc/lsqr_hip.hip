@@ -205,8 +205,9 @@ int ensure_absmax(lsqr_ctx *c) {
   if (c->absmax_valid) return LSQR_OK;
   HIPCHK(c, hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
   int grid = grid_for(c->n, kBlock * 8, 2048);
+  const bool us = c->cfg.model == LSQR_MODEL_US_SINGLE || c->cfg.model == LSQR_MODEL_US_POINTER;
   hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
-                     c->ND, c->d_counter + 2);
+                     c->ND, us ? 12 : -1, c->d_counter + 2);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 2, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
@@ -219,7 +220,7 @@ int ensure_absmax(lsqr_ctx *c) {
 int run_estimate(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
-    if constexpr (requires { M::SPF; }) {
+    if constexpr (requires { M::SPF; } || M::IS_US) {
       int st = ensure_absmax(c);
       if (st != LSQR_OK) return st;
     }
@@ -232,7 +233,7 @@ int run_estimate(lsqr_ctx *c) {
     } else if constexpr (M::IS_US) {
       hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
                          c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
-                         c->d_hparams, c->d_valid);
+                         c->mc, c->d_hparams, c->d_valid);
     } else {
       int grid = (int)((c->H + kBlock - 1) / kBlock);
       hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
@@ -259,8 +260,13 @@ int run_scan_ppl(lsqr_ctx *c) {
     size_t tpb = (tiles + max_blocks - 1) / max_blocks;
     int grid = (int)((tiles + tpb - 1) / tpb);
     ProfScope ps(c, KID_SCAN);
-    hipLaunchKernelGGL((k_scan<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream, c->d_data,
-                       c->stride, c->n, c->d_hparams + h0 * M::SP, hc, c->mc, c->d_votes + h0);
+    if (c->opt_filter)
+      hipLaunchKernelGGL((k_scan<M, PPL, true>), dim3(grid), dim3(kBlock), lds, c->stream, c->d_data,
+                         c->stride, c->n, c->d_hparams + h0 * M::SP, hc, c->mc, c->d_votes + h0);
+    else
+      hipLaunchKernelGGL((k_scan<M, PPL, false>), dim3(grid), dim3(kBlock), lds, c->stream,
+                         c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP, hc, c->mc,
+                         c->d_votes + h0);
     HIPCHK(c, hipGetLastError());
   }
   return LSQR_OK;

@@ -20,7 +20,7 @@ static const double kUsSvEps = 1.192092896e-07;  // ...Estimator.cxx:196,843 (FL
 template <bool SINGLE>
 struct USModel {
   enum {
-    ND = SINGLE ? 15 : 18, REC = ND, K = SINGLE ? 4 : 3, P = SINGLE ? 20 : 17, SP = P, PPL = 2,
+    ND = SINGLE ? 15 : 18, REC = ND, K = SINGLE ? 4 : 3, P = SINGLE ? 20 : 17, SP = P + 2, PPL = 2,
     IS_DENSE = 0, IS_US = 1,
     NC = SINGLE ? 12 : 9,                       // unknowns of the analytic system
     NMOM = 1 + NC * (NC + 1) / 2 + NC,          // {N, A^T A upper, A^T b}
@@ -79,7 +79,52 @@ struct USModel {
   static LSQR_HD double residual(const double *par, const double *x, const ModelConsts &) {
     return sqrt(dist_sq(par, x));
   }
-  static LSQR_HD void prepare(double *, const ModelConsts &) {}
+  // ---- fp64 fused / re-associated pre-filter ---------------------------------------------------
+  // filter_value() evaluates the same squared distance as dist_sq() but as R2*(T3*[u,v,0,1]) + t2 with
+  // fused multiply-adds (21 instead of 66 fp64 operations).  With u64 = 2^-53, X = max |entry| of the
+  // observations and S3 = max_j (|T3_j0| + |T3_j1|) X + |T3_j3|, every component of the mapped point is
+  // bounded by Q = sqrt(3) S3 + X and either evaluation is within Ee = 16 u64 (Q + 2X + |t1|max) of the
+  // exact component error e_i; for observations whose exact squared distance is <= 4 delta^2 the two
+  // squared distances are therefore within Ed = 4 sqrt(3) delta Ee + 3 Ee^2 + 16 u64 delta^2 of the exact
+  // one, i.e. within E = 2.02 Ed of each other (observations beyond 4 delta^2 are far from the test in
+  // both; requires E <= delta^2 / 4, else the filter is off for the hypothesis):
+  //     v <  delta^2 - E  =>  agrees;   v >= delta^2 + E  =>  does not;   otherwise dist_sq() decides.
+  static LSQR_HD void prepare(double *sp, const ModelConsts &c) {
+    const double X = c.absmax, u64 = 1.1102230246251565e-16, d2 = c.delta_sq;
+    double S3 = 0.0, t1 = 0.0;
+    bool finite = true;
+    for (int j = 0; j < 3; j++) {
+      double s = (fabs(sp[T3C + j]) + fabs(sp[T3C + 3 + j])) * X + fabs(sp[T3T + j]);
+      S3 = s > S3 ? s : S3;
+      if (SINGLE) t1 = fabs(sp[j]) > t1 ? fabs(sp[j]) : t1;
+    }
+    for (int j = 0; j < P; j++) finite = finite && sp[j] == sp[j];
+    const double Q = 1.7320508075688774 * S3 + X;
+    const double Ee = 16.0 * u64 * (Q + 2.0 * X + t1);
+    const double Ed = 4.0 * 1.7320508075688774 * c.delta * Ee + 3.0 * Ee * Ee + 16.0 * u64 * d2;
+    const double E = 2.02 * Ed;
+    bool ok = finite && X <= 1e100 && S3 <= 1e150 && E <= 0.25 * d2 && d2 > 0.0;
+    if (!finite) {  // NaN model: never agrees
+      sp[P] = sp[P + 1] = __builtin_nan("");
+    } else {
+      sp[P] = ok ? d2 - E : -INFINITY;      // below: certainly agrees
+      sp[P + 1] = ok ? d2 + E : INFINITY;   // at or above: certainly does not
+    }
+  }
+  static LSQR_HD double filter_value(const double *par, const double *x) {
+    const double u = x[13], v = x[14];
+    double p[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) p[j] = fma(par[T3C + j], u, fma(par[T3C + 3 + j], v, par[T3T + j]));
+    double d2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      double q = fma(x[3 * i], p[0], fma(x[3 * i + 1], p[1], fma(x[3 * i + 2], p[2], x[9 + i])));
+      double e = q - (SINGLE ? par[i] : x[15 + i]);
+      d2 = fma(e, e, d2);
+    }
+    return d2;
+  }
 
   // one row (j = 0..2) of the analytic system [u*R2 v*R2 R2 (-I)] x = rhs
   // (...Estimator.cxx:137-190 / :800-836)

@@ -14,7 +14,8 @@ template <bool SINGLE>
 __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ data, size_t stride,
                                                     size_t nobs,
                                                     const uint32_t *__restrict__ subsets,
-                                                    uint32_t H, double *__restrict__ hparams,
+                                                    uint32_t H, ModelConsts mc,
+                                                    double *__restrict__ hparams,
                                                     uint8_t *__restrict__ valid) {
   typedef USModel<SINGLE> M;
   constexpr int NC = M::NC, MR = 3 * M::K, LDA = 13;
@@ -41,10 +42,12 @@ __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ d
   int rank = wave_pinv_solve(MR, NC, A, LDA, V, LDA, b, kUsSvEps, 0.0, x, cw);
   bool ok = (rank == NC) && !__any(!in_range);
   if (lane == 0) {
-    double par[M::P];
+    double par[M::SP];
     if (ok) M::finish(x, par);
     const double qnan = __builtin_nan("");
-    for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = ok ? par[j] : qnan;
+    for (int j = 0; j < M::P; j++) par[j] = ok ? par[j] : qnan;
+    M::prepare(par, mc);
+    for (int j = 0; j < M::SP; j++) hparams[(size_t)h * M::SP + j] = par[j];
     valid[h] = ok ? 1 : 0;
   }
 }

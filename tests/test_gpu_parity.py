@@ -601,6 +601,75 @@ def test_filter_boundary_stress(ctx):
             assert votes[h] == O.scan(ocb, par[h], big)[0]
 
 
+@pytest.mark.parametrize("model,gen,k", US)
+def test_us_filter_and_plain_scan_agree(ctx, model, gen, k):
+    """the fused fp64 pre-filter of the US scan gives the votes of the exact predicate (and the
+    oracle's); the int outputFormat slot of the Frame (garbage as a double) must not disturb it."""
+    rec = gen(150_001, 0.4, seed=17 + model)[0]
+    rec[:, 12] = np.frombuffer(np.full(len(rec), 0x7ff8dead00000001, np.uint64).tobytes(), np.float64)
+    oc = O.cfg(model, 0, 3.0, 1)
+    ctx.set_model(model, 0, 3.0, L.LS_ANALYTIC).upload(rec)
+    ctx.hypotheses_sample(3, 0, 300)
+    ref = None
+    for filt in (1, 0):
+        ctx.set_option("scan_filter", filt)
+        ctx.scan()
+        _, _, votes = ctx.hypotheses(params=False)
+        if ref is None:
+            ref = votes.copy()
+        assert np.array_equal(votes, ref)
+    ctx.set_option("scan_filter", 1)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in range(0, 300, 37):
+        if valid[h]:
+            assert ref[h] == O.scan(oc, par[h], rec)[0]
+    assert ref.max() > 0.5 * len(rec)
+
+
+def test_us_filter_boundary_stress(ctx):
+    """frames whose mapped point sits within a few ulps of the delta-sphere around the target: the
+    fused filter must hand them to the exact predicate; votes stay bit-exact.  Then magnitudes for
+    which the error band is not small against delta^2: the filter must switch itself off."""
+    g = np.random.default_rng(12)
+    rec = synth.us_single(20_000, 0.0, seed=5, pixel_sigma=0.0)[0]
+    oc = O.cfg(O.US_SINGLE, 0, 3.0, 1)
+    ctx.set_model(L.US_SINGLE, 0, 3.0, L.LS_ANALYTIC).upload(rec)
+    subs = O.ctr_subsets(2, 0, 16, 8, 4).astype(np.uint32)   # hypotheses from frames 0..7 only
+    ctx.hypotheses_from_subsets(subs)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    h0 = int(np.flatnonzero(valid)[0])
+    P = par[h0]
+    R2 = rec[:, 0:9].reshape(-1, 3, 3)
+    T3 = np.stack([P[11:14], P[14:17]], axis=1)          # 3x2: the scaled columns of R3
+    p3 = rec[:, 13:15] @ T3.T + P[3:6]
+    q = np.einsum("mij,mj->mi", R2, p3) + rec[:, 9:12]
+    d = g.normal(size=(len(rec), 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rad = 3.0 * (1 + g.integers(-30, 31, len(rec)) * 2.0 ** -52)
+    rec2 = rec.copy()
+    rec2[8:, 9:12] += (P[0:3] + rad[:, None] * d - q)[8:]
+    ctx.upload(rec2)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par2, valid2, votes = ctx.hypotheses()
+    assert np.array_equal(par2[h0], P)
+    for h in range(16):
+        if valid2[h]:
+            assert votes[h] == O.scan(oc, par2[h], rec2)[0], h
+    assert 0.2 < votes[h0] / len(rec2) < 0.8
+    big = rec2.copy()
+    big[:, 9:12] *= 1e9                                  # |t2| ~ 1e11 against delta = 3
+    big[:8] = rec2[:8]
+    oc2 = O.cfg(O.US_SINGLE, 0, 1e-4, 1)
+    ctx.set_model(L.US_SINGLE, 0, 1e-4, L.LS_ANALYTIC).upload(big)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par3, valid3, votes3 = ctx.hypotheses()
+    for h in range(16):
+        if valid3[h]:
+            assert votes3[h] == O.scan(oc2, par3[h], big)[0], h
+
+
 ATTACH_SCRIPT = r"""
 import sys, numpy as np, torch
 torch.cuda.init()                      # torch's HIP runtime must come up before the library's
