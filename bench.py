@@ -174,9 +174,10 @@ def main():
         alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs_per_s = float(H) * a.points / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
-        filtered = a.workload in ("plane", "sphere", "us") and not a.no_filter
+        filtered = a.workload in ("plane", "sphere", "line", "us") and not a.no_filter
         kname = {"plane": "k_scan_f32<plane> (fp32 pre-filter + exact fp64 re-check)",
                  "sphere": "k_scan_f32<sphere> (fp32 pre-filter + exact fp64 re-check)",
+                 "line": "k_scan_f32<line> (fp32 pre-filter + exact fp64 re-check)",
                  "us": "k_scan<us> (fused fp64 pre-filter + exact fp64 re-check)"}.get(a.workload)
         eq_gops = pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9
         traffic = None

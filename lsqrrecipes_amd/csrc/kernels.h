@@ -161,7 +161,7 @@ __global__ void k_prepare(double *par, ModelConsts mc) {
 // (M::prepare_f32 states the error bound); a wave whose tile holds an ambiguous observation for the
 // current hypothesis re-evaluates that tile with the exact fp64 predicate, so the votes are
 // bit-identical to k_scan's.
-template <class M, int PPL>
+template <class M, int PPL, int GRAN = 0>
 __global__ __launch_bounds__(kBlock) void k_scan_f32(const double *__restrict__ data,
                                                            size_t stride, size_t n,
                                                            const double *__restrict__ sp,
@@ -195,8 +195,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_f32(const double *__restrict__ 
       }
     for (uint32_t h = 0; h < H; h++) {
       const v2f *f = (const v2f *)(spf + (size_t)h * M::SPF);  // wave-uniform -> scalar loads
-      const v2f fp[4] = {f[0], f[1], f[2], f[3]};
-      const float tin = f[4].x, tout = f[4].y;
+      v2f fp[M::NF];
+#pragma unroll
+      for (int q = 0; q < M::NF; q++) fp[q] = f[q];
+      const float tin = f[M::NF].x, tout = f[M::NF].y;
       v2f a[PPL / 2];
       unsigned long long may[PPL], any = 0;
 #pragma unroll
@@ -209,20 +211,34 @@ __global__ __launch_bounds__(kBlock) void k_scan_f32(const double *__restrict__ 
       }
       if (any == 0) continue;  // wave-uniform: no observation of this tile is near the model
       uint32_t c = 0;
-      unsigned long long amb = 0;
+      if constexpr (GRAN == 0) {
+        unsigned long long amb = 0;
 #pragma unroll
-      for (int q = 0; q < PPL / 2; q++) {
-        unsigned long long in0 = __ballot(__builtin_fabsf(a[q].x) < tin);
-        unsigned long long in1 = __ballot(__builtin_fabsf(a[q].y) < tin);
-        c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
-        amb |= (in0 ^ may[2 * q]) | (in1 ^ may[2 * q + 1]);
-      }
-      if (amb) {  // rare, wave-uniform: exact fp64 predicate for this tile and hypothesis
+        for (int q = 0; q < PPL / 2; q++) {
+          unsigned long long in0 = __ballot(__builtin_fabsf(a[q].x) < tin);
+          unsigned long long in1 = __ballot(__builtin_fabsf(a[q].y) < tin);
+          c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
+          amb |= (in0 ^ may[2 * q]) | (in1 ^ may[2 * q + 1]);
+        }
+        if (amb) {  // rare, wave-uniform: exact fp64 predicate for this tile and hypothesis
+          const double *hp = sp + (size_t)h * M::SP;
+          c = 0;
+#pragma unroll
+          for (int j = 0; j < PPL; j++)
+            c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
+        }
+      } else {  // re-check per packed pair (64 lanes x 2 observations) instead of per tile
         const double *hp = sp + (size_t)h * M::SP;
-        c = 0;
 #pragma unroll
-        for (int j = 0; j < PPL; j++)
-          c += (uint32_t)__builtin_popcountll(__ballot(M::agree(hp, rec[j], mc)));
+        for (int q = 0; q < PPL / 2; q++) {
+          unsigned long long in0 = __ballot(__builtin_fabsf(a[q].x) < tin);
+          unsigned long long in1 = __ballot(__builtin_fabsf(a[q].y) < tin);
+          if ((in0 ^ may[2 * q]) | (in1 ^ may[2 * q + 1])) {
+            in0 = __ballot(M::agree(hp, rec[2 * q], mc));
+            in1 = __ballot(M::agree(hp, rec[2 * q + 1], mc));
+          }
+          c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
+        }
       }
       if (leader && c) atomicAdd(&s_cnt[h], c);
     }

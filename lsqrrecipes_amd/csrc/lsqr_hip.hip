@@ -272,7 +272,7 @@ int run_scan_ppl(lsqr_ctx *c) {
   return LSQR_OK;
 }
 
-template <class M, int PPL>
+template <class M, int PPL, int GRAN = 0>
 int run_scan_f32(lsqr_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
   size_t tiles = (c->n + (size_t)kBlock * PPL - 1) / ((size_t)kBlock * PPL);
@@ -285,7 +285,7 @@ int run_scan_f32(lsqr_ctx *c) {
     size_t tpb = (tiles + max_blocks - 1) / max_blocks;
     int grid = (int)((tiles + tpb - 1) / tpb);
     ProfScope ps(c, KID_SCAN);
-    hipLaunchKernelGGL((k_scan_f32<M, PPL>), dim3(grid), dim3(kBlock), lds, c->stream,
+    hipLaunchKernelGGL((k_scan_f32<M, PPL, GRAN>), dim3(grid), dim3(kBlock), lds, c->stream,
                        c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
                        c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
     HIPCHK(c, hipGetLastError());
@@ -358,6 +358,13 @@ int run_scan(lsqr_ctx *c) {
     if constexpr (requires { M::SPF; }) {  // plane, sphere: fp32 pre-filter + exact re-evaluation
       if (c->opt_filter) {
         int ppl = c->opt_ppl ? c->opt_ppl : 4;  // measured best (tools/ab_scan.py)
+        // re-check granularity: per packed pair (line: wide band, ambiguous tiles are common) or per
+        // tile; scan_filter 2 / 3 force one or the other for A/B runs
+        const bool pair = c->opt_filter == 2 || (c->opt_filter == 1 && M::FGRAN == 1);
+        if (pair) {
+          if (ppl == 8) return run_scan_f32<M, 8, 1>(c);
+          return run_scan_f32<M, 4, 1>(c);
+        }
         if (ppl == 8) return run_scan_f32<M, 8>(c);
         if (ppl == 16) return run_scan_f32<M, 16>(c);
         return run_scan_f32<M, 4>(c);
@@ -1424,7 +1431,7 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_filter")) {
-    c->opt_filter = value != 0;
+    c->opt_filter = value < 0 ? 0 : (value > 3 ? 1 : value);  // 2 / 3: force pair / tile re-check
     return LSQR_OK;
   }
   if (!strcmp(name, "max_iterations")) {  // budget for lsqr_ransac (0 = reference behaviour)

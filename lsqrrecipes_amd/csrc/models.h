@@ -169,7 +169,7 @@ struct PlaneModel {
   //     |s32| <  T - E  =>  |s| < T   (certainly agrees)
   //     |s32| >= T + E  =>  |s| >= T  (certainly does not)
   // and only observations in the band in between are re-evaluated with the exact fp64 formula.
-  enum { SPF = 12 };  // (n0,n0) (n1,n1) (n2,n2) (-c,-c) tin tout 0 0: pairs feed v_pk_* directly
+  enum { NF = 4, SPF = 12, FGRAN = 0 };  // (n0,n0) (n1,n1) (n2,n2) (-c,-c) tin tout 0 0: pairs feed v_pk_* directly
   static LSQR_HD float round_down_f32(double v) {
     float f = (float)v;
     if ((double)f > v) f = nextafterf(f, -INFINITY);
@@ -292,6 +292,66 @@ struct LineModel {
   static LSQR_HD void prepare(double *, const ModelConsts &) {}
   static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) { return sqrt(dist_sq(sp, x)); }
 
+  // ---- fp32 pre-filter ------------------------------------------------------------------------
+  // filter_value() = |(x - a) x n|^2 in packed fp32 (the cross-product form has no cancellation of
+  // the along-line component).  Bound, with u = 2^-24, u64 = 2^-53, X = max |coordinate|,
+  // A = max |a_i|, W = X + A (bounds every |x_i - a_i|) and cap = 4 delta^2; for observations whose
+  // exact squared distance D* = |(x-a) x n|^2 is <= cap:
+  //   v32_i is within 2uW(1+u) of x_i - a_i and n32_i within u of n_i, so every cross-product
+  //   component is within ec = 6uW + u sqrt(cap) of the exact one (3 sqrt2 uW from the operands, uW
+  //   from the rounded product, u|c| from the fma), and the fp32 sum of squares within
+  //   E32 = 2 sqrt3 sqrt(cap) ec + 3 ec^2 + 4 u cap of D*;
+  //   the reference's fp64 expression |v - (v.n) n|^2 is within Eref = 2 sqrt3 sqrt(cap) ew + 3 ew^2 +
+  //   4 u64 cap, ew = 12 u64 W, of its exact value, which differs from D* by at most
+  //   Enn = 6 W^2 (| |n|^2 - 1 | + 4 u64)  (n is a unit vector only to rounding).
+  // With E = 1.01 (E32 + Eref + Enn):  s32 < delta^2 - E  =>  agrees;  s32 >= delta^2 + E  =>  does
+  // not (observations beyond cap evaluate above 3 delta^2 in fp32 as long as 6 sqrt3 uW <= delta/4,
+  // and E <= delta^2/4 is required); in between the exact fp64 predicate decides.
+  enum { NF = 6, SPF = 16, FGRAN = 1 };  // (-a_i,-a_i) x3, (n_i,n_i) x3, tin, tout, 0, 0
+  static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
+    const double X = c.absmax, u = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
+    for (int i = 0; i < SPF; i++) f[i] = 0.0f;
+    double A = 0.0, nn = 0.0;
+    bool ok = X >= 1e-10 && X <= 1e15;
+    for (int i = 0; i < D; i++) {
+      f[2 * i] = f[2 * i + 1] = -(float)sp[D + i];
+      f[6 + 2 * i] = f[7 + 2 * i] = (float)sp[i];
+      A = fabs(sp[D + i]) > A ? fabs(sp[D + i]) : A;
+      nn += sp[i] * sp[i];
+      ok = ok && fabs(sp[i]) <= 1.0000001;
+    }
+    ok = ok && A <= 1e15 && fabs(nn - 1.0) <= 1e-6;
+    const double W = X + A, cap = 4.0 * c.delta_sq, rc = 2.0 * c.delta, s3 = 1.7320508075688774;
+    const double ec = 6.0 * u * W * (1.0 + 4.0 * u) + u * rc;
+    const double E32 = 2.0 * s3 * rc * ec + 3.0 * ec * ec + 4.0 * u * cap;
+    const double ew = 12.0 * u64 * W;
+    const double Eref = 2.0 * s3 * rc * ew + 3.0 * ew * ew + 4.0 * u64 * cap;
+    const double Enn = 6.0 * W * W * (fabs(nn - 1.0) + 4.0 * u64);
+    const double E = 1.01 * (E32 + Eref + Enn);
+    ok = ok && 6.0 * s3 * u * W <= 0.25 * c.delta && E <= 0.25 * c.delta_sq && c.delta_sq > 1e-30 &&
+         c.delta_sq <= 1e30;
+    f[12] = ok ? PlaneModel<3>::round_down_f32(c.delta_sq - E) : -INFINITY;
+    f[13] = ok ? PlaneModel<3>::round_up_f32(c.delta_sq + E) : INFINITY;
+    if (!(sp[0] == sp[0])) f[12] = f[13] = __builtin_nanf("");  // NaN model: nothing agrees
+  }
+#if defined(__HIPCC__)
+  static __device__ inline v2f filter_value(const v2f *xs, const v2f *f) {
+    v2f v0 = xs[0] + f[0], v1 = xs[1] + f[1];
+    if constexpr (D == 3) {
+      v2f v2 = xs[2] + f[2];
+      v2f c0 = __builtin_elementwise_fma(v1, f[5], -(v2 * f[4]));
+      v2f c1 = __builtin_elementwise_fma(v2, f[3], -(v0 * f[5]));
+      v2f c2 = __builtin_elementwise_fma(v0, f[4], -(v1 * f[3]));
+      v2f s = c0 * c0;
+      s = __builtin_elementwise_fma(c1, c1, s);
+      return __builtin_elementwise_fma(c2, c2, s);
+    } else {
+      v2f c = __builtin_elementwise_fma(v0, f[4], -(v1 * f[3]));
+      return c * c;
+    }
+  }
+#endif
+
   static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
     PlaneModel<D>::accumulate(x, org, m);
   }
@@ -412,7 +472,7 @@ struct SphereModel {
   // its rounding) + 1e-12 Dcap (fp64 vs exact):
   //   |t| <  half - Ecap  =>  D_ref in [Dlo, Dhi]  (certainly agrees)
   //   |t| >= half + Ecap  =>  certainly does not;   in between: exact fp64 predicate.
-  enum { SPF = 12 };
+  enum { NF = 4, SPF = 12, FGRAN = 0 };
   static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
     const double X = c.absmax, u = 5.9604644775390625e-08;
     for (int i = 0; i < 12; i++) f[i] = 0.0f;

@@ -546,12 +546,13 @@ def test_large_batch_is_chunked(ctx):
 
 @pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3)])
 def test_filter_and_plain_scan_agree(ctx, model, dim):
-    """the fp32 pre-filter (plane) and every observations-per-lane variant give identical votes"""
+    """the fp32 pre-filter (either re-check granularity) and every observations-per-lane variant
+    give identical votes"""
     data = _data(model, dim, 200_003, 4321, outliers=0.5)
     ctx.set_model(model, dim, 0.5).upload(data)
     ctx.hypotheses_sample(11, 0, 700)
     ref = None
-    for ppl, filt in ((0, 1), (4, 0), (8, 0), (2, 0), (8, 1), (16, 1)):
+    for ppl, filt in ((0, 1), (4, 0), (8, 0), (2, 0), (8, 1), (16, 1), (4, 2), (8, 2), (4, 3)):
         ctx.set_option("scan_ppl", ppl)
         ctx.set_option("scan_filter", filt)
         ctx.scan()
@@ -735,6 +736,49 @@ def test_profile_counters(ctx):
     n, ms = ctx.profile_get("estimate")
     assert n == 1
     ctx.profile(False)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_line_filter_boundary_stress(ctx, dim):
+    """observations within a few fp64 ulps .. fp32 ulps of the delta-cylinder around a line: the
+    fp32 cross-product filter must route them to the exact predicate (bit-exact votes); then
+    magnitudes where its band is useless: it must switch itself off."""
+    g = np.random.default_rng(31 + dim)
+    d0 = np.array([0.48, 0.6, 0.64])[:dim]
+    d0 /= np.linalg.norm(d0)
+    a0 = np.array([700.0, -300.0, 500.0])[:dim]
+    m = 80_000
+    t = g.uniform(-1000, 1000, m)
+    perp = g.normal(size=(m, dim))
+    perp -= (perp @ d0)[:, None] * d0
+    perp /= np.linalg.norm(perp, axis=1)[:, None]
+    scale = np.where(np.arange(m) % 2 == 0, 2.0 ** -52, 1e-7)
+    rad = 0.5 * (1 + g.integers(-40, 41, m) * scale)
+    pts = np.ascontiguousarray(a0 + t[:, None] * d0 + rad[:, None] * perp)
+    pts[0] = a0 - 900 * d0
+    pts[1] = a0 + 900 * d0
+    oc = O.cfg(O.LINE, dim, 0.5)
+    ctx.set_model(L.LINE, dim, 0.5).upload(pts)
+    subs = np.vstack([[0, 1], O.ctr_subsets(4, 0, 63, m, 2)]).astype(np.uint32)
+    for filt in (1, 3, 0):
+        ctx.set_option("scan_filter", filt)
+        ctx.hypotheses_from_subsets(subs)
+        ctx.scan()
+        par, valid, votes = ctx.hypotheses()
+        assert abs(abs(par[0][:dim] @ d0) - 1) < 1e-9
+        for h in range(64):
+            if valid[h]:
+                assert votes[h] == O.scan(oc, par[h], pts)[0], (filt, h)
+        assert 0.2 < votes[0] / m < 0.8
+    ctx.set_option("scan_filter", 1)
+    big = pts * 1e9                                      # fp32 band >> delta^2: filter off
+    ctx.set_model(L.LINE, dim, 0.5).upload(big)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in (0, 5, 9):
+        if valid[h]:
+            assert votes[h] == O.scan(oc, par[h], big)[0]
 
 
 def test_sphere_filter_boundary_stress(ctx):
