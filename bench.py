@@ -38,8 +38,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=10_000_000)
-    ap.add_argument("--batch", type=int, default=4096, help="hypotheses per GPU per step")
+    ap.add_argument("--points", type=int, default=0, help="observations (0 = the BASELINE.json size of "
+                    "the workload: 10 M points, 2 M dense rows, 1 M US frames)")
+    ap.add_argument("--batch", type=int, default=0, help="hypotheses per GPU per step (0 = 4096; "
+                    "1024 for the dense system)")
     ap.add_argument("--workload", default="plane",
                     choices=["plane", "sphere", "line", "dense", "us"])
     ap.add_argument("--no-filter", action="store_true", help="plain fp64 scan (no fp32 pre-filter)")
@@ -96,6 +98,10 @@ def cpu_baseline(workload, data, delta):
 
 def main():
     a = parse()
+    if a.points <= 0:
+        a.points = {"dense": 2_000_000, "us": 1_000_000}.get(a.workload, 10_000_000)
+    if a.batch <= 0:
+        a.batch = 1024 if a.workload == "dense" else 4096
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -210,13 +210,19 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                asks for more (0 = the reference's behaviour: up to C(N,k));
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the
  *                host, 0 = in a single-lane device kernel (same lm_core.h code either way);
+ * "scan_index":  two-level scan of the point models over a spatial index of the observations
+ *                (Morton-sorted copy + one fp32 bounding box per cell of 256 observations, built on the
+ *                device once per upload): 1 (default) = used once an upload has seen >= 2048
+ *                hypotheses and holds >= 65536 observations, 0 = never, 2 = always.  Votes are
+ *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = default),
+ *                "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default);
  * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS
  *                (k_scan_dense_t), 0 = rows in registers, hypotheses through the scalar cache. */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,
- * 2 scan, 3 mask, 4 moments, 5 solve. */
+ * 2 scan, 3 mask, 4 moments, 5 solve, 6 spatial-index build (once per upload). */
 LSQR_API int lsqr_profile_enable(lsqr_ctx *ctx, int on);
 LSQR_API int lsqr_profile_get(lsqr_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);
 LSQR_API int lsqr_profile_reset(lsqr_ctx *ctx);

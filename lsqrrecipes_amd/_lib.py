@@ -14,7 +14,8 @@ OK, EMPTY, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE = range(6)
 PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER = 1, 2, 3, 4, 5, 6
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 LS_ANALYTIC, LS_ITERATIVE = 0, 1
-KERNEL_IDS = {"sample": 0, "estimate": 1, "scan": 2, "mask": 3, "moments": 4, "solve": 5}
+KERNEL_IDS = {"sample": 0, "estimate": 1, "scan": 2, "mask": 3, "moments": 4, "solve": 5,
+              "index": 6}
 
 
 class LsqrError(RuntimeError):

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "dense.h"
 #include "us_kernels.h"
+#include "cells.h"
 
 using namespace lsqr;
 
@@ -40,6 +41,14 @@ struct lsqr_ctx {
   float *d_hparams_f32 = nullptr;
   unsigned long long *d_amb = nullptr;  // worklist of the dense MFMA filter
   bool absmax_valid = false;
+  // spatial index of the point models (cells.h): Morton-sorted copy + one fp32 box per 128 records
+  double *d_sorted = nullptr;
+  CellBox *d_boxes = nullptr;
+  size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
+  uint32_t n_cells = 0, cell_pts = 0;
+  bool index_valid = false;
+  uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
+  int opt_index = 1, opt_cpt = 0, opt_cell = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   bool scanned = false;
@@ -72,7 +81,8 @@ struct lsqr_ctx {
 
 namespace {
 
-enum { KID_SAMPLE = 0, KID_ESTIMATE = 1, KID_SCAN = 2, KID_MASK = 3, KID_MOMENTS = 4, KID_SOLVE = 5 };
+enum { KID_SAMPLE = 0, KID_ESTIMATE = 1, KID_SCAN = 2, KID_MASK = 3, KID_MOMENTS = 4, KID_SOLVE = 5,
+       KID_INDEX = 6 };
 
 int fail(lsqr_ctx *c, int status, const char *fmt, ...) {
   if (c) {
@@ -293,7 +303,137 @@ int run_scan_f32(lsqr_ctx *c) {
   return LSQR_OK;
 }
 
+
+// ---- spatial index (cells.h) ------------------------------------------------------------------------
+void drop_index(lsqr_ctx *c) {
+  if (c->d_sorted) (void)hipFree(c->d_sorted);
+  if (c->d_boxes) (void)hipFree(c->d_boxes);
+  c->d_sorted = nullptr;
+  c->d_boxes = nullptr;
+  c->n_sorted = 0;
+  c->n_cells = 0;
+  c->index_valid = false;
+}
+
+template <int D>
+int build_index(lsqr_ctx *c, uint32_t cell_pts) {
+  drop_index(c);
+  c->cell_pts = cell_pts;
+  ProfScope ps(c, KID_INDEX);
+  const size_t n = c->n;
+  unsigned long long *d_b = nullptr;
+  uint32_t *d_keys = nullptr, *d_hist = nullptr, *d_bsum = nullptr;
+  auto cleanup = [&]() {
+    if (d_b) (void)hipFree(d_b);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_hist) (void)hipFree(d_hist);
+    if (d_bsum) (void)hipFree(d_bsum);
+  };
+#define IDXCHK(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      cleanup();                                                                              \
+      drop_index(c);                                                                          \
+      return fail(c, LSQR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                        \
+    }                                                                                         \
+  } while (0)
+  unsigned long long hb[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
+  IDXCHK(hipMalloc((void **)&d_b, sizeof hb));
+  IDXCHK(hipMemcpyAsync(d_b, hb, sizeof hb, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL((k_bounds<D>), dim3(grid_for(n, 256 * 8, 2048)), dim3(256), 0, c->stream,
+                     c->d_data, c->stride, n, d_b);
+  IDXCHK(hipGetLastError());
+  IDXCHK(hipMemcpyAsync(hb, d_b, sizeof hb, hipMemcpyDeviceToHost, c->stream));
+  IDXCHK(hipStreamSynchronize(c->stream));
+  if (hb[0] == ~0ULL) {  // no finite record at all: nothing can agree
+    cleanup();
+    c->index_valid = true;
+    return LSQR_OK;
+  }
+  IndexGrid g;
+  memset(&g, 0, sizeof g);
+  int total = 0;
+  while (total < 24 && ((size_t)4 << (total + 1)) <= n) total++;  // about 4 records per bin
+  int bits = total / D;
+  if (bits < 1) bits = 1;
+  if (D == 3 && bits > 8) bits = 8;
+  if (D == 2 && bits > 12) bits = 12;
+  g.bits = (uint32_t)bits;
+  g.nbins = 1u << (bits * D);
+  for (int d = 0; d < D; d++) {
+    double lo = ord_u64_inv(hb[d]), hi = ord_u64_inv(hb[3 + d]);
+    double sc = hi > lo ? (double)(1u << bits) / (hi - lo) : 0.0;
+    if (!(sc >= 0.0) || !(sc <= 1.7976931348623157e308)) sc = 0.0;
+    g.lo[d] = lo;
+    g.scale[d] = sc;
+  }
+  const uint32_t m = g.nbins + 1;
+  const uint32_t nblk = (m + kScanSpan - 1) / kScanSpan;
+  IDXCHK(hipMalloc((void **)&d_keys, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+  IDXCHK(hipMalloc((void **)&d_hist, (size_t)m * sizeof(uint32_t)));
+  IDXCHK(hipMalloc((void **)&d_bsum, (size_t)nblk * sizeof(uint32_t)));
+  IDXCHK(hipMemsetAsync(d_hist, 0, (size_t)m * sizeof(uint32_t), c->stream));
+  const unsigned gn = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL((k_keys<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n, g,
+                     d_keys, d_hist);
+  IDXCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_hist_blocksum, dim3(nblk), dim3(256), 0, c->stream, d_hist, m, d_bsum);
+  hipLaunchKernelGGL(k_hist_scan_bsum, dim3(1), dim3(256), 0, c->stream, d_bsum, nblk);
+  hipLaunchKernelGGL(k_hist_apply, dim3(nblk), dim3(256), 0, c->stream, d_hist, m, d_bsum);
+  IDXCHK(hipGetLastError());
+  uint32_t ns32 = 0;  // exclusive prefix at the "non-finite" bin = number of finite records
+  IDXCHK(hipMemcpyAsync(&ns32, d_hist + g.nbins, sizeof ns32, hipMemcpyDeviceToHost, c->stream));
+  IDXCHK(hipStreamSynchronize(c->stream));
+  if ((size_t)ns32 > n) {
+    cleanup();
+    return fail(c, LSQR_ERR_HIP, "index build: inconsistent histogram");
+  }
+  IDXCHK(hipMalloc((void **)&c->d_sorted, std::max<size_t>(n, 1) * D * sizeof(double)));
+  hipLaunchKernelGGL((k_scatter<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n,
+                     d_keys, d_hist, c->d_sorted);
+  IDXCHK(hipGetLastError());
+  c->n_sorted = ns32;
+  c->n_cells = (uint32_t)((c->n_sorted + cell_pts - 1) / cell_pts);
+  IDXCHK(hipMalloc((void **)&c->d_boxes, std::max<size_t>(c->n_cells, 1) * sizeof(CellBox)));
+  if (c->n_cells) {
+    hipLaunchKernelGGL((k_cell_boxes<D>), dim3((c->n_cells + 3) / 4), dim3(256), 0, c->stream,
+                       c->d_sorted, c->n_sorted, c->n_cells, cell_pts, c->d_boxes);
+    IDXCHK(hipGetLastError());
+  }
+  IDXCHK(hipStreamSynchronize(c->stream));
+  cleanup();
+#undef IDXCHK
+  c->index_valid = true;
+  return LSQR_OK;
+}
+
+template <class M, int PP, int CPT>
+int run_scan_cells(lsqr_ctx *c) {
+  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+  if (c->n_cells == 0) return LSQR_OK;
+  const size_t wtiles = ((size_t)c->n_cells + CPT - 1) / CPT;
+  uint32_t *d_next = (uint32_t *)(c->d_counter + 4);
+  for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
+    uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
+    size_t lds = (size_t)hc * sizeof(uint32_t);
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    size_t blocks = std::min<size_t>((wtiles + 3) / 4, (size_t)256 * per_cu);
+    ProfScope ps(c, KID_SCAN);
+    HIPCHK(c, hipMemsetAsync(d_next, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL((k_scan_cells<M, PP, CPT>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
+                       c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
+                       c->d_hparams + h0 * M::SP, c->d_hparams_f32 + h0 * M::SPF, hc, c->mc,
+                       c->d_votes + h0, d_next);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LSQR_OK;
+}
+
 int run_scan(lsqr_ctx *c) {
+  c->hyp_since_upload += c->H;
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     if constexpr (M::IS_DENSE) {  // default: MFMA filter + exact recheck of ambiguous pairs
@@ -355,8 +495,40 @@ int run_scan(lsqr_ctx *c) {
         return LSQR_OK;
       }
     }
-    if constexpr (requires { M::SPF; }) {  // plane, sphere: fp32 pre-filter + exact re-evaluation
-      if (c->opt_filter) {
+    if constexpr (requires { M::SPF; }) {  // plane, sphere, line: fp32 pre-filter + exact re-evaluation
+      // magnitudes the fp32 copies cannot hold (or NaN): the plain fp64 kernel below
+      const bool f32_ok = c->absmax_valid && c->mc.absmax <= 1e15;
+      if constexpr (requires { cell_survives((const M *)nullptr, (const float *)nullptr, 0.0f,
+                                             *(const CellBox *)nullptr); }) {
+        // two-level scan over the spatial index; auto: built once an upload has seen enough
+        // hypotheses to pay for the build (a few HBM passes)
+        const bool tuned_defaults = c->opt_filter == 1 && c->opt_ppl == 0;  // A/B knobs untouched
+        const bool want = c->opt_filter && f32_ok &&
+                          (c->opt_index == 2 ||
+                           (c->opt_index == 1 && tuned_defaults &&
+                            (c->index_valid || (c->n >= 65536 && c->hyp_since_upload >= 2048))));
+        if (want) {
+          const uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : 256;
+          if (!c->index_valid || c->cell_pts != cell_pts) {
+            int st = build_index<M::ND>(c, cell_pts);
+            if (st != LSQR_OK) return st;
+          }
+          const int cpt = c->opt_cpt ? c->opt_cpt : 1;
+          if (cell_pts == 128) {
+            if (cpt == 1) return run_scan_cells<M, 1, 1>(c);
+            if (cpt == 2) return run_scan_cells<M, 1, 2>(c);
+            return run_scan_cells<M, 1, 4>(c);
+          }
+          if (cell_pts == 512) {
+            if (cpt == 1) return run_scan_cells<M, 4, 1>(c);
+            return run_scan_cells<M, 4, 2>(c);
+          }
+          if (cpt == 1) return run_scan_cells<M, 2, 1>(c);
+          if (cpt == 2) return run_scan_cells<M, 2, 2>(c);
+          return run_scan_cells<M, 2, 4>(c);
+        }
+      }
+      if (c->opt_filter && f32_ok) {
         int ppl = c->opt_ppl ? c->opt_ppl : 4;  // measured best (tools/ab_scan.py)
         // re-check granularity: per packed pair (line: wide band, ambiguous tiles are common) or per
         // tile; scan_filter 2 / 3 force one or the other for A/B runs
@@ -717,6 +889,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drop_index(c);
   void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
@@ -793,6 +966,8 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->ND = lsqr_record_doubles(cfg);
   c->HS = dispatch(*cfg, [](auto tag) { return (int)decltype(tag)::type::SP; });
   c->has_model = true;
+  drop_index(c);
+  c->absmax_valid = false;
   c->H = 0;
   c->scanned = false;
   c->mask_valid = false;
@@ -808,6 +983,8 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   if (count > 0xFFFFFFF0ull) return fail(c, LSQR_ERR_INVALID, "too many observations");
   c->n = count;
   c->absmax_valid = false;
+  drop_index(c);
+  c->hyp_since_upload = 0;
   c->stride = stride_bytes / sizeof(double);
   c->H = 0;
   c->scanned = false;
@@ -1444,6 +1621,23 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "lm_host")) {
     c->opt_lm_host = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_index")) {  // 0 off, 1 auto, 2 always (point models)
+    if (value < 0 || value > 2) return fail(c, LSQR_ERR_INVALID, "scan_index must be 0, 1 or 2");
+    c->opt_index = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_cpt")) {  // cells per wave tile of the two-level scan
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail(c, LSQR_ERR_INVALID, "scan_cpt must be 0, 1, 2 or 4");
+    c->opt_cpt = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_cell")) {  // observations per cell of the spatial index
+    if (value != 0 && value != 128 && value != 256 && value != 512)
+      return fail(c, LSQR_ERR_INVALID, "scan_cell must be 0, 128, 256 or 512");
+    c->opt_cell = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_transposed")) {

@@ -868,3 +868,127 @@ def test_dense_mfma_filter_is_exact(ctx):
         assert O.agree(oc, x, rows[777]) == (rho < delta)
     ctx.set_option("scan_filter", 1)
     ctx.set_option("dense_transposed", 0)
+
+
+# ---- two-level scan over the spatial index (csrc/cells.h) -------------------------------------------
+def _scan_votes(ctx, index, cell=0, cpt=0):
+    ctx.set_option("scan_index", index)
+    ctx.set_option("scan_cell", cell)
+    ctx.set_option("scan_cpt", cpt)
+    ctx.scan()
+    _, _, v = ctx.hypotheses(params=False)
+    ctx.set_option("scan_index", 1)
+    ctx.set_option("scan_cell", 0)
+    ctx.set_option("scan_cpt", 0)
+    return v.copy()
+
+
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.PLANE, 2)])
+@pytest.mark.parametrize("n", [3, 127, 128, 129, 5000, 200_003])
+def test_cell_scan_matches_exhaustive_and_oracle(ctx, model, dim, n):
+    """the culled two-level scan (forced, any size) counts exactly what the exhaustive kernels and
+    the oracle count; ragged last cell, fewer observations than one cell, H not a multiple of 64"""
+    data = _data(model, dim, n, 777 + n, outliers=0.5)
+    H = 200
+    ctx.set_model(model, dim, 0.5).upload(data)
+    ctx.hypotheses_sample(21, 0, H)
+    plain = _scan_votes(ctx, 0)
+    for cell, cpt in ((0, 0), (128, 1), (128, 4), (256, 2), (512, 1), (512, 2)):
+        assert np.array_equal(_scan_votes(ctx, 2, cell, cpt), plain), (cell, cpt)
+    oc = O.cfg(model, dim, 0.5)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in range(0, H, 23):
+        if valid[h]:
+            assert plain[h] == O.scan(oc, par[h], data)[0]
+
+
+def test_cell_scan_nonfinite_duplicate_and_flat_data(ctx):
+    """NaN / inf observations never agree and are left out of the index; identical observations
+    and axis-aligned (zero-extent) cells must not break the box test"""
+    g = np.random.default_rng(9)
+    data = synth.plane(70_001, 0.5, seed=99)[0]
+    data[::1000, 0] = np.nan
+    data[1::1000, 1] = np.inf
+    data[2::1000, 2] = -np.inf
+    data[5000:9000] = data[4999]                  # 4000 identical observations
+    data[20_000:30_000, 2] = 12.25                # a flat slab: zero half extent in z
+    H = 130
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    subs = O.ctr_subsets(8, 0, H, len(data), 3)
+    subs[0] = [20_003, 20_004, 20_005]            # the plane z = 12.25 exactly
+    subs[1] = [4999, 5000, 5001]                  # degenerate (identical points)
+    ctx.hypotheses_from_subsets(subs)
+    plain = _scan_votes(ctx, 0)
+    assert np.array_equal(_scan_votes(ctx, 2), plain)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    assert not valid[1] and plain[1] == 0
+    assert plain[0] >= 10_000
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    for h in (0, 2, 50, 129):
+        if valid[h]:
+            assert plain[h] == O.scan(oc, par[h], data)[0]
+    # nothing finite at all
+    bad = np.full((300, 3), np.nan)
+    bad[:3] = [[0, 0, 0], [1, 0, 0], [0, 1, np.inf]]
+    ctx.upload(bad)
+    ctx.hypotheses_from_subsets(np.array([[0, 1, 2], [3, 4, 5]], dtype=np.uint32))
+    assert np.array_equal(_scan_votes(ctx, 2), _scan_votes(ctx, 0))
+
+
+def test_cell_scan_boundary_stress(ctx):
+    """observations within a few fp32 ulps of the band edge, the model plane cutting through every
+    cell, and a tiny delta that switches the fp32 filter off: votes stay bit-exact"""
+    g = np.random.default_rng(6)
+    n0 = np.array([0.36, 0.48, 0.8])
+    a0 = np.array([900.0, -700.0, 650.0])
+    base = g.uniform(-1000, 1000, (80_000, 3))
+    base -= ((base - a0) @ n0)[:, None] * n0
+    off = np.where(g.random(80_000) < 0.5, 0.5, -0.5) * (1 + g.integers(-40, 41, 80_000) * 1e-7)
+    pts = np.ascontiguousarray(base + off[:, None] * n0)
+    pts[:3] = [a0, a0 + np.array([1.0, 0, -0.45]) * 300, a0 + np.array([0, 1.0, -0.6]) * 300]
+    subs = np.vstack([[0, 1, 2], O.ctr_subsets(4, 0, 99, len(pts), 3)]).astype(np.uint32)
+    for delta in (0.5, 1e-9):
+        oc = O.cfg(O.PLANE, 3, delta)
+        ctx.set_model(L.PLANE, 3, delta).upload(pts)
+        ctx.hypotheses_from_subsets(subs)
+        plain = _scan_votes(ctx, 0)
+        assert np.array_equal(_scan_votes(ctx, 2), plain)
+        par, valid, _ = ctx.hypotheses(votes=False)
+        for h in (0, 1, 37, 99):
+            if valid[h]:
+                assert plain[h] == O.scan(oc, par[h], pts)[0]
+    # magnitudes beyond fp32: the index is bypassed (plain fp64 kernel), not misused
+    big = pts * 1e30
+    ctx.set_model(L.PLANE, 3, 0.5e30).upload(big)
+    ctx.hypotheses_from_subsets(subs)
+    v = _scan_votes(ctx, 2)
+    ocb = O.cfg(O.PLANE, 3, 0.5e30)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in (0, 5):
+        if valid[h]:
+            assert v[h] == O.scan(ocb, par[h], big)[0]
+
+
+def test_cell_scan_auto_mode_and_ransac(ctx):
+    """default options: the index is built once the upload has seen enough hypotheses, and
+    RANSAC::compute() gives the same result with and without it"""
+    data = synth.plane(300_000, 0.5, seed=31)[0]
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    ctx.profile(True)
+    ctx.hypotheses_sample(3, 0, 4096)
+    ctx.scan()
+    _, _, v_auto = ctx.hypotheses(params=False)
+    n_idx, _ = ctx.profile_get("index")
+    ctx.profile(False)
+    assert n_idx == 1, "index build expected on the first large batch"
+    assert np.array_equal(_scan_votes(ctx, 0), v_auto)
+    ctx.set_option("max_iterations", 20000)
+    r1 = ctx.ransac(0.999, seed=77)
+    ctx.set_option("scan_index", 0)
+    r0 = ctx.ransac(0.999, seed=77)
+    ctx.set_option("scan_index", 1)
+    ctx.set_option("max_iterations", 0)
+    assert r1["info"].iterations == r0["info"].iterations
+    assert r1["info"].best_index == r0["info"].best_index
+    assert np.array_equal(r1["consensus"], r0["consensus"])
+    assert np.array_equal(r1["params"], r0["params"])
