@@ -262,32 +262,171 @@ __global__ __launch_bounds__(256) void k_cell_boxes(const double *__restrict__ s
   }
 }
 
-// ---- level-1 tests (lane = hypothesis; hf = the hypothesis' fp32 filter parameters) ---------------
-// Each returns true unless NO point of the box can pass the model's candidate test |value| < tout
-// (models.h: prepare_f32), with tc = tout * (1 + 2^-20) rounded up.
-//
-// plane: candidate value s32(x) = fma chain of n32.x32 - c32, |s32(x) - n.(x-a)| <= B < E (prepare_f32).
-//   d32 = the same chain at the (fp32-exact) box centre, so |d32 - n.(ctr-a)| <= B;
-//   r32 = fma(|n0|,h0, fma(|n1|,h1, fma(|n2|,h2, tc))) >= (sum|n_i|h_i + tc)(1 - 4u)
-//                                                       >= sum|n_i| hx_i + tout      (hx_i = h_i/(1+2^-20), 4u < 2^-20)
-//   A point x of the box with |n.(x-a)| < T + 1e-14 X (everything the reference can count) has
-//   |n.(ctr-a)| < T + 1e-14 X + sum|n_i| hx_i, hence |d32| < T + B + 1e-14 X + sum|n_i| hx_i <= r32
-//   because tout >= T + 1.01 B + 1e-12 X.  So "|d32| < r32 is false" => no point of the cell agrees.
-//   tout = +inf (filter disabled) keeps every cell; tout = NaN (NaN model) drops every cell.
+// ---- per-model cell logic ------------------------------------------------------------------------------
+// A cell model CM provides
+//   Hyp                      per-lane hypothesis state (lane = hypothesis), built by load() from the
+//                            hypothesis' fp64 scan parameters (M::SP doubles)
+//   level1(hyp, box, cc, bc) conservative test "can any observation inside the box agree?" and the
+//                            NB per-(hypothesis, cell) values bc[] the second level needs:
+//                            bc[0..NV) feed value(), bc[NB-2] = tin, bc[NB-1] = tout
+//   value(xs, fp)            packed fp32 filter measure v of two observations with the guarantee
+//                            |v| < tin => agrees,  |v| >= tout => does not agree   (exact fp64 predicate
+//                            decides in between)
+// CellConsts are per-launch constants derived on the host (cell_consts<CM>()).
+struct CellConsts {
+  float f[8];
+};
+
+// Plane.  Observations are stored relative to the (fp32-exact) cell centre, x' = fl32(x - ctr), and the
+// level-1 pass evaluates d0 = n.ctr - n.a in fp64, so the fp32 arithmetic only ever sees cell-sized
+// numbers.  With u = 2^-24, h_i the half extents, rr* = sum|n_i|h_i, s* = n.(x-a) = n.x' + d0:
+//   s32 = fma(n32_0,x'_0, fma(n32_1,x'_1, fma(n32_2,x'_2, fl32(d0))))
+//   |s32 - s*| <= u rr* (x' rounding) + u rr* (n rounding) + u|d0| (d0 rounding)
+//                 + 3u(|d0| + rr*)(1+4u) (three fma results) + fp64 noise
+//              <= u(5.1 rr* + 4.1|d0|) + 2e-12 X
+// and a cell that passed level 1 has |d0| <= (rr + tout)(1 + 2^-18), so for every observation of a
+// surviving cell |s32 - s*| <= u(9.3 rr + 4.2 tout) + 2e-12 X <= E := 1.01u(9.4 rr + 4.3 T) + 3e-12 X.
+// The reference's fp64 s differs from s* by < 1e-13 X.  Hence with tin = (Tdn - E)(1 - 2^-22),
+// tout = (Tup + E)(1 + 2^-22) (Tdn <= T <= Tup the fp32 neighbours of the exact threshold T):
+//   |s32| < tin => |s_ref| < T (agrees);   |s32| >= tout => |s_ref| >= T (does not).
+// Level 1: an observation of the box with |s_ref| < T has |d0| < T + rr* + 1e-13 X, so
+// |fl32(d0)| < (rr + tout)(1 + 2^-19); "false" therefore proves that nothing in the cell agrees.
+// A NaN model (or a lane past the batch) gives d0 = NaN: never survives.  |n_i| > 1 (never produced by
+// estimate()) sets E = inf: every cell survives and every observation takes the exact path.
 template <int D>
-__device__ inline bool cell_survives(const PlaneModel<D> *, const float *hf, float tc,
-                                     const CellBox &b) {
-  float d = hf[3];
-  float r = tc;
-  if (D == 3) {
-    d = __builtin_fmaf(hf[2], b.c[2], d);
-    r = __builtin_fmaf(__builtin_fabsf(hf[2]), b.h[2], r);
+struct PlaneCell {
+  typedef PlaneModel<D> M;
+  enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0 };  // row = the fp64 scan parameters
+  struct Hyp {
+    double n[3], c;
+    float nf[3], e0;
+  };
+  static __device__ inline void load(const float *row, bool valid, const CellConsts &cc, Hyp &h) {
+    double r[2 * D];
+#pragma unroll
+    for (int i = 0; i < 2 * D; i++) {
+      const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, row[2 * i]) |
+                                      ((unsigned long long)__builtin_bit_cast(uint32_t, row[2 * i + 1]) << 32);
+      r[i] = __builtin_bit_cast(double, bits);
+    }
+    bool ok = true;
+    h.c = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double ni = i < D ? (valid ? r[i] : __builtin_nan("")) : 0.0;
+      h.n[i] = ni;
+      h.nf[i] = (float)ni;
+      if (i < D) {
+        h.c += ni * r[D + i];
+        ok = ok && fabs(ni) <= 1.0000001;
+      }
+    }
+    h.e0 = ok ? cc.f[2] : __builtin_inff();
   }
-  d = __builtin_fmaf(hf[1], b.c[1], d);
-  r = __builtin_fmaf(__builtin_fabsf(hf[1]), b.h[1], r);
-  d = __builtin_fmaf(hf[0], b.c[0], d);
-  r = __builtin_fmaf(__builtin_fabsf(hf[0]), b.h[0], r);
-  return __builtin_fabsf(d) < r;
+  static __device__ inline bool level1(const Hyp &h, const CellBox &b, const double *ctr,
+                                       const CellConsts &cc, float *bc) {
+    double d = -h.c;
+    float rr = 0.0f;
+#pragma unroll
+    for (int i = D - 1; i >= 0; i--) {
+      d = fma(h.n[i], ctr[i], d);
+      rr = __builtin_fmaf(__builtin_fabsf(h.nf[i]), b.h[i], rr);
+    }
+    const float d0 = (float)d;
+    const float E = __builtin_fmaf(rr, cc.f[3], h.e0);
+    const float tout = (cc.f[1] + E) * 1.0000003f;
+    const float tin = (cc.f[0] - E) * 0.9999997f;
+    bc[0] = h.nf[0], bc[1] = h.nf[1], bc[2] = h.nf[2], bc[3] = d0, bc[4] = tin, bc[5] = tout;
+    return __builtin_fabsf(d0) < (rr + tout) * 1.000004f;
+  }
+  static __device__ inline v2f value(const v2f *xs, const v2f *fp) {
+    v2f s = fp[3];
+    if (D == 3) s = __builtin_elementwise_fma(xs[2], fp[2], s);
+    s = __builtin_elementwise_fma(xs[1], fp[1], s);
+    s = __builtin_elementwise_fma(xs[0], fp[0], s);
+    return s;
+  }
+};
+
+inline float f32_up_host(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = nextafterf(f, INFINITY);
+  return f;
+}
+inline float f32_down_host(double v) {
+  float f = (float)v;
+  if ((double)f > v) f = nextafterf(f, -INFINITY);
+  return f;
+}
+template <int D>
+inline CellConsts cell_consts(const PlaneCell<D> *, const ModelConsts &mc) {
+  const double u = 5.9604644775390625e-08;
+  CellConsts cc;
+  memset(&cc, 0, sizeof cc);
+  cc.f[0] = f32_down_host(mc.thr);
+  cc.f[1] = f32_up_host(mc.thr);
+  cc.f[2] = f32_up_host((1.01 * 4.3 * u * mc.thr + 3e-12 * mc.absmax) * (1.0 + 1e-6));
+  cc.f[3] = f32_up_host(1.01 * 9.4 * u * (1.0 + 1e-6));
+  return cc;
+}
+
+// Sphere.  Observations stay in absolute coordinates; the second level is SphereModel's packed fp32
+// measure t = sum (x32_i - c32_i)^2 - mid with its (tin, tout) of prepare_f32 (models.h), whose bound
+// already holds for every observation with |x_i| <= X.  Level 1 bounds the squared distance from the
+// sphere centre over the box:  g_i = |ctr_i - c_i|, lo_i = max(g_i - hh_i, 0), hi_i = g_i + hh_i with
+// hh_i = h_i + e, e = 1.01 * 2u(X + C)(1 + u) >= the fp32 error of g_i (|ctr_i| <= X, |c_i| <= C), so
+// for every observation of the box  sum lo_i^2 (1 - 8u) <= D* <= sum hi_i^2 (1 + 8u)  (the factors
+// cover the fp32 evaluation of the two sums).  The reference agrees only for D_ref in [dlo, dhi]
+// (SphereModel::prepare; D_ref within 1e-12 relative of D*), so with f[10] = fl32_down(dlo (1 - 1e-9)),
+// f[11] = fl32_up(dhi (1 + 1e-9)):  dmax2 (1 + 8u) < f[10]  or  dmin2 (1 - 8u) > f[11]  proves that no
+// observation of the cell agrees.  Hypotheses whose filter is switched off (tout = +inf: literal
+// formula, magnitudes outside the validated range) keep every cell and take the exact path for
+// every observation; a NaN model fails both comparisons' complements and never survives.
+template <int D>
+struct SphereCell {
+  typedef SphereModel<D> M;
+  enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1 };
+  struct Hyp {
+    float nc[3], nmid, tin, tout, dlo, dhi;
+  };
+  static __device__ inline void load(const float *row, bool valid, const CellConsts &, Hyp &h) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) h.nc[i] = row[2 * i];
+    h.nmid = row[6];
+    h.tin = row[8];
+    h.tout = valid ? row[9] : __builtin_nanf("");
+    h.dlo = valid ? row[10] : __builtin_nanf("");
+    h.dhi = row[11];
+  }
+  static __device__ inline bool level1(const Hyp &h, const CellBox &b, const double *,
+                                       const CellConsts &cc, float *bc) {
+    float dmin2 = 0.0f, dmax2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const float g = __builtin_fabsf(b.c[i] + h.nc[i]);
+      const float e = (cc.f[0] + __builtin_fabsf(h.nc[i])) * cc.f[1];  // 1.01 * 2u (X + |c_i|)(1 + u)
+      const float hh = b.h[i] + e;
+      const float lo = __builtin_fmaxf(g - hh, 0.0f), hi = g + hh;
+      dmin2 = __builtin_fmaf(lo, lo, dmin2);
+      dmax2 = __builtin_fmaf(hi, hi, dmax2);
+    }
+    bc[0] = h.nc[0], bc[1] = h.nc[1], bc[2] = h.nc[2], bc[3] = h.nmid, bc[4] = h.tin, bc[5] = h.tout;
+    const bool off = h.tout == __builtin_inff();  // filter disabled: everything goes the exact way
+    const bool hit = (dmax2 * 1.000001f >= h.dlo) & (dmin2 * 0.999999f <= h.dhi);
+    return off | hit;
+  }
+  static __device__ inline v2f value(const v2f *xs, const v2f *fp) {
+    return M::filter_value(xs, fp);
+  }
+};
+template <int D>
+inline CellConsts cell_consts(const SphereCell<D> *, const ModelConsts &mc) {
+  const double u = 5.9604644775390625e-08;
+  CellConsts cc;
+  memset(&cc, 0, sizeof cc);
+  cc.f[0] = f32_up_host(mc.absmax);
+  cc.f[1] = f32_up_host(1.01 * 2.0 * u * (1.0 + 1e-6));
+  return cc;
 }
 
 // ---- the scan ----------------------------------------------------------------------------------------
@@ -295,19 +434,23 @@ __device__ inline bool cell_survives(const PlaneModel<D> *, const float *hf, flo
 // CPT cells whose observations stay in registers for the whole hypothesis loop.  Tiles are handed
 // out through an atomic counter (near-model cells cost several times more than far ones, a static
 // assignment leaves a long tail); the next 64 hypotheses' parameters are prefetched while the
-// current 64 are processed.
-template <class M, int PP, int CPT>
+// current 64 are processed.  Votes of the 64 hypotheses of a group are collected in one VGPR
+// (lane b = hypothesis h0 + b, v_readlane / v_writelane) and flushed with one LDS atomic per group.
+template <class CM, int PP, int CPT>
 __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
                                                     const CellBox *__restrict__ boxes,
                                                     uint32_t ncells, const double *__restrict__ sp,
-                                                    const float *__restrict__ spf, uint32_t H,
-                                                    ModelConsts mc, uint32_t *__restrict__ votes,
+                                                    const float *__restrict__ rows, uint32_t H,
+                                                    ModelConsts mc, CellConsts cc,
+                                                    uint32_t *__restrict__ votes,
                                                     uint32_t *__restrict__ next_tile) {
+  typedef typename CM::M M;
   constexpr int D = M::ND;
-  constexpr int NF = M::NF;
-  constexpr int CP = 128 * PP;  // observations per cell
-  constexpr int NV = M::SPF / 4;
-  static_assert(M::SPF % 4 == 0 && 2 * NF + 2 <= M::SPF, "fp32 parameter block layout");
+  constexpr int NB = CM::NB, NV = CM::NV;
+  constexpr int SPD = M::SP;
+  constexpr int ROW = CM::ROW, NR4 = ROW / 4;  // per-hypothesis row of the level-1 pass, 16-byte loads
+  constexpr int CP = 128 * PP;                 // observations per cell
+  static_assert(ROW % 4 == 0, "hypothesis rows are fetched as 16-byte loads");
   extern __shared__ uint32_t s_cnt[];
   for (uint32_t h = threadIdx.x; h < H; h += 256) s_cnt[h] = 0;
   __syncthreads();
@@ -320,9 +463,17 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
     if (wt >= wtiles) break;
     v2f xs[CPT][PP][3];
     CellBox bx[CPT];
+    double ctr[CPT][3];
 #pragma unroll
     for (int q = 0; q < CPT; q++) {
       const uint32_t cell = wt * CPT + q;
+      if (cell < ncells) {
+        bx[q] = boxes[cell];  // wave-uniform address -> scalar load
+      } else {
+        for (int d = 0; d < 3; d++) bx[q].c[d] = 0.0f, bx[q].h[d] = __builtin_nanf("");  // never survives
+      }
+#pragma unroll
+      for (int d = 0; d < 3; d++) ctr[q][d] = (double)bx[q].c[d];
 #pragma unroll
       for (int p = 0; p < PP; p++) {
         const size_t i0 = (size_t)cell * CP + p * 128 + lane, i1 = i0 + 64;
@@ -330,71 +481,63 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
         const double *p0 = sorted + (i0 < ns ? i0 : 0) * D, *p1 = sorted + (i1 < ns ? i1 : 0) * D;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          const float a0 = d < D ? (float)p0[d < D ? d : 0] : 0.0f;
-          const float a1 = d < D ? (float)p1[d < D ? d : 0] : 0.0f;
+          const double off = CM::RELATIVE ? ctr[q][d] : 0.0;
+          const float a0 = d < D ? (float)(p0[d < D ? d : 0] - off) : 0.0f;
+          const float a1 = d < D ? (float)(p1[d < D ? d : 0] - off) : 0.0f;
           xs[q][p][d].x = (d < D && !(i0 < ns)) ? __builtin_nanf("") : a0;
           xs[q][p][d].y = (d < D && !(i1 < ns)) ? __builtin_nanf("") : a1;
         }
       }
-      if (cell < ncells) {
-        bx[q] = boxes[cell];  // wave-uniform address -> scalar load
-      } else {
-        for (int d = 0; d < 3; d++) bx[q].c[d] = 0.0f, bx[q].h[d] = __builtin_nanf("");  // never survives
-      }
     }
-    // the hypothesis' fp32 block {v0,v0, v1,v1, ..., tin, tout, 0, 0} as 16-byte loads
-    float4 nxt[NV];
+    float4 nxt[NR4];
     {
-      const float4 *f4 = (const float4 *)(spf + (size_t)((uint32_t)lane < H ? lane : 0) * M::SPF);
+      const float4 *r4 = (const float4 *)(rows + (size_t)((uint32_t)lane < H ? lane : 0) * ROW);
 #pragma unroll
-      for (int k = 0; k < NV; k++) nxt[k] = f4[k];
+      for (int k = 0; k < NR4; k++) nxt[k] = r4[k];
     }
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
       const uint32_t h = h0 + lane;
-      float fl[M::SPF];
+      float row[ROW];
 #pragma unroll
-      for (int k = 0; k < NV; k++)
-        fl[4 * k] = nxt[k].x, fl[4 * k + 1] = nxt[k].y, fl[4 * k + 2] = nxt[k].z, fl[4 * k + 3] = nxt[k].w;
+      for (int k = 0; k < NR4; k++)
+        row[4 * k] = nxt[k].x, row[4 * k + 1] = nxt[k].y, row[4 * k + 2] = nxt[k].z, row[4 * k + 3] = nxt[k].w;
       if (h0 + 64 < H) {  // prefetch the next group
         const uint32_t hn = h + 64;
-        const float4 *f4 = (const float4 *)(spf + (size_t)(hn < H ? hn : 0) * M::SPF);
+        const float4 *r4 = (const float4 *)(rows + (size_t)(hn < H ? hn : 0) * ROW);
 #pragma unroll
-        for (int k = 0; k < NV; k++) nxt[k] = f4[k];
+        for (int k = 0; k < NR4; k++) nxt[k] = r4[k];
       }
-      float hf[NF];
-#pragma unroll
-      for (int k = 0; k < NF; k++) hf[k] = fl[2 * k];
-      const float tin = fl[2 * NF];
-      const float tout = h < H ? fl[2 * NF + 1] : __builtin_nanf("");
-      const float tc = tout * 1.00000096f;  // >= tout * (1 + 2^-20) after rounding
+      typename CM::Hyp hy;
+      CM::load(row, h < H, cc, hy);
       uint32_t accv = 0;  // lane b: votes of hypothesis h0 + b collected from this tile
 #pragma unroll
       for (int q = 0; q < CPT; q++) {
-        unsigned long long surv = __ballot(cell_survives((const M *)nullptr, hf, tc, bx[q]));
+        float bc[NB];
+        unsigned long long surv = __ballot(CM::level1(hy, bx[q], ctr[q], cc, bc));
         while (surv) {
           const int b = __builtin_ctzll(surv);
           asm("s_bitset0_b64 %0, %1" : "+s"(surv) : "s"(b));  // surv &= ~(1 << b)
-          v2f fp[NF];
+          v2f fp[NV];
 #pragma unroll
-          for (int k = 0; k < NF; k++) {
+          for (int k = 0; k < NV; k++) {
             float v = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hf[k]), b));
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[k]), b));
             fp[k].x = v;
             fp[k].y = v;
           }
-          const float btout =
-              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tout), b));
+          const float btout = __builtin_bit_cast(
+              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b));
           // candidate test on the smallest |value| of the lane: NaN rows are ignored by min
           v2f s[PP];
           float m = __builtin_inff();
 #pragma unroll
           for (int p = 0; p < PP; p++) {
-            s[p] = M::filter_value(xs[q][p], fp);
+            s[p] = CM::value(xs[q][p], fp);
             m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(s[p].x), __builtin_fabsf(s[p].y)));
           }
           if (__ballot(m < btout) == 0) continue;
-          const float btin =
-              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tin), b));
+          const float btin = __builtin_bit_cast(
+              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 2]), b));
           unsigned long long in[2 * PP], amb = 0;
 #pragma unroll
           for (int p = 0; p < PP; p++) {
@@ -404,7 +547,7 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
                    (in[2 * p + 1] ^ __ballot(__builtin_fabsf(s[p].y) < btout));
           }
           if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
-            const double *hp = sp + (size_t)(h0 + b) * M::SP;  // wave-uniform -> scalar loads
+            const double *hp = sp + (size_t)(h0 + b) * SPD;  // wave-uniform -> scalar loads
 #pragma unroll
             for (int p = 0; p < PP; p++) {
               const size_t i0 = (size_t)(wt * CPT + q) * CP + p * 128 + lane, i1 = i0 + 64;

@@ -304,6 +304,18 @@ int run_scan_f32(lsqr_ctx *c) {
 }
 
 
+// cell model of a point model (cells.h); models without one keep the exhaustive kernels
+template <class M>
+struct CellOf {};
+template <int D>
+struct CellOf<PlaneModel<D>> {
+  typedef PlaneCell<D> type;
+};
+template <int D>
+struct CellOf<SphereModel<D>> {
+  typedef SphereCell<D> type;
+};
+
 // ---- spatial index (cells.h) ------------------------------------------------------------------------
 void drop_index(lsqr_ctx *c) {
   if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -409,8 +421,10 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   return LSQR_OK;
 }
 
-template <class M, int PP, int CPT>
+template <class CM, int PP, int CPT>
 int run_scan_cells(lsqr_ctx *c) {
+  typedef typename CM::M M;
+  const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
   HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
   if (c->n_cells == 0) return LSQR_OK;
   const size_t wtiles = ((size_t)c->n_cells + CPT - 1) / CPT;
@@ -423,10 +437,12 @@ int run_scan_cells(lsqr_ctx *c) {
     size_t blocks = std::min<size_t>((wtiles + 3) / 4, (size_t)256 * per_cu);
     ProfScope ps(c, KID_SCAN);
     HIPCHK(c, hipMemsetAsync(d_next, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL((k_scan_cells<M, PP, CPT>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
-                       c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
-                       c->d_hparams + h0 * M::SP, c->d_hparams_f32 + h0 * M::SPF, hc, c->mc,
-                       c->d_votes + h0, d_next);
+    hipLaunchKernelGGL((k_scan_cells<CM, PP, CPT>), dim3((unsigned)blocks), dim3(256), lds,
+                       c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
+                       c->d_hparams + h0 * M::SP,
+                       CM::ROW_F32 ? c->d_hparams_f32 + h0 * M::SPF
+                                   : (const float *)(c->d_hparams + h0 * M::SP),
+                       hc, c->mc, cc, c->d_votes + h0, d_next);
     HIPCHK(c, hipGetLastError());
   }
   return LSQR_OK;
@@ -498,12 +514,12 @@ int run_scan(lsqr_ctx *c) {
     if constexpr (requires { M::SPF; }) {  // plane, sphere, line: fp32 pre-filter + exact re-evaluation
       // magnitudes the fp32 copies cannot hold (or NaN): the plain fp64 kernel below
       const bool f32_ok = c->absmax_valid && c->mc.absmax <= 1e15;
-      if constexpr (requires { cell_survives((const M *)nullptr, (const float *)nullptr, 0.0f,
-                                             *(const CellBox *)nullptr); }) {
+      if constexpr (requires { typename CellOf<M>::type; }) {
+        typedef typename CellOf<M>::type CM;
         // two-level scan over the spatial index; auto: built once an upload has seen enough
         // hypotheses to pay for the build (a few HBM passes)
         const bool tuned_defaults = c->opt_filter == 1 && c->opt_ppl == 0;  // A/B knobs untouched
-        const bool want = c->opt_filter && f32_ok &&
+        const bool want = c->opt_filter && f32_ok && c->mc.absmax >= 1e-10 &&
                           (c->opt_index == 2 ||
                            (c->opt_index == 1 && tuned_defaults &&
                             (c->index_valid || (c->n >= 65536 && c->hyp_since_upload >= 2048))));
@@ -515,17 +531,17 @@ int run_scan(lsqr_ctx *c) {
           }
           const int cpt = c->opt_cpt ? c->opt_cpt : 1;
           if (cell_pts == 128) {
-            if (cpt == 1) return run_scan_cells<M, 1, 1>(c);
-            if (cpt == 2) return run_scan_cells<M, 1, 2>(c);
-            return run_scan_cells<M, 1, 4>(c);
+            if (cpt == 1) return run_scan_cells<CM, 1, 1>(c);
+            if (cpt == 2) return run_scan_cells<CM, 1, 2>(c);
+            return run_scan_cells<CM, 1, 4>(c);
           }
           if (cell_pts == 512) {
-            if (cpt == 1) return run_scan_cells<M, 4, 1>(c);
-            return run_scan_cells<M, 4, 2>(c);
+            if (cpt == 1) return run_scan_cells<CM, 4, 1>(c);
+            return run_scan_cells<CM, 4, 2>(c);
           }
-          if (cpt == 1) return run_scan_cells<M, 2, 1>(c);
-          if (cpt == 2) return run_scan_cells<M, 2, 2>(c);
-          return run_scan_cells<M, 2, 4>(c);
+          if (cpt == 1) return run_scan_cells<CM, 2, 1>(c);
+          if (cpt == 2) return run_scan_cells<CM, 2, 2>(c);
+          return run_scan_cells<CM, 2, 4>(c);
         }
       }
       if (c->opt_filter && f32_ok) {

@@ -493,7 +493,10 @@ struct SphereModel {
     const double slack = Ecap + 2.0 * u * mid;  // mid itself is rounded to fp32
     f[8] = (ok && half - slack > 0.0) ? PlaneModel<3>::round_down_f32(half - slack) : -INFINITY;
     f[9] = ok ? PlaneModel<3>::round_up_f32(half + slack) : INFINITY;
-    if (!(sp[0] == sp[0]) || (dlo != dlo)) f[8] = f[9] = __builtin_nanf("");  // never agrees
+    // squared-radius interval rounded outwards for the cell test of the two-level scan (cells.h)
+    f[10] = ok ? PlaneModel<3>::round_down_f32(dlo * (1.0 - 1e-9)) : 0.0f;
+    f[11] = ok ? PlaneModel<3>::round_up_f32(dhi * (1.0 + 1e-9)) : INFINITY;
+    if (!(sp[0] == sp[0]) || (dlo != dlo)) f[8] = f[9] = f[10] = f[11] = __builtin_nanf("");  // never agrees
   }
 #if defined(__HIPCC__)
   static __device__ inline v2f filter_value(const v2f *xs, const v2f *f) {

@@ -883,8 +883,8 @@ def _scan_votes(ctx, index, cell=0, cpt=0):
     return v.copy()
 
 
-@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.PLANE, 2)])
-@pytest.mark.parametrize("n", [3, 127, 128, 129, 5000, 200_003])
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.PLANE, 2), (L.SPHERE, 3), (L.SPHERE, 2)])
+@pytest.mark.parametrize("n", [4, 127, 128, 129, 5000, 200_003])
 def test_cell_scan_matches_exhaustive_and_oracle(ctx, model, dim, n):
     """the culled two-level scan (forced, any size) counts exactly what the exhaustive kernels and
     the oracle count; ragged last cell, fewer observations than one cell, H not a multiple of 64"""
@@ -992,3 +992,35 @@ def test_cell_scan_auto_mode_and_ransac(ctx):
     assert r1["info"].best_index == r0["info"].best_index
     assert np.array_equal(r1["consensus"], r0["consensus"])
     assert np.array_equal(r1["params"], r0["params"])
+
+
+def test_cell_scan_sphere_boundary_stress(ctx):
+    """sphere: observations within a few fp32 ulps of both edges of the band, a sphere much larger
+    and one much smaller than a cell, a tiny-delta (literal formula) run: the two-level scan counts
+    exactly what the oracle counts"""
+    g = np.random.default_rng(18)
+    c0 = np.array([310.5, -420.25, 97.125])
+    r, delta = 512.0, 0.5
+    m = 90_000
+    u = g.normal(size=(m, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    edge = np.where(g.random(m) < 0.5, r + delta, r - delta)
+    rad = edge * (1 + g.integers(-60, 61, m) * 1e-8)
+    pts = np.ascontiguousarray(c0 + u * rad[:, None])
+    pts[60_000:] = g.uniform(-1000, 1000, (m - 60_000, 3))       # clutter
+    pts[:4] = c0 + r * np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]], float)
+    pts[4:8] = pts[70_000] + 0.7 * np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]], float)
+    subs = np.vstack([[0, 1, 2, 3], [4, 5, 6, 7], O.ctr_subsets(6, 0, 98, m, 4)]).astype(np.uint32)
+    for d in (delta, 1e-13):
+        oc = O.cfg(O.SPHERE, 3, d)
+        ctx.set_model(L.SPHERE, 3, d).upload(pts)
+        ctx.hypotheses_from_subsets(subs)
+        plain = _scan_votes(ctx, 0)
+        for cell in (128, 256, 512):
+            assert np.array_equal(_scan_votes(ctx, 2, cell, 1), plain), (d, cell)
+        par, valid, _ = ctx.hypotheses(votes=False)
+        for h in (0, 1, 2, 50, 99):
+            if valid[h]:
+                assert plain[h] == O.scan(oc, par[h], pts)[0], (d, h)
+        if d == delta:
+            assert 0.2 < plain[0] / m < 0.8
