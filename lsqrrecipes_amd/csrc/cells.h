@@ -35,7 +35,7 @@ constexpr int kCellPtsMin = 128;  // cell sizes are multiples of one packed fp32
 struct CellBox {  // 32 B: one s_load_dwordx8
   float c[3];     // centre (exactly representable, inside the box)
   float h[3];     // half extents, inflated: every point satisfies |x_i - c_i| * (1 + 2^-20) <= h_i
-  float pad[2];
+  float pad[2];   // pad[0]: bounding radius |h|, rounded up
 };
 
 // ---- index build ---------------------------------------------------------------------------------
@@ -257,7 +257,12 @@ __global__ __launch_bounds__(256) void k_cell_boxes(const double *__restrict__ s
         bx.h[d] = 0.0f;
       }
     }
-    bx.pad[0] = bx.pad[1] = 0.0f;
+    // bounding radius |h| (rounded up): every point of the cell is within pad[0] of the centre
+    double r2 = 0.0;
+    for (int d = 0; d < D; d++) r2 += (double)bx.h[d] * (double)bx.h[d];
+    const double rad = sqrt(r2) * (1.0 + 1e-6);
+    bx.pad[0] = rad <= 3.4e38 ? f32_up(rad) : __builtin_inff();
+    bx.pad[1] = 0.0f;
     boxes[cell] = bx;
   }
 }
@@ -276,6 +281,12 @@ __global__ __launch_bounds__(256) void k_cell_boxes(const double *__restrict__ s
 struct CellConsts {
   float f[8];
 };
+// an fp64 value fetched as two 32-bit words of a float row
+__device__ inline double f64_from(const float *w) {
+  const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, w[0]) |
+                                  ((unsigned long long)__builtin_bit_cast(uint32_t, w[1]) << 32);
+  return __builtin_bit_cast(double, bits);
+}
 
 // Plane.  Observations are stored relative to the (fp32-exact) cell centre, x' = fl32(x - ctr), and the
 // level-1 pass evaluates d0 = n.ctr - n.a in fp64, so the fp32 arithmetic only ever sees cell-sized
@@ -296,19 +307,16 @@ struct CellConsts {
 template <int D>
 struct PlaneCell {
   typedef PlaneModel<D> M;
-  enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0 };  // row = the fp64 scan parameters
+  enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 0, ROW2_OFF = 0 };  // row = fp64 scan parameters
   struct Hyp {
     double n[3], c;
     float nf[3], e0;
   };
-  static __device__ inline void load(const float *row, bool valid, const CellConsts &cc, Hyp &h) {
+  static __device__ inline void load(const float *row, const float *, bool valid,
+                                     const CellConsts &cc, Hyp &h) {
     double r[2 * D];
 #pragma unroll
-    for (int i = 0; i < 2 * D; i++) {
-      const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, row[2 * i]) |
-                                      ((unsigned long long)__builtin_bit_cast(uint32_t, row[2 * i + 1]) << 32);
-      r[i] = __builtin_bit_cast(double, bits);
-    }
+    for (int i = 0; i < 2 * D; i++) r[i] = f64_from(row + 2 * i);
     bool ok = true;
     h.c = 0.0;
 #pragma unroll
@@ -385,11 +393,12 @@ inline CellConsts cell_consts(const PlaneCell<D> *, const ModelConsts &mc) {
 template <int D>
 struct SphereCell {
   typedef SphereModel<D> M;
-  enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1 };
+  enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
   struct Hyp {
     float nc[3], nmid, tin, tout, dlo, dhi;
   };
-  static __device__ inline void load(const float *row, bool valid, const CellConsts &, Hyp &h) {
+  static __device__ inline void load(const float *row, const float *, bool valid,
+                                     const CellConsts &, Hyp &h) {
 #pragma unroll
     for (int i = 0; i < 3; i++) h.nc[i] = row[2 * i];
     h.nmid = row[6];
@@ -429,6 +438,98 @@ inline CellConsts cell_consts(const SphereCell<D> *, const ModelConsts &mc) {
   return cc;
 }
 
+// Line.  Like the plane: observations relative to the cell centre, and the level-1 pass works in fp64.
+//   v = ctr - a,  t = v.n,  w = v - t n   (offset of the centre from the line, w = ctr - p0, p0 on the line)
+// so that for an observation x = ctr + x' of the cell  (x - p0) = x' + w  and the model's measure
+// |(x - a) x n|^2 = |(x' + w) x n|^2  only involves cell-sized numbers.  The second level is
+// LineModel::filter_value() on (x', +w, n); its bound (models.h: prepare_f32) holds verbatim with
+// W replaced by Wc = 2R + rho >= max |x'_i| + |w|  (R = bounding radius of the cell, |w| <= R + rho for a
+// surviving cell) plus eta = 1e-12 (X + A) for the fp64 evaluation of w:
+//   ec = 6u Wc (1 + 4u) + u sqrt(cap) + 2 eta,   E32 = 2 sqrt3 sqrt(cap) ec + 3 ec^2 + 4u cap
+//   E = 1.01 E32 + 1.01 (Eref + Enn)      (the second term per hypothesis: f[15])
+// valid when 6 sqrt3 u Wc <= delta/4 and E <= delta^2/4 (otherwise tin = -inf, tout = +inf: exact path).
+// Level 1: dist = |w| (fp32 norm of fl32(w): within 4u dist + eta of exact); an observation of the cell
+// has |(x - a) x n| >= dist - R|n|, and D_ref >= |(x - a) x n|^2 - (Enn + Eref), so
+//   dist > R + rho,  rho = delta(1 + 1e-6) + sqrt(Enn + Eref) + 1.01 * 24u(X + A)   (f[14])
+// proves D_ref > delta^2 for the whole cell.  tout_abs = +inf (f[13]: the hypothesis' filter is off)
+// keeps every cell and sends every observation the exact way; NaN never survives.
+template <int D>
+struct LineCell {
+  typedef LineModel<D> M;
+  enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
+  struct Hyp {
+    double n[3], a[3];
+    float nf[3], rho, eh;
+    bool off;
+  };
+  static __device__ inline void load(const float *row, const float *row2, bool valid,
+                                     const CellConsts &, Hyp &h) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (i < D) {
+        h.n[i] = valid ? f64_from(row + 2 * i) : __builtin_nan("");
+        h.a[i] = f64_from(row + 2 * (D + i));
+      } else {
+        h.n[i] = 0.0, h.a[i] = 0.0;
+      }
+      h.nf[i] = (float)h.n[i];
+    }
+    h.off = valid && row2[1] == __builtin_inff();
+    h.rho = valid ? row2[2] : __builtin_nanf("");
+    h.eh = row2[3];
+  }
+  static __device__ inline bool level1(const Hyp &h, const CellBox &b, const double *ctr,
+                                       const CellConsts &cc, float *bc) {
+    double v[3], t = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      v[i] = ctr[i] - h.a[i];
+      t = fma(v[i], h.n[i], t);
+    }
+    float wf[3] = {0.0f, 0.0f, 0.0f}, d2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      wf[i] = (float)fma(-t, h.n[i], v[i]);
+      d2 = __builtin_fmaf(wf[i], wf[i], d2);
+    }
+    const float dist = __builtin_sqrtf(d2);
+    const float R = b.pad[0];
+    // cc.f: 0 Tdn, 1 Tup, 2 6u(1+4u), 3 u sqrt(cap) + 2 eta, 4 2 sqrt3 sqrt(cap), 5 4u cap,
+    //       6 delta / (4 * 6 sqrt3 u), 7 delta^2 / 4
+    const float Wc = (2.0f * R + h.rho) * 1.000001f;
+    const float ec = __builtin_fmaf(Wc, cc.f[2], cc.f[3]);
+    const float E32 = __builtin_fmaf(ec, cc.f[4], __builtin_fmaf(3.0f * ec, ec, cc.f[5]));
+    float E = __builtin_fmaf(E32, 1.0100001f, h.eh);
+    const bool ok = (Wc <= cc.f[6]) & (E <= cc.f[7]) & !h.off;
+    E = ok ? E : __builtin_inff();
+    bc[0] = wf[0], bc[1] = wf[1], bc[2] = wf[2];
+    bc[3] = h.nf[0], bc[4] = h.nf[1], bc[5] = h.nf[2];
+    bc[6] = (cc.f[0] - E) * 0.9999997f;
+    bc[7] = (cc.f[1] + E) * 1.0000003f;
+    return h.off | (dist <= R + h.rho);
+  }
+  static __device__ inline v2f value(const v2f *xs, const v2f *fp) {
+    return M::filter_value(xs, fp);
+  }
+};
+template <int D>
+inline CellConsts cell_consts(const LineCell<D> *, const ModelConsts &mc) {
+  const double u = 5.9604644775390625e-08, s3 = 1.7320508075688774;
+  const double rc = 2.0 * mc.delta, cap = 4.0 * mc.delta_sq;
+  const double eta = 1e-12 * 2.0 * mc.absmax;  // X + A <= 2X is enforced by prepare_f32 (A <= X: a is a datum)
+  CellConsts cc;
+  memset(&cc, 0, sizeof cc);
+  cc.f[0] = f32_down_host(mc.delta_sq);
+  cc.f[1] = f32_up_host(mc.delta_sq);
+  cc.f[2] = f32_up_host(6.0 * u * (1.0 + 4.0 * u) * (1.0 + 1e-6));
+  cc.f[3] = f32_up_host((u * rc + 2.0 * eta) * (1.0 + 1e-6));
+  cc.f[4] = f32_up_host(2.0 * s3 * rc * (1.0 + 1e-6));
+  cc.f[5] = f32_up_host(4.0 * u * cap * (1.0 + 1e-6));
+  cc.f[6] = f32_down_host(0.25 * mc.delta / (6.0 * s3 * u) * (1.0 - 1e-6));
+  cc.f[7] = f32_down_host(0.25 * mc.delta_sq * (1.0 - 1e-6));
+  return cc;
+}
+
 // ---- the scan ----------------------------------------------------------------------------------------
 // A cell is 128*PP consecutive records of the sorted copy (PP packed pairs per lane); a wave tile is
 // CPT cells whose observations stay in registers for the whole hypothesis loop.  Tiles are handed
@@ -440,7 +541,8 @@ template <class CM, int PP, int CPT>
 __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
                                                     const CellBox *__restrict__ boxes,
                                                     uint32_t ncells, const double *__restrict__ sp,
-                                                    const float *__restrict__ rows, uint32_t H,
+                                                    const float *__restrict__ rows,
+                                                    const float *__restrict__ spf, uint32_t H,
                                                     ModelConsts mc, CellConsts cc,
                                                     uint32_t *__restrict__ votes,
                                                     uint32_t *__restrict__ next_tile) {
@@ -449,6 +551,7 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
   constexpr int NB = CM::NB, NV = CM::NV;
   constexpr int SPD = M::SP;
   constexpr int ROW = CM::ROW, NR4 = ROW / 4;  // per-hypothesis row of the level-1 pass, 16-byte loads
+  constexpr int NR2 = CM::ROW2 / 4;            // optional second piece, taken from the fp32 block
   constexpr int CP = 128 * PP;                 // observations per cell
   static_assert(ROW % 4 == 0, "hypothesis rows are fetched as 16-byte loads");
   extern __shared__ uint32_t s_cnt[];
@@ -495,20 +598,39 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
 #pragma unroll
       for (int k = 0; k < NR4; k++) nxt[k] = r4[k];
     }
+    float4 nxt2[NR2 ? NR2 : 1];
+    if constexpr (NR2 > 0) {
+      const float4 *r4 = (const float4 *)(spf + (size_t)((uint32_t)lane < H ? lane : 0) * M::SPF +
+                                          CM::ROW2_OFF);
+#pragma unroll
+      for (int k = 0; k < NR2; k++) nxt2[k] = r4[k];
+    }
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
       const uint32_t h = h0 + lane;
       float row[ROW];
 #pragma unroll
       for (int k = 0; k < NR4; k++)
         row[4 * k] = nxt[k].x, row[4 * k + 1] = nxt[k].y, row[4 * k + 2] = nxt[k].z, row[4 * k + 3] = nxt[k].w;
+      float row2[NR2 ? 4 * NR2 : 4];
+      if constexpr (NR2 > 0) {
+#pragma unroll
+        for (int k = 0; k < NR2; k++)
+          row2[4 * k] = nxt2[k].x, row2[4 * k + 1] = nxt2[k].y, row2[4 * k + 2] = nxt2[k].z,
+                   row2[4 * k + 3] = nxt2[k].w;
+      }
       if (h0 + 64 < H) {  // prefetch the next group
         const uint32_t hn = h + 64;
         const float4 *r4 = (const float4 *)(rows + (size_t)(hn < H ? hn : 0) * ROW);
 #pragma unroll
         for (int k = 0; k < NR4; k++) nxt[k] = r4[k];
+        if constexpr (NR2 > 0) {
+          const float4 *q4 = (const float4 *)(spf + (size_t)(hn < H ? hn : 0) * M::SPF + CM::ROW2_OFF);
+#pragma unroll
+          for (int k = 0; k < NR2; k++) nxt2[k] = q4[k];
+        }
       }
       typename CM::Hyp hy;
-      CM::load(row, h < H, cc, hy);
+      CM::load(row, row2, h < H, cc, hy);
       uint32_t accv = 0;  // lane b: votes of hypothesis h0 + b collected from this tile
 #pragma unroll
       for (int q = 0; q < CPT; q++) {

@@ -315,6 +315,10 @@ template <int D>
 struct CellOf<SphereModel<D>> {
   typedef SphereCell<D> type;
 };
+template <int D>
+struct CellOf<LineModel<D>> {
+  typedef LineCell<D> type;
+};
 
 // ---- spatial index (cells.h) ------------------------------------------------------------------------
 void drop_index(lsqr_ctx *c) {
@@ -442,7 +446,7 @@ int run_scan_cells(lsqr_ctx *c) {
                        c->d_hparams + h0 * M::SP,
                        CM::ROW_F32 ? c->d_hparams_f32 + h0 * M::SPF
                                    : (const float *)(c->d_hparams + h0 * M::SP),
-                       hc, c->mc, cc, c->d_votes + h0, d_next);
+                       c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, cc, c->d_votes + h0, d_next);
     HIPCHK(c, hipGetLastError());
   }
   return LSQR_OK;

@@ -332,7 +332,13 @@ struct LineModel {
          c.delta_sq <= 1e30;
     f[12] = ok ? PlaneModel<3>::round_down_f32(c.delta_sq - E) : -INFINITY;
     f[13] = ok ? PlaneModel<3>::round_up_f32(c.delta_sq + E) : INFINITY;
-    if (!(sp[0] == sp[0])) f[12] = f[13] = __builtin_nanf("");  // NaN model: nothing agrees
+    // reach of the model for the cell test of the two-level scan (cells.h: LineCell): an observation
+    // whose fp32 distance from the line exceeds rho + (radius of its cell) cannot agree
+    f[14] = ok ? PlaneModel<3>::round_up_f32(c.delta * (1.0 + 1e-6) + sqrt(Enn + Eref) +
+                                             1.01 * 24.0 * u * W)
+               : INFINITY;
+    f[15] = ok ? PlaneModel<3>::round_up_f32(1.01 * (Eref + Enn)) : INFINITY;
+    if (!(sp[0] == sp[0])) f[12] = f[13] = f[14] = __builtin_nanf("");  // NaN model: nothing agrees
   }
 #if defined(__HIPCC__)
   static __device__ inline v2f filter_value(const v2f *xs, const v2f *f) {

@@ -883,7 +883,8 @@ def _scan_votes(ctx, index, cell=0, cpt=0):
     return v.copy()
 
 
-@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.PLANE, 2), (L.SPHERE, 3), (L.SPHERE, 2)])
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.PLANE, 2), (L.SPHERE, 3), (L.SPHERE, 2),
+                                       (L.LINE, 3), (L.LINE, 2)])
 @pytest.mark.parametrize("n", [4, 127, 128, 129, 5000, 200_003])
 def test_cell_scan_matches_exhaustive_and_oracle(ctx, model, dim, n):
     """the culled two-level scan (forced, any size) counts exactly what the exhaustive kernels and
@@ -1024,3 +1025,36 @@ def test_cell_scan_sphere_boundary_stress(ctx):
                 assert plain[h] == O.scan(oc, par[h], pts)[0], (d, h)
         if d == delta:
             assert 0.2 < plain[0] / m < 0.8
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_cell_scan_line_boundary_stress(ctx, dim):
+    """line: observations within a few fp64 / fp32 ulps of the delta-cylinder, clutter around it:
+    the two-level scan counts exactly what the exhaustive kernels and the oracle count"""
+    g = np.random.default_rng(131 + dim)
+    d0 = np.array([0.48, 0.6, 0.64])[:dim]
+    d0 /= np.linalg.norm(d0)
+    a0 = np.array([700.0, -300.0, 500.0])[:dim]
+    m = 90_000
+    t = g.uniform(-1000, 1000, m)
+    perp = g.normal(size=(m, dim))
+    perp -= (perp @ d0)[:, None] * d0
+    perp /= np.linalg.norm(perp, axis=1)[:, None]
+    scale = np.where(np.arange(m) % 2 == 0, 2.0 ** -52, 1e-7)
+    rad = 0.5 * (1 + g.integers(-40, 41, m) * scale)
+    pts = np.ascontiguousarray(a0 + t[:, None] * d0 + rad[:, None] * perp)
+    pts[60_000:] = g.uniform(-1000, 1000, (m - 60_000, dim))
+    pts[0] = a0 - 900 * d0
+    pts[1] = a0 + 900 * d0
+    oc = O.cfg(O.LINE, dim, 0.5)
+    ctx.set_model(L.LINE, dim, 0.5).upload(pts)
+    subs = np.vstack([[0, 1], O.ctr_subsets(4, 0, 99, m, 2)]).astype(np.uint32)
+    ctx.hypotheses_from_subsets(subs)
+    plain = _scan_votes(ctx, 0)
+    for cell in (128, 256, 512):
+        assert np.array_equal(_scan_votes(ctx, 2, cell, 1), plain), cell
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in (0, 1, 2, 50, 99):
+        if valid[h]:
+            assert plain[h] == O.scan(oc, par[h], pts)[0], h
+    assert 0.1 < plain[0] / m < 0.6
