@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--workload", default="plane",
                     choices=["plane", "sphere", "line", "dense", "us"])
     ap.add_argument("--no-filter", action="store_true", help="plain fp64 scan (no fp32 pre-filter)")
+    ap.add_argument("--no-index", action="store_true", help="exhaustive scan (no spatial index)")
     ap.add_argument("--outliers", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="observations for the CPU leg "
@@ -129,20 +130,23 @@ def main():
     ctx.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
     if a.no_filter:
         ctx.set_option("scan_filter", 0)
+    if a.no_index:
+        ctx.set_option("scan_index", 0)
     comm = Comm(dist, device)
     eng = ShardedRansac(ctx, comm)
     H = a.batch
     seed = 0xC0FFEE
 
     def step(i):
+        if comm.world == 1 and not force_dist:
+            # single GPU: the whole step is one chain on the device stream (lsqr_batch_fit)
+            r = ctx.batch_fit(seed, i * H, H)
+            if r["info"].best_votes == 0:
+                return None
+            return int(r["info"].best_votes), r["params"], int(r["info"].fit.n_used)
         votes, gidx, par = eng.batch(seed, i, H)
         if gidx is None:
             return None
-        if comm.world == 1 and not force_dist:
-            # single GPU: mask + fit stay on the device end to end
-            _, cnt = ctx.mask(par, want_mask=False)
-            fit, info = ctx.ls_fit(use_mask=True)
-            return votes, fit, cnt
         fit, cnt, info = eng.fit(par)
         return votes, fit, cnt
 
@@ -153,8 +157,10 @@ def main():
             torch.cuda.synchronize()
         comm.barrier()
 
+    ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
     for i in range(a.warmup):
         step(i)
+    n_idx, ms_idx = ctx.profile_get("index")
     ctx.profile(True)
     sync()
     t0 = time.perf_counter()
@@ -168,7 +174,9 @@ def main():
     n_mask, ms_mask = ctx.profile_get("mask")
     n_mom, ms_mom = ctx.profile_get("moments")
     n_est, ms_est = ctx.profile_get("estimate")
+    n_idx2, ms_idx2 = ctx.profile_get("index")
     ctx.profile(False)
+    idx = ctx.index_info()
 
     if rank == 0:
         total_hyp = H * a.gpus * a.steps
@@ -180,18 +188,24 @@ def main():
         alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs_per_s = float(H) * a.points / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
-        filtered = a.workload in ("plane", "sphere", "line", "us") and not a.no_filter
-        kname = {"plane": "k_scan_f32<plane> (fp32 pre-filter + exact fp64 re-check)",
-                 "sphere": "k_scan_f32<sphere> (fp32 pre-filter + exact fp64 re-check)",
-                 "line": "k_scan_f32<line> (fp32 pre-filter + exact fp64 re-check)",
-                 "us": "k_scan<us> (fused fp64 pre-filter + exact fp64 re-check)"}.get(a.workload)
+        filtered = a.workload in ("plane", "sphere", "line", "us", "dense") and not a.no_filter
+        if idx["built"] and not a.no_filter:
+            kname = ("k_scan_cells<%s> (two-level: fp32 cell-box culling over a Morton-sorted copy, "
+                     "packed fp32 filter + exact fp64 re-check in surviving cells)" % a.workload)
+        else:
+            kname = {"plane": "k_scan_f32<plane> (fp32 pre-filter + exact fp64 re-check)",
+                     "sphere": "k_scan_f32<sphere> (fp32 pre-filter + exact fp64 re-check)",
+                     "line": "k_scan_f32<line> (fp32 pre-filter + exact fp64 re-check)",
+                     "us": "k_scan<us> (fused fp64 pre-filter + exact fp64 re-check)",
+                     "dense": "k_scan_dense_mfma (fp64 MFMA filter + exact re-check worklist)"}.get(
+                         a.workload)
         eq_gops = pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tfile):
             try:
                 t = json.load(open(tfile))
-                key = "%s_%d_%d" % (a.workload, a.points, H)
+                key = "%s_%d_%d%s" % (a.workload, a.points, H, "_cells" if idx["built"] else "")
                 traffic = t.get(key)
             except Exception:
                 traffic = None
@@ -219,8 +233,10 @@ def main():
                          "launch_ms": scan_ms, "launches": int(n_scan),
                          "note": "achieved = algorithmic bytes (H*N*%d B per launch, SURVEY 8d) / "
                                  "launch time; the batched scan reads the observations once per "
-                                 "launch for all H hypotheses, so it is bound by VALU issue, not "
-                                 "HBM: see valu" % rec,
+                                 "launch for all H hypotheses (and the two-level scan proves most "
+                                 "(hypothesis, cell) pairs irrelevant without touching their "
+                                 "observations), so it is bound by VALU/SALU issue, not HBM: see valu "
+                                 "and traffic (measured HBM bytes per launch)" % rec,
                          "valu": {"pairs_per_s": pairs_per_s,
                                   "exact_fp64_ops_per_pair": OPS_PER_PAIR[a.workload],
                                   "exact_equivalent_gops": eq_gops,
@@ -228,12 +244,17 @@ def main():
                                   "fp64_issue_measured_gops": FP64_VALU_MEASURED_GOPS,
                                   "frac_of_peak": eq_gops / FP64_VALU_PEAK_GOPS,
                                   "frac_of_measured_issue_rate": eq_gops / FP64_VALU_MEASURED_GOPS,
-                                  "note": ("the pre-filter decides most pairs without the "
-                                           "exact fp64 formula, so the exact-equivalent rate may "
-                                           "exceed the fp64 issue roof") if filtered else
+                                  "note": ("culling and the pre-filter decide most pairs without "
+                                           "the exact fp64 formula, so the exact-equivalent rate "
+                                           "exceeds the fp64 issue roof") if filtered else
                                           "exact fp64 path: fraction of the fp64 add/mul issue rate"}},
             "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
                            "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1)},
+            "index": {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
+                      "build_ms": (ms_idx + ms_idx2) / max(n_idx + n_idx2, 1) if (n_idx + n_idx2) else None,
+                      "builds_in_warmup": int(n_idx), "builds_in_timed_region": int(n_idx2),
+                      "note": "one-time per upload (device counting sort on Morton keys + cell boxes); "
+                              "built inside the first scan once the upload has seen >= 2048 hypotheses"},
         }
         if a.gpus == 1 and dist is None and a.workload in ("plane", "sphere", "line"):
             ctx.set_option("max_iterations", 100000)

@@ -187,6 +187,14 @@ LSQR_API int lsqr_stats(lsqr_ctx *ctx, const double *params, int use_mask, doubl
 LSQR_API int lsqr_ransac(lsqr_ctx *ctx, double p, uint64_t seed, const uint32_t *subsets,
                          size_t n_subsets, double *params_out, uint8_t *consensus_out,
                          lsqr_ransac_info *info);
+/* One fixed-size batch of the same loop without the adaptive stopping rule: hypotheses
+ * [first_index, first_index + H) of the sampler stream `seed` are solved and scanned, the first
+ * hypothesis with the maximal vote count wins (the strict '>' of RANSAC.hxx:100), its consensus set
+ * (RANSAC.hxx:129-137) is fitted (leastSquaresEstimate, :138).  All device work is chained on the
+ * context's stream; the host synchronises once.  info->iterations = H, info->best_index is the
+ * stream index of the winner.  Returns LSQR_EMPTY when no hypothesis was valid or the fit failed. */
+LSQR_API int lsqr_batch_fit(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H,
+                            double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info);
 /* Exhaustive overload (RANSAC.h:111-113): all C(N,k) subsets in lexicographic order. */
 LSQR_API int lsqr_ransac_exhaustive(lsqr_ctx *ctx, double *params_out, uint8_t *consensus_out,
                                     lsqr_ransac_info *info);
@@ -219,6 +227,10 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS
  *                (k_scan_dense_t), 0 = rows in registers, hypotheses through the scalar cache. */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
+
+/* State of the spatial index of the current upload ("scan_index"): out = {built (0/1), indexed
+ * (finite) observations, cells, observations per cell}. */
+LSQR_API int lsqr_index_info(const lsqr_ctx *ctx, uint64_t out[4]);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,

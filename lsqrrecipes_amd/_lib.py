@@ -84,6 +84,8 @@ SIGNATURES = {
     "lsqr_stats": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     "lsqr_ransac": (C.c_int, [_ctx, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p,
                               C.c_void_p, C.POINTER(RansacInfo)]),
+    "lsqr_batch_fit": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p,
+                                 C.POINTER(RansacInfo)]),
     "lsqr_ransac_exhaustive": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_replay_init": (C.c_int, [C.c_size_t, C.c_int, C.c_double, _u64p]),
     "lsqr_replay": (C.c_size_t, [C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
@@ -91,6 +93,7 @@ SIGNATURES = {
     "lsqr_dedup_create": (C.c_void_p, [C.c_int]),
     "lsqr_dedup_destroy": (None, [C.c_void_p]),
     "lsqr_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
+    "lsqr_index_info": (C.c_int, [_ctx, _u64p]),
     "lsqr_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "lsqr_profile_get": (C.c_int, [_ctx, C.c_int, _u64p, _dp]),
     "lsqr_profile_reset": (C.c_int, [_ctx]),

@@ -188,6 +188,18 @@ class Context:
                     consensus=cons[:self.n] if (cons is not None and info.best_votes > 0) else None,
                     info=info)
 
+    def batch_fit(self, seed, first, H, want_consensus=False):
+        """One fixed-size batch end to end on the device (lsqr_batch_fit): winner of hypotheses
+        [first, first + H) of the sampler stream, its consensus set, the final fit."""
+        out = np.zeros(max(self.P, 32))
+        cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None
+        info = L.RansacInfo()
+        st = self._chk(self._lib.lsqr_batch_fit(self._h, seed, first, H, L.ptr(out), L.ptr(cons),
+                                                C.byref(info)), allow_empty=True)
+        return dict(status=st, fraction=info.fraction,
+                    params=out[:info.n_params].copy() if st == L.OK else np.zeros(0),
+                    consensus=cons[:self.n] if cons is not None else None, info=info)
+
     def ransac_exhaustive(self, want_consensus=True):
         out = np.zeros(max(self.P, 32))
         cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None
@@ -212,6 +224,13 @@ class Context:
         ms = C.c_double(0)
         self._chk(self._lib.lsqr_profile_get(self._h, L.KERNEL_IDS[name], C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def index_info(self):
+        """-> dict(built, observations, cells, cell_points) of the spatial index (scan_index)"""
+        out = (C.c_uint64 * 4)()
+        self._chk(self._lib.lsqr_index_info(self._h, out))
+        return {"built": bool(out[0]), "observations": int(out[1]), "cells": int(out[2]),
+                "cell_points": int(out[3])}
 
     def synchronize(self):
         self._chk(self._lib.lsqr_synchronize(self._h))

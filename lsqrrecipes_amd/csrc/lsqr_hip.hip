@@ -73,6 +73,11 @@ struct lsqr_ctx {
 
   bool prof = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // HIP-event pairs of profiled launches; resolved lazily (lsqr_profile_get) so that profiling
+  // adds no host synchronisation between kernels
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, int>> ev_pending;  // (kernel id, pair index)
+  int ev_next = 0;
   uint64_t launches[8] = {0};
   double ms[8] = {0};
 
@@ -102,21 +107,39 @@ int fail(lsqr_ctx *c, int status, const char *fmt, ...) {
                   __FILE__, __LINE__);                                                    \
   } while (0)
 
+void prof_flush(lsqr_ctx *c) {
+  for (auto &pe : c->ev_pending) {
+    float t = 0;
+    hipEvent_t e0 = c->ev_pool[2 * pe.second], e1 = c->ev_pool[2 * pe.second + 1];
+    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t, e0, e1) == hipSuccess) {
+      c->launches[pe.first]++;
+      c->ms[pe.first] += t;
+    }
+  }
+  c->ev_pending.clear();
+  c->ev_next = 0;
+}
+
 struct ProfScope {
   lsqr_ctx *c;
-  int id;
+  int id, pair = -1;
   ProfScope(lsqr_ctx *c, int id) : c(c), id(id) {
-    if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+    if (!c->prof) return;
+    constexpr int kPairs = 512;
+    if (c->ev_next >= kPairs) prof_flush(c);
+    if ((int)c->ev_pool.size() < 2 * (c->ev_next + 1)) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev_pool.push_back(a);
+      c->ev_pool.push_back(b);
+    }
+    pair = c->ev_next++;
+    (void)hipEventRecord(c->ev_pool[2 * pair], c->stream);
   }
   ~ProfScope() {
-    if (c->prof) {
-      float t = 0;
-      (void)hipEventRecord(c->ev1, c->stream);
-      (void)hipEventSynchronize(c->ev1);
-      (void)hipEventElapsedTime(&t, c->ev0, c->ev1);
-      c->launches[id]++;
-      c->ms[id] += t;
-    }
+    if (pair < 0) return;
+    (void)hipEventRecord(c->ev_pool[2 * pair + 1], c->stream);
+    c->ev_pending.push_back({id, pair});
   }
 };
 
@@ -786,7 +809,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
   });
 }
 
-int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t *count_out) {
+int launch_mask(lsqr_ctx *c, size_t begin, size_t end) {
   int st = ensure(c, &c->d_mask, &c->mask_cap, c->n);
   if (st != LSQR_OK) return st;
   st = dispatch(c->cfg, [&](auto tag) -> int {
@@ -806,6 +829,12 @@ int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t 
   if (st != LSQR_OK) return st;
   c->mask_valid = true;
   c->origin_valid = true;
+  return LSQR_OK;
+}
+
+int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t *count_out) {
+  int st = launch_mask(c, begin, end);
+  if (st != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
   if (mask_out)
@@ -814,6 +843,20 @@ int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (count_out) *count_out = *(unsigned long long *)c->h_pin;
   return LSQR_OK;
+}
+
+// the winner's scan parameters -> d_par, on the device (no host round trip between scan and mask)
+__global__ void k_take_best(const unsigned long long *__restrict__ packed,
+                            const double *__restrict__ hparams, int hs, double *__restrict__ par) {
+  const unsigned long long pk = *packed;
+  const int t = threadIdx.x;
+  if (t >= hs) return;
+  if (pk == 0) {
+    par[t] = __builtin_nan("");  // no valid hypothesis: nothing agrees
+    return;
+  }
+  const size_t idx = 0xFFFFFFFFull - (pk & 0xFFFFFFFFull);
+  par[t] = hparams[idx * (size_t)hs + t];
 }
 
 // ---- RANSAC.hxx replay --------------------------------------------------------------------------
@@ -915,6 +958,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1619,6 +1663,52 @@ int lsqr_ransac_exhaustive(lsqr_ctx *c, double *params_out, uint8_t *consensus_o
   return finish_ransac(c, has, best_params.data(), best, params_out, consensus_out, info);
 }
 
+// One fixed-size batch end to end, everything chained on the stream: sample -> solve -> scan ->
+// first-max winner -> consensus mask -> final fit; the host synchronises once (LM fits: once per
+// evaluation).
+int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double *params_out,
+                   uint8_t *consensus_out, lsqr_ransac_info *info) {
+  int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
+  if (st != LSQR_OK) return st;
+  if ((st = run_scan(c)) != LSQR_OK) return st;
+  c->scanned = true;
+  hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
+                     (uint32_t)c->H, c->d_counter + 1);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
+  hipLaunchKernelGGL(k_take_best, dim3(1), dim3(64), 0, c->stream, c->d_counter + 1, c->d_hparams,
+                     c->HS, c->d_par);
+  HIPCHK(c, hipGetLastError());
+  if ((st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
+  unsigned long long *pin2 = (unsigned long long *)((char *)c->h_pin + 8192);
+  HIPCHK(c, hipMemcpyAsync(pin2, c->d_counter, 2 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));  // {inliers, packed winner}
+  if (consensus_out)
+    HIPCHK(c, hipMemcpyAsync(consensus_out, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
+  SolveOut out;
+  memset(&out, 0, sizeof out);
+  if ((st = run_fit(c, 1, &out)) != LSQR_OK) return st;  // synchronises the stream
+  const unsigned long long cnt = pin2[0], pk = pin2[1];
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->fraction = c->n ? (double)cnt / (double)c->n : 0.0;
+    info->iterations = H;
+    info->evaluated = H;
+    info->best_votes = (uint32_t)(pk >> 32);
+    info->best_index = pk ? first + (0xFFFFFFFFull - (pk & 0xFFFFFFFFull)) : 0;
+    info->n_params = out.ok ? out.n_params : 0;
+    info->fit.n_params = info->n_params;
+    info->fit.lm_info = out.lm_info;
+    info->fit.lm_nfev = out.lm_nfev;
+    info->fit.n_used = cnt;
+    info->fit.cost = out.cost;
+  }
+  if (pk == 0 || !out.ok) return LSQR_EMPTY;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+  return LSQR_OK;
+}
+
 int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   if (!c || !name) return LSQR_ERR_INVALID;
   if (!strcmp(name, "scan_ppl")) {
@@ -1667,20 +1757,32 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);
 }
 
+int lsqr_index_info(const lsqr_ctx *c, uint64_t out[4]) {
+  if (!c || !out) return LSQR_ERR_INVALID;
+  out[0] = c->index_valid ? 1 : 0;
+  out[1] = c->n_sorted;
+  out[2] = c->n_cells;
+  out[3] = c->cell_pts;
+  return LSQR_OK;
+}
+
 // ---- measurement ------------------------------------------------------------------------------------------
 int lsqr_profile_enable(lsqr_ctx *c, int on) {
   if (!c) return LSQR_ERR_INVALID;
+  prof_flush(c);
   c->prof = on != 0;
   return LSQR_OK;
 }
 int lsqr_profile_get(lsqr_ctx *c, int id, uint64_t *launches, double *total_ms) {
   if (!c || id < 0 || id >= 8) return LSQR_ERR_INVALID;
+  prof_flush(c);
   if (launches) *launches = c->launches[id];
   if (total_ms) *total_ms = c->ms[id];
   return LSQR_OK;
 }
 int lsqr_profile_reset(lsqr_ctx *c) {
   if (!c) return LSQR_ERR_INVALID;
+  prof_flush(c);
   memset(c->launches, 0, sizeof c->launches);
   memset(c->ms, 0, sizeof c->ms);
   return LSQR_OK;

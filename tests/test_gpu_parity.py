@@ -1058,3 +1058,25 @@ def test_cell_scan_line_boundary_stress(ctx, dim):
         if valid[h]:
             assert plain[h] == O.scan(oc, par[h], pts)[0], h
     assert 0.1 < plain[0] / m < 0.6
+
+
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 2)])
+def test_batch_fit_equals_stepwise_path(ctx, model, dim):
+    """lsqr_batch_fit (one chain on the stream) = sample + scan + best + mask + fit step by step"""
+    data = _data(model, dim, 120_000, 4242, outliers=0.5)
+    ctx.set_model(model, dim, 0.5).upload(data)
+    H = 3000
+    r = ctx.batch_fit(99, 7000, H, want_consensus=True)
+    ctx.hypotheses_sample(99, 7000, H)
+    ctx.scan()
+    packed, bv, bi = ctx.best()
+    m, cnt = ctx.mask_from_hypothesis(bi)
+    fit, info = ctx.ls_fit(use_mask=True)
+    assert r["info"].best_votes == bv and r["info"].best_index == 7000 + bi
+    assert r["info"].fit.n_used == cnt and abs(r["fraction"] - cnt / len(data)) < 1e-15
+    assert np.array_equal(r["consensus"], m)
+    assert np.array_equal(r["params"], fit)
+    # nothing valid: identical observations -> every subset degenerate -> empty
+    ctx.upload(np.ones((500, dim)))
+    r = ctx.batch_fit(1, 0, 64)
+    assert r["status"] == L.EMPTY and r["info"].best_votes == 0 and len(r["params"]) == 0
