@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-index", action="store_true", help="exhaustive scan (no spatial index)")
     ap.add_argument("--outliers", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the adaptive RANSAC::compute() timing after the steps (profiling runs: "
+                         "keeps one launch shape per kernel)")
     ap.add_argument("--cpu-points", type=int, default=0, help="observations for the CPU leg "
                     "(0 = same as --points)")
     return ap.parse_args()
@@ -80,6 +83,22 @@ def cpu_baseline(workload, data, delta):
     c = O.cfg(model, 64 if workload == "dense" else 3, delta, O.LS_ALGEBRAIC)
     cores = 1
     t0 = time.perf_counter()
+    if workload == "dense":
+        # the adaptive bound never closes for k = 64 (w^64 underflows), so the CPU leg is a bounded
+        # sample of the metric's unit itself: minimal-subset solve + one full agree() pass
+        n = len(data)
+        subs = O.ctr_subsets(20261003, 0, 64, n, 64)
+        hyp = 0
+        while hyp < len(subs) and (hyp < 4 or time.perf_counter() - t0 < 12.0):
+            par = O.estimate(c, data[subs[hyp]])
+            if len(par):
+                O.scan(c, par, data)
+            hyp += 1
+        dt = time.perf_counter() - t0
+        return {"value": hyp / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
+                "sample": "oracle C port of DenseLinearEquationSystemParametersEstimator: %d hypotheses "
+                          "(64x64 minimal solve + full agree() pass over N=%d rows, no early exit) "
+                          "in %.2f s; 1 thread" % (hyp, n, dt)}
     if O.ref_available():
         r = O.ref_ransac(c, data, 0.999, seed=20261003)
         hyp = r["estimate_calls"]
@@ -111,12 +130,24 @@ def main():
     dist = None
     device = "cpu"
     force_dist = os.environ.get("LSQR_FORCE_DIST") == "1"  # exercise the RCCL path at world size 1
+    # rehearsal knobs (CPU tests / one-GPU boxes): LSQR_DIST_BACKEND=gloo keeps the collectives on
+    # the host, LSQR_SHARE_GPU=1 lets every rank use device 0.  The driver's runs use neither.
+    backend = os.environ.get("LSQR_DIST_BACKEND", "nccl")
+    if os.environ.get("LSQR_SHARE_GPU") == "1":
+        local = 0
     if a.gpus > 1 or force_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        device = "cuda:%d" % local
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if force_dist and "RANK" not in os.environ:  # stand-alone world of one rank
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            device = "cuda:%d" % local
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
     from lsqrrecipes_amd import _lib as L
     from lsqrrecipes_amd.context import Context
     from lsqrrecipes_amd.distributed import Comm, ShardedRansac
@@ -152,7 +183,7 @@ def main():
 
     def sync():
         ctx.synchronize()
-        if dist is not None:
+        if dist is not None and device != "cpu":
             import torch
             torch.cuda.synchronize()
         comm.barrier()
@@ -256,7 +287,7 @@ def main():
                       "note": "one-time per upload (device counting sort on Morton keys + cell boxes); "
                               "built inside the first scan once the upload has seen >= 2048 hypotheses"},
         }
-        if a.gpus == 1 and dist is None and a.workload in ("plane", "sphere", "line"):
+        if a.gpus == 1 and dist is None and a.workload in ("plane", "sphere", "line") and not a.no_end_to_end:
             ctx.set_option("max_iterations", 100000)
             # the whole RANSAC<T,S>::compute() (adaptive termination, p = 0.999) on the resident data
             ctx.ransac(0.999, seed=7, want_consensus=False)

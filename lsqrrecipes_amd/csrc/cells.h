@@ -71,16 +71,25 @@ __global__ __launch_bounds__(256) void k_bounds(const double *__restrict__ data,
       mx[d] = o > mx[d] ? o : mx[d];
     }
   }
+  __shared__ unsigned long long s_mn[4][D], s_mx[4][D];
   for (int d = 0; d < D; d++) {
     for (int o = 32; o > 0; o >>= 1) {
       unsigned long long a = __shfl_down(mn[d], o), b = __shfl_down(mx[d], o);
       mn[d] = a < mn[d] ? a : mn[d];
       mx[d] = b > mx[d] ? b : mx[d];
     }
-    if ((threadIdx.x & 63) == 0) {
-      if (mn[d] != ~0ULL) atomicMin(&out[d], mn[d]);
-      if (mx[d] != 0ULL) atomicMax(&out[3 + d], mx[d]);
+    if ((threadIdx.x & 63) == 0) s_mn[threadIdx.x >> 6][d] = mn[d], s_mx[threadIdx.x >> 6][d] = mx[d];
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {  // one pair of atomics per block and dimension
+    const int d = threadIdx.x;
+    unsigned long long a = s_mn[0][d], b = s_mx[0][d];
+    for (int w = 1; w < 4; w++) {
+      a = s_mn[w][d] < a ? s_mn[w][d] : a;
+      b = s_mx[w][d] > b ? s_mx[w][d] : b;
     }
+    if (a != ~0ULL) atomicMin(&out[d], a);
+    if (b != 0ULL) atomicMax(&out[3 + d], b);
   }
 }
 

@@ -5,10 +5,12 @@ CPU tests).  The path shards trivially: every rank scans 
 hypothesis stream against its replica of the observations; the exchange steps are tiny and
 latency-bound:
   C1  all-reduce(MAX) of one int64 = (votes << 32) | (0xFFFFFFFF - index in the global batch):
-      picks the earliest best hypothesis exactly as the strict '>' of RANSAC.hxx:100 does;
-      all-reduce(SUM) of the zero-padded winner parameters (x + 0 is exact) shares the model.
-  C2  all-reduce(SUM) of the fp64 moment block of each rank's observation slice for the final
-      fit (and of the {sum f^2, J^T J, J^T f} block per LM evaluation).
+      picks the earliest best hypothesis exactly as the strict '>' of RANSAC.hxx:100 does.  The
+      winner's parameters need no second exchange: the sampler is counter-based, so every rank
+      re-derives the winning subset from its stream index and solves it on its own replica of
+      the observations (bit-identical on every rank).
+  C2  all-reduce(SUM) of [fp64 moment block, inlier count] of each rank's observation slice for
+      the final fit (and of the {sum f^2, J^T J, J^T f} block per LM evaluation).
 `engine` is a lsqrrecipes_amd.context.Context (tests substitute an object with the same methods).
 """
 import numpy as np
@@ -81,12 +83,13 @@ class ShardedRansac:
             return 0, None, None
         wvotes = win >> 32
         in_batch = 0xFFFFFFFF - (win & 0xFFFFFFFF)
-        owner, lidx = divmod(in_batch, H)
-        par = np.zeros(e.P)
-        if owner == c.rank:
-            par, _ = e.hypothesis(lidx)
-        par = c.allreduce_sum_f64(par)  # zeros elsewhere: exact broadcast
-        return int(wvotes), batch_index * c.world * H + in_batch, par
+        gidx = batch_index * c.world * H + in_batch
+        if c.world == 1:
+            par, _ = e.hypothesis(in_batch)
+        else:
+            e.hypotheses_sample(seed, gidx, 1)  # stateless sampler: same subset, same bits everywhere
+            par, _ = e.hypothesis(0)
+        return int(wvotes), gidx, par
 
     def fit(self, params):
         """Consensus mask of `params` + final least-squares fit, observation range sharded."""
@@ -101,8 +104,10 @@ class ShardedRansac:
             origin = np.asarray(params[e.ND:2 * e.ND])
         else:
             origin = np.zeros(3)  # dense / US blocks are not taken about an origin
-        block = c.allreduce_sum_f64(e.moments(origin, lo, hi, phase=0, use_mask=True))
-        fit, info = e.solve_moments(block, origin)
+        blk = np.concatenate([e.moments(origin, lo, hi, phase=0, use_mask=True), [float(cnt)]])
+        blk = c.allreduce_sum_f64(blk)  # one fused exchange: moment block + inlier count
+        total = int(round(blk[-1]))
+        fit, info = e.solve_moments(blk[:-1], origin)
         iterative = (model == L.SPHERE and e.cfg.ls_type == L.LS_GEOMETRIC) or (
             model in (L.US_SINGLE, L.US_POINTER) and e.cfg.ls_type == L.LS_ITERATIVE)
         if len(fit) and iterative:
@@ -112,5 +117,4 @@ class ShardedRansac:
                 cont, xt, fit, info = e.lm_step(blk)
                 if not cont:
                     break
-        total = int(round(c.allreduce_sum_f64([float(cnt)])[0]))
         return fit, total, info
