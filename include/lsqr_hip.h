@@ -8,7 +8,7 @@
  *       -> ParametersEstimator<T,S>::agree()      parametersEstimators/ParametersEstimator.h:55
  *       -> ...::leastSquaresEstimate()            parametersEstimators/ParametersEstimator.h:51-53
  * for the Plane / Sphere / Line / DenseLinearEquationSystem / SinglePointTargetUSCalibration
- * estimators.  Plain C types only: no STL, no exceptions, no torch types cross this ABI.  Every
+ * estimators (and AbsoluteOrientation / PivotCalibration).  Plain C types only: no STL, no exceptions, no torch types cross this ABI.  Every
  * entry point returns an lsqr_status; LSQR_OK == 0.  The reference's "empty parameters vector"
  * failure convention (RANSAC.h:54-63) maps to LSQR_EMPTY (a normal outcome, not an error).
  *
@@ -24,6 +24,8 @@
  *                              (+4 B pad)} + Point2D             .../SinglePointTarget...h:45-48,
  *                                                                common/Frame.h:30-31,41
  *   CalibratedPointer DataType 18 slots (+ Point3D p)            .../SinglePointTarget...h:335-339
+ *   pair<Point3D,Point3D>      6 doubles (first, second)         .../AbsoluteOrientation...h:14-15
+ *   Frame                      13 slots (104 B)                  common/Frame.h:30-31,41
  * A caller's std::vector<T> is passed as (pointer, count, stride in bytes) without repacking.
  */
 #ifndef LSQR_HIP_H
@@ -57,7 +59,9 @@ typedef enum {
   LSQR_MODEL_LINE = 3,       /* LineParametersEstimator<dim>        params [dir(dim), a(dim)] */
   LSQR_MODEL_DENSE = 4,      /* DenseLinearEquationSystemParametersEstimator<double,n>, dim=n */
   LSQR_MODEL_US_SINGLE = 5,  /* SingleUnknownPointTargetUSCalibrationParametersEstimator      */
-  LSQR_MODEL_US_POINTER = 6  /* CalibratedPointerTargetUSCalibrationParametersEstimator       */
+  LSQR_MODEL_US_POINTER = 6, /* CalibratedPointerTargetUSCalibrationParametersEstimator       */
+  LSQR_MODEL_ABSOR = 7,      /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,t(3)] */
+  LSQR_MODEL_PIVOT = 8       /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)] */
 } lsqr_model;
 
 /* SphereParametersEstimator::LeastSquaresType (SphereParametersEstimator.h:28) and the US

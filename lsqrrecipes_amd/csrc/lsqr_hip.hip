@@ -18,6 +18,7 @@
 #include "dense.h"
 #include "us_kernels.h"
 #include "cells.h"
+#include "rigid.h"
 
 using namespace lsqr;
 
@@ -166,6 +167,8 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
       break;
     case LSQR_MODEL_US_SINGLE: return f(Tag<USModel<true>>{});
     case LSQR_MODEL_US_POINTER: return f(Tag<USModel<false>>{});
+    case LSQR_MODEL_ABSOR: return f(Tag<AbsOrModel>{});
+    case LSQR_MODEL_PIVOT: return f(Tag<PivotModel>{});
     case LSQR_MODEL_DENSE:
       if (cfg.dim >= 1 && cfg.dim <= 8) return f(Tag<DenseModel<8>>{});
       if (cfg.dim <= 16 && cfg.dim > 8) return f(Tag<DenseModel<16>>{});
@@ -738,7 +741,9 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
       if ((st = launch_solve_dense(c)) != LSQR_OK) return st;
       return read_out(c, out);
     } else {
-    if (!c->origin_valid) {  // default origin: the first observation
+    bool first_datum = !c->origin_valid;  // default origin: the first observation
+    if constexpr (requires { M::ORIGIN_FIRST; }) first_datum = true;  // parameters hold no point
+    if (first_datum) {
       HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND,
                                hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -983,6 +988,8 @@ int lsqr_min_subset(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_DENSE: return cfg->dim;
     case LSQR_MODEL_US_SINGLE: return 4;
     case LSQR_MODEL_US_POINTER: return 3;
+    case LSQR_MODEL_ABSOR: return 3;
+    case LSQR_MODEL_PIVOT: return 3;
   }
   return 0;
 }
@@ -995,6 +1002,8 @@ int lsqr_num_params(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_DENSE: return cfg->dim;
     case LSQR_MODEL_US_SINGLE: return 20;
     case LSQR_MODEL_US_POINTER: return 17;
+    case LSQR_MODEL_ABSOR: return 7;
+    case LSQR_MODEL_PIVOT: return 6;
   }
   return 0;
 }
@@ -1007,6 +1016,8 @@ int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_DENSE: return cfg->dim + 1;
     case LSQR_MODEL_US_SINGLE: return 15;
     case LSQR_MODEL_US_POINTER: return 18;
+    case LSQR_MODEL_ABSOR: return 6;
+    case LSQR_MODEL_PIVOT: return 13;
   }
   return 0;
 }

@@ -2,11 +2,15 @@
 // record that the ultrasound-calibration data types embed (rotation[3][3], translation[3], int
 // outputFormat: 104 bytes, common/Frame.h:30-31,41).  Only what the hot path reads is provided
 // (set/get of the matrix and translation, ZYX Euler composition, common/Frame.cxx:87-113); the
-// quaternion / interpolation utilities are out of scope.
+// interpolation utilities are out of scope.  The unit-quaternion
+// constructor / setter / getter and apply() are provided for the AbsoluteOrientation and
+// PivotCalibration estimators (common/Frame.cxx:174-198,208-247,750-771,952-991).
 #ifndef _FRAME_H_
 #define _FRAME_H_
 
 #include <cmath>
+
+#include "Point3D.h"
 
 namespace lsqrRecipes {
 
@@ -20,6 +24,56 @@ class Frame {
   int outputFormat;
 
   Frame() : outputFormat(MATRIX) { setIdentity(); }
+  // translation + unit quaternion [s, qx, qy, qz] (common/Frame.h:127)
+  Frame(double x, double y, double z, double s, double qx, double qy, double qz,
+        bool normalizeQuaternion = false)
+      : outputFormat(MATRIX) {
+    setTranslation(x, y, z);
+    setRotationQuaternion(s, qx, qy, qz, normalizeQuaternion);
+  }
+  void setRotationQuaternion(double s, double qx, double qy, double qz,
+                             bool normalizeQuaternion = false) {
+    if (normalizeQuaternion) {
+      const double norm = std::sqrt(s * s + qx * qx + qy * qy + qz * qz);
+      s /= norm; qx /= norm; qy /= norm; qz /= norm;
+    }
+    rotation[0][0] = 1 - 2 * (qy * qy + qz * qz);
+    rotation[0][1] = 2 * (qx * qy - s * qz);
+    rotation[0][2] = 2 * (qx * qz + s * qy);
+    rotation[1][0] = 2 * (qx * qy + s * qz);
+    rotation[1][1] = 1 - 2 * (qx * qx + qz * qz);
+    rotation[1][2] = 2 * (qy * qz - s * qx);
+    rotation[2][0] = 2 * (qx * qz - s * qy);
+    rotation[2][1] = 2 * (qy * qz + s * qx);
+    rotation[2][2] = 1 - 2 * (qx * qx + qy * qy);
+  }
+  // [s, qx, qy, qz]; the vector part is stabilised when the half angle is within 0.5 degrees of 90
+  void getRotationQuaternion(double q[4]) const {
+    const double small = 0.008726535498373935, halfPi = 3.14159265358979323846 / 2.0;
+    q[0] = 0.5 * std::sqrt(rotation[0][0] + rotation[1][1] + rotation[2][2] + 1);
+    const double halfTheta = std::acos(q[0]);
+    if (!(halfTheta > halfPi - small && halfTheta < halfPi + small)) {
+      const double denom = 4 * q[0];
+      q[1] = (rotation[2][1] - rotation[1][2]) / denom;
+      q[2] = (rotation[0][2] - rotation[2][0]) / denom;
+      q[3] = (rotation[1][0] - rotation[0][1]) / denom;
+    } else {
+      int i = 0;
+      if (rotation[1][1] > rotation[i][i]) i = 1;
+      if (rotation[2][2] > rotation[i][i]) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      const double w = std::sqrt(rotation[i][i] - rotation[j][j] - rotation[k][k] + 1);
+      q[i + 1] = w / 2.0;
+      q[j + 1] = (rotation[i][j] + rotation[j][i]) / (2 * w);
+      q[k + 1] = (rotation[i][k] + rotation[k][i]) / (2 * w);
+    }
+  }
+  void apply(const Point3D &p, Point3D &out) const {
+    double in[3] = {p[0], p[1], p[2]}, o[3];
+    apply(in, o);
+    out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
+  }
+  void apply(Point3D &p) const { apply(p, p); }
   void setIdentity() {
     for (int i = 0; i < 3; i++) {
       for (int j = 0; j < 3; j++) rotation[i][j] = (i == j) ? 1.0 : 0.0;

@@ -82,7 +82,8 @@ class RANSAC {
     if (!est || !est->deviceModel(cfg))
       throw std::runtime_error(
           "lsqrRecipes::RANSAC: this estimator has no device model; the MI355X drop-in covers "
-          "Plane/Sphere/Line/DenseLinearEquationSystem/SinglePointTargetUSCalibration only");
+          "Plane/Sphere/Line/DenseLinearEquationSystem/SinglePointTargetUSCalibration/"
+          "AbsoluteOrientation/PivotCalibration only");
   }
   static double finish(bool ok, const lsqr_ransac_info &info, const std::vector<double> &p,
                        const std::vector<uint8_t> &cons, std::vector<S> &parameters,

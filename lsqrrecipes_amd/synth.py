@@ -195,3 +195,65 @@ def us_pointer(m, outlier_frac=0.0, seed=SEEDS["us"] + 1, pixel_sigma=1.0):
         rec[idx, 15:18] = g.uniform(-100.0, 100.0, (n_out, 3))
         lab[idx] = False
     return np.ascontiguousarray(rec), np.concatenate([t3, w3, [mx, my]]), lab
+
+
+def quat_to_matrix(q):
+    """[s,qx,qy,qz] -> 3x3 rotation (common/Frame.cxx:750-771)."""
+    s, qx, qy, qz = q
+    return np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - s * qz), 2 * (qx * qz + s * qy)],
+                     [2 * (qx * qy + s * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - s * qx)],
+                     [2 * (qx * qz - s * qy), 2 * (qy * qz + s * qx), 1 - 2 * (qx * qx + qy * qy)]])
+
+
+def absolute_orientation(n, outlier_frac, seed=0x5EED0006, bounds=100.0, max_t=1000.0, sigma=0.5,
+                         outlier_shift=5.0):
+    """Paired points second = T first + noise (testing/AbsoluteOrientationParametersEstimatorTest.cxx:
+    33-79, examples/AbsoluteOrientation.cxx:36-90) -> (records (n,6), [s,qx,qy,qz,t], is_inlier)."""
+    g = _rng(seed)
+    qx = g.uniform(0.0, 1.0)
+    qy = g.uniform(0.0, np.sqrt(1.0 - qx * qx))
+    qz = g.uniform(0.0, np.sqrt(1.0 - qx * qx - qy * qy))
+    q = np.array([np.sqrt(1.0 - qx * qx - qy * qy - qz * qz), qx, qy, qz])
+    t = g.uniform(-max_t, max_t, 3)
+    R = quat_to_matrix(q)
+    first = g.uniform(-bounds, bounds, (n, 3))
+    second = first @ R.T + t + g.normal(0.0, sigma, (n, 3)) if sigma > 0 else first @ R.T + t
+    n_out = int(round(n * outlier_frac))
+    lab = np.ones(n, bool)
+    if n_out:
+        idx = g.permutation(n)[:n_out]
+        second[idx] += g.uniform(-1, 1, (n_out, 3)) * 10 * outlier_shift + outlier_shift
+        lab[idx] = False
+    return np.ascontiguousarray(np.hstack([first, second])), np.concatenate([q, t]), lab
+
+
+def frames_from_pose_rows(rows):
+    """rows 'x y z qx qy qz qs' (examples/readme.txt:30-34) -> Frame records (n,13): rotation 9,
+    translation 3, one unused slot (int outputFormat + padding)."""
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, 7)
+    out = np.zeros((len(rows), 13))
+    for i, (x, y, z, qx, qy, qz, qs) in enumerate(rows):
+        out[i, :9] = quat_to_matrix([qs, qx, qy, qz]).ravel()
+        out[i, 9:12] = (x, y, z)
+    return out
+
+
+def pivot(n, outlier_frac, seed=0x5EED0007, sigma=0.15):
+    """Synthetic pivoting poses: R_i tip + t_i = pivot (+ noise), outliers with displaced t."""
+    g = _rng(seed)
+    tip = np.array([-17.0, 1.0, -157.0])
+    piv = np.array([147.0, -63.0, -1042.0])
+    out = np.zeros((n, 13))
+    lab = np.ones(n, bool)
+    n_out = int(round(n * outlier_frac))
+    lab[g.permutation(n)[:n_out]] = False
+    for i in range(n):
+        q = g.normal(size=4)
+        q /= np.linalg.norm(q)
+        R = quat_to_matrix(q)
+        t = piv - R @ tip + g.normal(0.0, sigma, 3)
+        if not lab[i]:
+            t += g.uniform(-40, 40, 3)
+        out[i, :9] = R.ravel()
+        out[i, 9:12] = t
+    return out, np.concatenate([tip, piv]), lab

@@ -1,6 +1,7 @@
 /*
  * estimators.c -- oracle (TEST INFRASTRUCTURE ONLY, see lsqr_oracle.h): the five hot-path
- * estimators of /root/reference/parametersEstimators restated in plain C, fp64, operation
+ * estimators of /root/reference/parametersEstimators (and, SURVEY.md section 8f, the
+ * AbsoluteOrientation and PivotCalibration estimators) restated in plain C, fp64, operation
  * order preserved (compile with -ffp-contract=off, no -ffast-math).
  */
 #include "lsqr_oracle.h"
@@ -26,6 +27,8 @@ int orc_min_subset(const orc_cfg *c) {
     case ORC_DENSE: return c->dim;      /* DenseLinear...hxx:11 */
     case ORC_US_SINGLE: return 4;       /* SinglePointTarget...cxx:11 */
     case ORC_US_POINTER: return 3;      /* SinglePointTarget...cxx:665 */
+    case ORC_ABSOR: return 3;           /* AbsoluteOrientation...cxx:9 */
+    case ORC_PIVOT: return 3;           /* PivotCalibration...cxx:7 */
   }
   return 0;
 }
@@ -37,6 +40,8 @@ int orc_num_params(const orc_cfg *c) {
     case ORC_DENSE: return c->dim;
     case ORC_US_SINGLE: return 20;
     case ORC_US_POINTER: return 17;
+    case ORC_ABSOR: return 7; /* [s,qx,qy,qz,tx,ty,tz] */
+    case ORC_PIVOT: return 6; /* [DRF^t, W^t] */
   }
   return 0;
 }
@@ -48,6 +53,8 @@ int orc_record_doubles(const orc_cfg *c) {
     case ORC_DENSE: return c->dim + 1;
     case ORC_US_SINGLE: return 15;
     case ORC_US_POINTER: return 18;
+    case ORC_ABSOR: return 6;  /* std::pair<Point3D,Point3D> */
+    case ORC_PIVOT: return 13; /* Frame: rotation 9, translation 3, int outputFormat + pad */
   }
   return 0;
 }
@@ -384,6 +391,203 @@ static int dense_agree(int n, double delta, const double *par, const double *row
   return fabs(sum) < delta;
 }
 
+
+/* ================================================================== absolute orientation */
+/* vnl_vector<double>::normalize(): scale by 1/sqrt(sum of squares) unless the sum is zero
+ * (VNL absent from /root/reference: restated from its published source, parity unpinned) */
+static void vnl_normalize3(double *v) {
+  double tmp = 0;
+  int i;
+  for (i = 0; i < 3; i++) tmp += v[i] * v[i];
+  if (tmp != 0) {
+    tmp = 1.0 / sqrt(tmp);
+    for (i = 0; i < 3; i++) v[i] = tmp * v[i];
+  }
+}
+/* AbsoluteOrientationParametersEstimator.cxx:25-50 / :57-79: orthonormal triad of three points.
+ * Returns 0 when the points are collinear (:48, :78). */
+static int absor_triad(const double *p0, const double *p1, const double *p2, double mean[3],
+                       double R[3][3]) {
+  double x[3], y[3], z[3], d;
+  int i;
+  for (i = 0; i < 3; i++) mean[i] = (p0[i] + p1[i] + p2[i]) / 3.0;
+  for (i = 0; i < 3; i++) x[i] = p0[i] - mean[i];
+  vnl_normalize3(x);
+  for (i = 0; i < 3; i++) y[i] = p1[i] - mean[i];
+  d = 0;
+  for (i = 0; i < 3; i++) d += y[i] * x[i];
+  for (i = 0; i < 3; i++) y[i] = y[i] - d * x[i];
+  vnl_normalize3(y);
+  z[0] = x[1] * y[2] - x[2] * y[1];
+  z[1] = x[2] * y[0] - x[0] * y[2];
+  z[2] = x[0] * y[1] - x[1] * y[0];
+  d = 0;
+  for (i = 0; i < 3; i++) d += z[i] * z[i];
+  if (sqrt(d) < EPS) return 0;
+  for (i = 0; i < 3; i++) {
+    R[i][0] = x[i];
+    R[i][1] = y[i];
+    R[i][2] = z[i];
+  }
+  return 1;
+}
+/* common/Frame.cxx:952-991 getRotationQuaternion */
+static void frame_quaternion(double R[3][3], double q[4]) {
+  const double smallAngle = 0.008726535498373935, halfPI = 3.14159265358979323846 / 2.0;
+  double startSingularRange = halfPI - smallAngle, endSingularRange = halfPI + smallAngle;
+  double halfTheta;
+  q[0] = (0.5 * sqrt(R[0][0] + R[1][1] + R[2][2] + 1));
+  halfTheta = acos(q[0]);
+  if (!(halfTheta > startSingularRange && halfTheta < endSingularRange)) {
+    double denom = 4 * q[0];
+    q[1] = (R[2][1] - R[1][2]) / denom;
+    q[2] = (R[0][2] - R[2][0]) / denom;
+    q[3] = (R[1][0] - R[0][1]) / denom;
+  } else {
+    int i = 0, j, k;
+    double w;
+    if (R[1][1] > R[i][i]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    j = (i + 1) % 3;
+    k = (j + 1) % 3;
+    w = sqrt(R[i][i] - R[j][j] - R[k][k] + 1);
+    q[i + 1] = w / 2.0;
+    q[j + 1] = (R[i][j] + R[j][i]) / (2 * w);
+    q[k + 1] = (R[i][k] + R[k][i]) / (2 * w);
+  }
+}
+/* common/Frame.cxx:750-771 setRotationQuaternion */
+static void frame_from_quaternion(double s, double qx, double qy, double qz, int normalize,
+                                  double R[3][3]) {
+  if (normalize) {
+    double norm = sqrt(s * s + qx * qx + qy * qy + qz * qz);
+    s /= norm;
+    qx /= norm;
+    qy /= norm;
+    qz /= norm;
+  }
+  R[0][0] = 1 - 2 * (qy * qy + qz * qz);
+  R[0][1] = 2 * (qx * qy - s * qz);
+  R[0][2] = 2 * (qx * qz + s * qy);
+  R[1][0] = 2 * (qx * qy + s * qz);
+  R[1][1] = 1 - 2 * (qx * qx + qz * qz);
+  R[1][2] = 2 * (qy * qz - s * qx);
+  R[2][0] = 2 * (qx * qz - s * qy);
+  R[2][1] = 2 * (qy * qz + s * qx);
+  R[2][2] = 1 - 2 * (qx * qx + qy * qy);
+}
+/* AbsoluteOrientationParametersEstimator.cxx:14-105; record = [first(3), second(3)] */
+static int absor_estimate(const double *const *p, size_t n, double *out) {
+  double R1[3][3], R2[3][3], R[3][3], m1[3], m2[3], t[3], q[4];
+  int i, j, k;
+  if (n < 3) return 0;
+  if (!absor_triad(p[0], p[1], p[2], m1, R1)) return 0;
+  if (!absor_triad(p[0] + 3, p[1] + 3, p[2] + 3, m2, R2)) return 0;
+  for (i = 0; i < 3; i++) /* R = secondR * firstR^T (:86), vnl product = running sum from 0 */
+    for (j = 0; j < 3; j++) {
+      double sum = 0;
+      for (k = 0; k < 3; k++) sum += R2[i][k] * R1[j][k];
+      R[i][j] = sum;
+    }
+  for (i = 0; i < 3; i++) { /* t = meanSecond - R*meanFirst (:88) */
+    double sum = 0;
+    for (k = 0; k < 3; k++) sum += R[i][k] * m1[k];
+    t[i] = m2[i] - sum;
+  }
+  frame_quaternion(R, q);
+  for (i = 0; i < 4; i++) out[i] = q[i];
+  for (i = 0; i < 3; i++) out[4 + i] = t[i];
+  return 7;
+}
+/* AbsoluteOrientationParametersEstimator.cxx:316-327 (Frame ctor Frame.cxx:174-198 without
+ * normalisation, apply() Frame.cxx:229-247) */
+static int absor_agree(double delta_sq, const double *par, const double *rec) {
+  double R[3][3], x, y, z, dx, dy, dz;
+  frame_from_quaternion(par[0], par[1], par[2], par[3], 0, R);
+  x = R[0][0] * rec[0] + R[0][1] * rec[1] + R[0][2] * rec[2] + par[4];
+  y = R[1][0] * rec[0] + R[1][1] * rec[1] + R[1][2] * rec[2] + par[5];
+  z = R[2][0] * rec[0] + R[2][1] * rec[1] + R[2][2] * rec[2] + par[6];
+  dx = x - rec[3];
+  dy = y - rec[4];
+  dz = z - rec[5];
+  return ((dx * dx + dy * dy + dz * dz) < delta_sq);
+}
+/* AbsoluteOrientationParametersEstimator.cxx:123-198 (Horn) */
+static int absor_ls(const double *const *p, size_t n, double *out) {
+  double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0}, M[3][3], N[16], w[4], V[16], R[3][3], q[4];
+  double traceM, A12, A20, A01, mf[3];
+  size_t i;
+  int a, b;
+  if (n < 3) return 0;
+  for (i = 0; i < n; i++)
+    for (a = 0; a < 3; a++) {
+      m1[a] += p[i][a];
+      m2[a] += p[i][3 + a];
+    }
+  for (a = 0; a < 3; a++) {
+    m1[a] /= (double)(unsigned int)n;
+    m2[a] /= (double)(unsigned int)n;
+  }
+  memset(M, 0, sizeof M);
+  for (i = 0; i < n; i++)
+    for (a = 0; a < 3; a++)
+      for (b = 0; b < 3; b++) M[a][b] += p[i][a] * p[i][3 + b];
+  for (a = 0; a < 3; a++)
+    for (b = 0; b < 3; b++) M[a][b] += (m1[a] * m2[b]) * (double)(-((int)n)); /* :168 */
+  traceM = 0.0;
+  for (a = 0; a < 3; a++) traceM += M[a][a];
+  A12 = M[1][2] - M[2][1];
+  A20 = M[2][0] - M[0][2];
+  A01 = M[0][1] - M[1][0];
+  N[0] = traceM; N[1] = A12; N[2] = A20; N[3] = A01;
+  N[4] = A12; N[8] = A20; N[12] = A01;
+  for (a = 0; a < 3; a++)
+    for (b = 0; b < 3; b++)
+      N[(a + 1) * 4 + (b + 1)] = (a == b ? -traceM : 0.0) + (M[a][b] + M[b][a]);
+  orc_sym_eig(4, N, w, V); /* ascending: column 3 = largest (:187-195) */
+  for (a = 0; a < 4; a++) q[a] = V[a * 4 + 3];
+  for (a = 0; a < 4; a++) out[a] = q[a];
+  frame_from_quaternion(q[0], q[1], q[2], q[3], 1, R);
+  for (a = 0; a < 3; a++) mf[a] = R[a][0] * m1[0] + R[a][1] * m1[1] + R[a][2] * m1[2] + 0.0;
+  for (a = 0; a < 3; a++) out[4 + a] = m2[a] - mf[a];
+  return 7;
+}
+
+/* ================================================================== pivot calibration */
+/* record = Frame: rotation[3][3] slots 0..8, translation 9..11 (common/Frame.h:30-31) */
+/* PivotCalibrationParametersEstimator.cxx:9-50 (3 frames) and :63-96 (n frames): rows [R_i, -I],
+ * rhs -t_i, pseudo-inverse with singular values <= EPS zeroed, rank < 6 -> empty */
+static int pivot_solve(const double *const *f, size_t n, double *out) {
+  double *A, *b;
+  size_t i;
+  int r, c, rank;
+  if (n < 3) return 0;
+  A = (double *)calloc(3 * n * 6, sizeof(double));
+  b = (double *)calloc(3 * n, sizeof(double));
+  for (i = 0; i < n; i++)
+    for (r = 0; r < 3; r++) {
+      for (c = 0; c < 3; c++) A[(3 * i + r) * 6 + c] = f[i][3 * r + c];
+      A[(3 * i + r) * 6 + 3 + r] = -1.0;
+      b[3 * i + r] = -f[i][9 + r];
+    }
+  rank = orc_pinv_solve((int)(3 * n), 6, A, b, EPS, out);
+  free(A);
+  free(b);
+  return rank < 6 ? 0 : 6;
+}
+/* PivotCalibrationParametersEstimator.cxx:109-123: ||R*tDRF + t - tW|| < delta
+ * (Frame::apply Frame.cxx:208-227, Vector l2Norm = sqrt of the sum of squares) */
+static int pivot_agree(double delta, const double *par, const double *f) {
+  double x, y, z, dx, dy, dz;
+  x = f[0] * par[0] + f[1] * par[1] + f[2] * par[2] + f[9];
+  y = f[3] * par[0] + f[4] * par[1] + f[5] * par[2] + f[10];
+  z = f[6] * par[0] + f[7] * par[1] + f[8] * par[2] + f[11];
+  dx = x - par[3];
+  dy = y - par[4];
+  dz = z - par[5];
+  return sqrt(dx * dx + dy * dy + dz * dz) < delta;
+}
+
 /* ================================================================== US calibration */
 static void us_T3(int model, const double *par, double T3[3][4]) {
   /* SinglePointTarget...cxx:90-93 (single) / :745-748 (pointer) */
@@ -701,6 +905,8 @@ int orc_estimate(const orc_cfg *c, const double *const *recs, size_t n, double *
       return sphere_estimateNd(c->dim, recs, params);
     case ORC_LINE: return line_estimate(c->dim, c->delta * c->delta, recs, n, params);
     case ORC_DENSE: return dense_solve(c->dim, recs, n, params);
+    case ORC_ABSOR: return absor_estimate(recs, n, params);
+    case ORC_PIVOT: return pivot_solve(recs, n < 3 ? n : 3, params);
     case ORC_US_SINGLE: /* :17-25: exactly minForEstimate elements */
     case ORC_US_POINTER:
       if (n != (size_t)orc_min_subset(c)) return 0;
@@ -715,6 +921,8 @@ int orc_agree(const orc_cfg *c, const double *params, const double *rec) {
     case ORC_SPHERE: return sphere_agree(c->dim, c->delta, params, rec);
     case ORC_LINE: return line_agree(c->dim, c->delta * c->delta, params, rec);
     case ORC_DENSE: return dense_agree(c->dim, c->delta, params, rec);
+    case ORC_ABSOR: return absor_agree(c->delta * c->delta, params, rec);
+    case ORC_PIVOT: return pivot_agree(c->delta, params, rec);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_agree(c->model, c->delta * c->delta, params, rec);
   }
@@ -727,6 +935,8 @@ int orc_ls(const orc_cfg *c, const double *const *recs, size_t n, double *params
     case ORC_LINE: return cov_ls(c->dim, recs, n, 2, 1, params);
     case ORC_SPHERE: return sphere_ls(c, recs, n, params);
     case ORC_DENSE: return dense_solve(c->dim, recs, n, params);
+    case ORC_ABSOR: return absor_ls(recs, n, params);
+    case ORC_PIVOT: return pivot_solve(recs, n, params);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_ls(c, recs, n, params);
   }
@@ -791,6 +1001,22 @@ int orc_stats(const orc_cfg *c, const double *params, const double *data, size_t
         for (j = 0; j < d; j++) dist += x[j] * params[j];
         dist = fabs(dist - x[d]);
         break;
+      case ORC_ABSOR: { /* ||T*first - second|| */
+        double R[3][3], e[3];
+        frame_from_quaternion(params[0], params[1], params[2], params[3], 0, R);
+        for (j = 0; j < 3; j++)
+          e[j] = R[j][0] * x[0] + R[j][1] * x[1] + R[j][2] * x[2] + params[4 + j] - x[3 + j];
+        dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        break;
+      }
+      case ORC_PIVOT: { /* ||R*tDRF + t - tW|| */
+        double e[3];
+        for (j = 0; j < 3; j++)
+          e[j] = x[3 * j] * params[0] + x[3 * j + 1] * params[1] + x[3 * j + 2] * params[2] +
+                 x[9 + j] - params[3 + j];
+        dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        break;
+      }
       default: us_distance(c->model, params, x, &dist);
     }
     if (cnt == 0) mn = mx = dist;

@@ -41,7 +41,9 @@ enum {
   ORC_LINE = 3,    /* LineParametersEstimator<dim>                      params [dir(dim), a(dim)]    */
   ORC_DENSE = 4,   /* DenseLinearEquationSystemParametersEstimator<double,n>  params x(n), dim = n  */
   ORC_US_SINGLE = 5, /* SingleUnknownPointTargetUSCalibrationParametersEstimator  20 params         */
-  ORC_US_POINTER = 6 /* CalibratedPointerTargetUSCalibrationParametersEstimator   17 params         */
+  ORC_US_POINTER = 6, /* CalibratedPointerTargetUSCalibrationParametersEstimator  17 params         */
+  ORC_ABSOR = 7,   /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,tx,ty,tz]           */
+  ORC_PIVOT = 8    /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)]              */
 };
 
 enum { ORC_LS_ALGEBRAIC = 0, ORC_LS_GEOMETRIC = 1 }; /* sphere; US: 0 = ANALYTIC, 1 = ITERATIVE */
@@ -55,7 +57,8 @@ typedef struct {
 
 /* record layout: every datum is an array of doubles (Point<double,d>: d; AugmentedRow<double,n>:
  * n+1; US single: Frame(12 doubles + int + pad = 13 slots) + Point2D = 15 slots (120 B);
- * US pointer: 18 slots (144 B)).  "stride" arguments are in doubles. */
+ * US pointer: 18 slots (144 B); absolute orientation: pair<Point3D,Point3D> = 6; pivot: Frame = 13
+ * slots (104 B)).  "stride" arguments are in doubles. */
 int orc_min_subset(const orc_cfg *c);
 int orc_num_params(const orc_cfg *c);
 int orc_record_doubles(const orc_cfg *c);

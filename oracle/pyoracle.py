@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER = 1, 2, 3, 4, 5, 6
+PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT = 1, 2, 3, 4, 5, 6, 7, 8
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 
 

@@ -1,7 +1,9 @@
 // estimatorTests -- the assertions of the reference's ctest programs for the hot-path estimators
 // (testing/PlaneParametersEstimatorTest.cxx, SphereParametersEstimatorTest.cxx,
 // LineParametersEstimatorTest.cxx, DenseLinearEquationSystemParametersEstimatorTest.cxx,
-// SinglePointTargetUSCalibrationParametersEstimatorTest.cxx) re-written against the drop-in
+// SinglePointTargetUSCalibrationParametersEstimatorTest.cxx, and -- SURVEY.md section 8f --
+// AbsoluteOrientationParametersEstimatorTest.cxx, PivotCalibrationParametersEstimatorTest.cxx)
+// re-written against the drop-in
 // headers, plus RANSAC-level checks (the reference has none).  Runs on the GPU through the C++
 // API exactly as a user of the reference would call it.  Exit code 0 == all passed.
 #include <cmath>
@@ -13,8 +15,11 @@
 #include <string>
 #include <vector>
 
+#include "AbsoluteOrientationParametersEstimator.h"
 #include "DenseLinearEquationSystemParametersEstimator.h"
+#include "Frame.h"
 #include "LineParametersEstimator.h"
+#include "PivotCalibrationParametersEstimator.h"
 #include "PlaneParametersEstimator.h"
 #include "RANSAC.h"
 #include "SinglePointTargetUSCalibrationParametersEstimator.h"
@@ -334,6 +339,85 @@ static void ransacTest() {
   CHECK(threw);
 }
 
+static void absoluteOrientationTest() {  // testing/AbsoluteOrientationParametersEstimatorTest.cxx:19-118
+  typedef std::pair<Point3D, Point3D> DataType;
+  const int pairNum = 10;
+  const double bounds = 100.0, maxTranslation = 1000.0, noiseSigma = 5.0 / 3.0;
+  double qx = U(0.0, 1.0), qy = U(0.0, std::sqrt(1.0 - qx * qx));
+  double qz = U(0.0, std::sqrt(1.0 - qx * qx - qy * qy));
+  std::vector<double> known;
+  known.push_back(std::sqrt(1.0 - qx * qx - qy * qy - qz * qz));
+  known.push_back(qx); known.push_back(qy); known.push_back(qz);
+  for (int i = 0; i < 3; i++) known.push_back(U(-maxTranslation, maxTranslation));
+  Frame T(known[4], known[5], known[6], known[0], known[1], known[2], known[3]);
+  std::vector<DataType> clean, noisy, targets;
+  DataType pr, outlier;
+  for (int i = 0; i < pairNum; i++) {
+    for (int k = 0; k < 3; k++) pr.first[k] = U(-bounds, bounds);
+    T.apply(pr.first, pr.second);
+    clean.push_back(pr);
+    for (int k = 0; k < 3; k++) pr.second[k] += N(noiseSigma);
+    noisy.push_back(pr);
+    for (int k = 0; k < 3; k++) pr.first[k] = U(-bounds, bounds);
+    T.apply(pr.first, pr.second);
+    targets.push_back(pr);
+  }
+  for (int k = 0; k < 3; k++) outlier.first[k] = U(-bounds, bounds);
+  T.apply(outlier.first, outlier.second);
+  outlier.second[0] += 10 * noiseSigma;
+  AbsoluteOrientationParametersEstimator est(1.0);
+  const double distanceThreshold = 3.0 * noiseSigma;
+  std::vector<double> par;
+  for (int pass = 0; pass < 2; pass++) {  // exact from three clean pairs, LS from the noisy ones
+    if (pass == 0) est.estimate(clean, par);
+    else est.leastSquaresEstimate(noisy, par);
+    CHECK(par.size() == 7);
+    if (par.size() != 7) continue;
+    Frame E(par[4], par[5], par[6], par[0], par[1], par[2], par[3], true);
+    double worst = 0;
+    for (size_t i = 0; i < targets.size(); i++) {
+      Point3D q;
+      E.apply(targets[i].first, q);
+      worst = std::max(worst, std::sqrt(q.distanceSquared(targets[i].second)));
+    }
+    CHECK(worst < distanceThreshold);
+  }
+  CHECK(est.agree(known, clean[0]));
+  CHECK(!est.agree(known, outlier));
+}
+
+static void pivotTest(const char *file) {  // testing/PivotCalibrationParametersEstimatorTest.cxx:19-119
+  if (!file) return;
+  std::ifstream in(file);
+  CHECK(in.is_open());
+  std::vector<Frame> poses;
+  Frame f;
+  double x, y, z, qx, qy, qz, qs;
+  while (in >> x >> y >> z >> qx >> qy >> qz >> qs) {
+    f.setRotationQuaternion(qs, qx, qy, qz);
+    f.setTranslation(x, y, z);
+    poses.push_back(f);
+  }
+  CHECK(!poses.empty());
+  if (poses.empty()) return;
+  const double maxError = 1.0;
+  PivotCalibrationEstimator pivot(maxError);
+  const double knownExact[] = {-18.586, 1.98134, -157.439, 146.965, -62.0497, -1042.87};
+  const double knownLS[] = {-17.7799, 1.1113, -156.865, 146.901, -62.9689, -1042.14};
+  std::vector<Frame> mins(3);
+  mins[0] = poses[0];
+  mins[1] = poses[(unsigned)(poses.size() / 2.0)];
+  mins[2] = poses[poses.size() - 1];
+  std::vector<double> est;
+  pivot.estimate(mins, est);
+  CHECK(est.size() == 6);
+  for (size_t i = 0; i < est.size(); i++) CHECK(std::fabs(est[i] - knownExact[i]) < maxError);
+  for (size_t i = 0; i < mins.size() && est.size() == 6; i++) CHECK(pivot.agree(est, mins[i]));
+  pivot.leastSquaresEstimate(poses, est);
+  CHECK(est.size() == 6);
+  for (size_t i = 0; i < est.size(); i++) CHECK(std::fabs(est[i] - knownLS[i]) < maxError);
+}
+
 int main(int argc, char *argv[]) {
   try {
     planeTest();
@@ -341,6 +425,8 @@ int main(int argc, char *argv[]) {
     lineTest();
     denseTest(argc > 1 ? argv[1] : 0);
     usTest();
+    absoluteOrientationTest();
+    pivotTest(argc > 2 ? argv[2] : 0);
     ransacTest();
   } catch (std::exception &e) {
     std::printf("EXCEPTION: %s\n", e.what());

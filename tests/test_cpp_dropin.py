@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "examples", "build")
 PROGS = ["planeEstimation", "sphereEstimation", "lineEstimation", "linearEquationSystemSolver",
-         "crosswireUSCalibration", "estimatorTests"]
+         "crosswireUSCalibration", "AbsoluteOrientation", "pivotCalibration", "estimatorTests"]
 REFDATA = os.path.join(ROOT, "tests", "golden", "ref_data")
 
 
@@ -25,7 +25,9 @@ def test_reference_header_names_present():
     for h in ["RANSAC.h", "ParametersEstimator.h", "PlaneParametersEstimator.h",
               "SphereParametersEstimator.h", "LineParametersEstimator.h",
               "DenseLinearEquationSystemParametersEstimator.h",
-              "SinglePointTargetUSCalibrationParametersEstimator.h", "Point.h", "Point2D.h",
+              "SinglePointTargetUSCalibrationParametersEstimator.h",
+              "AbsoluteOrientationParametersEstimator.h", "PivotCalibrationParametersEstimator.h",
+              "Point.h", "Point2D.h",
               "Point3D.h", "Frame.h", "Epsilon.h", "copyright.h"]:
         assert os.path.exists(os.path.join(inc, h)), h
 
@@ -42,15 +44,25 @@ def _run(args):
 
 @pytest.mark.gpu
 def test_reference_style_estimator_tests_on_gpu():
-    out = _run(["estimatorTests", os.path.join(REFDATA, "augmentedMatrix.txt")])
+    out = _run(["estimatorTests", os.path.join(REFDATA, "augmentedMatrix.txt"),
+                os.path.join(REFDATA, "pivotCalibrationData.txt")])
     assert "all checks passed" in out
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog", ["planeEstimation", "sphereEstimation", "lineEstimation"])
+@pytest.mark.parametrize("prog", ["planeEstimation", "sphereEstimation", "lineEstimation",
+                                  "pivotCalibration"])
 def test_example_programs_on_gpu(prog):
     out = _run([prog])
     assert "RANSAC" in out
+
+
+@pytest.mark.gpu
+def test_section_8f_example_programs_on_gpu():
+    out = _run(["AbsoluteOrientation"])
+    assert "Exhaustive search transformation" in out
+    out = _run(["pivotCalibration", os.path.join(REFDATA, "pivotCalibrationDataWithOutliers.txt")])
+    assert "RANSAC translations" in out
 
 
 @pytest.mark.gpu

@@ -1080,3 +1080,111 @@ def test_batch_fit_equals_stepwise_path(ctx, model, dim):
     ctx.upload(np.ones((500, dim)))
     r = ctx.batch_fit(1, 0, 64)
     assert r["status"] == L.EMPTY and r["info"].best_votes == 0 and len(r["params"]) == 0
+
+
+# ---- AbsoluteOrientation and PivotCalibration on the device -----------------
+def _quat_close(got, want, tol=REL):
+    s = np.sign(got[:4] @ want[:4])            # q and -q are the same rotation
+    assert np.allclose(s * got[:4], want[:4], rtol=tol, atol=tol)
+    assert np.allclose(got[4:], want[4:], rtol=tol, atol=tol * max(1.0, np.abs(want[4:]).max()))
+
+
+@pytest.mark.parametrize("n", [3, 10, 1000, 20_003])
+def test_absolute_orientation_device_path(ctx, n):
+    """estimate() bit-exact, agree() scan and mask bit-exact, Horn fit within 1e-6 of the oracle"""
+    data, truth, lab = synth.absolute_orientation(n, 0.3 if n > 3 else 0.0, seed=500 + n)
+    oc = O.cfg(O.ABSOR, 3, 1.0)
+    ctx.set_model(L.ABSOR, 3, 1.0).upload(data)
+    H = 64
+    subs = O.ctr_subsets(9, 0, H, n, 3)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in range(H):
+        want = O.estimate(oc, data[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0)
+        if valid[h]:
+            assert np.array_equal(par[h], want), h
+            assert votes[h] == O.scan(oc, want, data)[0], h
+    packed, bv, bi = ctx.best()
+    m, cnt = ctx.mask_from_hypothesis(bi)
+    wcnt, wmask = O.scan(oc, par[bi], data)
+    assert cnt == wcnt == bv and np.array_equal(m, wmask)
+    fit, _ = ctx.ls_fit(use_mask=True)
+    _quat_close(fit, O.ls(oc, data, wmask))
+    fit_all, _ = ctx.ls_fit(use_mask=False)
+    _quat_close(fit_all, O.ls(oc, data))
+    st = ctx.stats(fit, use_mask=True)
+    assert np.allclose(st, O.stats(oc, fit, data, wmask), rtol=1e-9, atol=1e-9)
+
+
+def test_absolute_orientation_exhaustive_ransac_matches_oracle(ctx):
+    """examples/AbsoluteOrientation.cxx: exhaustive overload over all C(N,3) subsets"""
+    data, truth, lab = synth.absolute_orientation(12, 0.25, seed=77, sigma=0.3)
+    oc = O.cfg(O.ABSOR, 3, 1.0)
+    ctx.set_model(L.ABSOR, 3, 1.0).upload(data)
+    r = ctx.ransac_exhaustive()
+    w = O.ransac_exhaustive(oc, data)
+    assert r["fraction"] == w["fraction"]
+    assert np.array_equal(r["consensus"], w["consensus"])
+    _quat_close(r["params"], w["params"])
+    assert np.array_equal(r["consensus"].astype(bool), lab)
+    # collinear fiducials: every subset degenerate -> empty parameters, fraction 0
+    col = data.copy()
+    col[:, :3] = np.outer(np.arange(12), [1.0, 2.0, 3.0])
+    ctx.upload(col)
+    r = ctx.ransac_exhaustive()
+    assert r["fraction"] == 0 and len(r["params"]) == 0
+
+
+def test_pivot_calibration_device_path(ctx, golden_dir):
+    """the reference's own pivot calibration data: minimal solve, agree() scan, LS known answer"""
+    F = synth.frames_from_pose_rows(np.loadtxt(os.path.join(golden_dir, "ref_data",
+                                                            "pivotCalibrationData.txt")))
+    n = len(F)
+    oc = O.cfg(O.PIVOT, 3, 1.0)
+    ctx.set_model(L.PIVOT, 3, 1.0).upload(F)
+    subs = np.vstack([[0, int(n / 2.0), n - 1], O.ctr_subsets(2, 0, 63, n, 3)]).astype(np.uint32)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    assert valid[0]
+    assert np.allclose(par[0], [-18.586, 1.98134, -157.439, 146.965, -62.0497, -1042.87], atol=6e-3)
+    for h in range(64):
+        want = O.estimate(oc, F[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0)
+        if valid[h]:
+            assert np.allclose(par[h], want, rtol=REL, atol=1e-6)
+            assert votes[h] == O.scan(oc, par[h], F)[0]     # scan exact on the device's own model
+    fit, _ = ctx.ls_fit(use_mask=False)
+    assert np.allclose(fit, [-17.7799, 1.1113, -156.865, 146.901, -62.9689, -1042.14], atol=6e-3)
+    assert np.allclose(fit, O.ls(oc, F), rtol=REL, atol=1e-6)
+    m, cnt = ctx.mask(fit)
+    wcnt, wmask = O.scan(oc, fit, F)
+    assert cnt == wcnt and np.array_equal(m, wmask)
+    # identical poses: rank deficient -> empty
+    ctx.upload(np.repeat(F[:1], 5, axis=0))
+    ctx.hypotheses_from_subsets(np.array([[0, 1, 2]], dtype=np.uint32))
+    _, valid, _ = ctx.hypotheses(votes=False)
+    assert not valid[0]
+    fit, _ = ctx.ls_fit(use_mask=False)
+    assert len(fit) == 0
+
+
+def test_pivot_ransac_end_to_end(ctx, golden_dir):
+    """examples/pivotCalibration.cxx: the reference's outlier file (1/3 outliers) and a larger
+    synthetic set; same loop as the serial oracle on the same subset stream"""
+    F = synth.frames_from_pose_rows(np.loadtxt(os.path.join(golden_dir, "ref_data",
+                                                            "pivotCalibrationDataWithOutliers.txt")))
+    oc = O.cfg(O.PIVOT, 3, 1.0)
+    ctx.set_model(L.PIVOT, 3, 1.0).upload(F)
+    r = ctx.ransac(0.999, seed=3)
+    w = O.ransac(oc, F, 0.999, sampler="ctr", seed=3)
+    assert abs(int(r["info"].best_votes) - int(w["best_votes"])) <= 2
+    assert np.allclose(r["params"], [-17.78, 1.11, -156.87, 146.90, -62.97, -1042.14], atol=1.0)
+    assert np.allclose(r["params"], w["params"], rtol=1e-4, atol=1e-3)
+    big, truth, lab = synth.pivot(50_000, 0.4, seed=12)
+    ctx.upload(big)
+    r = ctx.ransac(0.999, seed=5)
+    assert np.allclose(r["params"], truth, atol=0.05)
+    assert abs(r["fraction"] - lab.mean()) < 0.02

@@ -186,3 +186,84 @@ def test_crosswire_experimental_data(golden_dir):
     assert st[2] < 3.0  # mean residual in mm
     an = O.us_analytic(O.US_SINGLE, rec)
     assert O.stats(c, ls, rec)[3] <= O.stats(c, an, rec)[3] + 1e-9  # LM does not worsen
+
+
+# ---- AbsoluteOrientation and PivotCalibration -------------------------------
+def _apply(par, pts):
+    R = synth.quat_to_matrix(par[:4] / np.linalg.norm(par[:4]))
+    return pts @ R.T + par[4:7]
+
+
+def test_absolute_orientation_like_reference_test():
+    """testing/AbsoluteOrientationParametersEstimatorTest.cxx:19-118: 10 pairs, noise sigma 5/3,
+    delta 1; exact estimate from clean pairs and LS from noisy pairs keep the maximal target
+    registration error below 3 sigma; agree() accepts a clean pair and rejects the outlier."""
+    sigma = 5.0 / 3.0
+    clean, truth, _ = synth.absolute_orientation(10, 0.0, seed=91, sigma=0.0)
+    noisy = clean.copy()
+    g = np.random.default_rng(5)
+    noisy[:, 3:] += g.normal(0, sigma, (10, 3))
+    targets = g.uniform(-100, 100, (10, 3))
+    want = _apply(truth, targets)
+    c = O.cfg(O.ABSOR, 3, 1.0)
+    exact = O.estimate(c, clean[:3])
+    assert len(exact) == 7
+    assert np.linalg.norm(_apply(exact, targets) - want, axis=1).max() < 1e-9
+    ls = O.ls(c, noisy)
+    assert len(ls) == 7
+    assert np.linalg.norm(_apply(ls, targets) - want, axis=1).max() < 3 * sigma
+    assert O.agree(c, truth, clean[0])
+    outlier = clean[1].copy()
+    outlier[3] += 10 * sigma
+    assert not O.agree(c, truth, outlier)
+    # collinear first points -> empty (AbsoluteOrientation...cxx:48)
+    col = clean[:3].copy()
+    col[:, :3] = np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]], float)
+    assert len(O.estimate(c, col)) == 0
+    assert len(O.estimate(c, clean[:2])) == 0 and len(O.ls(c, clean[:2])) == 0
+
+
+def test_absolute_orientation_ls_matches_svd_solution():
+    """Horn's quaternion solution equals the SVD (Kabsch) solution of the same least squares problem"""
+    data, truth, _ = synth.absolute_orientation(200, 0.0, seed=17, sigma=1.0)
+    ls = O.ls(O.cfg(O.ABSOR, 3, 1.0), data)
+    a, b = data[:, :3], data[:, 3:]
+    ma, mb = a.mean(0), b.mean(0)
+    U, _, Vt = np.linalg.svd((b - mb).T @ (a - ma))
+    D = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    assert np.allclose(synth.quat_to_matrix(ls[:4]), R, atol=1e-10)
+    assert np.allclose(ls[4:], mb - R @ ma, atol=1e-8)
+
+
+def test_pivot_calibration_known_answers_of_the_reference():
+    """testing/PivotCalibrationParametersEstimatorTest.cxx:47-119 on its own data file: the exact
+    estimate from poses {0, n/2, n-1} and the least squares estimate against the hard-coded vectors
+    (tolerance 1.0 there; reproduced here to the printed digits), agree() on the minimal set."""
+    rows = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "ref_data",
+                                   "pivotCalibrationData.txt"))
+    F = synth.frames_from_pose_rows(rows)
+    n = len(F)
+    assert n == 481
+    c = O.cfg(O.PIVOT, 3, 1.0)
+    mins = F[[0, int(n / 2.0), n - 1]]
+    exact = O.estimate(c, mins)
+    assert np.allclose(exact, [-18.586, 1.98134, -157.439, 146.965, -62.0497, -1042.87], atol=6e-3)
+    for f in mins:
+        assert O.agree(c, exact, f)
+    ls = O.ls(c, F)
+    assert np.allclose(ls, [-17.7799, 1.1113, -156.865, 146.901, -62.9689, -1042.14], atol=6e-3)
+    # rank deficiency: three identical poses -> empty (:44-45)
+    assert len(O.estimate(c, np.repeat(F[:1], 3, axis=0))) == 0
+
+
+def test_pivot_ransac_on_the_reference_outlier_file():
+    """examples/pivotCalibration.cxx on examples/Data/pivotCalibrationDataWithOutliers.txt: RANSAC
+    recovers the translations the clean file gives (within the 1 mm threshold)"""
+    rows = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "ref_data",
+                                   "pivotCalibrationDataWithOutliers.txt"))
+    F = synth.frames_from_pose_rows(rows)
+    c = O.cfg(O.PIVOT, 3, 1.0)
+    r = O.ransac(c, F, 0.999, sampler="ctr", seed=3)
+    assert 0.5 < r["fraction"] < 0.8
+    assert np.allclose(r["params"], [-17.78, 1.11, -156.87, 146.90, -62.97, -1042.14], atol=1.0)
