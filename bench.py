@@ -175,10 +175,10 @@ def main():
             if r["info"].best_votes == 0:
                 return None
             return int(r["info"].best_votes), r["params"], int(r["info"].fit.n_used)
-        votes, gidx, par = eng.batch(seed, i, H)
-        if gidx is None:
+        r = eng.step(seed, i, H)
+        if r is None:
             return None
-        fit, cnt, info = eng.fit(par)
+        votes, gidx, par, fit, cnt, info = r
         return votes, fit, cnt
 
     def sync():

@@ -1,9 +1,14 @@
 // crosswireUSCalibration -- counterpart of the reference's examples/crosswireUSCalibration.cxx
 // (:30-85): load tracker transformations (rows "R00 R01 R02 t0" x 3 per frame) and the 2D image
 // points of the cross-wire, calibrate analytically / iteratively and robustly with RANSAC.
-// usage: crosswireUSCalibration transformationsFile pointsFile     (without arguments: simulated)
+// usage: crosswireUSCalibration [transformationsFile pointsFile [outputXMLFile]]
+//        (without arguments: simulated data).  With an output file name the calibration T3 is
+//        written as an IGSTK "precomputed_transform" XML document, the wire format of the
+//        reference's example (:181-210).
 #include <cstdlib>
+#include <ctime>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 
 #include "RANSAC.h"
@@ -55,9 +60,29 @@ static void simulate(std::vector<DataType> &data) {
   }
 }
 
+// T3 = [m_x r1, m_y r2, r3 | t3] from the 20-vector [t1, t3, wz, wy, wx, m_x, m_y, m_x r1, m_y r2, r3]
+static bool writeIgstkXml(const char *fileName, const std::vector<double> &par, double meanError) {
+  std::ofstream out(fileName);
+  if (!out.is_open()) return false;
+  char stamp[64];
+  std::time_t now = std::time(0);
+  std::strftime(stamp, sizeof stamp, "%Y %b %d %H:%M:%S", std::localtime(&now));
+  out << std::fixed << std::setprecision(10);
+  out << "<?xml version=\"1.0\" encoding=\"ISO-8859-1\"?>\n\n";
+  out << "<precomputed_transform>\n\n";
+  out << "\t<description>\n\tUS calibration - Crosswire Phantom\n\t</description>\n\n";
+  out << "\t<computation_date>\n\t" << stamp << "\n\t</computation_date>\n\n";
+  out << "\t<transformation estimation_error=\"" << meanError << "\">\n";
+  for (int row = 0; row < 3; row++)
+    out << "\t" << par[11 + row] << "\t" << par[14 + row] << "\t" << par[17 + row] << "\t"
+        << par[3 + row] << "\n";
+  out << "\t</transformation>\n\n</precomputed_transform>\n";
+  return out.good();
+}
+
 int main(int argc, char *argv[]) {
   std::vector<DataType> data;
-  if (argc == 3) {
+  if (argc == 3 || argc == 4) {
     if (!load(argv[1], argv[2], data)) {
       std::cerr << "Failed to load data files.\n";
       return EXIT_FAILURE;
@@ -88,5 +113,9 @@ int main(int argc, char *argv[]) {
   std::cout << "\tPercentage of frames used: " << used << "\n";
   std::cout << "\tdistance to target over the consensus set: min " << mn << " max " << mx_
             << " mean " << mean << "\n";
+  if (argc == 4 && !writeIgstkXml(argv[3], params, mean)) {
+    std::cerr << "Failed to write " << argv[3] << "\n";
+    return EXIT_FAILURE;
+  }
   return (used > 0.5 && mx_ < 3.0) ? EXIT_SUCCESS : EXIT_FAILURE;
 }

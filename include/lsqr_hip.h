@@ -169,6 +169,15 @@ LSQR_API int lsqr_moments(lsqr_ctx *ctx, int use_mask, size_t begin, size_t end,
 /* Small solve (on the device) from a summed phase-0 block taken about `origin`. */
 LSQR_API int lsqr_solve_moments(lsqr_ctx *ctx, const double *block, const double *origin,
                                 double *params_out, lsqr_fit_info *info);
+/* Multi-GPU step, per rank, one host synchronisation: hypothesis `stream_index` of sampler stream
+ * `seed` (the global winner, re-derived locally -- the sampler is stateless) -> consensus mask over
+ * [begin, end) -> phase-0 block of that slice about the model's own point (plane / line: a, sphere: c,
+ * else zeros).  params_out: lsqr_num_params doubles; origin_out: 32 doubles (pass it to
+ * lsqr_solve_moments together with the summed block); block_out: lsqr_moments_len(cfg, 0) doubles;
+ * count_out: inliers of the slice.  LSQR_EMPTY if the subset is degenerate. */
+LSQR_API int lsqr_winner_moments(lsqr_ctx *ctx, uint64_t seed, uint64_t stream_index, size_t begin,
+                                 size_t end, double *params_out, double *origin_out,
+                                 double *block_out, uint64_t *count_out);
 /* Levenberg-Marquardt over summed phase-1 blocks (MINPACK lmder control flow on the device):
  *   lsqr_lm_begin(x0) -> x_trial;  repeat { block = sum over ranks of lsqr_moments(phase 1,
  *   x_trial);  lsqr_lm_step(block) -> cont, x_trial }  until !cont.  On the last step params_out

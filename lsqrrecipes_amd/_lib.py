@@ -78,6 +78,8 @@ SIGNATURES = {
                                C.c_void_p]),
     "lsqr_solve_moments": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.POINTER(FitInfo)]),
+    "lsqr_winner_moments": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, _u64p]),
     "lsqr_lm_begin": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "lsqr_lm_step": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                C.POINTER(FitInfo)]),

@@ -135,6 +135,17 @@ class Context:
                                          L.ptr(blk)))
         return blk
 
+    def winner_moments(self, seed, stream_index, begin=0, end=None):
+        """-> (params, origin(32), block, count): lsqr_winner_moments, one host synchronisation"""
+        end = self.n if end is None else end
+        par = np.zeros(max(self.P, 1))
+        org = np.zeros(32)
+        blk = np.zeros(self.moments_len(0))
+        cnt = C.c_uint64(0)
+        self._chk(self._lib.lsqr_winner_moments(self._h, seed, stream_index, begin, end, L.ptr(par),
+                                                L.ptr(org), L.ptr(blk), C.byref(cnt)))
+        return par, org, blk, cnt.value
+
     def solve_moments(self, block, origin):
         b = np.ascontiguousarray(block, dtype=np.float64)
         o = np.zeros(32)

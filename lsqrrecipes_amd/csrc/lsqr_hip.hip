@@ -1720,6 +1720,49 @@ int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double 
   return LSQR_OK;
 }
 
+// Second half of a multi-GPU step on one rank, chained on the stream with one synchronisation: the
+// winner is re-derived from its index in the (stateless) sampler stream, its consensus mask is taken
+// over this rank's observation slice [begin, end) and the slice's phase-0 moment block is reduced about
+// the model's own point (plane / line: a, sphere: c; zeros for the other models).
+int lsqr_winner_moments(lsqr_ctx *c, uint64_t seed, uint64_t stream_index, size_t begin, size_t end,
+                        double *params_out, double *origin_out, double *block_out,
+                        uint64_t *count_out) {
+  int st = lsqr_hypotheses_sample(c, seed, stream_index, 1, nullptr);
+  if (st != LSQR_OK) return st;
+  if (begin > end || end > c->n || !block_out) return fail(c, LSQR_ERR_INVALID, "bad range");
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams, sizeof(double) * c->HS, hipMemcpyDeviceToDevice,
+                           c->stream));
+  if ((st = launch_mask(c, begin, end)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemsetAsync(c->d_vec, 0, sizeof(double) * 32, c->stream));
+  const int m = c->cfg.model;
+  if (m == LSQR_MODEL_PLANE || m == LSQR_MODEL_LINE || m == LSQR_MODEL_SPHERE)
+    HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (m == LSQR_MODEL_SPHERE ? 0 : c->ND),
+                             sizeof(double) * c->ND, hipMemcpyDeviceToDevice, c->stream));
+  int nmom = 0;
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    return launch_moments<M>(c, 1, begin, end, 0, &nmom);
+  });
+  if (st != LSQR_OK) return st;
+  double *pin = (double *)((char *)c->h_pin + 16384);  // {valid, count, params[64], origin[32]}
+  HIPCHK(c, hipMemcpyAsync(pin, c->d_valid, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 1, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 2, c->d_hparams, sizeof(double) * c->P, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 66, c->d_vec, sizeof(double) * 32, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipMemcpyAsync(block_out, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (*(const uint8_t *)pin == 0) return LSQR_EMPTY;  // degenerate subset: not a possible winner
+  if (count_out) memcpy(count_out, pin + 1, sizeof(uint64_t));
+  if (params_out) memcpy(params_out, pin + 2, sizeof(double) * c->P);
+  if (origin_out) memcpy(origin_out, pin + 66, sizeof(double) * 32);
+  return LSQR_OK;
+}
+
 int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   if (!c || !name) return LSQR_ERR_INVALID;
   if (!strcmp(name, "scan_ppl")) {

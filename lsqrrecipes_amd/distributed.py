@@ -17,38 +17,57 @@ import numpy as np
 
 
 class Comm:
-    """Minimal collective interface over torch.distributed (or a no-op for world size 1)."""
+    """Minimal collective interface over torch.distributed (or a no-op for world size 1).
+    The messages are tiny (8 B .. 17 KB) and latency-bound, so the device and pinned host staging
+    buffers are allocated once and every exchange is copy-in, all_reduce, copy-out, one sync."""
 
     def __init__(self, dist=None, device="cpu"):
         self.dist = dist
         self.device = device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
+        self._bufs = {}
+
+    def _staging(self, dtype, n):
+        import torch
+        key = (dtype, n)
+        if key not in self._bufs:
+            on_gpu = str(self.device) != "cpu"
+            host = torch.zeros(n, dtype=dtype, pin_memory=on_gpu)
+            dev = torch.zeros(n, dtype=dtype, device=self.device) if on_gpu else host
+            self._bufs[key] = (host, dev)
+        return self._bufs[key]
+
+    def _allreduce(self, values, dtype, op):
+        import torch
+        host, dev = self._staging(dtype, len(values))
+        host.copy_(torch.as_tensor(values, dtype=dtype))
+        if dev is not host:
+            dev.copy_(host, non_blocking=True)
+        self.dist.all_reduce(dev, op=op)
+        if dev is not host:
+            host.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return host
 
     def allreduce_max_i64(self, value):
         if self.dist is None:
             return int(value)
         import torch
-        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return int(t.item())
+        return int(self._allreduce([int(value)], torch.int64, self.dist.ReduceOp.MAX)[0])
 
     def allreduce_sum_f64(self, arr):
+        a = np.asarray(arr, dtype=np.float64)
         if self.dist is None:
-            return np.asarray(arr, dtype=np.float64)
+            return a
         import torch
-        t = torch.tensor(np.asarray(arr, dtype=np.float64), dtype=torch.float64,
-                         device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        return self._allreduce(a, torch.float64, self.dist.ReduceOp.SUM).numpy().copy()
 
     def allreduce_max_f64(self, value):
         if self.dist is None:
             return float(value)
         import torch
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(self._allreduce([float(value)], torch.float64, self.dist.ReduceOp.MAX)[0])
 
     def barrier(self):
         if self.dist is not None:
@@ -91,6 +110,50 @@ class ShardedRansac:
             par, _ = e.hypothesis(0)
         return int(wvotes), gidx, par
 
+    def step(self, seed, batch_index, H):
+        """One whole multi-GPU step: batch() + fit() with the fewest host synchronisations the
+        engine offers.  Returns (votes, global_index, params_of_winner, fit, inliers, info) or None
+        when no hypothesis of the batch was valid."""
+        e, c = self.e, self.c
+        if not hasattr(e, "winner_moments"):
+            votes, gidx, par = self.batch(seed, batch_index, H)
+            if gidx is None:
+                return None
+            fit, total, info = self.fit(par)
+            return votes, gidx, par, fit, total, info
+        first = (batch_index * c.world + c.rank) * H
+        e.hypotheses_sample(seed, first, H)
+        e.scan()
+        packed, votes, idx = e.best()
+        mine = ((int(votes) << 32) | (0xFFFFFFFF - (c.rank * H + idx))) if packed else 0
+        win = c.allreduce_max_i64(mine)
+        if win == 0:
+            return None
+        in_batch = 0xFFFFFFFF - (win & 0xFFFFFFFF)
+        gidx = batch_index * c.world * H + in_batch
+        lo, hi = slice_bounds(e.n, c.rank, c.world)
+        par, origin, blk, cnt = e.winner_moments(seed, gidx, lo, hi)
+        blk = c.allreduce_sum_f64(np.concatenate([blk, [float(cnt)]]))
+        fit, info = e.solve_moments(blk[:-1], origin)
+        fit, info = self._refine(fit, info, lo, hi)
+        return int(win >> 32), gidx, par, fit, int(round(blk[-1])), info
+
+    def _refine(self, fit, info, lo, hi):
+        """LM refinement over the sharded observation range (sphere geometric / US iterative)."""
+        e, c = self.e, self.c
+        from . import _lib as L
+        model = e.cfg.model
+        iterative = (model == L.SPHERE and e.cfg.ls_type == L.LS_GEOMETRIC) or (
+            model in (L.US_SINGLE, L.US_POINTER) and e.cfg.ls_type == L.LS_ITERATIVE)
+        if len(fit) and iterative:
+            xt = e.lm_begin(fit)
+            while True:
+                blk = c.allreduce_sum_f64(e.moments(xt[:e.P], lo, hi, phase=1, use_mask=True))
+                cont, xt, fit, info = e.lm_step(blk)
+                if not cont:
+                    break
+        return fit, info
+
     def fit(self, params):
         """Consensus mask of `params` + final least-squares fit, observation range sharded."""
         e, c = self.e, self.c
@@ -103,18 +166,10 @@ class ShardedRansac:
         elif model in (L.PLANE, L.LINE):
             origin = np.asarray(params[e.ND:2 * e.ND])
         else:
-            origin = np.zeros(3)  # dense / US blocks are not taken about an origin
+            origin = np.zeros(3)  # dense / US / rigid blocks are not taken about a model point
         blk = np.concatenate([e.moments(origin, lo, hi, phase=0, use_mask=True), [float(cnt)]])
         blk = c.allreduce_sum_f64(blk)  # one fused exchange: moment block + inlier count
         total = int(round(blk[-1]))
         fit, info = e.solve_moments(blk[:-1], origin)
-        iterative = (model == L.SPHERE and e.cfg.ls_type == L.LS_GEOMETRIC) or (
-            model in (L.US_SINGLE, L.US_POINTER) and e.cfg.ls_type == L.LS_ITERATIVE)
-        if len(fit) and iterative:
-            xt = e.lm_begin(fit)
-            while True:
-                blk = c.allreduce_sum_f64(e.moments(xt[:e.P], lo, hi, phase=1, use_mask=True))
-                cont, xt, fit, info = e.lm_step(blk)
-                if not cont:
-                    break
+        fit, info = self._refine(fit, info, lo, hi)
         return fit, total, info

@@ -76,3 +76,21 @@ def test_example_data_file_programs_on_gpu():
                         os.path.join(REFDATA, "crossWirePhantom2DPoints.txt")],
                        capture_output=True, text=True, timeout=300)
     assert "54 frames" in r.stdout
+
+
+@pytest.mark.gpu
+def test_crosswire_writes_igstk_xml(tmp_path):
+    """the reference example's output wire format (examples/crosswireUSCalibration.cxx:181-210)"""
+    xml = tmp_path / "calibration.xml"
+    r = subprocess.run([os.path.join(BUILD, "crosswireUSCalibration"),
+                        os.path.join(REFDATA, "crossWirePhantomTransformations.txt"),
+                        os.path.join(REFDATA, "crossWirePhantom2DPoints.txt"), str(xml)],
+                       capture_output=True, text=True, timeout=300)
+    assert "54 frames" in r.stdout
+    if r.returncode == 0:
+        import xml.etree.ElementTree as ET
+        root = ET.parse(str(xml)).getroot()
+        assert root.tag == "precomputed_transform"
+        tr = root.find("transformation")
+        assert float(tr.attrib["estimation_error"]) >= 0
+        assert len(tr.text.split()) == 12

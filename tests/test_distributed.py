@@ -87,6 +87,9 @@ def _worker(rank, world, port, data, out):
     votes, gidx, par = sr.batch(seed=5, batch_index=0, H=24)
     fit, cnt, _ = sr.fit(par)
     votes2, gidx2, par2 = sr.batch(seed=5, batch_index=1, H=24)
+    st = sr.step(seed=5, batch_index=0, H=24)  # the one-call form (falls back to batch() + fit() here)
+    assert (st[0], st[1]) == (votes, gidx) and np.array_equal(st[2], par) and st[4] == cnt
+    assert np.allclose(st[3], fit, rtol=0, atol=1e-12)
     if rank == 0:
         out.put((votes, gidx, par, fit, cnt, votes2, gidx2))
     dist.barrier()

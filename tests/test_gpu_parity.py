@@ -1188,3 +1188,22 @@ def test_pivot_ransac_end_to_end(ctx, golden_dir):
     r = ctx.ransac(0.999, seed=5)
     assert np.allclose(r["params"], truth, atol=0.05)
     assert abs(r["fraction"] - lab.mean()) < 0.02
+
+
+@pytest.mark.parametrize("model,dim,ls", [(L.PLANE, 3, 0), (L.SPHERE, 3, L.LS_GEOMETRIC), (L.LINE, 3, 0)])
+def test_sharded_step_fused_equals_stepwise(ctx, model, dim, ls):
+    """ShardedRansac.step() through lsqr_winner_moments (one sync per half) = batch() + fit()"""
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+    data = _data(model, dim, 150_000, 999, outliers=0.5)
+    ctx.set_model(model, dim, 0.5, ls).upload(data)
+    sr = ShardedRansac(ctx, Comm(None))
+    votes, gidx, par = sr.batch(7, 3, 2500)
+    fit, cnt, info = sr.fit(par)
+    r = sr.step(7, 3, 2500)
+    assert (r[0], r[1]) == (votes, gidx) and np.array_equal(r[2], par)
+    assert r[4] == cnt and np.array_equal(r[3], fit)
+    # and the single-device chain gives the same winner and fit
+    b = ctx.batch_fit(7, 3 * 2500, 2500)
+    assert b["info"].best_votes == votes and b["info"].best_index == gidx
+    assert b["info"].fit.n_used == cnt
+    assert np.allclose(b["params"], fit, rtol=1e-9, atol=1e-9)
