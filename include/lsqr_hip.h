@@ -232,11 +232,12 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the
  *                host, 0 = in a single-lane device kernel (same lm_core.h code either way);
  * "scan_index":  two-level scan of the point models over a spatial index of the observations
- *                (Morton-sorted copy + one fp32 bounding box per cell of 256 observations, built on the
+ *                (Morton-sorted copy + one fp32 bounding box per cell of 256 / 512 observations, built on the
  *                device once per upload): 1 (default) = used once an upload has seen >= 2048
  *                hypotheses and holds >= 65536 observations, 0 = never, 2 = always.  Votes are
- *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = default),
- *                "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default);
+ *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = the
+ *                model's default), "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default), "scan_block":
+ *                workgroup size (256 / 1024), "scan_hsplit": hypothesis segments per tile (A/B knobs);
  * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS
  *                (k_scan_dense_t), 0 = rows in registers, hypotheses through the scalar cache. */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);

@@ -30,7 +30,9 @@
 
 namespace lsqr {
 
-constexpr int kCellPtsMin = 128;  // cell sizes are multiples of one packed fp32 pair per lane
+constexpr int kCellPtsMin = 128;
+constexpr uint32_t kQueues = 32;   // work queues of k_scan_cells (one atomic counter each)
+constexpr uint32_t kQueuePitch = 1088;  // uint32 words between counters: separate cache lines / channels  // cell sizes are multiples of one packed fp32 pair per lane
 
 struct CellBox {  // 32 B: one s_load_dwordx8
   float c[3];     // centre (exactly representable, inside the box)
@@ -317,6 +319,7 @@ template <int D>
 struct PlaneCell {
   typedef PlaneModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 0, ROW2_OFF = 0 };  // row = fp64 scan parameters
+  enum { DEFAULT_CELL = 512 };  // measured best (tools/ab_cells.py)
   struct Hyp {
     double n[3], c;
     float nf[3], e0;
@@ -403,6 +406,7 @@ template <int D>
 struct SphereCell {
   typedef SphereModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
+  enum { DEFAULT_CELL = 256 };  // absolute coordinates: wider band, whole-cell re-checks cost more
   struct Hyp {
     float nc[3], nmid, tin, tout, dlo, dhi;
   };
@@ -466,6 +470,7 @@ template <int D>
 struct LineCell {
   typedef LineModel<D> M;
   enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
+  enum { DEFAULT_CELL = 512 };
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;
@@ -546,15 +551,16 @@ inline CellConsts cell_consts(const LineCell<D> *, const ModelConsts &mc) {
 // assignment leaves a long tail); the next 64 hypotheses' parameters are prefetched while the
 // current 64 are processed.  Votes of the 64 hypotheses of a group are collected in one VGPR
 // (lane b = hypothesis h0 + b, v_readlane / v_writelane) and flushed with one LDS atomic per group.
-template <class CM, int PP, int CPT>
-__global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
+template <class CM, int PP, int CPT, int BS>
+__global__ __launch_bounds__(BS) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
                                                     const CellBox *__restrict__ boxes,
                                                     uint32_t ncells, const double *__restrict__ sp,
                                                     const float *__restrict__ rows,
                                                     const float *__restrict__ spf, uint32_t H,
                                                     ModelConsts mc, CellConsts cc,
                                                     uint32_t *__restrict__ votes,
-                                                    uint32_t *__restrict__ next_tile) {
+                                                    uint32_t *__restrict__ next_tile, uint32_t grab,
+                                                    uint32_t hsplit) {
   typedef typename CM::M M;
   constexpr int D = M::ND;
   constexpr int NB = CM::NB, NV = CM::NV;
@@ -564,15 +570,44 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
   constexpr int CP = 128 * PP;                 // observations per cell
   static_assert(ROW % 4 == 0, "hypothesis rows are fetched as 16-byte loads");
   extern __shared__ uint32_t s_cnt[];
-  for (uint32_t h = threadIdx.x; h < H; h += 256) s_cnt[h] = 0;
+  for (uint32_t h = threadIdx.x; h < H; h += BS) s_cnt[h] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint32_t wtiles = (ncells + CPT - 1) / CPT;
-  for (;;) {
-    uint32_t wt = 0;
-    if (lane == 0) wt = atomicAdd(next_tile, 1u);
-    wt = __builtin_amdgcn_readfirstlane(wt);
-    if (wt >= wtiles) break;
+  // Work unit = (wave tile, segment of the hypothesis range), handed out dynamically: near-model tiles
+  // cost 4x more than far ones and a wave only sees a handful of them.  One same-address atomic costs
+  // ~14 ns of L2 time (39 000 grabs on one counter serialise into 0.55 ms -- measured: the whole
+  // launch at H = 256), so the units are split over kQueues counters; a wave starts at its
+  // workgroup's queue and moves on (after a plain load says "empty") when a queue runs dry.
+  const uint32_t hseg = ((H + 63) / 64 + hsplit - 1) / hsplit * 64;  // hypotheses per segment
+  const uint32_t units = wtiles * hsplit;
+  const uint32_t qsize = (units + kQueues - 1) / kQueues;
+  uint32_t q = blockIdx.x % kQueues, tried = 0;
+  for (uint32_t un = 0, un_end = 0;; un++) {
+    if (un >= un_end) {
+      uint32_t t = ~0u;
+      while (tried < kQueues) {  // wave-uniform
+        const uint32_t qbase = q * qsize;
+        const uint32_t qlen = qbase >= units ? 0u : (units - qbase < qsize ? units - qbase : qsize);
+        uint32_t got = ~0u;
+        // the plain load may be stale (the counter only grows): at worst one useless atomic
+        if (lane == 0 && *(volatile const uint32_t *)&next_tile[q * kQueuePitch] < qlen)
+          got = atomicAdd(&next_tile[q * kQueuePitch], grab);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got < qlen) {
+          t = qbase + got;
+          un_end = qbase + (got + grab < qlen ? got + grab : qlen);
+          break;
+        }
+        q = q + 1 == kQueues ? 0 : q + 1;
+        tried++;
+      }
+      if (t == ~0u) break;
+      un = t;
+    }
+    const uint32_t wt = un / hsplit;
+    const uint32_t hbeg = (un - wt * hsplit) * hseg, hend = hbeg + hseg < H ? hbeg + hseg : H;
+    if (hbeg >= H) continue;
     v2f xs[CPT][PP][3];
     CellBox bx[CPT];
     double ctr[CPT][3];
@@ -603,18 +638,19 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
     }
     float4 nxt[NR4];
     {
-      const float4 *r4 = (const float4 *)(rows + (size_t)((uint32_t)lane < H ? lane : 0) * ROW);
+      const uint32_t hl = hbeg + lane;
+      const float4 *r4 = (const float4 *)(rows + (size_t)(hl < H ? hl : 0) * ROW);
 #pragma unroll
       for (int k = 0; k < NR4; k++) nxt[k] = r4[k];
     }
     float4 nxt2[NR2 ? NR2 : 1];
     if constexpr (NR2 > 0) {
-      const float4 *r4 = (const float4 *)(spf + (size_t)((uint32_t)lane < H ? lane : 0) * M::SPF +
-                                          CM::ROW2_OFF);
+      const uint32_t hl = hbeg + lane;
+      const float4 *r4 = (const float4 *)(spf + (size_t)(hl < H ? hl : 0) * M::SPF + CM::ROW2_OFF);
 #pragma unroll
       for (int k = 0; k < NR2; k++) nxt2[k] = r4[k];
     }
-    for (uint32_t h0 = 0; h0 < H; h0 += 64) {
+    for (uint32_t h0 = hbeg; h0 < hend; h0 += 64) {
       const uint32_t h = h0 + lane;
       float row[ROW];
 #pragma unroll
@@ -627,7 +663,7 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
           row2[4 * k] = nxt2[k].x, row2[4 * k + 1] = nxt2[k].y, row2[4 * k + 2] = nxt2[k].z,
                    row2[4 * k + 3] = nxt2[k].w;
       }
-      if (h0 + 64 < H) {  // prefetch the next group
+      if (h0 + 64 < hend) {  // prefetch the next group
         const uint32_t hn = h + 64;
         const float4 *r4 = (const float4 *)(rows + (size_t)(hn < H ? hn : 0) * ROW);
 #pragma unroll
@@ -707,8 +743,12 @@ __global__ __launch_bounds__(256) void k_scan_cells(const double *__restrict__ s
     }
   }
   __syncthreads();
-  for (uint32_t h = threadIdx.x; h < H; h += 256) {
-    uint32_t c = s_cnt[h];
+  // flush: every workgroup starts at a different hypothesis so that the global atomics of the
+  // workgroups finishing together do not all queue on the same addresses
+  const uint32_t rot = (blockIdx.x * 61u) % (H ? H : 1u);
+  for (uint32_t i = threadIdx.x; i < H; i += BS) {
+    const uint32_t h = i + rot < H ? i + rot : i + rot - H;
+    const uint32_t c = s_cnt[h];
     if (c) atomicAdd(&votes[h], c);
   }
 }

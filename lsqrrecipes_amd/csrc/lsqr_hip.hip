@@ -44,12 +44,13 @@ struct lsqr_ctx {
   bool absmax_valid = false;
   // spatial index of the point models (cells.h): Morton-sorted copy + one fp32 box per 128 records
   double *d_sorted = nullptr;
+  uint32_t *d_queues = nullptr;  // work-queue counters of k_scan_cells
   CellBox *d_boxes = nullptr;
   size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
-  int opt_index = 1, opt_cpt = 0, opt_cell = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
+  int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   bool scanned = false;
@@ -451,31 +452,47 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   return LSQR_OK;
 }
 
-template <class CM, int PP, int CPT>
-int run_scan_cells(lsqr_ctx *c) {
+template <class CM, int PP, int CPT, int BS>
+int launch_scan_cells(lsqr_ctx *c) {
   typedef typename CM::M M;
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
   HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
   if (c->n_cells == 0) return LSQR_OK;
   const size_t wtiles = ((size_t)c->n_cells + CPT - 1) / CPT;
-  uint32_t *d_next = (uint32_t *)(c->d_counter + 4);
+  constexpr int wpb = BS / 64;  // waves per workgroup
+  if (!c->d_queues) HIPCHK(c, hipMalloc((void **)&c->d_queues, kQueues * kQueuePitch * sizeof(uint32_t)));
+  uint32_t *d_next = c->d_queues;
   for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
     uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
     size_t lds = (size_t)hc * sizeof(uint32_t);
-    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    int per_cu = (int)std::min<size_t>(32 / wpb, (160 * 1024) / std::max<size_t>(lds, 1));
     if (per_cu < 1) per_cu = 1;
-    size_t blocks = std::min<size_t>((wtiles + 3) / 4, (size_t)256 * per_cu);
+    size_t blocks = std::min<size_t>((wtiles + wpb - 1) / wpb, (size_t)256 * per_cu);
+    // a unit is a whole tile by default: splitting the hypothesis range of a tile into segments
+    // (scan_hsplit) evens the load but every extra unit start measured ~20 us of exposed memory
+    // waiting (2.4 ms instead of 1.6 ms at 4 segments)
+    const size_t waves = blocks * wpb, groups = (hc + 63) / 64;
+    uint32_t hsplit = 1;
+    if (c->opt_hsplit > 0) hsplit = (uint32_t)std::min<size_t>(groups, (size_t)c->opt_hsplit);
+    const size_t units = wtiles * hsplit;
+    const uint32_t grab = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, units / (32 * waves)));
     ProfScope ps(c, KID_SCAN);
-    HIPCHK(c, hipMemsetAsync(d_next, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL((k_scan_cells<CM, PP, CPT>), dim3((unsigned)blocks), dim3(256), lds,
+    HIPCHK(c, hipMemsetAsync(d_next, 0, kQueues * kQueuePitch * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL((k_scan_cells<CM, PP, CPT, BS>), dim3((unsigned)blocks), dim3(BS), lds,
                        c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
                        c->d_hparams + h0 * M::SP,
                        CM::ROW_F32 ? c->d_hparams_f32 + h0 * M::SPF
                                    : (const float *)(c->d_hparams + h0 * M::SP),
-                       c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, cc, c->d_votes + h0, d_next);
+                       c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, cc, c->d_votes + h0, d_next, grab,
+                       hsplit);
     HIPCHK(c, hipGetLastError());
   }
   return LSQR_OK;
+}
+template <class CM, int PP, int CPT>
+int run_scan_cells(lsqr_ctx *c) {
+  if (c->opt_block == 1024) return launch_scan_cells<CM, PP, CPT, 1024>(c);
+  return launch_scan_cells<CM, PP, CPT, 256>(c);  // measured: 256 is 3-5 % faster than 1024
 }
 
 int run_scan(lsqr_ctx *c) {
@@ -554,7 +571,7 @@ int run_scan(lsqr_ctx *c) {
                            (c->opt_index == 1 && tuned_defaults &&
                             (c->index_valid || (c->n >= 65536 && c->hyp_since_upload >= 2048))));
         if (want) {
-          const uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : 256;
+          const uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : (uint32_t)CM::DEFAULT_CELL;
           if (!c->index_valid || c->cell_pts != cell_pts) {
             int st = build_index<M::ND>(c, cell_pts);
             if (st != LSQR_OK) return st;
@@ -958,7 +975,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_index(c);
-  void *bufs[] = {c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask,
+  void *bufs[] = {c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -1796,6 +1813,17 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     if (value != 0 && value != 1 && value != 2 && value != 4)
       return fail(c, LSQR_ERR_INVALID, "scan_cpt must be 0, 1, 2 or 4");
     c->opt_cpt = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_hsplit")) {  // hypothesis segments per tile of the two-level scan (0 = auto)
+    if (value < 0 || value > 128) return fail(c, LSQR_ERR_INVALID, "scan_hsplit must be 0..128");
+    c->opt_hsplit = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_block")) {  // workgroup size of the two-level scan
+    if (value != 0 && value != 256 && value != 1024)
+      return fail(c, LSQR_ERR_INVALID, "scan_block must be 0, 256 or 1024");
+    c->opt_block = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_cell")) {  // observations per cell of the spatial index

@@ -1207,3 +1207,35 @@ def test_sharded_step_fused_equals_stepwise(ctx, model, dim, ls):
     assert b["info"].best_votes == votes and b["info"].best_index == gidx
     assert b["info"].fit.n_used == cnt
     assert np.allclose(b["params"], fit, rtol=1e-9, atol=1e-9)
+
+
+def test_cell_scan_large_batches_lattice_data_and_state_changes(ctx):
+    """batches beyond one launch chunk (8192 hypotheses), integer-lattice observations (ties, cells
+    with zero extent), and the index following uploads / model changes"""
+    g = np.random.default_rng(44)
+    lat = g.integers(-40, 41, (120_000, 3)).astype(np.float64)      # ~1.5 observations per lattice site
+    lat[:30_000, 2] = np.round(0.5 * lat[:30_000, 0] - 0.25 * lat[:30_000, 1])   # a coarse plane
+    for model, delta in ((L.PLANE, 0.5), (L.SPHERE, 0.75), (L.LINE, 1.0)):
+        oc = O.cfg(model, 3, delta)
+        ctx.set_model(model, 3, delta).upload(lat)
+        assert not ctx.index_info()["built"]
+        ctx.hypotheses_sample(5, 0, 9000)
+        auto = _scan_votes(ctx, 1)                 # auto mode: 9000 >= 2048 and N >= 65536 -> index
+        assert ctx.index_info()["built"] and ctx.index_info()["observations"] == len(lat)
+        assert np.array_equal(_scan_votes(ctx, 0), auto)
+        par, valid, _ = ctx.hypotheses(votes=False)
+        for h in (0, 4095, 8191, 8192, 8999):
+            if valid[h]:
+                assert auto[h] == O.scan(oc, par[h], lat)[0], (model, h)
+    # a different upload drops the index; a small one never builds it in auto mode
+    small = _data(L.PLANE, 3, 5000, 3)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(small)
+    assert not ctx.index_info()["built"]
+    ctx.hypotheses_sample(5, 0, 4096)
+    v = _scan_votes(ctx, 1)
+    assert not ctx.index_info()["built"]
+    assert np.array_equal(_scan_votes(ctx, 2), v) and ctx.index_info()["built"]
+    # scan_index = 0 after a build keeps using the exhaustive kernel but does not drop the index
+    assert np.array_equal(_scan_votes(ctx, 0), v) and ctx.index_info()["built"]
+    ctx.set_model(L.LINE, 3, 0.5)                   # model change: parameters of the boxes differ
+    assert not ctx.index_info()["built"]

@@ -1,5 +1,5 @@
 # one two-level scan launch per requested variant (for rocprofv3 --pmc runs):
-#   python tools/cells_once.py plane N H cell:cpt,...
+#   python tools/cells_once.py plane N H cell:cpt:hsplit,...
 import sys, numpy as np
 sys.path.insert(0, '.')
 from lsqrrecipes_amd import _lib as L, synth
@@ -14,4 +14,5 @@ ctx.hypotheses_sample(1, 0, H)
 ctx.set_option('scan_index', 2)
 for v in variants:
     ctx.set_option('scan_cell', v[0]); ctx.set_option('scan_cpt', v[1])
+    ctx.set_option('scan_hsplit', v[2] if len(v) > 2 else 0)
     ctx.scan(); ctx.synchronize()
