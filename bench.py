@@ -205,6 +205,7 @@ def main():
     n_mask, ms_mask = ctx.profile_get("mask")
     n_mom, ms_mom = ctx.profile_get("moments")
     n_est, ms_est = ctx.profile_get("estimate")
+    n_sol, ms_sol = ctx.profile_get("solve")
     n_idx2, ms_idx2 = ctx.profile_get("index")
     ctx.profile(False)
     idx = ctx.index_info()
@@ -280,7 +281,8 @@ def main():
                                            "exceeds the fp64 issue roof") if filtered else
                                           "exact fp64 path: fraction of the fp64 add/mul issue rate"}},
             "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
-                           "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1)},
+                           "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1),
+                           "reduce_and_solve_per_step": ms_sol / max(a.steps, 1)},
             "index": {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
                       "build_ms": (ms_idx + ms_idx2) / max(n_idx + n_idx2, 1) if (n_idx + n_idx2) else None,
                       "builds_in_warmup": int(n_idx), "builds_in_timed_region": int(n_idx2),

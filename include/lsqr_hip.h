@@ -224,9 +224,10 @@ LSQR_API void lsqr_dedup_destroy(void *set);
 /* ---- tuning knobs (A/B measurements inside one process; defaults are the tuned values) --------- */
 /* "scan_ppl": observations per lane in k_scan (2, 4 or 8; 0 = model default);
  * "scan_filter": 1 = cheap pre-filter with a proven error band + exact fp64 re-evaluation of the
- *                ambiguous observations (bit-identical votes): packed fp32 for plane / sphere / line,
- *                fused fp64 for the US estimators, fp64 MFMA for the dense system; 0 = plain fp64
- *                scan; 2 / 3 = as 1 with the re-evaluation forced per packed pair / per tile;
+ *                ambiguous observations (bit-identical votes): packed fp32 for plane / sphere / line
+ *                and the US estimators, fp64 MFMA for the dense system; 0 = plain fp64 scan; 2 / 3 =
+ *                as 1 with the re-evaluation forced per packed pair / per tile (US: 2 = the fused
+ *                fp64 filter);
  * "max_iterations": stop lsqr_ransac after this many loop iterations even if the adaptive bound
  *                asks for more (0 = the reference's behaviour: up to C(N,k));
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the

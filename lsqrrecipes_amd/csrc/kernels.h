@@ -253,9 +253,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_f32(const double *__restrict__ 
 // max |x| over the first nd doubles of every record (bit patterns of non-negative doubles are
 // ordered like the values, so an integer atomicMax works)
 __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ data, size_t stride,
-                                                   size_t n, int nd, int skip,
+                                                   size_t n, int nd, int skip, int nrot,
                                                    unsigned long long *__restrict__ out) {
-  unsigned long long m = 0;
+  // out[0]: over all nd slots (but `skip`); out[1]: over the first nrot slots only
+  unsigned long long m = 0, mr = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock)
     for (int d = 0; d < nd; d++) {
@@ -265,12 +266,17 @@ __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ da
       if (!(v == v)) v = __builtin_inf();  // NaN observation: disables the filter
       __builtin_memcpy(&b, &v, 8);
       m = b > m ? b : m;
+      if (d < nrot) mr = b > mr ? b : mr;
     }
   for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long t = __shfl_down(m, o);
+    unsigned long long t = __shfl_down(m, o), tr = __shfl_down(mr, o);
     m = t > m ? t : m;
+    mr = tr > mr ? tr : mr;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0) {
+    if (m) atomicMax(out, m);
+    if (mr) atomicMax(out + 1, mr);
+  }
 }
 
 template <class M>

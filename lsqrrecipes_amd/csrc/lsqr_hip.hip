@@ -240,16 +240,17 @@ int grid_for(size_t items, int per_block, int max_blocks) {
 // ---- hypotheses ---------------------------------------------------------------------------------
 int ensure_absmax(lsqr_ctx *c) {
   if (c->absmax_valid) return LSQR_OK;
-  HIPCHK(c, hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_counter + 5, 0, 2 * sizeof(unsigned long long), c->stream));
   int grid = grid_for(c->n, kBlock * 8, 2048);
   const bool us = c->cfg.model == LSQR_MODEL_US_SINGLE || c->cfg.model == LSQR_MODEL_US_POINTER;
   hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
-                     c->ND, us ? 12 : -1, c->d_counter + 2);
+                     c->ND, us ? 12 : -1, us ? 9 : c->ND, c->d_counter + 5);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 2, sizeof(unsigned long long),
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 5, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(&c->mc.absmax, c->h_pin, sizeof(double));
+  memcpy(&c->mc.absmax_rot, (char *)c->h_pin + 8, sizeof(double));
   c->absmax_valid = true;
   return LSQR_OK;
 }
@@ -271,6 +272,9 @@ int run_estimate(lsqr_ctx *c) {
       hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
                          c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
                          c->mc, c->d_hparams, c->d_valid);
+      hipLaunchKernelGGL((k_prepare_f32_us<(M::K == 4)>), dim3((unsigned)((c->H + 255) / 256)),
+                         dim3(256), 0, c->stream, c->d_hparams, (uint32_t)c->H, c->mc,
+                         c->d_hparams_f32);
     } else {
       int grid = (int)((c->H + kBlock - 1) / kBlock);
       hipLaunchKernelGGL((k_estimate<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data,
@@ -558,7 +562,38 @@ int run_scan(lsqr_ctx *c) {
         return LSQR_OK;
       }
     }
-    if constexpr (requires { M::SPF; }) {  // plane, sphere, line: fp32 pre-filter + exact re-evaluation
+    if constexpr (M::IS_US) {  // packed fp32 pre-filter (scan_filter 1); 2 = the fused fp64 filter
+      if (c->opt_filter == 1 && c->absmax_valid && c->mc.absmax <= 1e15) {
+        constexpr bool SINGLE = M::K == 4;
+        const int np = c->opt_ppl == 2 ? 1 : 2;  // pairs of frames per lane (scan_ppl 2 / 4)
+        HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+        size_t tiles = (c->n + (size_t)kBlock * 2 * np - 1) / ((size_t)kBlock * 2 * np);
+        for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
+          uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
+          size_t lds = (size_t)hc * sizeof(uint32_t);
+          int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+          if (per_cu < 1) per_cu = 1;
+          size_t max_blocks = (size_t)256 * per_cu;
+          size_t tpb = (tiles + max_blocks - 1) / max_blocks;
+          int grid = (int)((tiles + tpb - 1) / tpb);
+          // few tiles (1 M frames = 977): split the hypothesis range over blockIdx.y to fill the chip
+          unsigned ysplit = (unsigned)std::min<size_t>(std::max<size_t>(1, (size_t)256 * 5 / (size_t)grid),
+                                                       std::max<size_t>(1, hc / 256));
+          if (c->opt_hsplit > 0) ysplit = (unsigned)c->opt_hsplit;
+          ProfScope ps(c, KID_SCAN);
+          if (np == 1)
+            hipLaunchKernelGGL((k_scan_us_f32<SINGLE, 1>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
+                               c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
+                               c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
+          else
+            hipLaunchKernelGGL((k_scan_us_f32<SINGLE, 2>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
+                               c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
+                               c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
+          HIPCHK(c, hipGetLastError());
+        }
+        return LSQR_OK;
+      }
+    } else if constexpr (requires { M::SPF; }) {  // plane, sphere, line: fp32 pre-filter + exact re-evaluation
       // magnitudes the fp32 copies cannot hold (or NaN): the plain fp64 kernel below
       const bool f32_ok = c->absmax_valid && c->mc.absmax <= 1e15;
       if constexpr (requires { typename CellOf<M>::type; }) {

@@ -126,6 +126,69 @@ struct USModel {
     return d2;
   }
 
+
+  // ---- packed fp32 pre-filter (us_kernels.h: k_scan_us_f32) ------------------------------------------
+  // Same measure as filter_value() in fp32, two frames per v_pk_* instruction.  u = 2^-24, X = max |entry|
+  // of the records, Rm = max |rotation entry| (both measured on upload), S3 as above, T1 = max |t1_j|:
+  //   p_j  = fma(c0_j,u, fma(c1_j,v, t3_j)):    |p_j| <= S3,  error <= 5u S3   (5 input / result roundings)
+  //   q_i  = fma(R_i0,p_0, ... + t2_i):          |q_i| <= Q = 3 Rm S3 + X,
+  //          error <= 3 Rm (u S3 + 5u S3) + u X + 3u Q <= 10u Q
+  //   e_i  = q_i - t1_i (or - p_i of the frame):  error Ee32 = u(10 Q + 2 (Q + T)) = 12u (Q + T),  T = T1 or X
+  // and the reference's fp64 e_i is within Ee64 = 16 u64 (Q + 2X + T) of exact.  For frames whose exact
+  // squared distance is <= 4 delta^2 (|e_i| <= 2 delta) the fp32 sum of squares is within
+  //   Ed = 4 sqrt3 delta (Ee32 + Ee64) + 3 (Ee32 + Ee64)^2 + 16 u delta^2
+  // of the reference's; frames beyond evaluate above 3 delta^2 as long as Ee32 + Ee64 <= delta / 8.
+  // With E = 1.01 Ed (required <= delta^2 / 4):  v < delta^2 - E => agrees,  v >= delta^2 + E => does not.
+  enum { SPF = 16 };  // c0(3) c1(3) t3(3) t1(3) tin tout 0 0
+  static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
+    const double X = c.absmax, Rm = c.absmax_rot, u = 5.9604644775390625e-08,
+                 u64 = 1.1102230246251565e-16, d2 = c.delta_sq;
+    double S3 = 0.0, T = SINGLE ? 0.0 : X;
+    bool finite = true;
+    for (int j = 0; j < 3; j++) {
+      double s = (fabs(sp[T3C + j]) + fabs(sp[T3C + 3 + j])) * X + fabs(sp[T3T + j]);
+      S3 = s > S3 ? s : S3;
+      if (SINGLE) T = fabs(sp[j]) > T ? fabs(sp[j]) : T;
+      f[j] = (float)sp[T3C + j];
+      f[3 + j] = (float)sp[T3C + 3 + j];
+      f[6 + j] = (float)sp[T3T + j];
+      f[9 + j] = SINGLE ? (float)sp[j] : 0.0f;
+    }
+    for (int j = 0; j < P; j++) finite = finite && sp[j] == sp[j];
+    const double Q = 3.0 * Rm * S3 + X;
+    const double Ee = 12.0 * u * (Q + T) + 16.0 * u64 * (Q + 2.0 * X + T);
+    const double Ed = 4.0 * 1.7320508075688774 * c.delta * Ee + 3.0 * Ee * Ee + 16.0 * u * d2;
+    const double E = 1.01 * Ed;
+    const bool ok = finite && X <= 1e15 && X >= 1e-10 && Rm <= 1e15 && S3 <= 1e15 && T <= 1e15 &&
+                    Ee <= 0.125 * c.delta && E <= 0.25 * d2 && d2 > 1e-30 && d2 <= 1e30;
+    f[12] = ok ? PlaneModel<3>::round_down_f32(d2 - E) : -INFINITY;
+    f[13] = ok ? PlaneModel<3>::round_up_f32(d2 + E) : INFINITY;
+    f[14] = f[15] = 0.0f;
+    if (!finite) f[12] = f[13] = __builtin_nanf("");  // NaN model: never agrees
+  }
+#if defined(__HIPCC__)
+  // xs: 14 (17) packed fields of two frames: R 0..8, t2 9..11, u 12, v 13, (p 14..16); f as above (scalars)
+  static __device__ inline v2f filter_value_f32(const v2f *xs, const float *f) {
+    v2f p[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      v2f t = {f[6 + j], f[6 + j]};
+      t = __builtin_elementwise_fma(xs[13], (v2f){f[3 + j], f[3 + j]}, t);
+      p[j] = __builtin_elementwise_fma(xs[12], (v2f){f[j], f[j]}, t);
+    }
+    v2f d2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      v2f q = __builtin_elementwise_fma(xs[3 * i + 2], p[2], xs[9 + i]);
+      q = __builtin_elementwise_fma(xs[3 * i + 1], p[1], q);
+      q = __builtin_elementwise_fma(xs[3 * i], p[0], q);
+      v2f e = SINGLE ? q - (v2f){f[9 + i], f[9 + i]} : q - xs[14 + i];
+      d2 = i == 0 ? e * e : __builtin_elementwise_fma(e, e, d2);
+    }
+    return d2;
+  }
+#endif
+
   // one row (j = 0..2) of the analytic system [u*R2 v*R2 R2 (-I)] x = rhs
   // (...Estimator.cxx:137-190 / :800-836)
   static LSQR_HD double row(const double *x, int j, double *a) {

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "us.h"
 #include "wave_linalg.h"
 
@@ -49,6 +50,112 @@ __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ d
     M::prepare(par, mc);
     for (int j = 0; j < M::SP; j++) hparams[(size_t)h * M::SP + j] = par[j];
     valid[h] = ok ? 1 : 0;
+  }
+}
+
+// fp32 filter block of every hypothesis (after k_estimate_us)
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_prepare_f32_us(const double *__restrict__ hparams, uint32_t H,
+                                                        ModelConsts mc, float *__restrict__ spf) {
+  typedef USModel<SINGLE> M;
+  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  double sp[M::SP];
+  for (int j = 0; j < M::SP; j++) sp[j] = hparams[(size_t)h * M::SP + j];
+  float f[M::SPF];
+  M::prepare_f32(sp, mc, f);
+  for (int j = 0; j < M::SPF; j++) spf[(size_t)h * M::SPF + j] = f[j];
+}
+
+// K2 for the US estimators with the packed fp32 pre-filter: every lane keeps NP pairs of frames as
+// fp32 fields in registers, the hypotheses' 14 fp32 parameters arrive through the scalar cache; a
+// v_min over the lane's values gives the one-compare "any candidate in this tile?" test; tiles with a
+// candidate take the inlier ballots, tiles with an observation inside the error band re-read the fp64
+// records and evaluate the exact predicate (bit-identical votes; same counting scheme as k_scan).
+template <bool SINGLE, int NP>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_scan_us_f32(const double *__restrict__ data, size_t stride,
+                                                        size_t n, const double *__restrict__ sp,
+                                                        const float *__restrict__ spf, uint32_t H,
+                                                        ModelConsts mc, uint32_t *__restrict__ votes) {
+  typedef USModel<SINGLE> M;
+  constexpr int NFLD = SINGLE ? 14 : 17;
+  extern __shared__ uint32_t s_cnt[];
+  // blockIdx.y selects a segment of the hypothesis range: more resident waves when the observations
+  // alone give fewer tiles than the chip has wave slots
+  {
+    const uint32_t hseg = (H + gridDim.y - 1) / gridDim.y, hb = blockIdx.y * hseg;
+    if (hb >= H) return;
+    sp += (size_t)hb * M::SP;
+    spf += (size_t)hb * M::SPF;
+    votes += hb;
+    H = hb + hseg < H ? hseg : H - hb;
+  }
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) s_cnt[h] = 0;
+  __syncthreads();
+  const size_t tile = (size_t)kBlock * 2 * NP;
+  const bool leader = (threadIdx.x & 63) == 0;
+  for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
+    v2f xs[NP][NFLD];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+      const size_t i0 = base + (size_t)(2 * q) * kBlock + threadIdx.x, i1 = i0 + kBlock;
+      const double *p0 = data + (i0 < n ? i0 : 0) * stride, *p1 = data + (i1 < n ? i1 : 0) * stride;
+#pragma unroll
+      for (int k = 0; k < NFLD; k++) {
+        const int slot = k < 12 ? k : k + 1;  // skip the int outputFormat slot 12
+        xs[q][k].x = i0 < n ? (float)p0[slot] : __builtin_nanf("");  // NaN never passes a '<'
+        xs[q][k].y = i1 < n ? (float)p1[slot] : __builtin_nanf("");
+      }
+    }
+    float nx[14];  // the next hypothesis' block is fetched (scalar loads) while the current one is used
+#pragma unroll
+    for (int k = 0; k < 14; k++) nx[k] = spf[k];
+    for (uint32_t h = 0; h < H; h++) {
+      float fl[14];
+#pragma unroll
+      for (int k = 0; k < 14; k++) fl[k] = nx[k];
+      {
+        const float *f = spf + (size_t)(h + 1 < H ? h + 1 : h) * M::SPF;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 14; k++) nx[k] = f[k];
+      }
+      const float tin = fl[12], tout = fl[13];
+      v2f v[NP];
+      float m = __builtin_inff();
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        v[q] = M::filter_value_f32(xs[q], fl);
+        m = __builtin_fminf(m, __builtin_fminf(v[q].x, v[q].y));
+      }
+      if (__ballot(m < tout) == 0) continue;  // no frame of this tile is near the target
+      uint32_t c = 0;
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        unsigned long long in0 = __ballot(v[q].x < tin), in1 = __ballot(v[q].y < tin);
+        if ((in0 ^ __ballot(v[q].x < tout)) | (in1 ^ __ballot(v[q].y < tout))) {
+          // a frame of this pair sits in the band: exact fp64 predicate (records re-read; one half
+          // of the pair at a time so that the fp64 record does not double the register footprint)
+          const double *hp = sp + (size_t)h * M::SP;
+          unsigned long long ex[2];
+#pragma nounroll
+          for (int half = 0; half < 2; half++) {
+            const size_t i = base + (size_t)(2 * q + half) * kBlock + threadIdx.x;
+            double r[M::REC];
+            M::load(data + (i < n ? i : 0) * stride, mc, r);
+            ex[half] = __ballot(i < n && M::agree(hp, r, mc));
+          }
+          in0 = ex[0];
+          in1 = ex[1];
+        }
+        c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
+      }
+      if (leader && c) atomicAdd(&s_cnt[h], c);
+    }
+  }
+  __syncthreads();
+  for (uint32_t h = threadIdx.x; h < H; h += kBlock) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
   }
 }
 

@@ -604,15 +604,16 @@ def test_filter_boundary_stress(ctx):
 
 @pytest.mark.parametrize("model,gen,k", US)
 def test_us_filter_and_plain_scan_agree(ctx, model, gen, k):
-    """the fused fp64 pre-filter of the US scan gives the votes of the exact predicate (and the
-    oracle's); the int outputFormat slot of the Frame (garbage as a double) must not disturb it."""
+    """the packed fp32 pre-filter (scan_filter 1) and the fused fp64 pre-filter (2) of the US scan give
+    the votes of the exact predicate (and the oracle's); the int outputFormat slot of the Frame
+    (garbage as a double) must not disturb them."""
     rec = gen(150_001, 0.4, seed=17 + model)[0]
     rec[:, 12] = np.frombuffer(np.full(len(rec), 0x7ff8dead00000001, np.uint64).tobytes(), np.float64)
     oc = O.cfg(model, 0, 3.0, 1)
     ctx.set_model(model, 0, 3.0, L.LS_ANALYTIC).upload(rec)
     ctx.hypotheses_sample(3, 0, 300)
     ref = None
-    for filt in (1, 0):
+    for filt in (1, 2, 0):
         ctx.set_option("scan_filter", filt)
         ctx.scan()
         _, _, votes = ctx.hypotheses(params=False)
@@ -650,14 +651,28 @@ def test_us_filter_boundary_stress(ctx):
     rec2 = rec.copy()
     rec2[8:, 9:12] += (P[0:3] + rad[:, None] * d - q)[8:]
     ctx.upload(rec2)
+    for filt in (1, 2):                                   # packed fp32 filter, fused fp64 filter
+        ctx.set_option("scan_filter", filt)
+        ctx.hypotheses_from_subsets(subs)
+        ctx.scan()
+        par2, valid2, votes = ctx.hypotheses()
+        assert np.array_equal(par2[h0], P)
+        for h in range(16):
+            if valid2[h]:
+                assert votes[h] == O.scan(oc, par2[h], rec2)[0], (filt, h)
+        assert 0.2 < votes[h0] / len(rec2) < 0.8
+    ctx.set_option("scan_filter", 1)
+    # frames a few fp32 ulps either side of the sphere as well
+    rad32 = 3.0 * (1 + g.integers(-30, 31, len(rec)) * 1e-7)
+    rec3 = rec.copy()
+    rec3[8:, 9:12] += (P[0:3] + rad32[:, None] * d - q)[8:]
+    ctx.upload(rec3)
     ctx.hypotheses_from_subsets(subs)
     ctx.scan()
-    par2, valid2, votes = ctx.hypotheses()
-    assert np.array_equal(par2[h0], P)
+    par3_, valid3_, votes_ = ctx.hypotheses()
     for h in range(16):
-        if valid2[h]:
-            assert votes[h] == O.scan(oc, par2[h], rec2)[0], h
-    assert 0.2 < votes[h0] / len(rec2) < 0.8
+        if valid3_[h]:
+            assert votes_[h] == O.scan(oc, par3_[h], rec3)[0], h
     big = rec2.copy()
     big[:, 9:12] *= 1e9                                  # |t2| ~ 1e11 against delta = 3
     big[:8] = rec2[:8]
