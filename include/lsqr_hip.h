@@ -239,6 +239,9 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = the
  *                model's default), "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default), "scan_block":
  *                workgroup size (256 / 1024), "scan_hsplit": hypothesis segments per tile (A/B knobs);
+ * "dense_fast_solve": 1 (default) = the n x n minimal solves of the dense system use elimination with
+ *                partial pivoting and only fall back to the SVD pseudo-inverse near the rank decision,
+ *                0 = always the SVD pseudo-inverse;
  * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS
  *                (k_scan_dense_t), 0 = rows in registers, hypotheses through the scalar cache. */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);

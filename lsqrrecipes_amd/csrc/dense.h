@@ -43,7 +43,7 @@ struct DenseModel {
 __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict__ data,
                                                        size_t stride, size_t nobs,
                                                        const uint32_t *__restrict__ subsets,
-                                                       uint32_t H, int n, int sp_stride,
+                                                       uint32_t H, int n, int sp_stride, int fast,
                                                        double *__restrict__ hparams,
                                                        uint8_t *__restrict__ valid) {
   extern __shared__ double sm[];
@@ -54,23 +54,35 @@ __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict
   double *A = sm, *V = A + n * lda, *b = V + n * lda, *cw = b + n, *x = cw + n;
   bool in_range = true;
   if (lane == 0) s_bad = 0;
-  for (int idx = lane; idx < n * n; idx += 256) {
-    int l = idx / n, c = idx % n;
-    size_t i = subsets[(size_t)h * n + l];
-    if (i >= nobs) {
-      in_range = false;
-      i = 0;
+  auto load_system = [&]() {
+    for (int idx = lane; idx < n * n; idx += 256) {
+      int l = idx / n, c = idx % n;
+      size_t i = subsets[(size_t)h * n + l];
+      if (i >= nobs) {
+        in_range = false;
+        i = 0;
+      }
+      A[c * lda + l] = data[i * stride + c];
     }
-    A[c * lda + l] = data[i * stride + c];
-  }
-  for (int l = lane; l < n; l += 256) {
-    size_t i = subsets[(size_t)h * n + l];
-    if (i >= nobs) i = 0;
-    b[l] = data[i * stride + n];
-  }
+    for (int l = lane; l < n; l += 256) {
+      size_t i = subsets[(size_t)h * n + l];
+      if (i >= nobs) i = 0;
+      b[l] = data[i * stride + n];
+    }
+  };
+  load_system();
   __syncthreads();
   if (!in_range) s_bad = 1;
-  int rank = block_pinv_solve<256>(n, n, A, lda, V, lda, b, kEPS, 0.0, x, cw);
+  // well-conditioned systems (all of them on ordinary data): elimination with partial pivoting;
+  // anything near the rank decision goes through the SVD pseudo-inverse as the reference does
+  int rank = n;
+  if (!fast || !block_gepp_solve<256>(n, A, lda, b, x)) {
+    __syncthreads();
+    load_system();
+    __syncthreads();
+    rank = block_pinv_solve<256>(n, n, A, lda, V, lda, b, kEPS, 0.0, x, cw);
+  }
+  __syncthreads();
   bool ok = (rank == n) && !s_bad;
   const double qnan = __builtin_nan("");
   for (int j = lane; j < sp_stride; j += 256)
@@ -466,27 +478,39 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
 
 // K5 dense: x = pinv(A) b from the normal equations block (DenseLinear...Estimator.hxx:64-96:
 // rank(A) < n -> empty).  One wave; G = A^T A (n x n) in LDS.
-__global__ __launch_bounds__(256) void k_solve_dense(const double *__restrict__ mom, int n,
+__global__ __launch_bounds__(256) void k_solve_dense(const double *__restrict__ mom, int n, int fast,
                                                      SolveOut *__restrict__ out) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x, nz = n + 1, lda = n | 1;
   const int ne = nz * (nz + 1) / 2;
   double *G = sm, *V = G + n * lda, *rhs = V + n * lda, *cw = rhs + n, *x = cw + n;
-  for (int idx = tid; idx < n * n; idx += 256) {
-    int i = idx / n, j = idx % n;
-    int a = i < j ? i : j, bb = i < j ? j : i;
-    int e = a * nz - a * (a - 1) / 2 + (bb - a);
-    G[j * lda + i] = mom[e];
-  }
-  for (int i = tid; i < n; i += 256) {
-    int e = i * nz - i * (i - 1) / 2 + (n - i);
-    rhs[i] = mom[e];
-  }
+  auto load_system = [&]() {
+    for (int idx = tid; idx < n * n; idx += 256) {
+      int i = idx / n, j = idx % n;
+      int a = i < j ? i : j, bb = i < j ? j : i;
+      int e = a * nz - a * (a - 1) / 2 + (bb - a);
+      G[j * lda + i] = mom[e];
+    }
+    for (int i = tid; i < n; i += 256) {
+      int e = i * nz - i * (i - 1) / 2 + (n - i);
+      rhs[i] = mom[e];
+    }
+  };
+  load_system();
   __syncthreads();
   double count = mom[ne];
   // sigma(A)^2 are the singular values of G: rank test relative to the largest one (the
-  // reference's absolute sigma <= 2.2e-16 test only ever fires for exactly singular systems)
-  int rank = block_pinv_solve<256>(n, n, G, lda, V, lda, rhs, 0.0, 1e-13, x, cw);
+  // reference's absolute sigma <= 2.2e-16 test only ever fires for exactly singular systems).
+  // Well-conditioned normal equations (every pivot > 1e-8 max|G|) are solved by elimination; anything
+  // closer to the rank decision goes through the eigen/SVD path that makes it.
+  int rank = n;
+  if (!fast || !block_gepp_solve<256>(n, G, lda, rhs, x)) {
+    __syncthreads();
+    load_system();
+    __syncthreads();
+    rank = block_pinv_solve<256>(n, n, G, lda, V, lda, rhs, 0.0, 1e-13, x, cw);
+  }
+  __syncthreads();
   bool ok = rank == n && count >= (double)n;
   if (tid == 0) {
     out->ok = ok ? 1 : 0;

@@ -50,6 +50,7 @@ struct lsqr_ctx {
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
+  int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
@@ -266,8 +267,8 @@ int run_estimate(lsqr_ctx *c) {
     if constexpr (M::IS_DENSE) {
       hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256),
                          dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
-                         c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP, c->d_hparams,
-                         c->d_valid);
+                         c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP,
+                         c->opt_dense_fast, c->d_hparams, c->d_valid);
     } else if constexpr (M::IS_US) {
       hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
                          c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
@@ -693,7 +694,7 @@ int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, in
 int launch_solve_dense(lsqr_ctx *c) {
   ProfScope ps(c, KID_SOLVE);
   hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(256), dense_lds_bytes(c->cfg.dim), c->stream,
-                     c->d_mom, (int)c->cfg.dim, c->d_out);
+                     c->d_mom, (int)c->cfg.dim, c->opt_dense_fast, c->d_out);
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
 }
@@ -1865,6 +1866,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     if (value != 0 && value != 128 && value != 256 && value != 512)
       return fail(c, LSQR_ERR_INVALID, "scan_cell must be 0, 128, 256 or 512");
     c->opt_cell = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
+    c->opt_dense_fast = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_transposed")) {

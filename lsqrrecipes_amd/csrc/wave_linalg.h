@@ -134,6 +134,87 @@ __device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double 
   return s_rank;
 }
 
+// Fast path of the n x n minimal solves: Gaussian elimination with partial pivoting on the system in
+// LDS (A column-major, element (row i, col j) at A[j*lda + i]; A and b destroyed), T threads.  The
+// reference solves through an SVD pseudo-inverse and declares the system singular when a singular value
+// is <= 2.2e-16 (DenseLinear...Estimator.hxx:38-45); for a well-conditioned system both give the
+// same solution to rounding (cond * eps).  The fast path only ACCEPTS when every pivot exceeds
+// 1e-8 * max(1, max|A|) -- far from the rank decision -- and reports false otherwise, in which case the
+// caller reloads the system and takes the SVD path, which makes the reference's rank decision.
+template <int T>
+__device__ inline bool block_gepp_solve(int n, double *A, int lda, double *b, double *x) {
+  __shared__ int s_p, s_fail;
+  __shared__ double s_piv, s_amax, s_red[T / 64];
+  const int tid = threadIdx.x;
+  double am = 0.0;
+  for (int idx = tid; idx < n * n; idx += T) {
+    double v = fabs(A[(idx / n) * lda + idx % n]);
+    am = v > am ? v : (v == v ? am : INFINITY);  // NaN poisons the fast path
+  }
+  am = wave_max(am);
+  if ((tid & 63) == 0) s_red[tid >> 6] = am;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  if (tid == 0) {
+    double m = s_red[0];
+    for (int w = 1; w < T / 64; w++) m = s_red[w] > m ? s_red[w] : m;
+    s_amax = m;
+  }
+  __syncthreads();
+  const double tol = 1e-8 * (s_amax > 1.0 ? s_amax : 1.0);
+  if (!(s_amax <= 1e150)) return false;
+  for (int k = 0; k < n; k++) {
+    if (tid < 64) {  // pivot search in column k (n <= 64: one element per lane)
+      double v = (tid >= k && tid < n) ? fabs(A[k * lda + tid]) : -1.0;
+      int idx = tid;
+      for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi < idx)) v = ov, idx = oi;
+      }
+      if (tid == 0) {
+        s_p = idx;
+        s_piv = A[k * lda + idx];
+        if (!(v > tol)) s_fail = 1;
+      }
+    }
+    __syncthreads();
+    if (s_fail) return false;
+    const int p = s_p;
+    const double rpiv = 1.0 / s_piv;
+    if (p != k) {
+      for (int j = k + tid; j < n; j += T) {
+        double t = A[j * lda + k];
+        A[j * lda + k] = A[j * lda + p];
+        A[j * lda + p] = t;
+      }
+      if (tid == T - 1) {
+        double t = b[k];
+        b[k] = b[p];
+        b[p] = t;
+      }
+      __syncthreads();
+    }
+    for (int i = k + 1 + tid; i < n; i += T) A[k * lda + i] *= rpiv;  // multipliers
+    __syncthreads();
+    const int w = n - k - 1;
+    for (int idx = tid; idx < w * w; idx += T) {
+      const int i = k + 1 + idx % w, j = k + 1 + idx / w;
+      A[j * lda + i] = fma(-A[k * lda + i], A[j * lda + k], A[j * lda + i]);
+    }
+    for (int i = k + 1 + tid; i < n; i += T) b[i] = fma(-A[k * lda + i], b[k], b[i]);
+    __syncthreads();
+  }
+  for (int k = n - 1; k >= 0; k--) {  // back substitution
+    if (tid == 0) x[k] = b[k] / A[k * lda + k];
+    __syncthreads();
+    const double xk = x[k];
+    for (int i = tid; i < k; i += T) b[i] = fma(-A[k * lda + i], xk, b[i]);
+    __syncthreads();
+  }
+  return true;
+}
+
 __device__ inline int wave_pinv_solve(int m, int n, double *A, int lda, double *V, int ldv,
                                       const double *b, double tol_abs, double tol_rel, double *x,
                                       double *cwork) {

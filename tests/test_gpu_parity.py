@@ -1254,3 +1254,40 @@ def test_cell_scan_large_batches_lattice_data_and_state_changes(ctx):
     assert np.array_equal(_scan_votes(ctx, 0), v) and ctx.index_info()["built"]
     ctx.set_model(L.LINE, 3, 0.5)                   # model change: parameters of the boxes differ
     assert not ctx.index_info()["built"]
+
+
+@pytest.mark.parametrize("ncol", [5, 33, 64])
+def test_dense_fast_and_svd_minimal_solves_agree(ctx, ncol):
+    """the elimination fast path of the n x n minimal solves and the SVD pseudo-inverse give the
+    same models (to rounding) and the same validity; singular, nearly singular and badly scaled
+    subsets fall back to the SVD path and get the reference's rank decision"""
+    m = 4000
+    rows = synth.dense(m, ncol, 0.1, seed=140 + ncol)[0]
+    rows[10] = rows[11]                                   # exactly repeated row
+    rows[20, :ncol] = rows[21, :ncol] + 1e-9 * np.random.default_rng(1).normal(size=ncol)  # sigma_min ~ 1e-9: SVD path
+    rows[30:30 + ncol] *= 1e-12                           # tiny magnitudes: max|A| < 1
+    oc = O.cfg(O.DENSE, ncol, 0.1)
+    ctx.set_model(L.DENSE, ncol, 0.1).upload(rows)
+    H = 40
+    subs = O.ctr_subsets(13, 0, H, m, ncol)
+    subs[1][:2] = [10, 11]
+    subs[2][:2] = [20, 21]
+    subs[3] = np.arange(30, 30 + ncol)
+    res = []
+    for fast in (1, 0):
+        ctx.set_option("dense_fast_solve", fast)
+        ctx.hypotheses_from_subsets(subs)
+        ctx.scan()
+        res.append(ctx.hypotheses())
+    ctx.set_option("dense_fast_solve", 1)
+    (pf, vf, cf), (ps, vs, cs) = res
+    assert np.array_equal(vf, vs)
+    assert not vf[1]
+    for h in range(H):
+        want = O.estimate(oc, rows[subs[h]])
+        assert bool(vf[h]) == (len(want) > 0), h
+        if vf[h]:
+            scale = max(1.0, np.abs(ps[h]).max())
+            tol = 1e-8 if h not in (2, 3) else 1e-3    # ill-conditioned on purpose: both paths are SVD
+            assert np.abs(pf[h] - ps[h]).max() <= tol * scale, h
+            assert cf[h] == O.scan(oc, pf[h], rows)[0]
