@@ -1291,3 +1291,25 @@ def test_dense_fast_and_svd_minimal_solves_agree(ctx, ncol):
             tol = 1e-8 if h not in (2, 3) else 1e-3    # ill-conditioned on purpose: both paths are SVD
             assert np.abs(pf[h] - ps[h]).max() <= tol * scale, h
             assert cf[h] == O.scan(oc, pf[h], rows)[0]
+
+
+def test_sharded_step_dense_and_us(ctx):
+    """ShardedRansac.step() (lsqr_winner_moments) for the models without an origin convention"""
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+    rows = synth.dense(60_000, 16, 0.05, seed=71)[0]
+    ctx.set_model(L.DENSE, 16, 0.1).upload(rows)
+    sr = ShardedRansac(ctx, Comm(None))
+    votes, gidx, par = sr.batch(3, 1, 300)
+    fit, cnt, info = sr.fit(par)
+    r = sr.step(3, 1, 300)
+    assert (r[0], r[1], r[4]) == (votes, gidx, cnt) and np.array_equal(r[2], par)
+    assert np.allclose(r[3], fit, rtol=1e-12, atol=1e-12)
+    rec = synth.us_single(30_000, 0.3, seed=8)[0]
+    for ls in (L.LS_ANALYTIC, L.LS_ITERATIVE):
+        ctx.set_model(L.US_SINGLE, 0, 3.0, ls).upload(rec)
+        sr = ShardedRansac(ctx, Comm(None))
+        votes, gidx, par = sr.batch(5, 0, 200)
+        fit, cnt, info = sr.fit(par)
+        r = sr.step(5, 0, 200)
+        assert (r[0], r[1], r[4]) == (votes, gidx, cnt) and np.array_equal(r[2], par)
+        assert len(r[3]) == len(fit) and np.allclose(r[3], fit, rtol=1e-9, atol=1e-9)
