@@ -25,6 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+try:  # BASELINE.json's metric string, verbatim
+    METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+except Exception:
+    METRIC = "RANSAC hypotheses/sec + final-fit residual, 10M pts, 1/2/4/8 GPU"
+
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_GOPS = 39321.6  # 256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz: fp64 add/mul issue rate
 #                                (= the 78.6 TFLOP/s vector fp64 peak counting an FMA as one op;
@@ -242,7 +247,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "RANSAC hypotheses/sec + final-fit residual, 10M pts",
+            "metric": METRIC,
             "value": value, "unit": "hypotheses/s", "n_gpus": a.gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

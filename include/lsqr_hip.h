@@ -26,6 +26,7 @@
  *   CalibratedPointer DataType 18 slots (+ Point3D p)            .../SinglePointTarget...h:335-339
  *   pair<Point3D,Point3D>      6 doubles (first, second)         .../AbsoluteOrientation...h:14-15
  *   Frame                      13 slots (104 B)                  common/Frame.h:30-31,41
+ *   Ray3D                      6 doubles (Point3D p, Vector3D n) common/Ray3D.h:23-24
  * A caller's std::vector<T> is passed as (pointer, count, stride in bytes) without repacking.
  */
 #ifndef LSQR_HIP_H
@@ -61,7 +62,8 @@ typedef enum {
   LSQR_MODEL_US_SINGLE = 5,  /* SingleUnknownPointTargetUSCalibrationParametersEstimator      */
   LSQR_MODEL_US_POINTER = 6, /* CalibratedPointerTargetUSCalibrationParametersEstimator       */
   LSQR_MODEL_ABSOR = 7,      /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,t(3)] */
-  LSQR_MODEL_PIVOT = 8       /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)] */
+  LSQR_MODEL_PIVOT = 8,      /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)] */
+  LSQR_MODEL_RAY = 9         /* RayIntersectionParametersEstimator      params [x, y, z]          */
 } lsqr_model;
 
 /* SphereParametersEstimator::LeastSquaresType (SphereParametersEstimator.h:28) and the US
@@ -75,6 +77,8 @@ typedef struct {
   double delta;    /* constructor argument, NOT squared (PlaneParametersEstimator.hxx:13-17) */
   int32_t ls_type; /* sphere / US only */
   int32_t reserved;
+  double aux;      /* RAY: minimalAngularDeviation in radians (RayIntersection...Estimator.h:34-35);
+                      unused by the other models */
 } lsqr_model_cfg;
 
 typedef struct lsqr_ctx lsqr_ctx; /* owns a device, a stream and all device buffers */

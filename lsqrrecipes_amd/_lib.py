@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsqr_hip.so")
 
 OK, EMPTY, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE = range(6)
-PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT = 1, 2, 3, 4, 5, 6, 7, 8
+PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY = 1, 2, 3, 4, 5, 6, 7, 8, 9
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 LS_ANALYTIC, LS_ITERATIVE = 0, 1
 KERNEL_IDS = {"sample": 0, "estimate": 1, "scan": 2, "mask": 3, "moments": 4, "solve": 5,
@@ -26,7 +26,7 @@ class LsqrError(RuntimeError):
 
 class ModelCfg(C.Structure):
     _fields_ = [("model", C.c_int32), ("dim", C.c_int32), ("delta", C.c_double),
-                ("ls_type", C.c_int32), ("reserved", C.c_int32)]
+                ("ls_type", C.c_int32), ("reserved", C.c_int32), ("aux", C.c_double)]
 
 
 class FitInfo(C.Structure):

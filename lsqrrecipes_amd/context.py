@@ -39,8 +39,8 @@ class Context:
                                            self._lib.lsqr_last_error(self._h).decode()))
 
     # ---- model / data -------------------------------------------------------------------
-    def set_model(self, model, dim=3, delta=0.5, ls_type=L.LS_GEOMETRIC):
-        self.cfg = L.ModelCfg(int(model), int(dim), float(delta), int(ls_type), 0)
+    def set_model(self, model, dim=3, delta=0.5, ls_type=L.LS_GEOMETRIC, aux=0.0):
+        self.cfg = L.ModelCfg(int(model), int(dim), float(delta), int(ls_type), 0, float(aux))
         self._chk(self._lib.lsqr_set_model(self._h, C.byref(self.cfg)))
         self.K = self._lib.lsqr_min_subset(C.byref(self.cfg))
         self.P = self._lib.lsqr_num_params(C.byref(self.cfg))

@@ -171,6 +171,7 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
     case LSQR_MODEL_US_POINTER: return f(Tag<USModel<false>>{});
     case LSQR_MODEL_ABSOR: return f(Tag<AbsOrModel>{});
     case LSQR_MODEL_PIVOT: return f(Tag<PivotModel>{});
+    case LSQR_MODEL_RAY: return f(Tag<RayModel>{});
     case LSQR_MODEL_DENSE:
       if (cfg.dim >= 1 && cfg.dim <= 8) return f(Tag<DenseModel<8>>{});
       if (cfg.dim <= 16 && cfg.dim > 8) return f(Tag<DenseModel<16>>{});
@@ -1043,6 +1044,7 @@ int lsqr_min_subset(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_US_POINTER: return 3;
     case LSQR_MODEL_ABSOR: return 3;
     case LSQR_MODEL_PIVOT: return 3;
+    case LSQR_MODEL_RAY: return 2;
   }
   return 0;
 }
@@ -1057,6 +1059,7 @@ int lsqr_num_params(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_US_POINTER: return 17;
     case LSQR_MODEL_ABSOR: return 7;
     case LSQR_MODEL_PIVOT: return 6;
+    case LSQR_MODEL_RAY: return 3;
   }
   return 0;
 }
@@ -1071,6 +1074,7 @@ int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_US_POINTER: return 18;
     case LSQR_MODEL_ABSOR: return 6;
     case LSQR_MODEL_PIVOT: return 13;
+    case LSQR_MODEL_RAY: return 6;
   }
   return 0;
 }
@@ -1088,6 +1092,10 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->mc.dim = cfg->dim;
   c->mc.ls_type = cfg->ls_type;
   c->mc.thr = square_threshold(c->mc.delta_sq);
+  {  // RayIntersectionParametersEstimator.cxx:13-14
+    double ce = sin(cfg->aux);
+    c->mc.aux = ce * ce;
+  }
   c->mc.absmax = 0.0;
   c->K = lsqr_min_subset(cfg);
   c->P = lsqr_num_params(cfg);

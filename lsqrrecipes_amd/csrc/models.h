@@ -25,6 +25,7 @@ struct ModelConsts {
   double thr;     // plane: smallest T >= 0 with fl(T*T) >= delta_sq, so that s*s < delta_sq <=> |s| < T
   double absmax;  // max |coordinate| over the uploaded observations (error band of the fp32 filter)
   double absmax_rot;  // US records: max |entry| of the rotation slots 0..8 (else = absmax)
+  double aux;         // RAY: sin(minimalAngularDeviation)^2 (RayIntersection...Estimator.cxx:13-14)
 };
 
 // Exact restatement of "x*x < q" as "|x| < T" (fl(x*x) is monotone in |x|).

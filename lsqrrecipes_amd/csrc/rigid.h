@@ -1,6 +1,7 @@
-// rigid.h -- the two rigid-transform estimators of SURVEY.md section 8(f):
+// rigid.h -- the small geometric estimators of SURVEY.md section 8(f):
 //   AbsOrModel   AbsoluteOrientationParametersEstimator      (parametersEstimators/AbsoluteOrientation...cxx)
 //   PivotModel   PivotCalibrationEstimator                   (parametersEstimators/PivotCalibration...cxx)
+//   RayModel     RayIntersectionParametersEstimator          (parametersEstimators/RayIntersection...cxx)
 // Same contract as models.h: estimate() / agree() follow the reference's operation order (this TU is
 // compiled with -ffp-contract=off); the final fits reduce shifted moments / normal equations in one
 // pass and solve them with the small dense kernels.  Frame arithmetic restated from common/Frame.cxx.
@@ -261,6 +262,96 @@ struct PivotModel {
     // the reference declares rank deficiency for singular values <= 2.2e-16 (absolute, :88-91);
     // on the normal equations that is sigma^2: a relative 1e-13 as for the dense system
     return spd_solve_eig(6, G, rhs, 1e-13, par, work) == 6;
+  }
+};
+
+// ------------------------------------------------------------------------ ray intersection
+// record: Ray3D = [p(3), n(3)] (common/Ray3D.h:23-24), r(t) = p + t n, t >= 0, |n| = 1 assumed by the
+// reference; parameters [x, y, z].
+struct RayModel {
+  enum { ND = 6, K = 2, P = 3, SP = 3, REC = 6, PPL = 4, IS_DENSE = 0, IS_US = 0, ORIGIN_FIRST = 1 };
+  // {N, sum n n^T (upper 6), sum (p - (n.p) n) (3)}
+  enum { NMOM = 1 + 6 + 3 };
+  static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
+    for (int i = 0; i < 6; i++) rec[i] = p[i];
+  }
+  // RayIntersection...Estimator.cxx:23-72 (Goldman, Graphics Gems p.304): mid-point of the common
+  // perpendicular; empty for (nearly) parallel rays (:51) and when a line parameter is negative (:63)
+  static LSQR_HD bool estimate(const double (*r)[ND], const ModelConsts &c, double *par) {
+    const double *p1 = r[0], *n1 = r[0] + 3, *p2 = r[1], *n2 = r[1] + 3;
+    double p21[3], x[3];
+    p21[0] = p2[0] - p1[0];
+    p21[1] = p2[1] - p1[1];
+    p21[2] = p2[2] - p1[2];
+    x[0] = n1[1] * n2[2] - n1[2] * n2[1];
+    x[1] = n1[2] * n2[0] - n1[0] * n2[2];
+    x[2] = n1[0] * n2[1] - n1[1] * n2[0];
+    double denominator = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    if (denominator < c.aux) return false;
+    double t1 = (x[0] * (p21[1] * n2[2] - p21[2] * n2[1]) - x[1] * (p21[0] * n2[2] - p21[2] * n2[0]) +
+                 x[2] * (p21[0] * n2[1] - p21[1] * n2[0])) / denominator;
+    double t2 = (x[0] * (p21[1] * n1[2] - p21[2] * n1[1]) - x[1] * (p21[0] * n1[2] - p21[2] * n1[0]) +
+                 x[2] * (p21[0] * n1[1] - p21[1] * n1[0])) / denominator;
+    if (t1 < 0 || t2 < 0) return false;
+    par[0] = (p1[0] + t1 * n1[0] + p2[0] + t2 * n2[0]) / 2.0;
+    par[1] = (p1[1] + t1 * n1[1] + p2[1] + t2 * n2[1]) / 2.0;
+    par[2] = (p1[2] + t1 * n1[2] + p2[2] + t2 * n2[2]) / 2.0;
+    return par[0] == par[0] && par[1] == par[1] && par[2] == par[2];  // NaN rays give no model
+  }
+  static LSQR_HD void prepare(double *, const ModelConsts &) {}
+  // RayIntersection...Estimator.cxx:163-177
+  static LSQR_HD bool agree(const double *sp, const double *x, const ModelConsts &c) {
+    const double *p = x, *n = x + 3;
+    double t = n[0] * (sp[0] - p[0]) + n[1] * (sp[1] - p[1]) + n[2] * (sp[2] - p[2]);
+    double dx = sp[0] - p[0] - t * n[0];
+    double dy = sp[1] - p[1] - t * n[1];
+    double dz = sp[2] - p[2] - t * n[2];
+    return t >= 0 && (dx * dx + dy * dy + dz * dz < c.delta_sq);
+  }
+  // distance of the point from the ray's line (Ray3D::distance)
+  static LSQR_HD double residual(const double *sp, const double *x, const ModelConsts &) {
+    const double *p = x, *n = x + 3;
+    double t = n[0] * (sp[0] - p[0]) + n[1] * (sp[1] - p[1]) + n[2] * (sp[2] - p[2]);
+    double dx = sp[0] - p[0] - t * n[0], dy = sp[1] - p[1] - t * n[1], dz = sp[2] - p[2] - t * n[2];
+    return sqrt(dx * dx + dy * dy + dz * dz);
+  }
+  // RayIntersection...Estimator.cxx:103-127, ray origins taken about org (first ray's origin):
+  //   [N I - sum n n^T] (x - org) = sum (p' - (n.p') n),  p' = p - org
+  static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
+    const double *n = x + 3;
+    double q[3] = {x[0] - org[0], x[1] - org[1], x[2] - org[2]};
+    m[0] += 1.0;
+    int k = 1;
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++, k++) m[k] = fma(n[a], n[b], m[k]);
+    double s = n[0] * q[0] + n[1] * q[1] + n[2] * q[2];
+    for (int a = 0; a < 3; a++) m[7 + a] += q[a] - s * n[a];
+  }
+  // :129-143: pseudo-inverse of the 3x3 system, rank < 3 (all rays parallel) -> empty.  The reference
+  // needs >= 0 rays only; an empty or single-ray set is rank deficient and comes out empty as well.
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &, double *par) {
+    const double N = m[0];
+    double A[9], w[3], V[9], y[3];
+    int k = 1;
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++, k++) A[a * 3 + b] = A[b * 3 + a] = (a == b ? N : 0.0) - m[k];
+    double amax = 0.0;
+    for (int i = 0; i < 9; i++) amax = fabs(A[i]) > amax ? fabs(A[i]) : amax;
+    sym_eig(3, A, w, V);
+    // singular values of the symmetric A are |w|; zero_out_absolute(EPS) drops those <= EPS
+    for (int j = 0; j < 3; j++)
+      if (!(fabs(w[j]) > kEPS) || !(fabs(w[j]) > 1e-14 * amax)) return false;
+    for (int j = 0; j < 3; j++) {
+      double t = 0;
+      for (int i = 0; i < 3; i++) t += V[i * 3 + j] * m[7 + i];
+      y[j] = t / w[j];
+    }
+    for (int i = 0; i < 3; i++) {
+      double t = 0;
+      for (int j = 0; j < 3; j++) t += V[i * 3 + j] * y[j];
+      par[i] = t + org[i];
+    }
+    return true;
   }
 };
 

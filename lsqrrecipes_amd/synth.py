@@ -257,3 +257,19 @@ def pivot(n, outlier_frac, seed=0x5EED0007, sigma=0.15):
         out[i, :9] = R.ravel()
         out[i, 9:12] = t
     return out, np.concatenate([tip, piv]), lab
+
+
+def rays(n, outlier_frac, seed=0x5EED0008, max_range=1000.0, sigma=0.3):
+    """Rays p + t n that (approximately) meet in one point (testing/RayIntersectionParametersTest.cxx:
+    27-56) -> (records (n,6) = [p, n], point (3), is_inlier)."""
+    g = _rng(seed)
+    target = g.uniform(-max_range, max_range, 3)
+    p = g.uniform(-max_range, max_range, (n, 3))
+    lab = np.ones(n, bool)
+    n_out = int(round(n * outlier_frac))
+    lab[g.permutation(n)[:n_out]] = False
+    aim = np.where(lab[:, None], target + g.normal(0.0, sigma, (n, 3)) if sigma > 0 else target,
+                   g.uniform(-max_range, max_range, (n, 3)))
+    d = aim - p
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    return np.ascontiguousarray(np.hstack([p, d])), target, lab

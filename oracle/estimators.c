@@ -29,6 +29,7 @@ int orc_min_subset(const orc_cfg *c) {
     case ORC_US_POINTER: return 3;      /* SinglePointTarget...cxx:665 */
     case ORC_ABSOR: return 3;           /* AbsoluteOrientation...cxx:9 */
     case ORC_PIVOT: return 3;           /* PivotCalibration...cxx:7 */
+    case ORC_RAY: return 2;             /* RayIntersection...cxx:11 */
   }
   return 0;
 }
@@ -42,6 +43,7 @@ int orc_num_params(const orc_cfg *c) {
     case ORC_US_POINTER: return 17;
     case ORC_ABSOR: return 7; /* [s,qx,qy,qz,tx,ty,tz] */
     case ORC_PIVOT: return 6; /* [DRF^t, W^t] */
+    case ORC_RAY: return 3;   /* [x,y,z] */
   }
   return 0;
 }
@@ -55,6 +57,7 @@ int orc_record_doubles(const orc_cfg *c) {
     case ORC_US_POINTER: return 18;
     case ORC_ABSOR: return 6;  /* std::pair<Point3D,Point3D> */
     case ORC_PIVOT: return 13; /* Frame: rotation 9, translation 3, int outputFormat + pad */
+    case ORC_RAY: return 6;    /* Ray3D: Point3D p, Vector3D n (common/Ray3D.h:23-24) */
   }
   return 0;
 }
@@ -588,6 +591,71 @@ static int pivot_agree(double delta, const double *par, const double *f) {
   return sqrt(dx * dx + dy * dy + dz * dz) < delta;
 }
 
+
+/* ================================================================== ray intersection */
+/* RayIntersectionParametersEstimator.cxx:23-72; record = [p(3), n(3)] */
+static int ray_estimate(double cross_eps, const double *const *r, size_t n, double *out) {
+  const double *p1, *n1, *p2, *n2;
+  double p21[3], x[3], denominator, t1, t2;
+  if (n < 2) return 0;
+  p1 = r[0]; n1 = r[0] + 3; p2 = r[1]; n2 = r[1] + 3;
+  p21[0] = p2[0] - p1[0];
+  p21[1] = p2[1] - p1[1];
+  p21[2] = p2[2] - p1[2];
+  x[0] = n1[1] * n2[2] - n1[2] * n2[1];
+  x[1] = n1[2] * n2[0] - n1[0] * n2[2];
+  x[2] = n1[0] * n2[1] - n1[1] * n2[0];
+  denominator = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  if (denominator < cross_eps) return 0;
+  t1 = (x[0] * (p21[1] * n2[2] - p21[2] * n2[1]) - x[1] * (p21[0] * n2[2] - p21[2] * n2[0]) +
+        x[2] * (p21[0] * n2[1] - p21[1] * n2[0])) / denominator;
+  t2 = (x[0] * (p21[1] * n1[2] - p21[2] * n1[1]) - x[1] * (p21[0] * n1[2] - p21[2] * n1[0]) +
+        x[2] * (p21[0] * n1[1] - p21[1] * n1[0])) / denominator;
+  if (t1 < 0 || t2 < 0) return 0;
+  out[0] = (p1[0] + t1 * n1[0] + p2[0] + t2 * n2[0]) / 2.0;
+  out[1] = (p1[1] + t1 * n1[1] + p2[1] + t2 * n2[1]) / 2.0;
+  out[2] = (p1[2] + t1 * n1[2] + p2[2] + t2 * n2[2]) / 2.0;
+  if (out[0] != out[0] || out[1] != out[1] || out[2] != out[2]) return 0;
+  return 3;
+}
+/* RayIntersectionParametersEstimator.cxx:163-177 */
+static int ray_agree(double delta_sq, const double *par, const double *r) {
+  const double *p = r, *n = r + 3;
+  double t = n[0] * (par[0] - p[0]) + n[1] * (par[1] - p[1]) + n[2] * (par[2] - p[2]);
+  double dx = par[0] - p[0] - t * n[0];
+  double dy = par[1] - p[1] - t * n[1];
+  double dz = par[2] - p[2] - t * n[2];
+  return t >= 0 && (dx * dx + dy * dy + dz * dz < delta_sq);
+}
+/* RayIntersectionParametersEstimator.cxx:95-143 */
+static int ray_ls(const double *const *r, size_t n, double *out) {
+  double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  size_t i;
+  int rank;
+  for (i = 0; i < n; i++) {
+    const double *p = r[i], *d = r[i] + 3;
+    double s;
+    A[0] += -(d[0] * d[0]);
+    A[1] += -(d[0] * d[1]);
+    A[2] += -(d[0] * d[2]);
+    A[4] += -(d[1] * d[1]);
+    A[5] += -(d[1] * d[2]);
+    A[8] += -(d[2] * d[2]);
+    s = d[0] * p[0] + d[1] * p[1] + d[2] * p[2];
+    b[0] += p[0] - s * d[0];
+    b[1] += p[1] - s * d[1];
+    b[2] += p[2] - s * d[2];
+  }
+  A[0] += (double)n;
+  A[3] = A[1];
+  A[4] += (double)n;
+  A[6] = A[2];
+  A[7] = A[5];
+  A[8] += (double)n;
+  rank = orc_pinv_solve(3, 3, A, b, EPS, out);
+  return rank < 3 ? 0 : 3;
+}
+
 /* ================================================================== US calibration */
 static void us_T3(int model, const double *par, double T3[3][4]) {
   /* SinglePointTarget...cxx:90-93 (single) / :745-748 (pointer) */
@@ -907,6 +975,7 @@ int orc_estimate(const orc_cfg *c, const double *const *recs, size_t n, double *
     case ORC_DENSE: return dense_solve(c->dim, recs, n, params);
     case ORC_ABSOR: return absor_estimate(recs, n, params);
     case ORC_PIVOT: return pivot_solve(recs, n < 3 ? n : 3, params);
+    case ORC_RAY: return ray_estimate(sin(c->aux) * sin(c->aux), recs, n, params);
     case ORC_US_SINGLE: /* :17-25: exactly minForEstimate elements */
     case ORC_US_POINTER:
       if (n != (size_t)orc_min_subset(c)) return 0;
@@ -923,6 +992,7 @@ int orc_agree(const orc_cfg *c, const double *params, const double *rec) {
     case ORC_DENSE: return dense_agree(c->dim, c->delta, params, rec);
     case ORC_ABSOR: return absor_agree(c->delta * c->delta, params, rec);
     case ORC_PIVOT: return pivot_agree(c->delta, params, rec);
+    case ORC_RAY: return ray_agree(c->delta * c->delta, params, rec);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_agree(c->model, c->delta * c->delta, params, rec);
   }
@@ -937,6 +1007,7 @@ int orc_ls(const orc_cfg *c, const double *const *recs, size_t n, double *params
     case ORC_DENSE: return dense_solve(c->dim, recs, n, params);
     case ORC_ABSOR: return absor_ls(recs, n, params);
     case ORC_PIVOT: return pivot_solve(recs, n, params);
+    case ORC_RAY: return ray_ls(recs, n, params);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_ls(c, recs, n, params);
   }
@@ -1014,6 +1085,13 @@ int orc_stats(const orc_cfg *c, const double *params, const double *data, size_t
         for (j = 0; j < 3; j++)
           e[j] = x[3 * j] * params[0] + x[3 * j + 1] * params[1] + x[3 * j + 2] * params[2] +
                  x[9 + j] - params[3 + j];
+        dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        break;
+      }
+      case ORC_RAY: { /* distance of the point from the ray's line */
+        double t = x[3] * (params[0] - x[0]) + x[4] * (params[1] - x[1]) + x[5] * (params[2] - x[2]);
+        double e[3];
+        for (j = 0; j < 3; j++) e[j] = params[j] - x[j] - t * x[3 + j];
         dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
         break;
       }

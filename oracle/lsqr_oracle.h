@@ -43,7 +43,8 @@ enum {
   ORC_US_SINGLE = 5, /* SingleUnknownPointTargetUSCalibrationParametersEstimator  20 params         */
   ORC_US_POINTER = 6, /* CalibratedPointerTargetUSCalibrationParametersEstimator  17 params         */
   ORC_ABSOR = 7,   /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,tx,ty,tz]           */
-  ORC_PIVOT = 8    /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)]              */
+  ORC_PIVOT = 8,   /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)]              */
+  ORC_RAY = 9      /* RayIntersectionParametersEstimator      params [x,y,z]; record Ray3D = [p(3), n(3)] */
 };
 
 enum { ORC_LS_ALGEBRAIC = 0, ORC_LS_GEOMETRIC = 1 }; /* sphere; US: 0 = ANALYTIC, 1 = ITERATIVE */
@@ -53,6 +54,7 @@ typedef struct {
   int dim;      /* point dimension, or n for ORC_DENSE; ignored for US models */
   double delta; /* constructor argument (NOT squared) */
   int ls_type;
+  double aux;   /* ORC_RAY: minimalAngularDeviation (radians) */
 } orc_cfg;
 
 /* record layout: every datum is an array of doubles (Point<double,d>: d; AugmentedRow<double,n>:

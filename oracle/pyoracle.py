@@ -9,12 +9,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT = 1, 2, 3, 4, 5, 6, 7, 8
+PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY = 1, 2, 3, 4, 5, 6, 7, 8, 9
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 
 
 class Cfg(C.Structure):
-    _fields_ = [("model", C.c_int), ("dim", C.c_int), ("delta", C.c_double), ("ls_type", C.c_int)]
+    _fields_ = [("model", C.c_int), ("dim", C.c_int), ("delta", C.c_double), ("ls_type", C.c_int),
+                ("aux", C.c_double)]
 
 
 class Trace(C.Structure):
@@ -117,8 +118,8 @@ def _d(a):
     return a.ctypes.data_as(_dp)
 
 
-def cfg(model, dim=3, delta=0.5, ls_type=LS_GEOMETRIC):
-    return Cfg(model, dim, float(delta), ls_type)
+def cfg(model, dim=3, delta=0.5, ls_type=LS_GEOMETRIC, aux=0.0):
+    return Cfg(model, dim, float(delta), ls_type, float(aux))
 
 
 def as_records(c, data):

@@ -21,6 +21,7 @@
 #include "LineParametersEstimator.h"
 #include "PivotCalibrationParametersEstimator.h"
 #include "PlaneParametersEstimator.h"
+#include "RayIntersectionParametersEstimator.h"
 #include "RANSAC.h"
 #include "SinglePointTargetUSCalibrationParametersEstimator.h"
 #include "SphereParametersEstimator.h"
@@ -386,6 +387,34 @@ static void absoluteOrientationTest() {  // testing/AbsoluteOrientationParameter
   CHECK(!est.agree(known, outlier));
 }
 
+static void rayIntersectionTest() {  // testing/RayIntersectionParametersTest.cxx:15-117
+  const unsigned NUM_RAYS = 10;
+  const double NOISE_SIGMA = 20.0, maxRange = 1000.0, maxDistanceToRay = 0.5;
+  Point3D known;
+  for (int k = 0; k < 3; k++) known[k] = U(-maxRange, maxRange);
+  std::vector<Ray3D> rayData, noNoise;
+  Ray3D ray;
+  for (unsigned i = 0; i < NUM_RAYS + 2; i++) {
+    for (int k = 0; k < 3; k++) ray.p[k] = U(-maxRange, maxRange);
+    for (int k = 0; k < 3; k++) ray.n[k] = known[k] + (i < NUM_RAYS ? N(NOISE_SIGMA) : 0.0) - ray.p[k];
+    ray.n.normalize();
+    (i < NUM_RAYS ? rayData : noNoise).push_back(ray);
+  }
+  RayIntersectionParametersEstimator est(maxDistanceToRay);
+  std::vector<double> pt(3);
+  for (int k = 0; k < 3; k++) pt[k] = known[k];
+  CHECK(est.agree(pt, noNoise[0]));
+  est.estimate(noNoise, pt);
+  CHECK(pt.size() == 3);
+  if (pt.size() == 3) {
+    Point3D tmp;
+    for (int k = 0; k < 3; k++) tmp[k] = pt[k];
+    CHECK(std::sqrt(tmp.distanceSquared(known)) <= maxDistanceToRay);
+  }
+  est.leastSquaresEstimate(rayData, pt);
+  CHECK(pt.size() == 3);
+}
+
 static void pivotTest(const char *file) {  // testing/PivotCalibrationParametersEstimatorTest.cxx:19-119
   if (!file) return;
   std::ifstream in(file);
@@ -426,6 +455,7 @@ int main(int argc, char *argv[]) {
     denseTest(argc > 1 ? argv[1] : 0);
     usTest();
     absoluteOrientationTest();
+    rayIntersectionTest();
     pivotTest(argc > 2 ? argv[2] : 0);
     ransacTest();
   } catch (std::exception &e) {

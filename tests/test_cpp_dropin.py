@@ -9,7 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "examples", "build")
 PROGS = ["planeEstimation", "sphereEstimation", "lineEstimation", "linearEquationSystemSolver",
-         "crosswireUSCalibration", "AbsoluteOrientation", "pivotCalibration", "estimatorTests"]
+         "crosswireUSCalibration", "AbsoluteOrientation", "pivotCalibration",
+         "rayIntersectionEstimation", "estimatorTests"]
 REFDATA = os.path.join(ROOT, "tests", "golden", "ref_data")
 
 
@@ -27,6 +28,7 @@ def test_reference_header_names_present():
               "DenseLinearEquationSystemParametersEstimator.h",
               "SinglePointTargetUSCalibrationParametersEstimator.h",
               "AbsoluteOrientationParametersEstimator.h", "PivotCalibrationParametersEstimator.h",
+              "RayIntersectionParametersEstimator.h", "Ray3D.h", "Vector3D.h",
               "Point.h", "Point2D.h",
               "Point3D.h", "Frame.h", "Epsilon.h", "copyright.h"]:
         assert os.path.exists(os.path.join(inc, h)), h
@@ -51,7 +53,7 @@ def test_reference_style_estimator_tests_on_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog", ["planeEstimation", "sphereEstimation", "lineEstimation",
-                                  "pivotCalibration"])
+                                  "pivotCalibration", "rayIntersectionEstimation"])
 def test_example_programs_on_gpu(prog):
     out = _run([prog])
     assert "RANSAC" in out

@@ -1313,3 +1313,47 @@ def test_sharded_step_dense_and_us(ctx):
         r = sr.step(5, 0, 200)
         assert (r[0], r[1], r[4]) == (votes, gidx, cnt) and np.array_equal(r[2], par)
         assert len(r[3]) == len(fit) and np.allclose(r[3], fit, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [2, 100, 30_007])
+def test_ray_intersection_device_path(ctx, n):
+    """RayIntersection: estimate() / agree() bit-exact, least squares within 1e-6, RANSAC = serial loop"""
+    aux = 0.017453292519943295769236907684886
+    data, target, lab = synth.rays(n, 0.3 if n > 2 else 0.0, seed=600 + n)
+    oc = O.cfg(O.RAY, 3, 1.0, aux=aux)
+    ctx.set_model(L.RAY, 3, 1.0, aux=aux).upload(data)
+    H = 64
+    subs = O.ctr_subsets(19, 0, H, n, 2)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in range(H):
+        want = O.estimate(oc, data[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0), h
+        if valid[h]:
+            assert np.array_equal(par[h], want), h
+            assert votes[h] == O.scan(oc, want, data)[0], h
+    if valid.any():
+        packed, bv, bi = ctx.best()
+        m, cnt = ctx.mask_from_hypothesis(bi)
+        wcnt, wmask = O.scan(oc, par[bi], data)
+        assert cnt == wcnt == bv and np.array_equal(m, wmask)
+        if cnt >= 2:
+            fit, _ = ctx.ls_fit(use_mask=True)
+            want = O.ls(oc, data, wmask)
+            assert len(fit) == len(want)
+            if len(want):
+                assert np.allclose(fit, want, rtol=REL, atol=1e-6)
+    if n > 2:
+        r = ctx.ransac(0.999, seed=2)
+        w = O.ransac(oc, data, 0.999, sampler="ctr", seed=2)
+        assert r["info"].iterations == w["iters"]
+        assert np.array_equal(r["consensus"], w["consensus"])
+        assert np.allclose(r["params"], w["params"], rtol=REL, atol=1e-6)
+        assert np.linalg.norm(r["params"] - target) < 1.0
+    # all rays parallel: the least squares system is rank deficient -> empty
+    par_rays = np.repeat(data[:1], 5, axis=0)
+    par_rays[:, :3] += np.arange(5)[:, None]
+    ctx.upload(par_rays)
+    fit, _ = ctx.ls_fit(use_mask=False)
+    assert len(fit) == 0

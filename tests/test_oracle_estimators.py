@@ -267,3 +267,33 @@ def test_pivot_ransac_on_the_reference_outlier_file():
     r = O.ransac(c, F, 0.999, sampler="ctr", seed=3)
     assert 0.5 < r["fraction"] < 0.8
     assert np.allclose(r["params"], [-17.78, 1.11, -156.87, 146.90, -62.97, -1042.14], atol=1.0)
+
+
+def test_ray_intersection_like_reference_test():
+    """testing/RayIntersectionParametersTest.cxx:58-117: agree() at the known point, two clean rays
+    meet within the distance threshold, least squares over noisy rays succeeds; plus the degenerate
+    cases of estimate() (parallel rays, intersection behind an origin)."""
+    clean, target, _ = synth.rays(2, 0.0, seed=3, sigma=0.0)
+    noisy, target2, _ = synth.rays(10, 0.0, seed=4, sigma=20.0)
+    c = O.cfg(O.RAY, 3, 0.5, aux=0.017453292519943295769236907684886)
+    assert O.agree(c, target, clean[0])
+    est = O.estimate(c, clean)
+    assert len(est) == 3 and np.linalg.norm(est - target) <= 0.5
+    ls = O.ls(c, noisy)
+    assert len(ls) == 3 and np.linalg.norm(ls - target2) < 3 * 20.0
+    par = clean.copy()
+    par[1, 3:] = par[0, 3:]                       # parallel rays (:51)
+    assert len(O.estimate(c, par)) == 0
+    back = clean.copy()
+    back[1, 3:] *= -1                             # the lines meet, the rays do not (:63)
+    assert len(O.estimate(c, back)) == 0
+    assert not O.agree(c, target, back[1])        # t < 0 (:177)
+    # (all rays parallel: the reference's absolute sigma <= 2.2e-16 rank test (:134-138) only fires when the
+    # rounding noise of 1 - |n|^2 happens to vanish; the literal restatement inherits that, the device
+    # declares rank deficiency relative to the largest singular value -- tests/test_gpu_parity.py)
+    # the least squares point minimises the sum of squared point-line distances
+    A = np.zeros((3, 3)); b = np.zeros(3)
+    for p_, n_ in zip(noisy[:, :3], noisy[:, 3:]):
+        Pm = np.eye(3) - np.outer(n_, n_)
+        A += Pm; b += Pm @ p_
+    assert np.allclose(ls, np.linalg.solve(A, b), rtol=1e-10, atol=1e-8)
