@@ -172,6 +172,7 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
     case LSQR_MODEL_ABSOR: return f(Tag<AbsOrModel>{});
     case LSQR_MODEL_PIVOT: return f(Tag<PivotModel>{});
     case LSQR_MODEL_RAY: return f(Tag<RayModel>{});
+    case LSQR_MODEL_LINE2D: return f(Tag<Line2DModel>{});
     case LSQR_MODEL_DENSE:
       if (cfg.dim >= 1 && cfg.dim <= 8) return f(Tag<DenseModel<8>>{});
       if (cfg.dim <= 16 && cfg.dim > 8) return f(Tag<DenseModel<16>>{});
@@ -343,6 +344,10 @@ struct CellOf {};
 template <int D>
 struct CellOf<PlaneModel<D>> {
   typedef PlaneCell<D> type;
+};
+template <>
+struct CellOf<Line2DModel> {  // same agree() as the 2-D hyperplane
+  typedef PlaneCell<2> type;
 };
 template <int D>
 struct CellOf<SphereModel<D>> {
@@ -1045,6 +1050,7 @@ int lsqr_min_subset(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_ABSOR: return 3;
     case LSQR_MODEL_PIVOT: return 3;
     case LSQR_MODEL_RAY: return 2;
+    case LSQR_MODEL_LINE2D: return 2;
   }
   return 0;
 }
@@ -1060,6 +1066,7 @@ int lsqr_num_params(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_ABSOR: return 7;
     case LSQR_MODEL_PIVOT: return 6;
     case LSQR_MODEL_RAY: return 3;
+    case LSQR_MODEL_LINE2D: return 4;
   }
   return 0;
 }
@@ -1075,6 +1082,7 @@ int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_ABSOR: return 6;
     case LSQR_MODEL_PIVOT: return 13;
     case LSQR_MODEL_RAY: return 6;
+    case LSQR_MODEL_LINE2D: return 2;
   }
   return 0;
 }

@@ -2,6 +2,7 @@
 //   AbsOrModel   AbsoluteOrientationParametersEstimator      (parametersEstimators/AbsoluteOrientation...cxx)
 //   PivotModel   PivotCalibrationEstimator                   (parametersEstimators/PivotCalibration...cxx)
 //   RayModel     RayIntersectionParametersEstimator          (parametersEstimators/RayIntersection...cxx)
+//   Line2DModel  Line2DParametersEstimator                   (parametersEstimators/Line2DParametersEstimator.cxx)
 // Same contract as models.h: estimate() / agree() follow the reference's operation order (this TU is
 // compiled with -ffp-contract=off); the final fits reduce shifted moments / normal equations in one
 // pass and solve them with the small dense kernels.  Frame arithmetic restated from common/Frame.cxx.
@@ -262,6 +263,52 @@ struct PivotModel {
     // the reference declares rank deficiency for singular values <= 2.2e-16 (absolute, :88-91);
     // on the normal equations that is sigma^2: a relative 1e-13 as for the dense system
     return spd_solve_eig(6, G, rhs, 1e-13, par, work) == 6;
+  }
+};
+
+// ------------------------------------------------------------------------ 2-D line (normal form)
+// Line2DParametersEstimator: parameters [n_x, n_y, a_x, a_y]; agree() is the 2-D hyperplane test
+// (.cxx:117-121 == PlaneParametersEstimator.hxx:196-203), so the scan -- exhaustive kernels, fp32 filter,
+// two-level cell scan -- is PlaneModel<2>'s; estimate() and the closed-form fit are its own.
+struct Line2DModel : PlaneModel<2> {
+  // .cxx:9-27: normal (y1 - y0, x0 - x1); "too close" when its squared length is below delta^2
+  static LSQR_HD bool estimate(const double (*r)[ND], const ModelConsts &c, double *par) {
+    double nx = r[1][1] - r[0][1];
+    double ny = r[0][0] - r[1][0];
+    double normSquared = nx * nx + ny * ny;
+    if (normSquared < c.delta_sq) return false;
+    double norm = sqrt(nx * nx + ny * ny);
+    par[0] = nx / norm;
+    par[1] = ny / norm;
+    par[2] = r[0][0];
+    par[3] = r[0][1];
+    return par[0] == par[0] && par[1] == par[1];  // NaN / inf points give no model
+  }
+  // .cxx:44-100 on shifted moments {N, sum x', sum x'x'^T}: closed-form eigenvector of the 2x2 covariance,
+  // with the reference's 1e-12 thresholds on the diagonal entries
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &, double *par) {
+    const double N = m[0];
+    if (N < 2.0) return false;
+    const double mx = m[1] / N, my = m[2] / N;
+    const double c11 = m[3] - N * mx * mx, c12 = m[4] - N * mx * my, c22 = m[5] - N * my * my;
+    double nx, ny;
+    if (c11 < 1e-12) {
+      nx = 1.0;
+      ny = 0.0;
+      if (c22 < 1e-12) return false;  // all the points are the "same" point
+    } else {
+      double lambda1 = (c11 + c22 + sqrt((c11 - c22) * (c11 - c22) + 4 * c12 * c12)) / 2.0;
+      nx = -c12;
+      ny = lambda1 - c22;
+      double norm = sqrt(nx * nx + ny * ny);
+      nx /= norm;
+      ny /= norm;
+    }
+    par[0] = nx;
+    par[1] = ny;
+    par[2] = mx + org[0];
+    par[3] = my + org[1];
+    return true;
   }
 };
 

@@ -30,6 +30,7 @@ int orc_min_subset(const orc_cfg *c) {
     case ORC_ABSOR: return 3;           /* AbsoluteOrientation...cxx:9 */
     case ORC_PIVOT: return 3;           /* PivotCalibration...cxx:7 */
     case ORC_RAY: return 2;             /* RayIntersection...cxx:11 */
+    case ORC_LINE2D: return 2;          /* Line2DParametersEstimator.cxx:6 */
   }
   return 0;
 }
@@ -44,6 +45,7 @@ int orc_num_params(const orc_cfg *c) {
     case ORC_ABSOR: return 7; /* [s,qx,qy,qz,tx,ty,tz] */
     case ORC_PIVOT: return 6; /* [DRF^t, W^t] */
     case ORC_RAY: return 3;   /* [x,y,z] */
+    case ORC_LINE2D: return 4; /* [n_x,n_y,a_x,a_y] */
   }
   return 0;
 }
@@ -58,6 +60,7 @@ int orc_record_doubles(const orc_cfg *c) {
     case ORC_ABSOR: return 6;  /* std::pair<Point3D,Point3D> */
     case ORC_PIVOT: return 13; /* Frame: rotation 9, translation 3, int outputFormat + pad */
     case ORC_RAY: return 6;    /* Ray3D: Point3D p, Vector3D n (common/Ray3D.h:23-24) */
+    case ORC_LINE2D: return 2; /* Point2D */
   }
   return 0;
 }
@@ -592,6 +595,60 @@ static int pivot_agree(double delta, const double *par, const double *f) {
 }
 
 
+
+/* ================================================================== 2-D line, normal form */
+/* Line2DParametersEstimator.cxx:9-27 */
+static int line2d_estimate(double delta_sq, const double *const *p, size_t n, double *out) {
+  double nx, ny, normSquared, norm;
+  if (n < 2) return 0;
+  nx = p[1][1] - p[0][1];
+  ny = p[0][0] - p[1][0];
+  normSquared = nx * nx + ny * ny;
+  if (normSquared < delta_sq) return 0;
+  norm = sqrt(nx * nx + ny * ny);
+  out[0] = nx / norm;
+  out[1] = ny / norm;
+  out[2] = p[0][0];
+  out[3] = p[0][1];
+  if (out[0] != out[0] || out[1] != out[1]) return 0;
+  return 4;
+}
+/* Line2DParametersEstimator.cxx:44-100 */
+static int line2d_ls(const double *const *p, size_t n, double *out) {
+  double meanX = 0, meanY = 0, nx, ny, norm, c11 = 0, c12 = 0, c22 = 0;
+  int i, dataSize = (int)n;
+  if (n < 2) return 0;
+  for (i = 0; i < dataSize; i++) {
+    meanX += p[i][0];
+    meanY += p[i][1];
+    c11 += p[i][0] * p[i][0];
+    c12 += p[i][0] * p[i][1];
+    c22 += p[i][1] * p[i][1];
+  }
+  meanX /= dataSize;
+  meanY /= dataSize;
+  c11 -= dataSize * meanX * meanX;
+  c12 -= dataSize * meanX * meanY;
+  c22 -= dataSize * meanY * meanY;
+  if (c11 < 1e-12) {
+    nx = 1.0;
+    ny = 0.0;
+    if (c22 < 1e-12) return 0;
+  } else {
+    double lambda1 = (c11 + c22 + sqrt((c11 - c22) * (c11 - c22) + 4 * c12 * c12)) / 2.0;
+    nx = -c12;
+    ny = lambda1 - c22;
+    norm = sqrt(nx * nx + ny * ny);
+    nx /= norm;
+    ny /= norm;
+  }
+  out[0] = nx;
+  out[1] = ny;
+  out[2] = meanX;
+  out[3] = meanY;
+  return 4;
+}
+
 /* ================================================================== ray intersection */
 /* RayIntersectionParametersEstimator.cxx:23-72; record = [p(3), n(3)] */
 static int ray_estimate(double cross_eps, const double *const *r, size_t n, double *out) {
@@ -976,6 +1033,7 @@ int orc_estimate(const orc_cfg *c, const double *const *recs, size_t n, double *
     case ORC_ABSOR: return absor_estimate(recs, n, params);
     case ORC_PIVOT: return pivot_solve(recs, n < 3 ? n : 3, params);
     case ORC_RAY: return ray_estimate(sin(c->aux) * sin(c->aux), recs, n, params);
+    case ORC_LINE2D: return line2d_estimate(c->delta * c->delta, recs, n, params);
     case ORC_US_SINGLE: /* :17-25: exactly minForEstimate elements */
     case ORC_US_POINTER:
       if (n != (size_t)orc_min_subset(c)) return 0;
@@ -993,6 +1051,7 @@ int orc_agree(const orc_cfg *c, const double *params, const double *rec) {
     case ORC_ABSOR: return absor_agree(c->delta * c->delta, params, rec);
     case ORC_PIVOT: return pivot_agree(c->delta, params, rec);
     case ORC_RAY: return ray_agree(c->delta * c->delta, params, rec);
+    case ORC_LINE2D: return plane_agree(2, c->delta * c->delta, params, rec); /* .cxx:117-121 */
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_agree(c->model, c->delta * c->delta, params, rec);
   }
@@ -1008,6 +1067,7 @@ int orc_ls(const orc_cfg *c, const double *const *recs, size_t n, double *params
     case ORC_ABSOR: return absor_ls(recs, n, params);
     case ORC_PIVOT: return pivot_solve(recs, n, params);
     case ORC_RAY: return ray_ls(recs, n, params);
+    case ORC_LINE2D: return line2d_ls(recs, n, params);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_ls(c, recs, n, params);
   }
@@ -1088,6 +1148,9 @@ int orc_stats(const orc_cfg *c, const double *params, const double *data, size_t
         dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
         break;
       }
+      case ORC_LINE2D:
+        dist = fabs(params[0] * (x[0] - params[2]) + params[1] * (x[1] - params[3]));
+        break;
       case ORC_RAY: { /* distance of the point from the ray's line */
         double t = x[3] * (params[0] - x[0]) + x[4] * (params[1] - x[1]) + x[5] * (params[2] - x[2]);
         double e[3];

@@ -44,7 +44,8 @@ enum {
   ORC_US_POINTER = 6, /* CalibratedPointerTargetUSCalibrationParametersEstimator  17 params         */
   ORC_ABSOR = 7,   /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,tx,ty,tz]           */
   ORC_PIVOT = 8,   /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)]              */
-  ORC_RAY = 9      /* RayIntersectionParametersEstimator      params [x,y,z]; record Ray3D = [p(3), n(3)] */
+  ORC_RAY = 9,     /* RayIntersectionParametersEstimator      params [x,y,z]; record Ray3D = [p(3), n(3)] */
+  ORC_LINE2D = 10  /* Line2DParametersEstimator               params [n_x,n_y,a_x,a_y]; record Point2D    */
 };
 
 enum { ORC_LS_ALGEBRAIC = 0, ORC_LS_GEOMETRIC = 1 }; /* sphere; US: 0 = ANALYTIC, 1 = ITERATIVE */

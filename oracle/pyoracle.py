@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY = 1, 2, 3, 4, 5, 6, 7, 8, 9
+PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY, LINE2D = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 
 

@@ -18,6 +18,7 @@
 #include "AbsoluteOrientationParametersEstimator.h"
 #include "DenseLinearEquationSystemParametersEstimator.h"
 #include "Frame.h"
+#include "Line2DParametersEstimator.h"
 #include "LineParametersEstimator.h"
 #include "PivotCalibrationParametersEstimator.h"
 #include "PlaneParametersEstimator.h"
@@ -184,6 +185,18 @@ static void lineTest() {  // testing/LineParametersEstimatorTest.cxx:98-213
   }
   est.leastSquaresEstimate(noisy, params);
   CHECK(params.size() == 4 && std::fabs(params[0] * d[0] + params[1] * d[1]) > COS5);
+  // the same assertions for Line2DParametersEstimator (normal form): testing/Line...Test.cxx:121-213
+  Line2DParametersEstimator est2(0.5);
+  const double nrm[2] = {-d[1], d[0]};
+  est2.estimate(two, params);
+  CHECK(params.size() == 4);
+  if (params.size() == 4) {
+    CHECK(std::fabs(params[0] * nrm[0] + params[1] * nrm[1]) > COS5);
+    CHECK(est2.agree(params, two[1]));
+    CHECK(!est2.agree(params, off));
+  }
+  est2.leastSquaresEstimate(noisy, params);
+  CHECK(params.size() == 4 && std::fabs(params[0] * nrm[0] + params[1] * nrm[1]) > COS5);
 }
 
 static void denseTest(const char *matrixFile) {  // testing/DenseLinear...Test.cxx:72-209

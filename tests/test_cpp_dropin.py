@@ -29,6 +29,7 @@ def test_reference_header_names_present():
               "SinglePointTargetUSCalibrationParametersEstimator.h",
               "AbsoluteOrientationParametersEstimator.h", "PivotCalibrationParametersEstimator.h",
               "RayIntersectionParametersEstimator.h", "Ray3D.h", "Vector3D.h",
+              "Line2DParametersEstimator.h",
               "Point.h", "Point2D.h",
               "Point3D.h", "Frame.h", "Epsilon.h", "copyright.h"]:
         assert os.path.exists(os.path.join(inc, h)), h

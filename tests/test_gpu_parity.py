@@ -1357,3 +1357,37 @@ def test_ray_intersection_device_path(ctx, n):
     ctx.upload(par_rays)
     fit, _ = ctx.ls_fit(use_mask=False)
     assert len(fit) == 0
+
+
+@pytest.mark.parametrize("n", [2, 500, 150_000])
+def test_line2d_device_path(ctx, n):
+    """Line2DParametersEstimator: estimate() bit-exact, the scan (exhaustive and two-level) bit-exact,
+    closed-form fit within 1e-6, RANSAC equal to the serial loop"""
+    data = synth.line(n, 0.4 if n > 2 else 0.0, seed=700 + n, dim=2)[0] if n > 2 else \
+        np.array([[1.0, 2.0], [40.0, -7.5]])
+    oc = O.cfg(O.LINE2D, 2, 0.5)
+    ctx.set_model(L.LINE2D, 2, 0.5).upload(data)
+    H = 100
+    subs = O.ctr_subsets(29, 0, H, n, 2)
+    ctx.hypotheses_from_subsets(subs)
+    plain = _scan_votes(ctx, 0)
+    assert np.array_equal(_scan_votes(ctx, 2), plain)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in range(0, H, 7):
+        want = O.estimate(oc, data[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0)
+        if valid[h]:
+            assert np.array_equal(par[h], want)
+            assert plain[h] == O.scan(oc, want, data)[0]
+    fit, _ = ctx.ls_fit(use_mask=False)
+    want = O.ls(oc, data)
+    assert len(fit) == len(want) == 4
+    assert np.allclose(fit, want, rtol=REL, atol=1e-6)
+    if n > 2:
+        r = ctx.ransac(0.999, seed=6)
+        w = O.ransac(oc, data, 0.999, sampler="ctr", seed=6)
+        assert r["info"].iterations == w["iters"] and np.array_equal(r["consensus"], w["consensus"])
+        assert np.allclose(r["params"], w["params"], rtol=REL, atol=1e-6)
+    ctx.upload(np.repeat(data[:1], 4, axis=0))           # all the same point -> empty
+    fit, _ = ctx.ls_fit(use_mask=False)
+    assert len(fit) == 0

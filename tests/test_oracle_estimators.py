@@ -297,3 +297,27 @@ def test_ray_intersection_like_reference_test():
         Pm = np.eye(3) - np.outer(n_, n_)
         A += Pm; b += Pm @ p_
     assert np.allclose(ls, np.linalg.solve(A, b), rtol=1e-10, atol=1e-8)
+
+
+def test_line2d_like_reference_test():
+    """testing/LineParametersEstimatorTest.cxx:121-213 for Line2DParametersEstimator: two exact points
+    and 20 noisy ones, delta 0.5: normal within 5 degrees of the truth, point on the line within delta;
+    agree() on / 2 delta off; the degenerate cases of estimate() and the fit."""
+    g = np.random.default_rng(23)
+    p0, p1 = g.uniform(-100, 100, 2), g.uniform(-100, 100, 2)
+    d = (p1 - p0) / np.linalg.norm(p1 - p0)
+    nrm = np.array([-d[1], d[0]])
+    c = O.cfg(O.LINE2D, 2, 0.5)
+    est = O.estimate(c, np.array([p0, p1]))
+    assert len(est) == 4 and abs(est[:2] @ nrm) > COS5 and abs((est[2:] - p0) @ nrm) < 0.5
+    assert O.agree(c, est, p1) and not O.agree(c, est, p1 + 1.0 * nrm)
+    pts = p0 + np.outer(g.uniform(-100, 100, 20), d) + g.normal(0, 0.2, (20, 2))
+    ls = O.ls(c, pts)
+    assert len(ls) == 4 and abs(ls[:2] @ nrm) > COS5 and abs((ls[2:] - p0) @ nrm) < 0.5
+    assert len(O.estimate(c, np.array([p0, p0 + 0.1]))) == 0            # closer than delta
+    assert len(O.ls(c, np.repeat([p0], 5, axis=0))) == 0                 # all the same point
+    vert = np.stack([np.full(6, 3.0), np.arange(6.0)], axis=1)           # zero variance in x: n = (1, 0)
+    assert np.allclose(O.ls(c, vert)[:2], [1.0, 0.0])
+    # agrees with the hyperplane estimator's fit up to the sign of the normal
+    pl = O.ls(O.cfg(O.PLANE, 2, 0.5), pts)
+    assert abs(abs(pl[:2] @ ls[:2]) - 1) < 1e-9 and np.allclose(pl[2:], ls[2:], atol=1e-9)
