@@ -160,4 +160,40 @@ LSQR_HD int spd_solve_eig(int n, double *g, const double *rhs, double rtol, doub
   return rank;
 }
 
+// Fast path of spd_solve_eig for well-conditioned systems: Cholesky of the diagonally scaled matrix
+// (unit diagonal).  Returns false -- nothing written to x -- unless every pivot exceeds 1e-8, i.e. far
+// from the 1e-13 rank decision of spd_solve_eig, which the caller then takes.  g is NOT modified;
+// work: n*n + n doubles.
+LSQR_HD bool spd_solve_chol(int n, const double *g, const double *rhs, double *x, double *work) {
+  double *l = work, *d = work + n * n;
+  for (int i = 0; i < n; i++) {
+    if (!(g[i * n + i] > 0.0)) return false;
+    d[i] = 1.0 / sqrt(g[i * n + i]);
+  }
+  for (int j = 0; j < n; j++) {
+    double s = g[j * n + j] * d[j] * d[j];
+    for (int k = 0; k < j; k++) s -= l[j * n + k] * l[j * n + k];
+    if (!(s > 1e-8)) return false;
+    const double ljj = sqrt(s);
+    l[j * n + j] = ljj;
+    for (int i = j + 1; i < n; i++) {
+      double t = g[i * n + j] * d[i] * d[j];
+      for (int k = 0; k < j; k++) t -= l[i * n + k] * l[j * n + k];
+      l[i * n + j] = t / ljj;
+    }
+  }
+  for (int i = 0; i < n; i++) {  // L y = D rhs
+    double t = rhs[i] * d[i];
+    for (int k = 0; k < i; k++) t -= l[i * n + k] * x[k];
+    x[i] = t / l[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {  // L^T z = y, x = D z
+    double t = x[i];
+    for (int k = i + 1; k < n; k++) t -= l[k * n + i] * x[k];
+    x[i] = t / l[i * n + i];
+  }
+  for (int i = 0; i < n; i++) x[i] *= d[i];
+  return true;
+}
+
 }  // namespace lsqr
