@@ -38,6 +38,51 @@ struct DenseModel {
   static LSQR_HD void prepare(double *, const ModelConsts &) {}
 };
 
+// K3 dense: consensus mask of one model.  The generic k_mask gives every lane its own 520-byte row,
+// i.e. 64 cache lines per load instruction (measured 1.3 TB/s); here each wave stages 32 rows in LDS
+// with coalesced loads (pitch n+1 padded to odd: conflict-free row reads) and lane r < 32 evaluates row
+// r with the reference's running sum (bit-identical to DenseModel::agree).
+template <int NR>
+__global__ __launch_bounds__(256) void k_mask_dense(const double *__restrict__ data, size_t stride,
+                                                    size_t begin, size_t end, int n,
+                                                    const double *__restrict__ par, double delta,
+                                                    uint8_t *__restrict__ mask,
+                                                    unsigned long long *__restrict__ counter) {
+  constexpr int ROWS = 32;
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pitch = (n + 1) | 1;
+  double *tile = sm + (size_t)wave * ROWS * pitch;
+  double x[NR];
+#pragma unroll
+  for (int i = 0; i < NR; i++) x[i] = i < n ? par[i] : 0.0;
+  uint32_t local = 0;
+  const size_t nw = (size_t)gridDim.x * 4;
+  for (size_t base = begin + ((size_t)blockIdx.x * 4 + wave) * ROWS; base < end; base += nw * ROWS) {
+    const int rows = (int)(end - base < (size_t)ROWS ? end - base : (size_t)ROWS);
+    const int total = rows * (n + 1);
+    // stride == n + 1 doubles is the tight layout; any stride is handled row by row
+    for (int idx = lane; idx < total; idx += 64) {
+      const int r = idx / (n + 1), c = idx - r * (n + 1);
+      tile[r * pitch + c] = data[(base + r) * stride + c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rows) {
+      const double *row = tile + lane * pitch;
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < NR; i++) sum += (i < n ? row[i] : 0.0) * x[i];
+      sum -= row[n];
+      const bool a = fabs(sum) < delta;
+      mask[base + lane] = a ? 1 : 0;
+      local += a ? 1u : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+  if (lane == 0 && local) atomicAdd(counter, (unsigned long long)local);
+}
+
 // K1 dense: one wave per hypothesis; n x n system in LDS; x = pinv(A) b, singular if any
 // sigma <= EPS (DenseLinear...Estimator.hxx:17-49)
 __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict__ data,

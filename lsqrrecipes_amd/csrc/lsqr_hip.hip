@@ -884,6 +884,15 @@ int launch_mask(lsqr_ctx *c, size_t begin, size_t end) {
       HIPCHK(c, hipGetLastError());
     }
     ProfScope ps(c, KID_MASK);
+    if constexpr (M::IS_DENSE) {  // wide rows: LDS-staged, coalesced
+      const int n = c->cfg.dim;
+      const size_t lds = sizeof(double) * 4 * 32 * ((n + 1) | 1);
+      int grid = grid_for(end - begin, 4 * 32 * 4, 256 * 4);
+      hipLaunchKernelGGL((k_mask_dense<M::NR>), dim3(grid), dim3(256), lds, c->stream, c->d_data,
+                         c->stride, begin, end, n, c->d_par, c->mc.delta, c->d_mask, c->d_counter);
+      HIPCHK(c, hipGetLastError());
+      return LSQR_OK;
+    }
     int grid = grid_for(end - begin, kBlock * 8, 256 * 8);
     hipLaunchKernelGGL((k_mask<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
                        begin, end, c->d_par, c->mc, c->d_mask, c->d_counter);
