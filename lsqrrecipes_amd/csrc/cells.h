@@ -319,7 +319,7 @@ template <int D>
 struct PlaneCell {
   typedef PlaneModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 0, ROW2_OFF = 0 };  // row = fp64 scan parameters
-  enum { DEFAULT_CELL = 512 };  // measured best (tools/ab_cells.py)
+  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0 };  // measured best (tools/ab_cells.py)
   struct Hyp {
     double n[3], c;
     float nf[3], e0;
@@ -406,7 +406,8 @@ template <int D>
 struct SphereCell {
   typedef SphereModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
-  enum { DEFAULT_CELL = 256 };  // absolute coordinates: wider band, whole-cell re-checks cost more
+  enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // absolute coordinates: wider band, whole-cell re-checks
+                                                    // cost more; LDS broadcast measured 5 % faster here
   struct Hyp {
     float nc[3], nmid, tin, tout, dlo, dhi;
   };
@@ -470,7 +471,7 @@ template <int D>
 struct LineCell {
   typedef LineModel<D> M;
   enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
-  enum { DEFAULT_CELL = 512 };
+  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0 };
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;
@@ -551,7 +552,7 @@ inline CellConsts cell_consts(const LineCell<D> *, const ModelConsts &mc) {
 // assignment leaves a long tail); the next 64 hypotheses' parameters are prefetched while the
 // current 64 are processed.  Votes of the 64 hypotheses of a group are collected in one VGPR
 // (lane b = hypothesis h0 + b, v_readlane / v_writelane) and flushed with one LDS atomic per group.
-template <class CM, int PP, int CPT, int BS>
+template <class CM, int PP, int CPT, int BS, bool LDSB = false>
 __global__ __launch_bounds__(BS) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
                                                     const CellBox *__restrict__ boxes,
                                                     uint32_t ncells, const double *__restrict__ sp,
@@ -573,6 +574,8 @@ __global__ __launch_bounds__(BS) void k_scan_cells(const double *__restrict__ so
   for (uint32_t h = threadIdx.x; h < H; h += BS) s_cnt[h] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  // LDSB: per-wave broadcast area behind the counters (H rounded up to 4): 64 lanes x 8 floats
+  float *s_bc = (float *)(s_cnt + ((H + 3) & ~3u)) + (size_t)(threadIdx.x >> 6) * 512;
   const uint32_t wtiles = (ncells + CPT - 1) / CPT;
   // Work unit = (wave tile, segment of the hypothesis range), handed out dynamically: near-model tiles
   // cost 4x more than far ones and a wave only sees a handful of them.  One same-address atomic costs
@@ -681,19 +684,39 @@ __global__ __launch_bounds__(BS) void k_scan_cells(const double *__restrict__ so
       for (int q = 0; q < CPT; q++) {
         float bc[NB];
         unsigned long long surv = __ballot(CM::level1(hy, bx[q], ctr[q], cc, bc));
+        if (LDSB && surv) {  // the lane's values -> LDS; survivors are fetched with uniform-address reads
+          float4 w0, w1;
+          w0.x = bc[0], w0.y = NB > 1 ? bc[1 < NB ? 1 : 0] : 0.0f, w0.z = NB > 2 ? bc[2 < NB ? 2 : 0] : 0.0f,
+          w0.w = NB > 3 ? bc[3 < NB ? 3 : 0] : 0.0f;
+          w1.x = NB > 4 ? bc[4 < NB ? 4 : 0] : 0.0f, w1.y = NB > 5 ? bc[5 < NB ? 5 : 0] : 0.0f,
+          w1.z = NB > 6 ? bc[6 < NB ? 6 : 0] : 0.0f, w1.w = NB > 7 ? bc[7 < NB ? 7 : 0] : 0.0f;
+          ((float4 *)s_bc)[2 * lane] = w0;
+          ((float4 *)s_bc)[2 * lane + 1] = w1;
+        }
         while (surv) {
           const int b = __builtin_ctzll(surv);
           asm("s_bitset0_b64 %0, %1" : "+s"(surv) : "s"(b));  // surv &= ~(1 << b)
           v2f fp[NV];
+          float btout, btin_l = 0.0f;
+          if (LDSB) {
+            static_assert(NB <= 8, "broadcast area holds 8 floats per lane");
+            const float4 r0 = ((const float4 *)s_bc)[2 * b], r1 = ((const float4 *)s_bc)[2 * b + 1];
+            const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-          for (int k = 0; k < NV; k++) {
-            float v = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[k]), b));
-            fp[k].x = v;
-            fp[k].y = v;
+            for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
+            btout = rb[NB - 1];
+            btin_l = rb[NB - 2];
+          } else {
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+              float v = __builtin_bit_cast(
+                  float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[k]), b));
+              fp[k].x = v;
+              fp[k].y = v;
+            }
+            btout = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b));
           }
-          const float btout = __builtin_bit_cast(
-              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b));
           // candidate test on the smallest |value| of the lane: NaN rows are ignored by min
           v2f s[PP];
           float m = __builtin_inff();
@@ -703,8 +726,9 @@ __global__ __launch_bounds__(BS) void k_scan_cells(const double *__restrict__ so
             m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(s[p].x), __builtin_fabsf(s[p].y)));
           }
           if (__ballot(m < btout) == 0) continue;
-          const float btin = __builtin_bit_cast(
-              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 2]), b));
+          const float btin = LDSB ? btin_l
+                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                                  __builtin_bit_cast(int, bc[NB - 2]), b));
           unsigned long long in[2 * PP], amb = 0;
 #pragma unroll
           for (int p = 0; p < PP; p++) {

@@ -463,7 +463,7 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   return LSQR_OK;
 }
 
-template <class CM, int PP, int CPT, int BS>
+template <class CM, int PP, int CPT, int BS, bool LDSB = false>
 int launch_scan_cells(lsqr_ctx *c) {
   typedef typename CM::M M;
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
@@ -475,7 +475,7 @@ int launch_scan_cells(lsqr_ctx *c) {
   uint32_t *d_next = c->d_queues;
   for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
     uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
-    size_t lds = (size_t)hc * sizeof(uint32_t);
+    size_t lds = (size_t)((hc + 3) & ~3u) * sizeof(uint32_t) + (LDSB ? (size_t)wpb * 2048 : 0);
     int per_cu = (int)std::min<size_t>(32 / wpb, (160 * 1024) / std::max<size_t>(lds, 1));
     if (per_cu < 1) per_cu = 1;
     size_t blocks = std::min<size_t>((wtiles + wpb - 1) / wpb, (size_t)256 * per_cu);
@@ -489,7 +489,7 @@ int launch_scan_cells(lsqr_ctx *c) {
     const uint32_t grab = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, units / (32 * waves)));
     ProfScope ps(c, KID_SCAN);
     HIPCHK(c, hipMemsetAsync(d_next, 0, kQueues * kQueuePitch * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL((k_scan_cells<CM, PP, CPT, BS>), dim3((unsigned)blocks), dim3(BS), lds,
+    hipLaunchKernelGGL((k_scan_cells<CM, PP, CPT, BS, LDSB>), dim3((unsigned)blocks), dim3(BS), lds,
                        c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
                        c->d_hparams + h0 * M::SP,
                        CM::ROW_F32 ? c->d_hparams_f32 + h0 * M::SPF
@@ -503,6 +503,10 @@ int launch_scan_cells(lsqr_ctx *c) {
 template <class CM, int PP, int CPT>
 int run_scan_cells(lsqr_ctx *c) {
   if (c->opt_block == 1024) return launch_scan_cells<CM, PP, CPT, 1024>(c);
+  // hypothesis broadcast to the survivors: v_readlane, or (scan_block 257 / the model's choice)
+  // uniform-address LDS reads
+  if (c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST))
+    return launch_scan_cells<CM, PP, CPT, 256, true>(c);
   return launch_scan_cells<CM, PP, CPT, 256>(c);  // measured: 256 is 3-5 % faster than 1024
 }
 
@@ -1882,8 +1886,8 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_block")) {  // workgroup size of the two-level scan
-    if (value != 0 && value != 256 && value != 1024)
-      return fail(c, LSQR_ERR_INVALID, "scan_block must be 0, 256 or 1024");
+    if (value != 0 && value != 256 && value != 257 && value != 1024)
+      return fail(c, LSQR_ERR_INVALID, "scan_block must be 0, 256, 257 (256 + LDS broadcast) or 1024");
     c->opt_block = value;
     return LSQR_OK;
   }

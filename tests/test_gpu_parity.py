@@ -913,6 +913,11 @@ def test_cell_scan_matches_exhaustive_and_oracle(ctx, model, dim, n):
     plain = _scan_votes(ctx, 0)
     for cell, cpt in ((0, 0), (128, 1), (128, 4), (256, 2), (512, 1), (512, 2)):
         assert np.array_equal(_scan_votes(ctx, 2, cell, cpt), plain), (cell, cpt)
+    for block in (256, 257, 1024):      # v_readlane / LDS broadcast of the hypothesis, 16-wave workgroups
+        ctx.set_option("scan_block", block)
+        v = _scan_votes(ctx, 2)
+        ctx.set_option("scan_block", 0)
+        assert np.array_equal(v, plain), block
     oc = O.cfg(model, dim, 0.5)
     par, valid, _ = ctx.hypotheses(votes=False)
     for h in range(0, H, 23):
