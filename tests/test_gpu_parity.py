@@ -1398,3 +1398,28 @@ def test_line2d_device_path(ctx, n):
     ctx.upload(np.repeat(data[:1], 4, axis=0))           # all the same point -> empty
     fit, _ = ctx.ls_fit(use_mask=False)
     assert len(fit) == 0
+
+
+@pytest.mark.parametrize("model", [L.PLANE, L.SPHERE, L.LINE])
+def test_filters_and_cell_scan_across_scales(ctx, model):
+    """the error bands of the fp32 filters and of the box tests scale with the data: the same scene at
+    magnitudes from 1e-6 to 1e9 (thresholds from 'a few ulps of fp32' to 'most of the scene'), off-centre
+    by 50 scene sizes, must give the votes of the plain fp64 kernel in every mode"""
+    base = _data(model, 3, 70_000, 2024, outliers=0.5)          # scene size ~ 1000, delta 0.5
+    ref_subs = O.ctr_subsets(41, 0, 160, len(base), {L.PLANE: 3, L.SPHERE: 4, L.LINE: 2}[model])
+    for scale in (1e-6, 1e-3, 1.0, 1e4, 1e9):
+        for rel_delta, shift in ((0.5, 0.0), (1e-4, 0.0), (40.0, 0.0), (0.5, 5e4)):
+            data = np.ascontiguousarray((base + shift) * scale)
+            delta = rel_delta * scale
+            ctx.set_model(model, 3, delta).upload(data)
+            ctx.hypotheses_from_subsets(ref_subs)
+            ctx.set_option("scan_filter", 0)
+            exact = _scan_votes(ctx, 0)
+            ctx.set_option("scan_filter", 1)
+            assert np.array_equal(_scan_votes(ctx, 0), exact), (scale, rel_delta, shift, "filter")
+            assert np.array_equal(_scan_votes(ctx, 2), exact), (scale, rel_delta, shift, "cells")
+    oc = O.cfg(model, 3, delta)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in (0, 77, 159):
+        if valid[h]:
+            assert exact[h] == O.scan(oc, par[h], data)[0]
