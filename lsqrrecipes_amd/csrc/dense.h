@@ -336,6 +336,99 @@ __global__ __launch_bounds__(256) void k_scan_dense_mfma(
   }
 }
 
+// Second arrangement of the same filter (default): wave w owns hypotheses 16w..16w+15 of the current
+// 64-hypothesis block and ALL 64 rows of the tile (four 16 x 16 accumulators, one per row group).  Its B
+// fragments -- 16 doubles per lane -- come straight from global memory / L2 into registers, one block
+// ahead, so the hypothesis loop has no LDS writes and no barriers (the row tile in LDS is read-only
+// there); LDS per workgroup drops to 34 KB + counters: three workgroups per CU.
+template <int NR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_scan_dense_mfma2(
+    const double *__restrict__ data, size_t stride, size_t m, size_t rows_per_block,
+    const double *__restrict__ sp, const double *__restrict__ thr, uint32_t H, int n,
+    uint32_t *__restrict__ votes, unsigned long long *__restrict__ amb_list,
+    unsigned int *__restrict__ amb_count, uint32_t hyp_base) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  static_assert(NR == 64, "fragment bookkeeping below assumes 64 padded unknowns");
+  extern __shared__ double sm[];
+  double *At = sm;                  // 64 rows x pitch
+  double *bv = At + 64 * kDmPitch;  // 64 right-hand sides
+  uint32_t *s_cnt = (uint32_t *)(bv + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, k4 = lane >> 4;
+  const uint32_t nhb = (H + 63) / 64;
+  for (uint32_t h = tid; h < H; h += 256) s_cnt[h] = 0;
+  size_t lo = (size_t)blockIdx.x * rows_per_block;
+  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
+  double nb[16], nti = -1.0, nto = -1.0;
+  auto fetch_hyp = [&](uint32_t hb) {
+    const uint32_t h = hb * 64 + wave * 16 + c16;
+    const double *row = sp + (size_t)(h < H ? h : 0) * NR;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int kk = 4 * q + k4;
+      nb[q] = (h < H && kk < n) ? row[kk] : 0.0;
+    }
+    nti = h < H ? thr[2 * (size_t)h] : -1.0;
+    nto = h < H ? thr[2 * (size_t)h + 1] : -1.0;
+  };
+  if (lo < hi) fetch_hyp(0);
+  for (size_t base = lo; base < hi; base += 64) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      int r = idx >> 6, kk = idx & 63;
+      size_t row = base + r;
+      At[r * kDmPitch + kk] = (row < hi && kk < n) ? data[row * stride + kk] : 0.0;
+    }
+    if (tid < 64) {
+      size_t row = base + tid;
+      bv[tid] = row < hi ? data[row * stride + n] : __builtin_nan("");  // NaN: row never counts
+    }
+    __syncthreads();
+    for (uint32_t hb = 0; hb < nhb; hb++) {
+      double b[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) b[q] = nb[q];
+      const double ti = nti, to = nto;
+      fetch_hyp(hb + 1 < nhb ? hb + 1 : 0);  // next block (or block 0 for the next row tile)
+      d4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double *ap = At + c16 * kDmPitch + k4;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * kDmPitch + 4 * q], b[q], acc[t], 0, 0, 0);
+      }
+      // D layout: column (hypothesis) = lane & 15, row = (lane >> 4) + 4 * reg (+ 16 * row group)
+      uint32_t c = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int r = t * 16 + k4 + 4 * rg;
+          const double res = fabs(acc[t][rg] - bv[r]);
+          c += res < ti ? 1u : 0u;
+          if (res >= ti && res < to) {  // ambiguous: decided exactly by k_dense_recheck
+            unsigned slot = atomicAdd(amb_count, 1u);
+            if (slot < kAmbCap)
+              amb_list[slot] = ((unsigned long long)(base + r) << 32) |
+                               (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
+          }
+        }
+      }
+      c += __shfl_xor(c, 16);  // lanes l, l^16, l^32, l^48 hold the same hypothesis column
+      c += __shfl_xor(c, 32);
+      if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + wave * 16 + c16], c);
+    }
+  }
+  __syncthreads();
+  for (uint32_t h = tid; h < H; h += 256) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
+  }
+}
+
 // exact decision of the pairs the MFMA filter could not classify
 template <int NR>
 __global__ __launch_bounds__(256) void k_dense_recheck(const double *__restrict__ data,

@@ -50,7 +50,7 @@ struct lsqr_ctx {
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
-  int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
@@ -525,7 +525,7 @@ int run_scan(lsqr_ctx *c) {
           double *d_thr = c->d_partials;  // scratch: 2 doubles per hypothesis (H <= 2^20 checked)
           if (c->H * 2 > (size_t)kDenseBlocks * 2160) return fail(c, LSQR_ERR_INVALID, "batch too large");
           size_t tiles = (c->n + 63) / 64;
-          size_t nblk = std::min<size_t>(tiles, 512);
+          size_t nblk = std::min<size_t>(tiles, c->opt_dense_v1 ? 512 : 768);  // 2 / 3 workgroups per CU
           size_t rpb = (tiles + nblk - 1) / nblk * 64;
           nblk = (c->n + rpb - 1) / rpb;
           {
@@ -536,6 +536,18 @@ int run_scan(lsqr_ctx *c) {
             HIPCHK(c, hipGetLastError());
             for (size_t h0 = 0; h0 < c->H; h0 += kDmHypChunk) {
               uint32_t hc = (uint32_t)std::min<size_t>(kDmHypChunk, c->H - h0);
+              if constexpr (M::NR == 64) {
+                if (!c->opt_dense_v1) {  // default: B fragments in registers, no barriers per block
+                  size_t lds2 = sizeof(double) * (64 * kDmPitch + 64) + sizeof(uint32_t) * hc;
+                  hipLaunchKernelGGL((k_scan_dense_mfma2<64>), dim3((unsigned)nblk), dim3(256), lds2,
+                                     c->stream, c->d_data, c->stride, c->n, rpb,
+                                     c->d_hparams + h0 * M::NR, d_thr + 2 * h0, hc, (int)c->cfg.dim,
+                                     c->d_votes + h0, c->d_amb, (unsigned int *)(c->d_counter + 3),
+                                     (uint32_t)h0);
+                  HIPCHK(c, hipGetLastError());
+                  continue;
+                }
+              }
               size_t lds = sizeof(double) * (2 * 64 * kDmPitch + 3 * 64) + sizeof(uint32_t) * hc;
               hipLaunchKernelGGL((k_scan_dense_mfma<M::NR>), dim3((unsigned)nblk), dim3(256), lds,
                                  c->stream, c->d_data, c->stride, c->n, rpb,
@@ -1895,6 +1907,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     if (value != 0 && value != 128 && value != 256 && value != 512)
       return fail(c, LSQR_ERR_INVALID, "scan_cell must be 0, 128, 256 or 512");
     c->opt_cell = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_scan_v1")) {  // 1: first MFMA scan arrangement (hypothesis block through LDS)
+    c->opt_dense_v1 = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse

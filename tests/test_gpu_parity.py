@@ -1423,3 +1423,21 @@ def test_filters_and_cell_scan_across_scales(ctx, model):
     for h in (0, 77, 159):
         if valid[h]:
             assert exact[h] == O.scan(oc, par[h], data)[0]
+
+
+def test_dense_mfma_scan_arrangements_agree(ctx):
+    """both arrangements of the fp64 MFMA filter scan (hypothesis block through LDS / B fragments in
+    registers) and the exact VALU kernel count the same votes; ragged row and hypothesis counts"""
+    rows = synth.dense(70_013, 64, 0.05, seed=313)[0]
+    ctx.set_model(L.DENSE, 64, 0.1).upload(rows)
+    ctx.hypotheses_sample(17, 0, 333)
+    res = []
+    for v1, filt in ((0, 1), (1, 1), (0, 0)):
+        ctx.set_option("dense_scan_v1", v1)
+        ctx.set_option("scan_filter", filt)
+        ctx.scan()
+        res.append(ctx.hypotheses(params=False)[2].copy())
+    ctx.set_option("dense_scan_v1", 0)
+    ctx.set_option("scan_filter", 1)
+    assert np.array_equal(res[0], res[2]) and np.array_equal(res[1], res[2])
+    assert res[0].max() > 1000
