@@ -211,6 +211,7 @@ def main():
     n_mom, ms_mom = ctx.profile_get("moments")
     n_est, ms_est = ctx.profile_get("estimate")
     n_sol, ms_sol = ctx.profile_get("solve")
+    n_smp, ms_smp = ctx.profile_get("sample")
     n_idx2, ms_idx2 = ctx.profile_get("index")
     ctx.profile(False)
     idx = ctx.index_info()
@@ -285,7 +286,8 @@ def main():
                                            "the exact fp64 formula, so the exact-equivalent rate "
                                            "exceeds the fp64 issue roof") if filtered else
                                           "exact fp64 path: fraction of the fp64 add/mul issue rate"}},
-            "kernels_ms": {"estimate": ms_est / max(n_est, 1), "scan": scan_ms,
+            "kernels_ms": {"sample": ms_smp / max(n_smp, 1), "estimate": ms_est / max(n_est, 1),
+                           "scan": scan_ms,
                            "mask": ms_mask / max(n_mask, 1), "moments": ms_mom / max(n_mom, 1),
                            "reduce_and_solve_per_step": ms_sol / max(a.steps, 1)},
             "index": {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],

@@ -38,6 +38,38 @@ __global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t first
   for (int l = 0; l < K; l++) subsets[(size_t)h * K + l] = idx[l];
 }
 
+// K0 for large subsets (the dense system draws 64 rows per hypothesis): one WAVE per hypothesis.
+// ctr_subset() walks the sorted list of earlier draws (O(k^2) dependent steps on one lane: 0.7 ms for
+// 1024 x 64 draws); here lane j holds sorted[j] and the walk becomes the fixed point
+//     v = rank + #{chosen <= v}      (ballot + popcount, a few rounds)
+// followed by a one-lane shift to insert v.  Same selection rule, same output (test_device_sampler_*).
+__global__ __launch_bounds__(64) void k_sample_wave(uint64_t seed, uint64_t first, uint32_t H,
+                                                    uint64_t n, int K,
+                                                    uint32_t *__restrict__ subsets) {
+  const uint32_t hyp = blockIdx.x;
+  if (hyp >= H) return;
+  const int lane = threadIdx.x;
+  const uint64_t h = first + hyp;
+  uint32_t sorted = 0xFFFFFFFFu;  // lanes >= number of draws so far hold the sentinel
+  uint32_t mine = 0;              // lane l keeps draw l (draw order)
+  for (int l = 0; l < K; l++) {
+    const uint64_t u = mix64(seed + 0x9E3779B97F4A7C15ULL * (h * 64ULL + (uint64_t)l + 1ULL));
+    const uint32_t rank = (uint32_t)mulhi64(u, n - (uint64_t)l);
+    uint32_t v = rank, cnt = 0;
+    for (;;) {
+      cnt = (uint32_t)__builtin_popcountll(__ballot(sorted <= v));
+      const uint32_t nv = rank + cnt;
+      if (nv == v) break;
+      v = nv;
+    }
+    const uint32_t up = __shfl_up(sorted, 1);
+    if ((uint32_t)lane == cnt) sorted = v;
+    else if ((uint32_t)lane > cnt) sorted = up;
+    if (lane == l) mine = v;
+  }
+  if (lane < K) subsets[(size_t)hyp * K + lane] = mine;
+}
+
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_estimate(const double *__restrict__ data,
                                                      size_t stride, size_t n,

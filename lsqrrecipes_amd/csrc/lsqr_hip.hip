@@ -1218,8 +1218,8 @@ int lsqr_hypotheses_sample(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
     if (c->K <= 4)
       hipLaunchKernelGGL((k_sample<4>), dim3(grid), dim3(kBlock), 0, c->stream, seed, first,
                          (uint32_t)H, (uint64_t)c->n, c->K, c->d_subsets);
-    else
-      hipLaunchKernelGGL((k_sample<64>), dim3(grid), dim3(kBlock), 0, c->stream, seed, first,
+    else  // large subsets: one wave per hypothesis
+      hipLaunchKernelGGL(k_sample_wave, dim3((unsigned)H), dim3(64), 0, c->stream, seed, first,
                          (uint32_t)H, (uint64_t)c->n, c->K, c->d_subsets);
     HIPCHK(c, hipGetLastError());
   }
