@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <set>
@@ -49,6 +50,7 @@ struct lsqr_ctx {
   size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
+  bool index_failed = false;  // build failed on this upload: stay on the exhaustive kernels
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
   int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
@@ -373,6 +375,8 @@ template <int D>
 int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   drop_index(c);
   c->cell_pts = cell_pts;
+  if (getenv("LSQR_TEST_FAIL_INDEX"))  // test hook: behave as if the sorted copy could not be allocated
+    return fail(c, LSQR_ERR_HIP, "index build failure requested by LSQR_TEST_FAIL_INDEX");
   ProfScope ps(c, KID_INDEX);
   const size_t n = c->n;
   unsigned long long *d_b = nullptr;
@@ -624,29 +628,37 @@ int run_scan(lsqr_ctx *c) {
         // two-level scan over the spatial index; auto: built once an upload has seen enough
         // hypotheses to pay for the build (a few HBM passes)
         const bool tuned_defaults = c->opt_filter == 1 && c->opt_ppl == 0;  // A/B knobs untouched
-        const bool want = c->opt_filter && f32_ok && c->mc.absmax >= 1e-10 &&
+        const bool want = c->opt_filter && f32_ok && c->mc.absmax >= 1e-10 && !c->index_failed &&
                           (c->opt_index == 2 ||
                            (c->opt_index == 1 && tuned_defaults &&
                             (c->index_valid || (c->n >= 65536 && c->hyp_since_upload >= 2048))));
         if (want) {
           const uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : (uint32_t)CM::DEFAULT_CELL;
+          bool usable = true;
           if (!c->index_valid || c->cell_pts != cell_pts) {
-            int st = build_index<M::ND>(c, cell_pts);
-            if (st != LSQR_OK) return st;
+            // the index is an accelerator: if it cannot be built (typically no memory for the sorted
+            // copy) this upload keeps the exhaustive kernels instead of failing the scan
+            if (build_index<M::ND>(c, cell_pts) != LSQR_OK) {
+              (void)hipGetLastError();
+              c->index_failed = true;
+              usable = false;
+            }
           }
           const int cpt = c->opt_cpt ? c->opt_cpt : 1;
-          if (cell_pts == 128) {
-            if (cpt == 1) return run_scan_cells<CM, 1, 1>(c);
-            if (cpt == 2) return run_scan_cells<CM, 1, 2>(c);
-            return run_scan_cells<CM, 1, 4>(c);
+          if (usable) {
+            if (cell_pts == 128) {
+              if (cpt == 1) return run_scan_cells<CM, 1, 1>(c);
+              if (cpt == 2) return run_scan_cells<CM, 1, 2>(c);
+              return run_scan_cells<CM, 1, 4>(c);
+            }
+            if (cell_pts == 512) {
+              if (cpt == 1) return run_scan_cells<CM, 4, 1>(c);
+              return run_scan_cells<CM, 4, 2>(c);
+            }
+            if (cpt == 1) return run_scan_cells<CM, 2, 1>(c);
+            if (cpt == 2) return run_scan_cells<CM, 2, 2>(c);
+            return run_scan_cells<CM, 2, 4>(c);
           }
-          if (cell_pts == 512) {
-            if (cpt == 1) return run_scan_cells<CM, 4, 1>(c);
-            return run_scan_cells<CM, 4, 2>(c);
-          }
-          if (cpt == 1) return run_scan_cells<CM, 2, 1>(c);
-          if (cpt == 2) return run_scan_cells<CM, 2, 2>(c);
-          return run_scan_cells<CM, 2, 4>(c);
         }
       }
       if (c->opt_filter && f32_ok) {
@@ -1153,6 +1165,7 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   c->n = count;
   c->absmax_valid = false;
   drop_index(c);
+  c->index_failed = false;
   c->hyp_since_upload = 0;
   c->stride = stride_bytes / sizeof(double);
   c->H = 0;

@@ -1441,3 +1441,23 @@ def test_dense_mfma_scan_arrangements_agree(ctx):
     ctx.set_option("scan_filter", 1)
     assert np.array_equal(res[0], res[2]) and np.array_equal(res[1], res[2])
     assert res[0].max() > 1000
+
+
+def test_cell_scan_falls_back_when_the_index_cannot_be_built(ctx):
+    """the spatial index is an accelerator: a failed build (simulated) must leave the scan on the
+    exhaustive kernels with the same votes, for the rest of the upload"""
+    data = _data(L.PLANE, 3, 90_000, 77, outliers=0.5)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    ctx.hypotheses_sample(2, 0, 3000)
+    ref = _scan_votes(ctx, 0)
+    os.environ["LSQR_TEST_FAIL_INDEX"] = "1"
+    try:
+        assert np.array_equal(_scan_votes(ctx, 2), ref)
+        assert not ctx.index_info()["built"]
+    finally:
+        del os.environ["LSQR_TEST_FAIL_INDEX"]
+    assert np.array_equal(_scan_votes(ctx, 2), ref)      # still disabled for this upload
+    assert not ctx.index_info()["built"]
+    ctx.upload(data)                                     # a new upload may try again
+    ctx.hypotheses_sample(2, 0, 3000)
+    assert np.array_equal(_scan_votes(ctx, 2), ref) and ctx.index_info()["built"]
