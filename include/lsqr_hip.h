@@ -64,7 +64,8 @@ typedef enum {
   LSQR_MODEL_ABSOR = 7,      /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,t(3)] */
   LSQR_MODEL_PIVOT = 8,      /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)] */
   LSQR_MODEL_RAY = 9,        /* RayIntersectionParametersEstimator      params [x, y, z]          */
-  LSQR_MODEL_LINE2D = 10     /* Line2DParametersEstimator               params [n_x, n_y, a_x, a_y] */
+  LSQR_MODEL_LINE2D = 10,    /* Line2DParametersEstimator               params [n_x, n_y, a_x, a_y] */
+  LSQR_MODEL_PHANTOM = 11    /* PlanePhantomUSCalibrationParametersEstimator  31 frames, 41 params */
 } lsqr_model;
 
 /* SphereParametersEstimator::LeastSquaresType (SphereParametersEstimator.h:28) and the US

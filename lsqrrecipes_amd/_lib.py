@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsqr_hip.so")
 
 OK, EMPTY, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE = range(6)
-PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY, LINE2D = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY, LINE2D, PHANTOM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 LS_ANALYTIC, LS_ITERATIVE = 0, 1
 KERNEL_IDS = {"sample": 0, "estimate": 1, "scan": 2, "mask": 3, "moments": 4, "solve": 5,

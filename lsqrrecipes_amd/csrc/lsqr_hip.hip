@@ -20,6 +20,7 @@
 #include "us_kernels.h"
 #include "cells.h"
 #include "rigid.h"
+#include "phantom.h"
 
 using namespace lsqr;
 
@@ -57,6 +58,10 @@ struct lsqr_ctx {
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   bool scanned = false;
+
+  double *d_rows = nullptr;  // plane phantom: the data rows a_i as an n x 32 matrix (phantom.h)
+  size_t rows_cap = 0;
+  bool rows_valid = false;
 
   uint8_t *d_mask = nullptr;
   size_t mask_cap = 0;
@@ -175,6 +180,7 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
     case LSQR_MODEL_PIVOT: return f(Tag<PivotModel>{});
     case LSQR_MODEL_RAY: return f(Tag<RayModel>{});
     case LSQR_MODEL_LINE2D: return f(Tag<Line2DModel>{});
+    case LSQR_MODEL_PHANTOM: return f(Tag<PhantomModel>{});
     case LSQR_MODEL_DENSE:
       if (cfg.dim >= 1 && cfg.dim <= 8) return f(Tag<DenseModel<8>>{});
       if (cfg.dim <= 16 && cfg.dim > 8) return f(Tag<DenseModel<16>>{});
@@ -268,7 +274,10 @@ int run_estimate(lsqr_ctx *c) {
       if (st != LSQR_OK) return st;
     }
     ProfScope ps(c, KID_ESTIMATE);
-    if constexpr (M::IS_DENSE) {
+    if constexpr (requires { M::IS_PHANTOM; }) {
+      hipLaunchKernelGGL(k_estimate_phantom, dim3((unsigned)c->H), dim3(256), 0, c->stream, c->d_data,
+                         c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid);
+    } else if constexpr (M::IS_DENSE) {
       hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256),
                          dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
                          c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP,
@@ -688,8 +697,10 @@ int run_scan(lsqr_ctx *c) {
 
 // ---- moments / solves ---------------------------------------------------------------------------
 // phase 0: the model's LS moment block about d_vec (origin); phase 1: LM block at d_vec (x trial)
-int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int *nmom) {
-  const int n = c->cfg.dim, ne = dense_ne(n), ps = dense_pstride(n);
+// sum z z^T over rows [begin, end) of a row-major matrix whose rows hold n + 1 entries z
+int launch_syrk(lsqr_ctx *c, const double *data, size_t stride, int n, int use_mask, size_t begin,
+                size_t end, int *nmom) {
+  const int ne = dense_ne(n), ps = dense_pstride(n);
   size_t cnt = end - begin;
   int nb = grid_for(cnt, kSyrkTile * 8, kDenseBlocks);
   size_t chunk = (cnt + nb - 1) / nb;
@@ -701,17 +712,17 @@ int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, in
     ProfScope ps_(c, KID_MOMENTS);
     if (c->opt_filter) {  // default: matrix-core SYRK
       if (c->opt_syrk_diag == 1)  // diagnostics (tools/syrk_ab.py): loads only / MFMAs only
-        hipLaunchKernelGGL(k_syrk_mfma<1>, dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride,
+        hipLaunchKernelGGL(k_syrk_mfma<1>, dim3(nb), dim3(256), 0, c->stream, data, stride,
                            begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
       else if (c->opt_syrk_diag == 2)
-        hipLaunchKernelGGL(k_syrk_mfma<2>, dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride,
+        hipLaunchKernelGGL(k_syrk_mfma<2>, dim3(nb), dim3(256), 0, c->stream, data, stride,
                            begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
       else
-        hipLaunchKernelGGL(k_syrk_mfma<0>, dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride,
+        hipLaunchKernelGGL(k_syrk_mfma<0>, dim3(nb), dim3(256), 0, c->stream, data, stride,
                            begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
     } else {
       size_t lds = sizeof(double) * kSyrkTile * ((n + 1) | 1) + kSyrkTile;
-      hipLaunchKernelGGL(k_syrk_dense, dim3(nb), dim3(256), lds, c->stream, c->d_data, c->stride,
+      hipLaunchKernelGGL(k_syrk_dense, dim3(nb), dim3(256), lds, c->stream, data, stride,
                          begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
     }
     HIPCHK(c, hipGetLastError());
@@ -725,6 +736,71 @@ int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, in
   return LSQR_OK;
 }
 
+int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int *nmom) {
+  return launch_syrk(c, c->d_data, c->stride, (int)c->cfg.dim, use_mask, begin, end, nmom);
+}
+
+// plane phantom: the Gram matrix of the data rows (upper triangle, 496 sums) + the row count.  The rows
+// are materialised once per upload (256 B per frame) and summed on the matrix cores by the dense SYRK.
+int launch_moments_phantom(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int *nmom) {
+  if (!c->rows_valid) {
+    int st = ensure(c, &c->d_rows, &c->rows_cap, std::max<size_t>(c->n, 1) * 32);
+    if (st != LSQR_OK) return st;
+    ProfScope ps(c, KID_MOMENTS);
+    hipLaunchKernelGGL(k_phantom_rows, dim3((unsigned)((c->n * 8 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_data, c->stride, c->n, c->d_rows);
+    HIPCHK(c, hipGetLastError());
+    c->rows_valid = true;
+  }
+  return launch_syrk(c, c->d_rows, 32, 30, use_mask, begin, end, nmom);
+}
+
+// plane phantom: both fits from the Gram block on the host (31-dimensional, like the LM control flow)
+void phantom_solve_block(const lsqr_model_cfg &cfg, const double *blk, SolveOut *out) {
+  memset(out, 0, sizeof *out);
+  const int N = 31;
+  if (!(blk[496] >= 31.0)) return;  // PlanePhantom...Estimator.cxx:139-141: fewer than 31 frames
+  double G[N * N], a[N * N], w[N], v[N * N], x[N], par[64];
+  for (int i = 0; i < N; i++)
+    for (int j = i; j < N; j++) G[i * N + j] = G[j * N + i] = blk[i * N - i * (i - 1) / 2 + (j - i)];
+  for (int i = 0; i < N * N; i++) {
+    if (!(fabs(G[i]) <= 1e300)) return;  // non-finite data: no estimate
+    a[i] = G[i];
+  }
+  sym_eig(N, a, w, v);  // ascending: column 0 belongs to the smallest singular value of the row matrix
+  for (int j = 0; j < N; j++) x[j] = v[j * N];
+  if (!PhantomModel::finish(x, par)) return;
+  if (cfg.ls_type != LSQR_LS_ITERATIVE) {
+    double e[N], cost = 0;  // e = x scaled as finish() scales it
+    double den = sqrt(x[27] * x[27] + x[28] * x[28] + x[29] * x[29]);
+    for (int j = 0; j < N; j++) e[j] = x[j] / den;
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) cost += e[i] * G[i * N + j] * e[j];
+    out->ok = 1;
+    out->n_params = PhantomModel::P;
+    out->cost = cost > 0 ? cost : 0.0;
+    for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
+    return;
+  }
+  // .cxx:357-453: Levenberg-Marquardt on the 11 minimal parameters from the analytic estimate
+  LmState s;
+  double blk78[LM_MOM_MAX];
+  lm_init(s, 11, par, 10e-16, 10e-16, 10e-16, 5000, 100.0);
+  for (;;) {
+    phantom_lm_block(G, s.xtrial, blk78);
+    if (!lm_advance(s, blk78)) break;
+  }
+  const bool ok = s.info >= 1 && s.info <= 4;
+  for (int j = 0; j < 11; j++) par[j] = s.x[j];
+  PhantomModel::expand(par);
+  out->ok = ok ? 1 : 0;
+  out->n_params = ok ? PhantomModel::P : 0;
+  out->lm_info = s.info;
+  out->lm_nfev = s.nfev;
+  out->cost = s.fnorm * s.fnorm;
+  for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
+}
+
 int launch_solve_dense(lsqr_ctx *c) {
   ProfScope ps(c, KID_SOLVE);
   hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(256), dense_lds_bytes(c->cfg.dim), c->stream,
@@ -735,7 +811,10 @@ int launch_solve_dense(lsqr_ctx *c) {
 
 template <class M>
 int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase, int *nmom) {
-  if constexpr (M::IS_DENSE) {
+  if constexpr (requires { M::IS_PHANTOM; }) {
+    if (phase != 0) return fail(c, LSQR_ERR_INVALID, "the phantom's iterative fit runs on the phase-0 block");
+    return launch_moments_phantom(c, use_mask, begin, end, nmom);
+  } else if constexpr (M::IS_DENSE) {
     if (phase != 0) return fail(c, LSQR_ERR_INVALID, "dense model has no iterative phase");
     return launch_moments_dense(c, use_mask, begin, end, nmom);
   } else {
@@ -823,7 +902,14 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     int nmom = 0, st;
-    if constexpr (M::IS_DENSE) {
+    if constexpr (requires { M::IS_PHANTOM; }) {
+      if ((st = launch_moments_phantom(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
+      HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToHost,
+                               c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      phantom_solve_block(c->cfg, (const double *)c->h_pin, out);
+      return LSQR_OK;
+    } else if constexpr (M::IS_DENSE) {
       if ((st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
       if ((st = launch_solve_dense(c)) != LSQR_OK) return st;
       return read_out(c, out);
@@ -1054,7 +1140,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_index(c);
-  void *bufs[] = {c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask,
+  void *bufs[] = {c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -1088,6 +1174,7 @@ int lsqr_min_subset(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_PIVOT: return 3;
     case LSQR_MODEL_RAY: return 2;
     case LSQR_MODEL_LINE2D: return 2;
+    case LSQR_MODEL_PHANTOM: return 31;
   }
   return 0;
 }
@@ -1104,6 +1191,7 @@ int lsqr_num_params(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_PIVOT: return 6;
     case LSQR_MODEL_RAY: return 3;
     case LSQR_MODEL_LINE2D: return 4;
+    case LSQR_MODEL_PHANTOM: return 41;
   }
   return 0;
 }
@@ -1120,6 +1208,7 @@ int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_PIVOT: return 13;
     case LSQR_MODEL_RAY: return 6;
     case LSQR_MODEL_LINE2D: return 2;
+    case LSQR_MODEL_PHANTOM: return 15;
   }
   return 0;
 }
@@ -1149,6 +1238,7 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->has_model = true;
   drop_index(c);
   c->absmax_valid = false;
+  c->rows_valid = false;
   c->H = 0;
   c->scanned = false;
   c->mask_valid = false;
@@ -1164,6 +1254,7 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   if (count > 0xFFFFFFF0ull) return fail(c, LSQR_ERR_INVALID, "too many observations");
   c->n = count;
   c->absmax_valid = false;
+  c->rows_valid = false;
   drop_index(c);
   c->index_failed = false;
   c->hyp_since_upload = 0;
@@ -1362,7 +1453,9 @@ int lsqr_moments_len(const lsqr_model_cfg *cfg, int phase) {
   if (!cfg) return 0;
   return dispatch(*cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
-    if constexpr (M::IS_DENSE) {
+    if constexpr (requires { M::IS_PHANTOM; }) {
+      return phase == 0 ? dense_ne(30) + 1 : 0;
+    } else if constexpr (M::IS_DENSE) {
       return phase == 0 ? dense_ne(cfg->dim) + 1 : 0;
     } else {
       if (phase == 0) return (int)M::NMOM;
@@ -1407,6 +1500,15 @@ int lsqr_solve_moments(lsqr_ctx *c, const double *block, const double *origin, d
   if (st != LSQR_OK) return st;
   if (!block || !origin) return fail(c, LSQR_ERR_INVALID, "null argument");
   int nmom = lsqr_moments_len(&c->cfg, 0);
+  if (c->cfg.model == LSQR_MODEL_PHANTOM) {  // solved on the host from the Gram block
+    SolveOut out;
+    phantom_solve_block(c->cfg, block, &out);
+    fill_info(out, info);
+    if (!out.ok) return LSQR_EMPTY;
+    if (params_out)
+      for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+    return LSQR_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_mom, block, sizeof(double) * nmom, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_vec, origin, sizeof(double) * std::min(c->ND, 32),

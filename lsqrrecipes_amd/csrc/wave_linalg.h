@@ -31,13 +31,11 @@ __device__ inline double wave_max(double v) {
 // T = threads of the calling workgroup (64 or 256): T/32 lanes share one column pair, each taking
 // every (T/32)-th row; the lanes of a pair are consecutive, so their partial dot products combine
 // with wave shuffles.
+// One-sided Jacobi sweeps (see block_pinv_solve): A (m x n, column-major) becomes U*S, V (n x n)
+// accumulates the rotations.
 template <int T>
-__device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double *V, int ldv,
-                                       const double *b, double tol_abs, double tol_rel, double *x,
-                                       double *cwork) {
+__device__ inline void block_jacobi_svd(int m, int n, double *A, int lda, double *V, int ldv) {
   constexpr int LPP = T / 32;  // lanes per pair
-  __shared__ int s_rank;
-  __shared__ double s_smax;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < n * n; idx += T) {
     int r = idx % n, c = idx / n;
@@ -102,6 +100,16 @@ __device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double 
     }
     if (!any_rot) break;
   }
+}
+
+template <int T>
+__device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double *V, int ldv,
+                                       const double *b, double tol_abs, double tol_rel, double *x,
+                                       double *cwork) {
+  __shared__ int s_rank;
+  __shared__ double s_smax;
+  const int tid = threadIdx.x;
+  block_jacobi_svd<T>(m, n, A, lda, V, ldv);
   // singular values and projections of b
   double s2 = 0, d = 0;
   if (tid < n)
@@ -132,6 +140,41 @@ __device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double 
   }
   __syncthreads();
   return s_rank;
+}
+
+// Right singular vector of the smallest singular value of A (m x n, n <= 64; destroyed) -> x (n),
+// unit length; *n_positive = number of singular values > 0 (vnl_svd's default rank: only exact zeros
+// are dropped).  All T threads call it.
+template <int T>
+__device__ inline void block_null_vector(int m, int n, double *A, int lda, double *V, int ldv,
+                                         double *x, int *n_positive) {
+  __shared__ int s_jmin, s_npos;
+  const int tid = threadIdx.x;
+  block_jacobi_svd<T>(m, n, A, lda, V, ldv);
+  double s2 = 0;
+  if (tid < n)
+    for (int k = 0; k < m; k++) {
+      double a = A[tid * lda + k];
+      s2 = fma(a, a, s2);
+    }
+  if (tid < 64) {
+    double v = tid < n ? s2 : INFINITY;
+    int idx = tid;
+    for (int o = 32; o > 0; o >>= 1) {
+      double ov = __shfl_xor(v, o);
+      int oi = __shfl_xor(idx, o);
+      if (ov < v || (ov == v && oi < idx)) v = ov, idx = oi;
+    }
+    int npos = __builtin_popcountll(__ballot(tid < n && s2 > 0.0));
+    if (tid == 0) {
+      s_jmin = idx;
+      s_npos = npos;
+    }
+  }
+  __syncthreads();
+  if (tid < n) x[tid] = V[s_jmin * ldv + tid];
+  if (tid == 0) *n_positive = s_npos;
+  __syncthreads();
 }
 
 // Fast path of the n x n minimal solves: Gaussian elimination with partial pivoting on the system in

@@ -273,3 +273,88 @@ def rays(n, outlier_frac, seed=0x5EED0008, max_range=1000.0, sigma=0.3):
     d = aim - p
     d /= np.linalg.norm(d, axis=1)[:, None]
     return np.ascontiguousarray(np.hstack([p, d])), target, lab
+
+
+def _zyx(az, ay, ax):
+    cx, cy, cz, sx, sy, sz = np.cos(ax), np.cos(ay), np.cos(az), np.sin(ax), np.sin(ay), np.sin(az)
+    return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                     [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                     [-sy, cy * sx, cy * cx]])
+
+
+def phantom_params(omega1_yx, t1_z, t3, omega3_zyx, m_x, m_y):
+    """the 41-vector of PlanePhantomUSCalibrationParametersEstimator from its 11 minimal entries
+    (PlanePhantomUSCalibrationParametersEstimator.cxx:383-452)"""
+    R1 = np.array([-np.sin(omega1_yx[0]), np.cos(omega1_yx[0]) * np.sin(omega1_yx[1]),
+                   np.cos(omega1_yx[0]) * np.cos(omega1_yx[1])])
+    R3 = _zyx(*omega3_zyx)
+    p = [omega1_yx[0], omega1_yx[1], t1_z, *t3, *omega3_zyx, m_x, m_y]
+    for a in range(3):
+        p += [m_x * R3[j, 0] * R1[a] for j in range(3)]
+    for a in range(3):
+        p += [m_y * R3[j, 1] * R1[a] for j in range(3)]
+    for a in range(3):
+        p += [t3[j] * R1[a] for j in range(3)]
+    p += list(R1)
+    return np.array(p)
+
+
+def plane_phantom(n, outlier_frac, seed=0x5EED0009, pixel_sigma=1.0):
+    """Plane-phantom US calibration frames (testing/PlanePhantomUSCalibrationParametersEstimatorTest.cxx:
+    382-548): image point q, pose T2 such that T1 T2 T3 q lies on the phantom plane z = 0.
+    -> (records (n,15) as the US single layout, true 41-vector, is_inlier)."""
+    g = _rng(seed)
+    m_x, m_y = 0.143, 0.139
+    o3 = g.uniform(0.0, np.pi, 3)          # x, y, z
+    t3 = g.uniform(-100, 100, 3)
+    t1 = g.uniform(-100, 100, 3)
+    o1 = g.uniform(0.0, np.pi, 3)          # x, y, z
+    R3 = _zyx(o3[2], o3[1], o3[0])
+    T3 = np.column_stack([m_x * R3[:, 0], m_y * R3[:, 1], R3[:, 2], t3])
+    R1 = _zyx(o1[2], o1[1], o1[0])
+    truth = phantom_params([o1[1], o1[0]], t1[2], t3, [o3[2], o3[1], o3[0]], m_x, m_y)
+    rec = np.zeros((n, 15))
+    lab = np.ones(n, bool)
+    n_out = int(round(n * outlier_frac))
+    lab[g.permutation(n)[:n_out]] = False
+    for i in range(n):
+        q = np.array([g.uniform(0, 640), g.uniform(0, 480)])
+        pi = np.array([g.uniform(-100, 100), g.uniform(-100, 100), 0.0])
+        if not lab[i]:
+            pi[2] = g.uniform(20.0, 100.0) * (1 if g.random() < 0.5 else -1)   # off the plane
+        o2 = g.uniform(0.0, np.pi, 3)
+        R2 = _zyx(o2[2], o2[1], o2[0])
+        qt = T3 @ np.array([q[0], q[1], 0.0, 1.0])
+        pt = R1.T @ (pi - t1)               # T1^-1 p
+        t2 = pt - R2 @ qt
+        rec[i, 0:9] = R2.ravel()
+        rec[i, 9:12] = t2
+        rec[i, 13:15] = q + (g.normal(0.0, pixel_sigma, 2) if pixel_sigma > 0 else 0.0)
+    return rec, truth, lab
+
+
+def phantom_check(est, truth, trans_eps=3.0, ang_eps=0.08726646259971647884618453842445, scale_eps=1.0):
+    """The acceptance test of testing/PlanePhantomUSCalibrationParametersEstimatorTest.cxx:277-379:
+    only T3 is checked (t3 within 3 mm, one of the two Euler solutions within 5 degrees, scales
+    within 1.0); the rotation is rebuilt from the derived products est[11..13], est[20..22], est[38]."""
+    est = np.asarray(est, dtype=np.float64)
+    if est.size == 0:
+        return False
+    r1 = est[11:14] / (est[9] * est[38])
+    r2 = est[20:23] / (est[10] * est[38])
+    R = np.column_stack([r1, r2, np.cross(r1, r2)])
+    small, half_pi = 0.008726535498373935, np.pi / 2
+    h = np.hypot(R[0, 0], R[1, 0])
+    y1, y2 = np.arctan2(-R[2, 0], h), np.arctan2(-R[2, 0], -h)
+    if abs(y1 - half_pi) > small and abs(y1 + half_pi) > small:
+        c1, c2 = np.cos(y1), np.cos(y2)
+        z1, x1 = np.arctan2(R[1, 0] / c1, R[0, 0] / c1), np.arctan2(R[2, 1] / c1, R[2, 2] / c1)
+        z2, x2 = np.arctan2(R[1, 0] / c2, R[0, 0] / c2), np.arctan2(R[2, 1] / c2, R[2, 2] / c2)
+    else:
+        z1 = z2 = 0.0
+        x1 = x2 = np.arctan2(R[0, 1], R[1, 1])
+    t = truth[6:9]
+    ang = (np.all(np.abs(np.array([z1, y1, x1]) - t) < ang_eps)
+           or np.all(np.abs(np.array([z2, y2, x2]) - t) < ang_eps))
+    return bool(np.all(np.abs(est[3:6] - truth[3:6]) < trans_eps) and ang
+                and abs(est[9] - truth[9]) < scale_eps and abs(est[10] - truth[10]) < scale_eps)

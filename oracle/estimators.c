@@ -31,6 +31,7 @@ int orc_min_subset(const orc_cfg *c) {
     case ORC_PIVOT: return 3;           /* PivotCalibration...cxx:7 */
     case ORC_RAY: return 2;             /* RayIntersection...cxx:11 */
     case ORC_LINE2D: return 2;          /* Line2DParametersEstimator.cxx:6 */
+    case ORC_PHANTOM: return 31;        /* PlanePhantomUSCalibration...cxx:10 */
   }
   return 0;
 }
@@ -46,6 +47,7 @@ int orc_num_params(const orc_cfg *c) {
     case ORC_PIVOT: return 6; /* [DRF^t, W^t] */
     case ORC_RAY: return 3;   /* [x,y,z] */
     case ORC_LINE2D: return 4; /* [n_x,n_y,a_x,a_y] */
+    case ORC_PHANTOM: return 41;
   }
   return 0;
 }
@@ -61,6 +63,7 @@ int orc_record_doubles(const orc_cfg *c) {
     case ORC_PIVOT: return 13; /* Frame: rotation 9, translation 3, int outputFormat + pad */
     case ORC_RAY: return 6;    /* Ray3D: Point3D p, Vector3D n (common/Ray3D.h:23-24) */
     case ORC_LINE2D: return 2; /* Point2D */
+    case ORC_PHANTOM: return 15; /* Frame + Point2D, as ORC_US_SINGLE */
   }
   return 0;
 }
@@ -596,6 +599,210 @@ static int pivot_agree(double delta, const double *par, const double *f) {
 
 
 
+
+/* ================================================================== plane-phantom US calibration */
+/* PlanePhantomUSCalibrationParametersEstimator.{h,cxx}; record = US single record (Frame T2 slots
+ * 0..11, Point2D q slots 13..14); parameters: 11 minimal [omega1_y, omega1_x, t1_z, t3(3), omega3_z,
+ * omega3_y, omega3_x, m_x, m_y] + 30 derived products (.cxx:325-354) = 41. */
+/* the data row a_i of the homogeneous system (.cxx:163-193); f_i = a_i . e(parameters) */
+static void phantom_row(const double *rec, double a[31]) {
+  double u = rec[US_Q], v = rec[US_Q + 1];
+  int j;
+  for (j = 0; j < 9; j++) {
+    a[j] = rec[j] * u;
+    a[9 + j] = rec[j] * v;
+    a[18 + j] = rec[j];
+  }
+  a[27] = rec[US_T2];
+  a[28] = rec[US_T2 + 1];
+  a[29] = rec[US_T2 + 2];
+  a[30] = 1;
+}
+/* .cxx:73-135: the 31-term sum in the reference's order (u*R2*p, left to right) */
+static double phantom_err(const double *par, const double *rec) {
+  double u = rec[US_Q], v = rec[US_Q + 1], err;
+  const double *R2 = rec, *t2 = rec + US_T2;
+  err = u * R2[0] * par[11] + u * R2[1] * par[12] + u * R2[2] * par[13] + u * R2[3] * par[14] +
+        u * R2[4] * par[15] + u * R2[5] * par[16] + u * R2[6] * par[17] + u * R2[7] * par[18] +
+        u * R2[8] * par[19] + v * R2[0] * par[20] + v * R2[1] * par[21] + v * R2[2] * par[22] +
+        v * R2[3] * par[23] + v * R2[4] * par[24] + v * R2[5] * par[25] + v * R2[6] * par[26] +
+        v * R2[7] * par[27] + v * R2[8] * par[28] + R2[0] * par[29] + R2[1] * par[30] +
+        R2[2] * par[31] + R2[3] * par[32] + R2[4] * par[33] + R2[5] * par[34] + R2[6] * par[35] +
+        R2[7] * par[36] + R2[8] * par[37] + t2[0] * par[38] + t2[1] * par[39] + t2[2] * par[40] +
+        par[2];
+  return err;
+}
+static int phantom_agree(double delta_sq, const double *par, const double *rec) {
+  double err = phantom_err(par, rec);
+  return (err * err < delta_sq);
+}
+/* the 30 derived entries from the 11 minimal ones (.cxx:383-452) */
+static void phantom_expand(double *p) {
+  double cy = cos(p[0]), sy = sin(p[0]), cx = cos(p[1]), sx = sin(p[1]);
+  double R1[3], R3[9], cz, sz, mx = p[9], my = p[10];
+  int k = 11, a, j;
+  R1[0] = -sy;
+  R1[1] = cy * sx;
+  R1[2] = cy * cx;
+  cz = cos(p[6]); sz = sin(p[6]);
+  cy = cos(p[7]); sy = sin(p[7]);
+  cx = cos(p[8]); sx = sin(p[8]);
+  R3[0] = cz * cy; R3[1] = cz * sy * sx - sz * cx; R3[2] = cz * sy * cx + sz * sx;
+  R3[3] = sz * cy; R3[4] = sz * sy * sx + cz * cx; R3[5] = sz * sy * cx - cz * sx;
+  R3[6] = -sy;     R3[7] = cy * sx;                R3[8] = cy * cx;
+  for (a = 0; a < 3; a++)
+    for (j = 0; j < 3; j++) p[k++] = mx * R3[3 * j + 0] * R1[a];
+  for (a = 0; a < 3; a++)
+    for (j = 0; j < 3; j++) p[k++] = my * R3[3 * j + 1] * R1[a];
+  for (a = 0; a < 3; a++)
+    for (j = 0; j < 3; j++) p[k++] = p[3 + j] * R1[a];
+  for (a = 0; a < 3; a++) p[k++] = R1[a];
+}
+/* .cxx:137-355 */
+int orc_phantom_analytic(const double *const *recs, size_t n, double *out) {
+  const double smallAngle = 0.008726535498373935, halfPI = 1.5707963267948966192313216916398;
+  double *A, *U, s[31], V[31 * 31], x[31], denominator, scaleFactor, t1_z, R1_31, R1_32, R1_33;
+  double omega1_y, omega1_x, t3[3], r1[3], r2[3], r3[3], m_x, m_y, R3[9], U3[9], s3[3], V3[9];
+  double omega3_z, omega3_y, omega3_x, nrm;
+  size_t i;
+  int j, k, rank = 0;
+  if (n < 31) return 0;
+  A = (double *)malloc(n * 31 * sizeof(double));
+  U = (double *)malloc(n * 31 * sizeof(double));
+  for (i = 0; i < n; i++) phantom_row(recs[i], A + 31 * i);
+  orc_svd((int)n, 31, A, U, s, V); /* singular values descending: column 30 = smallest (:203) */
+  free(A);
+  free(U);
+  for (j = 0; j < 31; j++) rank += (s[j] > 0.0); /* vnl_svd default: only exact zeros are dropped */
+  if (rank < 31) return 0;
+  for (j = 0; j < 31; j++) x[j] = V[j * 31 + 30];
+  denominator = sqrt(x[27] * x[27] + x[28] * x[28] + x[29] * x[29]);
+  if (denominator < EPS) return 0;
+  scaleFactor = 1 / denominator;
+  for (j = 0; j < 31; j++) x[j] *= scaleFactor;
+  t1_z = x[30];
+  R1_31 = x[27];
+  R1_32 = x[28];
+  R1_33 = x[29];
+  omega1_y = atan2(-R1_31, sqrt(R1_32 * R1_32 + R1_33 * R1_33));
+  if (fabs(omega1_y - halfPI) > smallAngle && fabs(omega1_y + halfPI) > smallAngle) {
+    double cy = cos(omega1_y);
+    omega1_x = atan2(R1_32 / cy, R1_33 / cy);
+  } else {
+    omega1_x = 0.0;
+  }
+  for (j = 0; j < 3; j++) t3[j] = (x[18 + j] / R1_31 + x[21 + j] / R1_32 + x[24 + j] / R1_33) / 3.0;
+  for (j = 0; j < 3; j++) {
+    r1[j] = (x[j] / R1_31 + x[3 + j] / R1_32 + x[6 + j] / R1_33) / 3.0;
+    r2[j] = (x[9 + j] / R1_31 + x[12 + j] / R1_32 + x[15 + j] / R1_33) / 3.0;
+  }
+  m_x = sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+  nrm = r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2];
+  if (nrm != 0) for (j = 0; j < 3; j++) r1[j] = (1.0 / sqrt(nrm)) * r1[j];
+  m_y = sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+  nrm = r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2];
+  if (nrm != 0) for (j = 0; j < 3; j++) r2[j] = (1.0 / sqrt(nrm)) * r2[j];
+  r3[0] = r1[1] * r2[2] - r1[2] * r2[1];
+  r3[1] = r1[2] * r2[0] - r1[0] * r2[2];
+  r3[2] = r1[0] * r2[1] - r1[1] * r2[0];
+  for (j = 0; j < 3; j++) {
+    R3[3 * j + 0] = r1[j];
+    R3[3 * j + 1] = r2[j];
+    R3[3 * j + 2] = r3[j];
+  }
+  orc_svd(3, 3, R3, U3, s3, V3);
+  for (j = 0; j < 3; j++)
+    for (k = 0; k < 3; k++) {
+      double sum = 0;
+      int l;
+      for (l = 0; l < 3; l++) sum += U3[3 * j + l] * V3[3 * k + l];
+      R3[3 * j + k] = sum;
+    }
+  omega3_y = atan2(-R3[6], sqrt(R3[0] * R3[0] + R3[3] * R3[3]));
+  if (fabs(omega3_y - halfPI) > smallAngle && fabs(omega3_y + halfPI) > smallAngle) {
+    double cy = cos(omega3_y);
+    omega3_z = atan2(R3[3] / cy, R3[0] / cy);
+    omega3_x = atan2(R3[7] / cy, R3[8] / cy);
+  } else {
+    omega3_z = 0;
+    omega3_x = atan2(R3[1], R3[4]);
+  }
+  out[0] = omega1_y; out[1] = omega1_x; out[2] = t1_z;
+  out[3] = t3[0]; out[4] = t3[1]; out[5] = t3[2];
+  out[6] = omega3_z; out[7] = omega3_y; out[8] = omega3_x;
+  out[9] = m_x; out[10] = m_y;
+  k = 11;
+  {
+    double R1[3];
+    int a;
+    R1[0] = R1_31; R1[1] = R1_32; R1[2] = R1_33;
+    for (a = 0; a < 3; a++)
+      for (j = 0; j < 3; j++) out[k++] = m_x * R3[3 * j + 0] * R1[a];
+    for (a = 0; a < 3; a++)
+      for (j = 0; j < 3; j++) out[k++] = m_y * R3[3 * j + 1] * R1[a];
+    for (a = 0; a < 3; a++)
+      for (j = 0; j < 3; j++) out[k++] = t3[j] * R1[a];
+    for (a = 0; a < 3; a++) out[k++] = R1[a];
+  }
+  return 41;
+}
+typedef struct { const double *const *recs; } phantom_lm_ctx;
+/* .cxx:564-670 (f); the reference runs vnl_levenberg_marquardt WITHOUT a gradient (:552), i.e.
+ * MINPACK lmdif: the Jacobian comes from forward differences with step sqrt(eps) |x_j| */
+static void phantom_fvec(const phantom_lm_ctx *c, int m, const double *x, double *fvec) {
+  double p[41];
+  int i;
+  for (i = 0; i < 11; i++) p[i] = x[i];
+  phantom_expand(p);
+  for (i = 0; i < m; i++) fvec[i] = phantom_err(p, c->recs[i]);
+}
+static void phantom_lm_fcn(void *vctx, int m, int n, const double *x, double *fvec, double *fjac,
+                           int iflag) {
+  const phantom_lm_ctx *c = (const phantom_lm_ctx *)vctx;
+  if (iflag == 1) {
+    phantom_fvec(c, m, x, fvec);
+  } else { /* fdjac2 */
+    const double eps = sqrt(2.220446049250313e-16);
+    double *f0 = (double *)malloc(2 * (size_t)m * sizeof(double)), *f1 = f0 + m, xx[11];
+    int i, j;
+    phantom_fvec(c, m, x, f0);
+    for (j = 0; j < n; j++) {
+      double h = eps * fabs(x[j]);
+      if (h == 0.0) h = eps;
+      for (i = 0; i < n; i++) xx[i] = x[i];
+      xx[j] = x[j] + h;
+      phantom_fvec(c, m, xx, f1);
+      for (i = 0; i < m; i++) fjac[(size_t)i * n + j] = (f1[i] - f0[i]) / h;
+    }
+    free(f0);
+  }
+}
+/* .cxx:357-453 */
+int orc_phantom_iterative(const double *const *recs, size_t n, const double *init, double *out,
+                          int *info_out, int *nfev_out) {
+  double x[11];
+  int info, nfev, i;
+  phantom_lm_ctx c;
+  c.recs = recs;
+  for (i = 0; i < 11; i++) x[i] = init[i];
+  info = orc_lmder(phantom_lm_fcn, &c, (int)n, 11, x, 10e-16, 10e-16, 10e-16, 5000, 100.0, &nfev,
+                   NULL, NULL);
+  if (info_out) *info_out = info;
+  if (nfev_out) *nfev_out = nfev;
+  for (i = 0; i < 11; i++) out[i] = x[i];
+  phantom_expand(out);
+  if (info < 1 || info > 4) return 0;
+  return 41;
+}
+/* .cxx:36-57 */
+static int phantom_ls(const orc_cfg *c, const double *const *recs, size_t n, double *out) {
+  double init[41];
+  if (n < 31) return 0;
+  if (c->ls_type == ORC_LS_ALGEBRAIC) return orc_phantom_analytic(recs, n, out);
+  if (!orc_phantom_analytic(recs, n, init)) return 0;
+  return orc_phantom_iterative(recs, n, init, out, NULL, NULL);
+}
+
 /* ================================================================== 2-D line, normal form */
 /* Line2DParametersEstimator.cxx:9-27 */
 static int line2d_estimate(double delta_sq, const double *const *p, size_t n, double *out) {
@@ -1034,6 +1241,9 @@ int orc_estimate(const orc_cfg *c, const double *const *recs, size_t n, double *
     case ORC_PIVOT: return pivot_solve(recs, n < 3 ? n : 3, params);
     case ORC_RAY: return ray_estimate(sin(c->aux) * sin(c->aux), recs, n, params);
     case ORC_LINE2D: return line2d_estimate(c->delta * c->delta, recs, n, params);
+    case ORC_PHANTOM: /* .cxx:16-24: exactly 31 elements */
+      if (n != 31) return 0;
+      return orc_phantom_analytic(recs, n, params);
     case ORC_US_SINGLE: /* :17-25: exactly minForEstimate elements */
     case ORC_US_POINTER:
       if (n != (size_t)orc_min_subset(c)) return 0;
@@ -1052,6 +1262,7 @@ int orc_agree(const orc_cfg *c, const double *params, const double *rec) {
     case ORC_PIVOT: return pivot_agree(c->delta, params, rec);
     case ORC_RAY: return ray_agree(c->delta * c->delta, params, rec);
     case ORC_LINE2D: return plane_agree(2, c->delta * c->delta, params, rec); /* .cxx:117-121 */
+    case ORC_PHANTOM: return phantom_agree(c->delta * c->delta, params, rec);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_agree(c->model, c->delta * c->delta, params, rec);
   }
@@ -1068,6 +1279,7 @@ int orc_ls(const orc_cfg *c, const double *const *recs, size_t n, double *params
     case ORC_PIVOT: return pivot_solve(recs, n, params);
     case ORC_RAY: return ray_ls(recs, n, params);
     case ORC_LINE2D: return line2d_ls(recs, n, params);
+    case ORC_PHANTOM: return phantom_ls(c, recs, n, params);
     case ORC_US_SINGLE:
     case ORC_US_POINTER: return us_ls(c, recs, n, params);
   }
@@ -1151,6 +1363,7 @@ int orc_stats(const orc_cfg *c, const double *params, const double *data, size_t
       case ORC_LINE2D:
         dist = fabs(params[0] * (x[0] - params[2]) + params[1] * (x[1] - params[3]));
         break;
+      case ORC_PHANTOM: dist = fabs(phantom_err(params, x)); break; /* .cxx:455-549 */
       case ORC_RAY: { /* distance of the point from the ray's line */
         double t = x[3] * (params[0] - x[0]) + x[4] * (params[1] - x[1]) + x[5] * (params[2] - x[2]);
         double e[3];

@@ -45,7 +45,8 @@ enum {
   ORC_ABSOR = 7,   /* AbsoluteOrientationParametersEstimator  params [s,qx,qy,qz,tx,ty,tz]           */
   ORC_PIVOT = 8,   /* PivotCalibrationEstimator               params [DRF^t(3), W^t(3)]              */
   ORC_RAY = 9,     /* RayIntersectionParametersEstimator      params [x,y,z]; record Ray3D = [p(3), n(3)] */
-  ORC_LINE2D = 10  /* Line2DParametersEstimator               params [n_x,n_y,a_x,a_y]; record Point2D    */
+  ORC_LINE2D = 10, /* Line2DParametersEstimator               params [n_x,n_y,a_x,a_y]; record Point2D    */
+  ORC_PHANTOM = 11 /* PlanePhantomUSCalibrationParametersEstimator  41 params; record as ORC_US_SINGLE     */
 };
 
 enum { ORC_LS_ALGEBRAIC = 0, ORC_LS_GEOMETRIC = 1 }; /* sphere; US: 0 = ANALYTIC, 1 = ITERATIVE */
@@ -81,6 +82,9 @@ int orc_sphere_geometric(int dim, const double *const *recs, size_t n, const dou
 int orc_us_analytic(int model, const double *const *recs, size_t n, double *params);
 int orc_us_iterative(int model, const double *const *recs, size_t n, const double *init,
                      double *params, int *info, int *nfev);
+int orc_phantom_analytic(const double *const *recs, size_t n, double *params);
+int orc_phantom_iterative(const double *const *recs, size_t n, const double *init, double *params,
+                          int *info, int *nfev);
 /* residual statistics as getDistanceStatistics(): out = {min, max, mean, sumsq} */
 int orc_stats(const orc_cfg *c, const double *params, const double *data, size_t n,
               size_t stride, const uint8_t *mask, double out[4]);

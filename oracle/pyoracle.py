@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY, LINE2D = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY, LINE2D, PHANTOM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 
 
@@ -341,3 +341,22 @@ def us_iterative(model, recs, init):
                            C.byref(info), C.byref(nfev))
     # the last iterate is returned even when the reference would report failure (info not in 1..4)
     return out[:(20 if model == US_SINGLE else 17)].copy(), info.value, nfev.value
+
+
+def phantom_analytic(recs):
+    a = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, 15)
+    rows = [np.ascontiguousarray(a[i]) for i in range(a.shape[0])]
+    out = np.zeros(41)
+    n = lib().orc_phantom_analytic(_ptrs(rows), len(rows), _d(out))
+    return out[:n].copy()
+
+
+def phantom_iterative(recs, init):
+    a = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, 15)
+    rows = [np.ascontiguousarray(a[i]) for i in range(a.shape[0])]
+    init = np.ascontiguousarray(init, dtype=np.float64)
+    out = np.zeros(41)
+    info, nfev = C.c_int(0), C.c_int(0)
+    lib().orc_phantom_iterative(_ptrs(rows), len(rows), _d(init), _d(out), C.byref(info),
+                                C.byref(nfev))
+    return out.copy(), info.value, nfev.value

@@ -1461,3 +1461,97 @@ def test_cell_scan_falls_back_when_the_index_cannot_be_built(ctx):
     ctx.upload(data)                                     # a new upload may try again
     ctx.hypotheses_sample(2, 0, 3000)
     assert np.array_equal(_scan_votes(ctx, 2), ref) and ctx.index_info()["built"]
+
+
+# ---- PlanePhantomUSCalibration ---------------------------------------------------
+def _phantom_close(got, want, rtol=REL, atol=1e-6):
+    """The sign of a singular vector is arbitrary (PlanePhantom...Estimator.cxx:215-218 says as much of
+    its scale factor): T3 (entries 3..10) is unaffected, t1_z and the 30 derived products flip together."""
+    assert len(got) == len(want) == 41
+    s = 1.0 if np.dot(got[38:41], want[38:41]) >= 0 else -1.0
+    assert np.allclose(got[3:11], want[3:11], rtol=rtol, atol=atol)
+    assert np.allclose(s * got[11:41], want[11:41], rtol=rtol, atol=atol)
+    assert np.isclose(s * got[2], want[2], rtol=rtol, atol=atol)
+
+
+def test_plane_phantom_device_path(ctx):
+    """PlanePhantomUSCalibration: 31-frame null-vector solves against the oracle's SVD, agree() scan
+    bit-exact on the device's own models, both least squares fits from the Gram matrix."""
+    clean, truth, _ = synth.plane_phantom(80, 0.0, seed=41, pixel_sigma=0.0)
+    noisy, _, _ = synth.plane_phantom(80, 0.0, seed=41, pixel_sigma=1.0)
+    oc = O.cfg(O.PHANTOM, 0, 3.0, 1)
+    ctx.set_model(L.PHANTOM, 0, 3.0, L.LS_ITERATIVE).upload(clean)
+    assert (ctx.K, ctx.P, ctx.ND) == (31, 41, 15)
+    H = 24
+    subs = np.vstack([np.arange(31, dtype=np.uint32)[None, :], O.ctr_subsets(51, 0, H - 1, 80, 31)])
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    assert valid.all()
+    assert synth.phantom_check(par[0], truth) and votes[0] == 80
+    for h in range(H):
+        want = O.estimate(oc, clean[subs[h]])
+        _phantom_close(par[h], want, rtol=1e-5, atol=1e-5)   # null vector of an exact system: cond * eps
+        assert votes[h] == O.scan(oc, par[h], clean)[0]
+    # noisy frames: the minimal models differ, the scan must still match the oracle bit for bit
+    ctx.upload(noisy)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    for h in range(H):
+        want = O.estimate(oc, noisy[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0)
+        _phantom_close(par[h], want, rtol=1e-5, atol=1e-5)
+        wcnt, wmask = O.scan(oc, par[h], noisy)
+        assert votes[h] == wcnt
+    m, cnt = ctx.mask(par[3])
+    wcnt, wmask = O.scan(oc, par[3], noisy)
+    assert cnt == wcnt and np.array_equal(m, wmask)
+    # least squares, analytic then iterative (the reference test's sequence, .cxx:167-186)
+    ctx.set_model(L.PHANTOM, 0, 3.0, L.LS_ANALYTIC).upload(noisy)
+    an, _ = ctx.ls_fit(use_mask=False)
+    want = O.ls(O.cfg(O.PHANTOM, 0, 3.0, 0), noisy)
+    _phantom_close(an, want)
+    assert synth.phantom_check(an, truth)
+    ctx.set_model(L.PHANTOM, 0, 3.0, L.LS_ITERATIVE).upload(noisy)
+    it, info = ctx.ls_fit(use_mask=False)
+    want = O.ls(oc, noisy)
+    # the reference differentiates numerically (lmdif), the device path analytically: same minimum
+    _phantom_close(it, want, rtol=1e-5, atol=1e-5)
+    assert synth.phantom_check(it, truth)
+    assert 1 <= info.lm_info <= 4
+    st_it, st_an = ctx.stats(it), ctx.stats(an)
+    assert st_it[3] <= st_an[3] + 1e-9
+    assert np.allclose(st_it, O.stats(oc, it, noisy), rtol=1e-9, atol=1e-12)
+    # masked fit = fit of the subset
+    mask = np.zeros(80, dtype=np.uint8)
+    mask[5:70] = 1
+    ctx.set_mask(mask)
+    fit, _ = ctx.ls_fit(use_mask=True)
+    _phantom_close(fit, O.ls(oc, noisy, mask), rtol=1e-5, atol=1e-5)
+    # fewer than 31 frames: no estimate (.cxx:139-141)
+    ctx.upload(noisy[:31])
+    ctx.set_mask(np.r_[np.ones(30, np.uint8), np.zeros(1, np.uint8)])
+    fit, _ = ctx.ls_fit(use_mask=True)
+    assert len(fit) == 0
+
+
+def test_plane_phantom_ransac_end_to_end(ctx):
+    """examples/planeUSCalibration.cxx: RANSAC over the phantom estimator (k = 31, p = 0.999); same loop
+    as the serial oracle on the same subset stream, then a large frame set through the batch chain."""
+    rec, truth, lab = synth.plane_phantom(150, 0.08, seed=43, pixel_sigma=0.0)
+    oc = O.cfg(O.PHANTOM, 0, 2.0, 1)
+    ctx.set_model(L.PHANTOM, 0, 2.0, L.LS_ITERATIVE).upload(rec)
+    r = ctx.ransac(0.999, seed=9)
+    w = O.ransac(oc, rec, 0.999, sampler="ctr", seed=9)
+    assert r["info"].iterations == w["iters"]
+    assert np.array_equal(r["consensus"], w["consensus"])
+    assert np.array_equal(r["consensus"].astype(bool), lab)
+    assert synth.phantom_check(r["params"], truth)
+    _phantom_close(r["params"], w["params"], rtol=1e-4, atol=1e-4)
+    big, truth, lab = synth.plane_phantom(60_000, 0.05, seed=44, pixel_sigma=0.0)
+    ctx.upload(big)
+    b = ctx.batch_fit(3, 0, 512, want_consensus=True)
+    assert np.array_equal(b["consensus"].astype(bool), lab)
+    assert b["info"].best_votes == lab.sum() == b["info"].fit.n_used
+    assert synth.phantom_check(b["params"], truth)

@@ -321,3 +321,38 @@ def test_line2d_like_reference_test():
     # agrees with the hyperplane estimator's fit up to the sign of the normal
     pl = O.ls(O.cfg(O.PLANE, 2, 0.5), pts)
     assert abs(abs(pl[:2] @ ls[:2]) - 1) < 1e-9 and np.allclose(pl[2:], ls[2:], atol=1e-9)
+
+
+# ---- PlanePhantomUSCalibration -------------------------------------------------
+def test_plane_phantom_like_reference_test():
+    """testing/PlanePhantomUSCalibrationParametersEstimatorTest.cxx:131-187: 50 frames, pixel noise 1,
+    delta 3: minimal estimate from the first 31 clean frames, then the analytic and the iterative
+    least squares on the noisy frames, each within the test's tolerances (synth.phantom_check)."""
+    c = O.cfg(O.PHANTOM, 0, 3.0, 1)
+    clean, truth, _ = synth.plane_phantom(50, 0.0, seed=31, pixel_sigma=0.0)
+    ex = O.estimate(c, clean[:31])
+    assert len(ex) == 41
+    assert synth.phantom_check(ex, truth)
+    assert O.agree(c, ex, clean[0]) and O.agree(c, ex, clean[45])
+    assert len(O.estimate(c, clean[:30])) == 0 and len(O.estimate(c, clean[:32])) == 0  # exactly 31 (.cxx:19)
+    noisy, truth, _ = synth.plane_phantom(50, 0.0, seed=31, pixel_sigma=1.0)
+    an = O.ls(O.cfg(O.PHANTOM, 0, 3.0, 0), noisy)
+    it = O.ls(c, noisy)
+    assert len(an) == 41 and len(it) == 41
+    assert synth.phantom_check(an, truth) and synth.phantom_check(it, truth)
+    sse = lambda p: O.stats(c, p, noisy)[3]
+    assert sse(it) <= sse(an) + 1e-9  # LM does not worsen the analytic start
+    # the 30 trailing entries are products of the 11 (.cxx:325-354)
+    assert np.allclose(it[38:41], [-np.sin(it[0]), np.cos(it[0]) * np.sin(it[1]), np.cos(it[0]) * np.cos(it[1])])
+    assert np.allclose(it[29:32], it[3:6] * it[38])
+
+
+def test_plane_phantom_ransac_rejects_off_plane_frames():
+    """RANSAC over the phantom estimator (k = 31): frames whose target point is off the plane are
+    not in the consensus set."""
+    rec, truth, lab = synth.plane_phantom(120, 0.1, seed=32, pixel_sigma=0.0)  # k = 31: noise-free inliers
+    c = O.cfg(O.PHANTOM, 0, 3.0, 1)
+    r = O.ransac(c, rec, 0.99, seed=5)
+    assert len(r["params"]) == 41
+    assert synth.phantom_check(r["params"], truth)
+    assert not r["consensus"][~lab].any() and r["consensus"][lab].mean() > 0.9
