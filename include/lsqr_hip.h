@@ -187,13 +187,21 @@ LSQR_API int lsqr_winner_moments(lsqr_ctx *ctx, uint64_t seed, uint64_t stream_i
 /* Levenberg-Marquardt over summed phase-1 blocks (MINPACK lmder control flow on the device):
  *   lsqr_lm_begin(x0) -> x_trial;  repeat { block = sum over ranks of lsqr_moments(phase 1,
  *   x_trial);  lsqr_lm_step(block) -> cont, x_trial }  until !cont.  On the last step params_out
- *   receives the full parameter vector (status LSQR_EMPTY if LM did not converge). */
+ *   receives the full parameter vector (status LSQR_EMPTY if LM did not converge).
+ *   LSQR_MODEL_PHANTOM: every residual is linear in 31 functions of the parameters, so the phase-1
+ *   block is the phase-0 Gram block (independent of x_trial) and the first lsqr_lm_step runs the whole
+ *   minimisation from x0 on it (cont = 0). */
 LSQR_API int lsqr_lm_begin(lsqr_ctx *ctx, const double *x0, double *x_trial_out);
 LSQR_API int lsqr_lm_step(lsqr_ctx *ctx, const double *block, double *x_trial_out, int *cont,
                           double *params_out, lsqr_fit_info *info);
 /* residual statistics as getDistanceStatistics() (SphereParametersEstimator.hxx:341-377):
  * out = {min, max, mean, sum of squares} */
 LSQR_API int lsqr_stats(lsqr_ctx *ctx, const double *params, int use_mask, double out[4]);
+/* the residual of every record in [begin, end) under `params`, in record order: the `distances`
+ * vector of PlanePhantomUSCalibrationParametersEstimator::getDistanceStatistics (.cxx:455-549);
+ * defined for every model (the quantity lsqr_stats summarises).  out: end - begin doubles (host). */
+LSQR_API int lsqr_residuals(lsqr_ctx *ctx, const double *params, size_t begin, size_t end,
+                            double *out);
 
 /* ---- whole path: RANSAC<T,S>::compute() ------------------------------------------------------ */
 /* Probabilistic overload (RANSAC.h:75-79).  Subsets come from `subsets` (n_subsets tuples, draw

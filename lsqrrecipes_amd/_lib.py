@@ -84,6 +84,7 @@ SIGNATURES = {
     "lsqr_lm_step": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                C.POINTER(FitInfo)]),
     "lsqr_stats": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    "lsqr_residuals": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "lsqr_ransac": (C.c_int, [_ctx, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p,
                               C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_batch_fit": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p,

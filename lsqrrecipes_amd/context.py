@@ -158,6 +158,7 @@ class Context:
 
     def lm_begin(self, x0):
         x = np.zeros(32)
+        x0 = np.asarray(x0, dtype=np.float64)[:32]
         x[:len(x0)] = x0
         xt = np.zeros(32)
         self._chk(self._lib.lsqr_lm_begin(self._h, L.ptr(x), L.ptr(xt)))
@@ -166,7 +167,7 @@ class Context:
     def lm_step(self, block):
         b = np.ascontiguousarray(block, dtype=np.float64)
         xt = np.zeros(32)
-        out = np.zeros(32)
+        out = np.zeros(max(self.P, 64))
         cont = C.c_int(0)
         info = L.FitInfo()
         st = self._chk(self._lib.lsqr_lm_step(self._h, L.ptr(b), L.ptr(xt), C.byref(cont),
@@ -177,6 +178,14 @@ class Context:
         p = np.ascontiguousarray(params, dtype=np.float64)
         out = np.zeros(4)
         self._chk(self._lib.lsqr_stats(self._h, L.ptr(p), int(use_mask), L.ptr(out)))
+        return out
+
+    def residuals(self, params, begin=0, end=None):
+        """the model's residual of every record in [begin, end) (lsqr_residuals)"""
+        end = self.n if end is None else end
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        out = np.zeros(end - begin)
+        self._chk(self._lib.lsqr_residuals(self._h, L.ptr(p), begin, end, L.ptr(out)))
         return out
 
     # ---- whole path ---------------------------------------------------------------------

@@ -551,4 +551,21 @@ __global__ __launch_bounds__(kBlock) void k_stats(const double *__restrict__ dat
   }
 }
 
+// the model's residual of every record in [begin, end) (PlanePhantom...Estimator.cxx:455-549 returns
+// the whole vector next to the statistics)
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_residuals(const double *__restrict__ data, size_t stride,
+                                                      size_t begin, size_t end,
+                                                      const double *__restrict__ par, ModelConsts mc,
+                                                      double *__restrict__ out) {
+  double pv[M::P];
+  for (int k = 0; k < M::P; k++) pv[k] = par[k];
+  for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < end;
+       i += (size_t)gridDim.x * kBlock) {
+    double x[M::REC];
+    M::load(data + i * stride, mc, x);
+    out[i - begin] = M::residual(pv, x, mc);
+  }
+}
+
 }  // namespace lsqr

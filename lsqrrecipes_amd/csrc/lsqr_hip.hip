@@ -755,14 +755,38 @@ int launch_moments_phantom(lsqr_ctx *c, int use_mask, size_t begin, size_t end, 
   return launch_syrk(c, c->d_rows, 32, 30, use_mask, begin, end, nmom);
 }
 
+// PlanePhantom...Estimator.cxx:357-453: Levenberg-Marquardt on the 11 minimal parameters, every
+// evaluation a function of the Gram matrix G (31 x 31, full); s: initialised by lm_init
+void phantom_lm(const double *G, LmState &s, SolveOut *out) {
+  double blk78[LM_MOM_MAX], par[64];
+  for (;;) {
+    phantom_lm_block(G, s.xtrial, blk78);
+    if (!lm_advance(s, blk78)) break;
+  }
+  const bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
+  for (int j = 0; j < 11; j++) par[j] = s.x[j];
+  PhantomModel::expand(par);
+  memset(out, 0, sizeof *out);
+  out->ok = ok ? 1 : 0;
+  out->n_params = ok ? PhantomModel::P : 0;
+  out->lm_info = s.info;
+  out->lm_nfev = s.nfev;
+  out->cost = s.fnorm * s.fnorm;
+  for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
+}
+
+void phantom_unpack(const double *blk, double *G) {
+  for (int i = 0; i < 31; i++)
+    for (int j = i; j < 31; j++) G[i * 31 + j] = G[j * 31 + i] = blk[i * 31 - i * (i - 1) / 2 + (j - i)];
+}
+
 // plane phantom: both fits from the Gram block on the host (31-dimensional, like the LM control flow)
 void phantom_solve_block(const lsqr_model_cfg &cfg, const double *blk, SolveOut *out) {
   memset(out, 0, sizeof *out);
   const int N = 31;
   if (!(blk[496] >= 31.0)) return;  // PlanePhantom...Estimator.cxx:139-141: fewer than 31 frames
   double G[N * N], a[N * N], w[N], v[N * N], x[N], par[64];
-  for (int i = 0; i < N; i++)
-    for (int j = i; j < N; j++) G[i * N + j] = G[j * N + i] = blk[i * N - i * (i - 1) / 2 + (j - i)];
+  phantom_unpack(blk, G);
   for (int i = 0; i < N * N; i++) {
     if (!(fabs(G[i]) <= 1e300)) return;  // non-finite data: no estimate
     a[i] = G[i];
@@ -782,23 +806,9 @@ void phantom_solve_block(const lsqr_model_cfg &cfg, const double *blk, SolveOut 
     for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
     return;
   }
-  // .cxx:357-453: Levenberg-Marquardt on the 11 minimal parameters from the analytic estimate
   LmState s;
-  double blk78[LM_MOM_MAX];
   lm_init(s, 11, par, 10e-16, 10e-16, 10e-16, 5000, 100.0);
-  for (;;) {
-    phantom_lm_block(G, s.xtrial, blk78);
-    if (!lm_advance(s, blk78)) break;
-  }
-  const bool ok = s.info >= 1 && s.info <= 4;
-  for (int j = 0; j < 11; j++) par[j] = s.x[j];
-  PhantomModel::expand(par);
-  out->ok = ok ? 1 : 0;
-  out->n_params = ok ? PhantomModel::P : 0;
-  out->lm_info = s.info;
-  out->lm_nfev = s.nfev;
-  out->cost = s.fnorm * s.fnorm;
-  for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
+  phantom_lm(G, s, out);
 }
 
 int launch_solve_dense(lsqr_ctx *c) {
@@ -812,7 +822,7 @@ int launch_solve_dense(lsqr_ctx *c) {
 template <class M>
 int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase, int *nmom) {
   if constexpr (requires { M::IS_PHANTOM; }) {
-    if (phase != 0) return fail(c, LSQR_ERR_INVALID, "the phantom's iterative fit runs on the phase-0 block");
+    (void)phase;  // the LM block at any x is a function of the Gram block
     return launch_moments_phantom(c, use_mask, begin, end, nmom);
   } else if constexpr (M::IS_DENSE) {
     if (phase != 0) return fail(c, LSQR_ERR_INVALID, "dense model has no iterative phase");
@@ -874,7 +884,8 @@ int read_out(lsqr_ctx *c, SolveOut *o) {
 bool wants_lm(const lsqr_model_cfg &cfg) {
   return (cfg.model == LSQR_MODEL_SPHERE && cfg.ls_type == LSQR_LS_GEOMETRIC) ||
          ((cfg.model == LSQR_MODEL_US_SINGLE || cfg.model == LSQR_MODEL_US_POINTER) &&
-          cfg.ls_type == LSQR_LS_ITERATIVE);
+          cfg.ls_type == LSQR_LS_ITERATIVE) ||
+         (cfg.model == LSQR_MODEL_PHANTOM && cfg.ls_type == LSQR_LS_ITERATIVE);
 }
 
 void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, double *gtol,
@@ -887,6 +898,10 @@ void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, 
   *gtol = 10e-16;
   *maxfev = 500;
   if (cfg.model == LSQR_MODEL_US_SINGLE) {  // SinglePointTarget...Estimator.cxx:287-295
+    *n = 11;
+    *ftol = *xtol = *gtol = 10e-16;
+    *maxfev = 5000;
+  } else if (cfg.model == LSQR_MODEL_PHANTOM) {  // PlanePhantom...Estimator.cxx:368-376
     *n = 11;
     *ftol = *xtol = *gtol = 10e-16;
     *maxfev = 5000;
@@ -1454,7 +1469,7 @@ int lsqr_moments_len(const lsqr_model_cfg *cfg, int phase) {
   return dispatch(*cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     if constexpr (requires { M::IS_PHANTOM; }) {
-      return phase == 0 ? dense_ne(30) + 1 : 0;
+      return phase == 0 || phase == 1 ? dense_ne(30) + 1 : 0;  // phase 1: the same block (lsqr_hip.h)
     } else if constexpr (M::IS_DENSE) {
       return phase == 0 ? dense_ne(cfg->dim) + 1 : 0;
     } else {
@@ -1543,7 +1558,7 @@ int lsqr_lm_begin(lsqr_ctx *c, const double *x0, double *x_trial_out) {
   int n, maxfev;
   double ftol, xtol, gtol;
   lm_settings(c->cfg, &n, &ftol, &xtol, &gtol, &maxfev);
-  if (c->opt_lm_host) {
+  if (c->opt_lm_host || c->cfg.model == LSQR_MODEL_PHANTOM) {
     lm_init(c->h_lm, n, x0, ftol, xtol, gtol, maxfev, 100.0);
     if (x_trial_out)
       for (int j = 0; j < n; j++) x_trial_out[j] = x0[j];
@@ -1570,6 +1585,18 @@ int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *con
   if (!block || !cont) return fail(c, LSQR_ERR_INVALID, "null argument");
   int nmom = lsqr_moments_len(&c->cfg, 1);
   if (nmom <= 0) return fail(c, LSQR_ERR_INVALID, "model has no iterative phase");
+  if (c->cfg.model == LSQR_MODEL_PHANTOM) {  // the whole minimisation on the (summed) Gram block
+    double G[31 * 31];
+    SolveOut out;
+    phantom_unpack(block, G);
+    phantom_lm(G, c->h_lm, &out);
+    *cont = 0;
+    fill_info(out, info);
+    if (!out.ok) return LSQR_EMPTY;
+    if (params_out)
+      for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+    return LSQR_OK;
+  }
   if (c->opt_lm_host) {
     LmState &s = c->h_lm;
     bool go = lm_advance(s, block);
@@ -1674,6 +1701,31 @@ int lsqr_stats(lsqr_ctx *c, const double *params, int use_mask, double out[4]) {
   out[1] = mx;
   out[2] = sum / cnt;
   out[3] = sq;
+  return LSQR_OK;
+}
+
+int lsqr_residuals(lsqr_ctx *c, const double *params, size_t begin, size_t end, double *out) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!params || !out || begin > end || end > c->n) return fail(c, LSQR_ERR_INVALID, "bad argument");
+  if (begin == end) return LSQR_OK;
+  // staged through d_rows (the phantom's row matrix is rebuilt on the next fit)
+  c->rows_valid = false;
+  if ((st = ensure(c, &c->d_rows, &c->rows_cap, end - begin)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice, c->stream));
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    int grid = grid_for(end - begin, kBlock, 256 * 8);
+    hipLaunchKernelGGL((k_residuals<M>), dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
+                       begin, end, c->d_par, c->mc, c->d_rows);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  });
+  if (st != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(out, c->d_rows, sizeof(double) * (end - begin), hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LSQR_OK;
 }
 

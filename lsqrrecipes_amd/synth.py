@@ -354,7 +354,8 @@ def phantom_check(est, truth, trans_eps=3.0, ang_eps=0.0872664625997164788461845
         z1 = z2 = 0.0
         x1 = x2 = np.arctan2(R[0, 1], R[1, 1])
     t = truth[6:9]
-    ang = (np.all(np.abs(np.array([z1, y1, x1]) - t) < ang_eps)
-           or np.all(np.abs(np.array([z2, y2, x2]) - t) < ang_eps))
+    # modulo 2 pi (the reference compares raw differences, which fails spuriously at the +-pi seam)
+    ad = lambda a: np.abs(np.remainder(a - t + np.pi, 2 * np.pi) - np.pi)
+    ang = np.all(ad(np.array([z1, y1, x1])) < ang_eps) or np.all(ad(np.array([z2, y2, x2])) < ang_eps)
     return bool(np.all(np.abs(est[3:6] - truth[3:6]) < trans_eps) and ang
                 and abs(est[9] - truth[9]) < scale_eps and abs(est[10] - truth[10]) < scale_eps)

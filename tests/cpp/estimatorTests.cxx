@@ -2,7 +2,8 @@
 // (testing/PlaneParametersEstimatorTest.cxx, SphereParametersEstimatorTest.cxx,
 // LineParametersEstimatorTest.cxx, DenseLinearEquationSystemParametersEstimatorTest.cxx,
 // SinglePointTargetUSCalibrationParametersEstimatorTest.cxx, and -- SURVEY.md section 8f --
-// AbsoluteOrientationParametersEstimatorTest.cxx, PivotCalibrationParametersEstimatorTest.cxx)
+// AbsoluteOrientationParametersEstimatorTest.cxx, PivotCalibrationParametersEstimatorTest.cxx,
+// PlanePhantomUSCalibrationParametersEstimatorTest.cxx)
 // re-written against the drop-in
 // headers, plus RANSAC-level checks (the reference has none).  Runs on the GPU through the C++
 // API exactly as a user of the reference would call it.  Exit code 0 == all passed.
@@ -21,6 +22,7 @@
 #include "Line2DParametersEstimator.h"
 #include "LineParametersEstimator.h"
 #include "PivotCalibrationParametersEstimator.h"
+#include "PlanePhantomUSCalibrationParametersEstimator.h"
 #include "PlaneParametersEstimator.h"
 #include "RayIntersectionParametersEstimator.h"
 #include "RANSAC.h"
@@ -293,6 +295,120 @@ static void usTest() {  // testing/SinglePointTargetUSCalibration...Test.cxx:179
   }
 }
 
+// testing/PlanePhantomUSCalibrationParametersEstimatorTest.cxx:277-379: only T3 is compared (3 mm, 5
+// degrees on one of the two Euler solutions, scale 1.0)
+static bool phantomClose(const std::vector<double> &e, const double t3[3], const double w3[3],
+                         double mx, double my) {
+  if (e.size() != 41) return false;
+  const double ANG = 0.08726646259971647884618453842445, small = 0.008726535498373935,
+               halfPI = 1.5707963267948966192313216916398;
+  double r1[3], r2[3], R[3][3];
+  for (int j = 0; j < 3; j++) {
+    r1[j] = e[11 + j] / (e[9] * e[38]);
+    r2[j] = e[20 + j] / (e[10] * e[38]);
+  }
+  double r3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  for (int j = 0; j < 3; j++) R[j][0] = r1[j], R[j][1] = r2[j], R[j][2] = r3[j];
+  const double h = std::sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
+  const double y1 = std::atan2(-R[2][0], h), y2 = std::atan2(-R[2][0], -h);
+  double z1, z2, x1, x2;
+  if (std::fabs(y1 - halfPI) > small && std::fabs(y1 + halfPI) > small) {
+    double c1 = std::cos(y1), c2 = std::cos(y2);
+    z1 = std::atan2(R[1][0] / c1, R[0][0] / c1), x1 = std::atan2(R[2][1] / c1, R[2][2] / c1);
+    z2 = std::atan2(R[1][0] / c2, R[0][0] / c2), x2 = std::atan2(R[2][1] / c2, R[2][2] / c2);
+  } else {
+    z1 = z2 = 0;
+    x1 = x2 = std::atan2(R[0][1], R[1][1]);
+  }
+  // w3 = {x, y, z}
+  // angles compared modulo 2 pi (the reference compares raw differences, which fails spuriously when
+  // a true angle sits at the +-pi seam)
+  auto ad = [](double a, double b) { return std::fabs(std::remainder(a - b, 2 * 3.14159265358979323846)); };
+  bool ang = (ad(z1, w3[2]) < ANG && ad(y1, w3[1]) < ANG && ad(x1, w3[0]) < ANG) ||
+             (ad(z2, w3[2]) < ANG && ad(y2, w3[1]) < ANG && ad(x2, w3[0]) < ANG);
+  bool tr = std::fabs(e[3] - t3[0]) < 3.0 && std::fabs(e[4] - t3[1]) < 3.0 && std::fabs(e[5] - t3[2]) < 3.0;
+  const bool ok = ang && tr && std::fabs(e[9] - mx) < 1.0 && std::fabs(e[10] - my) < 1.0;
+  if (!ok) {
+    std::printf("  phantom estimate t3 %.6g %.6g %.6g  w3(z,y,x) %.6g %.6g %.6g | %.6g %.6g %.6g  m %.6g %.6g\n", e[3],
+                e[4], e[5], z1, y1, x1, z2, y2, x2, e[9], e[10]);
+    std::printf("  expected         t3 %.6g %.6g %.6g  w3(z,y,x) %.6g %.6g %.6g  m %.6g %.6g\n", t3[0], t3[1],
+                t3[2], w3[2], w3[1], w3[0], mx, my);
+  }
+  return ok;
+}
+
+static void phantomTest() {  // testing/PlanePhantomUSCalibration...Test.cxx:131-187, data :382-548
+  typedef PlanePhantomUSCalibrationParametersEstimator Est;
+  typedef Est::DataType D;
+  const double PI = 3.14159265358979323846, mx = 0.143, my = 0.139;
+  Frame T3, T1;
+  double w3[3] = {U(0, PI), U(0, PI), U(0, PI)}, t3[3] = {U(-100, 100), U(-100, 100), U(-100, 100)};
+  T3.setRotationEulerAngles(w3[0], w3[1], w3[2]);
+  T3.setTranslation(t3);
+  double t1[3] = {U(-100, 100), U(-100, 100), U(-100, 100)}, R1[3][3];
+  T1.setRotationEulerAngles(U(0, PI), U(0, PI), U(0, PI));
+  T1.getRotationMatrix(R1);
+  std::vector<D> clean, noisy;
+  for (int i = 0; i < 50; i++) {
+    D d;
+    double u = U(0, 640), v = U(0, 480), q[3] = {mx * u, my * v, 0}, q3[3], rq[3];
+    double onPlane[3] = {U(-100, 100), U(-100, 100), 0.0}, inTracker[3];
+    for (int r = 0; r < 3; r++) {
+      inTracker[r] = 0;
+      for (int c = 0; c < 3; c++) inTracker[r] += R1[c][r] * (onPlane[c] - t1[c]);
+    }
+    d.T2.setRotationEulerAngles(U(0, PI), U(0, PI), U(0, PI));
+    T3.apply(q, q3);
+    d.T2.apply(q3, rq);
+    d.T2.setTranslation(inTracker[0] - rq[0], inTracker[1] - rq[1], inTracker[2] - rq[2]);
+    d.q[0] = u;
+    d.q[1] = v;
+    clean.push_back(d);
+    d.q[0] += N(1.0);
+    d.q[1] += N(1.0);
+    noisy.push_back(d);
+  }
+  Est est(3.0);
+  std::vector<D> minimal(clean.begin(), clean.begin() + 31);
+  std::vector<double> params;
+  est.estimate(minimal, params);
+  CHECK(phantomClose(params, t3, w3, mx, my));
+  if (params.size() == 41) CHECK(est.agree(params, clean[0]));
+  std::vector<D> tooMany(clean.begin(), clean.begin() + 32);
+  est.estimate(tooMany, params);
+  CHECK(params.empty());  // exactly 31 elements required (.cxx:19)
+  est.setLeastSquaresType(Est::ANALYTIC);
+  est.leastSquaresEstimate(noisy, params);
+  CHECK(phantomClose(params, t3, w3, mx, my));
+  std::vector<double> analytic(params), distances;
+  est.setLeastSquaresType(Est::ITERATIVE);
+  est.leastSquaresEstimate(noisy, params);
+  CHECK(phantomClose(params, t3, w3, mx, my));
+  double mn, mxd, mean, sseIt = 0, sseAn = 0;
+  if (params.size() == 41 && analytic.size() == 41) {
+    Est::getDistanceStatistics(params, noisy, distances, mn, mxd, mean);
+    CHECK(distances.size() == noisy.size());
+    double s = 0;
+    for (size_t i = 0; i < distances.size(); i++) {
+      sseIt += distances[i] * distances[i];
+      s += distances[i];
+      CHECK(distances[i] >= mn && distances[i] <= mxd);
+    }
+    CHECK(std::fabs(s / distances.size() - mean) < 1e-9);
+    Est::getDistanceStatistics(analytic, noisy, distances, mn, mxd, mean);
+    for (size_t i = 0; i < distances.size(); i++) sseAn += distances[i] * distances[i];
+    CHECK(sseIt <= sseAn + 1e-9);
+    // refinement from a caller-supplied start reaches the same minimum
+    std::vector<D *> ptrs;
+    for (size_t i = 0; i < noisy.size(); i++) ptrs.push_back(&noisy[i]);
+    std::vector<double> refined;
+    est.iterativeLeastSquaresEstimate(ptrs, analytic, refined);
+    CHECK(refined.size() == 41);
+    if (refined.size() == 41)
+      for (int j = 3; j < 11; j++) CHECK(std::fabs(refined[j] - params[j]) < 1e-6 * (1 + std::fabs(params[j])));
+  }
+}
+
 static void ransacTest() {
   typedef Point<double, 3> P;
   std::vector<P> data;
@@ -467,6 +583,7 @@ int main(int argc, char *argv[]) {
     lineTest();
     denseTest(argc > 1 ? argv[1] : 0);
     usTest();
+    phantomTest();
     absoluteOrientationTest();
     rayIntersectionTest();
     pivotTest(argc > 2 ? argv[2] : 0);

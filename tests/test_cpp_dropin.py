@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "examples", "build")
 PROGS = ["planeEstimation", "sphereEstimation", "lineEstimation", "linearEquationSystemSolver",
          "crosswireUSCalibration", "AbsoluteOrientation", "pivotCalibration",
-         "rayIntersectionEstimation", "estimatorTests"]
+         "rayIntersectionEstimation", "planeUSCalibration", "estimatorTests"]
 REFDATA = os.path.join(ROOT, "tests", "golden", "ref_data")
 
 
@@ -27,6 +27,7 @@ def test_reference_header_names_present():
               "SphereParametersEstimator.h", "LineParametersEstimator.h",
               "DenseLinearEquationSystemParametersEstimator.h",
               "SinglePointTargetUSCalibrationParametersEstimator.h",
+              "PlanePhantomUSCalibrationParametersEstimator.h",
               "AbsoluteOrientationParametersEstimator.h", "PivotCalibrationParametersEstimator.h",
               "RayIntersectionParametersEstimator.h", "Ray3D.h", "Vector3D.h",
               "Line2DParametersEstimator.h",
@@ -54,7 +55,8 @@ def test_reference_style_estimator_tests_on_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog", ["planeEstimation", "sphereEstimation", "lineEstimation",
-                                  "pivotCalibration", "rayIntersectionEstimation"])
+                                  "pivotCalibration", "rayIntersectionEstimation",
+                                  "planeUSCalibration"])
 def test_example_programs_on_gpu(prog):
     out = _run([prog])
     assert "RANSAC" in out

@@ -1523,6 +1523,18 @@ def test_plane_phantom_device_path(ctx):
     st_it, st_an = ctx.stats(it), ctx.stats(an)
     assert st_it[3] <= st_an[3] + 1e-9
     assert np.allclose(st_it, O.stats(oc, it, noisy), rtol=1e-9, atol=1e-12)
+    res = ctx.residuals(it)
+    assert res.shape == (80,) and res.min() == st_it[0] and res.max() == st_it[1]
+    assert np.isclose(res.mean(), st_it[2], rtol=1e-12) and np.isclose((res ** 2).sum(), st_it[3], rtol=1e-12)
+    assert np.array_equal(ctx.residuals(it, 10, 20), res[10:20])
+    # refinement from a caller-supplied start (iterativeLeastSquaresEstimate): lm_begin / one lm_step on
+    # the Gram block
+    blk = ctx.moments(np.zeros(32), phase=1)
+    assert len(blk) == ctx.moments_len(1) == 497 and blk[496] == 80
+    ctx.lm_begin(an[:11])
+    cont, _, ref, info2 = ctx.lm_step(blk)
+    assert not cont and 1 <= info2.lm_info <= 4
+    _phantom_close(ref, it, rtol=1e-7, atol=1e-7)
     # masked fit = fit of the subset
     mask = np.zeros(80, dtype=np.uint8)
     mask[5:70] = 1
@@ -1555,3 +1567,28 @@ def test_plane_phantom_ransac_end_to_end(ctx):
     assert np.array_equal(b["consensus"].astype(bool), lab)
     assert b["info"].best_votes == lab.sum() == b["info"].fit.n_used
     assert synth.phantom_check(b["params"], truth)
+
+
+def test_plane_phantom_sharded_step(ctx):
+    """multi-GPU step for the phantom: the slice's Gram block is what ranks exchange (497 doubles), the
+    solve (analytic + LM) runs from the summed block; world 1 must equal the single-device chain"""
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+    rec, truth, lab = synth.plane_phantom(20_000, 0.05, seed=45, pixel_sigma=0.0)
+    rec[:, 13:15] += np.random.default_rng(1).normal(0, 0.05, (len(rec), 2))   # mild pixel noise
+    ctx.set_model(L.PHANTOM, 0, 2.0, L.LS_ITERATIVE).upload(rec)
+    sr = ShardedRansac(ctx, Comm(None))
+    r = sr.step(7, 0, 512)
+    b = ctx.batch_fit(7, 0, 512)
+    assert r is not None and (r[0], r[1]) == (b["info"].best_votes, b["info"].best_index)
+    assert r[4] == b["info"].fit.n_used
+    _phantom_close(r[3], b["params"], rtol=1e-9, atol=1e-9)
+    assert synth.phantom_check(r[3], truth)
+    # two slices summed = one pass (what a world-2 all-reduce produces)
+    half = len(rec) // 2
+    m, _ = ctx.mask(b["params"])
+    blk = ctx.moments(np.zeros(3), 0, half, use_mask=True) + ctx.moments(np.zeros(3), half, len(rec), use_mask=True)
+    whole = ctx.moments(np.zeros(3), use_mask=True)
+    assert blk[-1] == whole[-1] == m.sum()
+    assert np.allclose(blk, whole, rtol=1e-12, atol=1e-9)
+    fit, _ = ctx.solve_moments(blk, np.zeros(3))
+    _phantom_close(fit, b["params"], rtol=1e-7, atol=1e-7)
