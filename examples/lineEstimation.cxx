@@ -1,10 +1,18 @@
-// lineEstimation -- counterpart of the reference's examples/lineEstimation.cxx.
+// lineEstimation -- counterpart of the reference's examples/lineEstimation.cxx; both fits are also
+// saved as Open Inventor scenes (leastSquaresLineEstimation.iv, RANSACLineEstimation.iv).
 #include <cstdlib>
 #include <iostream>
 
 #include "LineParametersEstimator.h"
 #include "RANSAC.h"
 #include "common.h"
+#include "oiv.h"
+
+// scene files go to $LSQR_OIV_DIR (default: the working directory, as the reference's example does)
+static std::string oivPath(const char *name) {
+  const char *dir = std::getenv("LSQR_OIV_DIR");
+  return std::string(dir ? dir : ".") + "/" + name;
+}
 
 int main() {
   const unsigned int DIM = 3;
@@ -33,12 +41,21 @@ int main() {
   lsqrRecipes::LineParametersEstimator<DIM> estimator(0.5);
   estimator.leastSquaresEstimate(data, params);
   printVec("Least squares line parameters [direction,a]", params);
-  double used = lsqrRecipes::RANSAC<P, double>::compute(params, &estimator, data, 0.999);
+  if (!params.empty()) {
+    OivScene scene(oivPath("leastSquaresLineEstimation.iv"));
+    scene.observations(data, classify(estimator, params, data), 50.0);
+    scene.line(params);
+  }
+  std::vector<bool> consensus;
+  double used = lsqrRecipes::RANSAC<P, double>::compute(params, &estimator, data, 0.999, &consensus);
   if (params.empty()) return EXIT_FAILURE;
   printVec("RANSAC line parameters [direction,a]", params);
   double dot = 0;
   for (unsigned i = 0; i < DIM; i++) dot += params[i] * d[i];
   std::cout << "\tDot product of real and computed directions[+-1=correct]: " << dot << "\n";
   std::cout << "\tPercentage of points which were used for final estimate: " << used << "\n";
+  OivScene scene(oivPath("RANSACLineEstimation.iv"));
+  scene.observations(data, consensus, 50.0);
+  scene.line(params);
   return std::fabs(std::fabs(dot) - 1.0) < 1e-5 ? EXIT_SUCCESS : EXIT_FAILURE;
 }

@@ -1,13 +1,22 @@
 // planeEstimation -- counterpart of the reference's examples/planeEstimation.cxx (main :60-148,
 // generateData :152-200) on the MI355X drop-in: synthesise points near a random plane plus outliers,
 // fit by plain least squares, then robustly with RANSAC; print the same quantities.  Returns non-zero
-// if the robust fit misses the known plane.  usage: planeEstimation [inliers outliers]
+// if the robust fit misses the known plane.  Both fits are also saved as Open Inventor scenes
+// (leastSquaresPlaneEstimation.iv, RANSACPlaneEstimation.iv; reference :65-66,:110,:145).
+// usage: planeEstimation [inliers outliers]
 #include <cstdlib>
 #include <iostream>
 
 #include "PlaneParametersEstimator.h"
 #include "RANSAC.h"
 #include "common.h"
+#include "oiv.h"
+
+// scene files go to $LSQR_OIV_DIR (default: the working directory, as the reference's example does)
+static std::string oivPath(const char *name) {
+  const char *dir = std::getenv("LSQR_OIV_DIR");
+  return std::string(dir ? dir : ".") + "/" + name;
+}
 
 int main(int argc, char *argv[]) {
   const unsigned int DIM = 3;
@@ -57,8 +66,12 @@ int main(int argc, char *argv[]) {
     }
     std::cout << "\tDot product of real and computed normals[+-1=correct]: " << dot << "\n";
     std::cout << "\tCheck if computed point is on known plane [0=correct]: " << off << "\n\n";
+    OivScene scene(oivPath("leastSquaresPlaneEstimation.iv"));
+    scene.observations(data, classify(estimator, params, data), 50.0);
+    scene.plane(params);
   }
-  double used = lsqrRecipes::RANSAC<P, double>::compute(params, &estimator, data, 0.999);
+  std::vector<bool> consensus;
+  double used = lsqrRecipes::RANSAC<P, double>::compute(params, &estimator, data, 0.999, &consensus);
   if (params.empty()) {
     std::cout << "RANSAC estimate failed, degenerate configuration?\n";
     return EXIT_FAILURE;
@@ -72,5 +85,8 @@ int main(int argc, char *argv[]) {
   std::cout << "\tDot product of real and computed normals[+-1=correct]: " << dot << "\n";
   std::cout << "\tCheck if computed point is on known plane [0=correct]: " << off << "\n\n";
   std::cout << "\tPercentage of points which were used for final estimate: " << used << "\n\n";
+  OivScene scene(oivPath("RANSACPlaneEstimation.iv"));
+  scene.observations(data, consensus, 50.0);
+  scene.plane(params);
   return (std::fabs(std::fabs(dot) - 1.0) < 1e-5 && std::fabs(off) < 0.5) ? EXIT_SUCCESS : EXIT_FAILURE;
 }

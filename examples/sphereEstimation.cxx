@@ -6,6 +6,13 @@
 #include "RANSAC.h"
 #include "SphereParametersEstimator.h"
 #include "common.h"
+#include "oiv.h"
+
+// scene files go to $LSQR_OIV_DIR (default: the working directory, as the reference's example does)
+static std::string oivPath(const char *name) {
+  const char *dir = std::getenv("LSQR_OIV_DIR");
+  return std::string(dir ? dir : ".") + "/" + name;
+}
 
 int main() {
   const unsigned int DIM = 3;
@@ -43,6 +50,11 @@ int main() {
   estimator.setLeastSquaresType(Est::GEOMETRIC);
   estimator.leastSquaresEstimate(data, params);
   printVec("Geometric least squares parameters [c,r] (all data, outliers included)", params);
+  if (!params.empty()) {
+    OivScene scene(oivPath("leastSquaresSphereEstimation.iv"));
+    scene.observations(data, classify(estimator, params, data), 15.0);
+    scene.sphere(params);
+  }
   std::vector<bool> consensus;
   double used = lsqrRecipes::RANSAC<P, double>::compute(params, &estimator, data, 0.999, &consensus);
   if (params.empty()) {
@@ -58,6 +70,9 @@ int main() {
   std::cout << "\tDifference between real and computed radius: " << params[DIM] - r << "\n";
   std::cout << "\tPercentage of points which were used for final estimate: " << used << "\n";
   std::cout << "\tResidual over all data: min " << mn << " max " << mx << " mean " << mean << "\n";
+  OivScene scene(oivPath("RANSACSphereEstimation.iv"));
+  scene.observations(data, consensus, 15.0);
+  scene.sphere(params);
   return (std::sqrt(dc) < 1.0 && std::fabs(params[DIM] - r) < 1.0 && used > 0.5) ? EXIT_SUCCESS
                                                                                   : EXIT_FAILURE;
 }

@@ -40,8 +40,11 @@ def _run(args):
     if not os.path.exists(os.path.join(BUILD, args[0])):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")],
                               stdout=subprocess.DEVNULL)
+    env = dict(os.environ)
+    env.setdefault("LSQR_OIV_DIR", os.path.join(BUILD, "scenes"))  # .iv scenes of the 3-D examples
+    os.makedirs(env["LSQR_OIV_DIR"], exist_ok=True)
     r = subprocess.run([os.path.join(BUILD, args[0])] + args[1:], capture_output=True, text=True,
-                       timeout=300)
+                       timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -99,3 +102,24 @@ def test_crosswire_writes_igstk_xml(tmp_path):
         tr = root.find("transformation")
         assert float(tr.attrib["estimation_error"]) >= 0
         assert len(tr.text.split()) == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,shape", [("planeEstimation", "IndexedFaceSet"), ("sphereEstimation", "Sphere"),
+                                        ("lineEstimation", "LineSet")])
+def test_examples_write_open_inventor_scenes(prog, shape):
+    """the reference's 3-D examples save their fits as Open Inventor scenes
+    (examples/planeEstimation.cxx:205-330): one ball per observation, green inside the consensus set,
+    plus the estimated model"""
+    _run([prog])
+    stem = prog.replace("Estimation", "").capitalize()
+    for kind in ("leastSquares", "RANSAC"):
+        path = os.path.join(BUILD, "scenes", "%s%sEstimation.iv" % (kind, stem))
+        text = open(path).read()
+        assert text.startswith("#Inventor V2.1 ascii")
+        assert text.count("Separator {") == 101 and text.count("Transform {") >= 100   # 100 observations + the model
+        assert text.count("{") == text.count("}")
+        assert shape in text.split("Separator {")[-1]
+        if kind == "RANSAC":   # consensus set green (noise 0.4 against delta 0.5: most of the 90), outliers red
+            green, red = text.count("ambientColor 0.0 1.0 0.0"), text.count("ambientColor 1.0 0.0 0.0")
+            assert green + red == 100 and 30 <= green <= 92
