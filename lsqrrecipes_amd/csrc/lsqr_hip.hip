@@ -253,7 +253,8 @@ int ensure_absmax(lsqr_ctx *c) {
   if (c->absmax_valid) return LSQR_OK;
   HIPCHK(c, hipMemsetAsync(c->d_counter + 5, 0, 2 * sizeof(unsigned long long), c->stream));
   int grid = grid_for(c->n, kBlock * 8, 2048);
-  const bool us = c->cfg.model == LSQR_MODEL_US_SINGLE || c->cfg.model == LSQR_MODEL_US_POINTER;
+  const bool us = c->cfg.model == LSQR_MODEL_US_SINGLE || c->cfg.model == LSQR_MODEL_US_POINTER ||
+                  c->cfg.model == LSQR_MODEL_PHANTOM;  // Frame records: int slot 12, rotation first
   hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
                      c->ND, us ? 12 : -1, us ? 9 : c->ND, c->d_counter + 5);
   HIPCHK(c, hipGetLastError());
@@ -277,6 +278,8 @@ int run_estimate(lsqr_ctx *c) {
     if constexpr (requires { M::IS_PHANTOM; }) {
       hipLaunchKernelGGL(k_estimate_phantom, dim3((unsigned)c->H), dim3(256), 0, c->stream, c->d_data,
                          c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid);
+      hipLaunchKernelGGL((k_prepare_f32_us<M>), dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0,
+                         c->stream, c->d_hparams, (uint32_t)c->H, c->mc, c->d_hparams_f32);
     } else if constexpr (M::IS_DENSE) {
       hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256),
                          dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
@@ -286,7 +289,7 @@ int run_estimate(lsqr_ctx *c) {
       hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
                          c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
                          c->mc, c->d_hparams, c->d_valid);
-      hipLaunchKernelGGL((k_prepare_f32_us<(M::K == 4)>), dim3((unsigned)((c->H + 255) / 256)),
+      hipLaunchKernelGGL((k_prepare_f32_us<M>), dim3((unsigned)((c->H + 255) / 256)),
                          dim3(256), 0, c->stream, c->d_hparams, (uint32_t)c->H, c->mc,
                          c->d_hparams_f32);
     } else {
@@ -598,9 +601,8 @@ int run_scan(lsqr_ctx *c) {
         return LSQR_OK;
       }
     }
-    if constexpr (M::IS_US) {  // packed fp32 pre-filter (scan_filter 1); 2 = the fused fp64 filter
+    if constexpr (requires { M::NF32; }) {  // packed fp32 pre-filter (scan_filter 1); US: 2 = the fused fp64 filter
       if (c->opt_filter == 1 && c->absmax_valid && c->mc.absmax <= 1e15) {
-        constexpr bool SINGLE = M::K == 4;
         const int np = c->opt_ppl == 2 ? 1 : 2;  // pairs of frames per lane (scan_ppl 2 / 4)
         HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
         size_t tiles = (c->n + (size_t)kBlock * 2 * np - 1) / ((size_t)kBlock * 2 * np);
@@ -618,11 +620,11 @@ int run_scan(lsqr_ctx *c) {
           if (c->opt_hsplit > 0) ysplit = (unsigned)c->opt_hsplit;
           ProfScope ps(c, KID_SCAN);
           if (np == 1)
-            hipLaunchKernelGGL((k_scan_us_f32<SINGLE, 1>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
+            hipLaunchKernelGGL((k_scan_us_f32<M, 1>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
                                c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
                                c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
           else
-            hipLaunchKernelGGL((k_scan_us_f32<SINGLE, 2>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
+            hipLaunchKernelGGL((k_scan_us_f32<M, 2>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
                                c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
                                c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
           HIPCHK(c, hipGetLastError());
@@ -740,6 +742,16 @@ int launch_moments_dense(lsqr_ctx *c, int use_mask, size_t begin, size_t end, in
   return launch_syrk(c, c->d_data, c->stride, (int)c->cfg.dim, use_mask, begin, end, nmom);
 }
 
+void phantom_to_out(const PhantomFit &f, SolveOut *out) {
+  memset(out, 0, sizeof *out);
+  out->ok = f.ok;
+  out->n_params = f.ok ? PhantomModel::P : 0;
+  out->lm_info = f.lm_info;
+  out->lm_nfev = f.lm_nfev;
+  out->cost = f.cost;
+  for (int j = 0; j < PhantomModel::P; j++) out->params[j] = f.params[j];
+}
+
 // plane phantom: the Gram matrix of the data rows (upper triangle, 496 sums) + the row count.  The rows
 // are materialised once per upload (256 B per frame) and summed on the matrix cores by the dense SYRK.
 int launch_moments_phantom(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int *nmom) {
@@ -755,60 +767,11 @@ int launch_moments_phantom(lsqr_ctx *c, int use_mask, size_t begin, size_t end, 
   return launch_syrk(c, c->d_rows, 32, 30, use_mask, begin, end, nmom);
 }
 
-// PlanePhantom...Estimator.cxx:357-453: Levenberg-Marquardt on the 11 minimal parameters, every
-// evaluation a function of the Gram matrix G (31 x 31, full); s: initialised by lm_init
-void phantom_lm(const double *G, LmState &s, SolveOut *out) {
-  double blk78[LM_MOM_MAX], par[64];
-  for (;;) {
-    phantom_lm_block(G, s.xtrial, blk78);
-    if (!lm_advance(s, blk78)) break;
-  }
-  const bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
-  for (int j = 0; j < 11; j++) par[j] = s.x[j];
-  PhantomModel::expand(par);
-  memset(out, 0, sizeof *out);
-  out->ok = ok ? 1 : 0;
-  out->n_params = ok ? PhantomModel::P : 0;
-  out->lm_info = s.info;
-  out->lm_nfev = s.nfev;
-  out->cost = s.fnorm * s.fnorm;
-  for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
-}
-
-void phantom_unpack(const double *blk, double *G) {
-  for (int i = 0; i < 31; i++)
-    for (int j = i; j < 31; j++) G[i * 31 + j] = G[j * 31 + i] = blk[i * 31 - i * (i - 1) / 2 + (j - i)];
-}
-
-// plane phantom: both fits from the Gram block on the host (31-dimensional, like the LM control flow)
+// plane phantom: both fits from the Gram block on the host (phantom.h)
 void phantom_solve_block(const lsqr_model_cfg &cfg, const double *blk, SolveOut *out) {
-  memset(out, 0, sizeof *out);
-  const int N = 31;
-  if (!(blk[496] >= 31.0)) return;  // PlanePhantom...Estimator.cxx:139-141: fewer than 31 frames
-  double G[N * N], a[N * N], w[N], v[N * N], x[N], par[64];
-  phantom_unpack(blk, G);
-  for (int i = 0; i < N * N; i++) {
-    if (!(fabs(G[i]) <= 1e300)) return;  // non-finite data: no estimate
-    a[i] = G[i];
-  }
-  sym_eig(N, a, w, v);  // ascending: column 0 belongs to the smallest singular value of the row matrix
-  for (int j = 0; j < N; j++) x[j] = v[j * N];
-  if (!PhantomModel::finish(x, par)) return;
-  if (cfg.ls_type != LSQR_LS_ITERATIVE) {
-    double e[N], cost = 0;  // e = x scaled as finish() scales it
-    double den = sqrt(x[27] * x[27] + x[28] * x[28] + x[29] * x[29]);
-    for (int j = 0; j < N; j++) e[j] = x[j] / den;
-    for (int i = 0; i < N; i++)
-      for (int j = 0; j < N; j++) cost += e[i] * G[i * N + j] * e[j];
-    out->ok = 1;
-    out->n_params = PhantomModel::P;
-    out->cost = cost > 0 ? cost : 0.0;
-    for (int j = 0; j < PhantomModel::P; j++) out->params[j] = par[j];
-    return;
-  }
-  LmState s;
-  lm_init(s, 11, par, 10e-16, 10e-16, 10e-16, 5000, 100.0);
-  phantom_lm(G, s, out);
+  PhantomFit f;
+  phantom_fit_block(blk, cfg.ls_type == LSQR_LS_ITERATIVE, &f);
+  phantom_to_out(f, out);
 }
 
 int launch_solve_dense(lsqr_ctx *c) {
@@ -1588,8 +1551,10 @@ int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *con
   if (c->cfg.model == LSQR_MODEL_PHANTOM) {  // the whole minimisation on the (summed) Gram block
     double G[31 * 31];
     SolveOut out;
+    PhantomFit f;
     phantom_unpack(block, G);
-    phantom_lm(G, c->h_lm, &out);
+    phantom_lm(G, c->h_lm, &f);
+    phantom_to_out(f, &out);
     *cont = 0;
     fill_info(out, info);
     if (!out.ok) return LSQR_EMPTY;

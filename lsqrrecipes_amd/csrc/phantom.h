@@ -18,16 +18,24 @@
 // reference fixes the scale factor's sign arbitrarily too (.cxx:215-218), it flips T1 and leaves
 // agree() -- a squared quantity -- unchanged.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#endif
+#include <string.h>
 
+#include "lm_core.h"
 #include "models.h"
+#if defined(__HIPCC__)
 #include "wave_linalg.h"
+#endif
 
 namespace lsqr {
 
 struct PhantomModel {
   enum { ND = 15, K = 31, P = 41, SP = 41, REC = 15, PPL = 2, IS_DENSE = 0, IS_US = 0, IS_PHANTOM = 1 };
   enum { NMOM = 1, NE = 31, NX = 11 };
+  // packed fp32 pre-filter of the scan (us_kernels.h: k_scan_us_f32): c0(3) c1(3) t3(3) R1(3) t1_z 0 tin tout
+  enum { SPF = 16, NF32 = 16, TIN = 14, NFLD = 14 };
   static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
 #pragma unroll
     for (int i = 0; i < ND; i++) rec[i] = (i == 12) ? 0.0 : p[i];
@@ -64,6 +72,83 @@ struct PhantomModel {
     return fabs(err(sp, x));
   }
   static LSQR_HD void prepare(double *, const ModelConsts &) {}
+
+  // ---- packed fp32 pre-filter ---------------------------------------------------------------------------
+  // The 30 products are m_x R3[:,0] R1[a], m_y R3[:,1] R1[a], t3 R1[a] (.cxx:325-354), so the error factors
+  // as  err = R1 . (R2 p + t2) + t1_z,  p = u c0 + v c1 + t3  with c0 = m_x R3[:,0], c1 = m_y R3[:,1]:
+  // 18 fused fp32 operations per frame instead of 62 fp64 ones.  c0, c1 are taken from the products of the
+  // largest |R1[a]| (>= 1/sqrt 3) and the factorisation is CHECKED against all 30 products; a parameter
+  // vector that does not factor (relative 1e-11) gets tin = -inf / tout = +inf, i.e. the exact predicate for
+  // every frame.  Bound: with X >= |u|, |v|, |t2|, Rm >= |R2 entries| (k_absmax),
+  //   s_j = (|c0_j| + |c1_j|) X + |t3_j|,  Q = Rm (s_0 + s_1 + s_2) + X,  W = (|R1_0|+|R1_1|+|R1_2|) Q + |t1_z|
+  // bounds every partial sum of either evaluation; the fp32 evaluation (inputs rounded once, 18 fma in
+  // chains of depth <= 9) is within 20 u32 W of the exact value, the reference's fp64 31-term sum (each
+  // term two products of rounded factors) within 64 u64 W, the refactoring (one division, one product per
+  // coefficient) within 8 u64 W.  |err| is compared with T = c.thr (|s| < T <=> fl(s s) < delta^2,
+  // models.h square_threshold):  v < T - E => agrees,  v >= T + E => does not.
+  static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
+    const double X = c.absmax, Rm = c.absmax_rot, u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
+    const double *R1 = sp + 38;
+    int a = fabs(R1[0]) >= fabs(R1[1]) ? 0 : 1;
+    if (fabs(R1[2]) > fabs(R1[a])) a = 2;
+    double c0[3], c1[3], t3[3], scale = 0.0, dev = 0.0;
+    bool finite = true;
+    for (int j = 0; j < P; j++) finite = finite && sp[j] == sp[j];
+    for (int j = 0; j < 3; j++) {
+      c0[j] = sp[11 + 3 * a + j] / R1[a];
+      c1[j] = sp[20 + 3 * a + j] / R1[a];
+      t3[j] = sp[29 + 3 * a + j] / R1[a];
+    }
+    for (int b = 0; b < 3; b++)
+      for (int j = 0; j < 3; j++) {
+        const double q0 = c0[j] * R1[b], q1 = c1[j] * R1[b], q2 = t3[j] * R1[b];
+        const double d0 = fabs(sp[11 + 3 * b + j] - q0), d1 = fabs(sp[20 + 3 * b + j] - q1),
+                     d2 = fabs(sp[29 + 3 * b + j] - q2);
+        // deviation weighted as the term enters the sum (u, v <= X; 1)
+        dev = fmax(dev, fmax(fmax(d0, d1) * X, d2));
+        scale = fmax(scale, fmax(fmax(fabs(q0), fabs(q1)) * X, fabs(q2)));
+      }
+    double S = 0.0;
+    for (int j = 0; j < 3; j++) S += (fabs(c0[j]) + fabs(c1[j])) * X + fabs(t3[j]);
+    const double Q = Rm * S + X;
+    const double W = (fabs(R1[0]) + fabs(R1[1]) + fabs(R1[2])) * Q + fabs(sp[2]);
+    const double E = 1.01 * ((20.0 * u32 + 72.0 * u64) * W);
+    const double T = c.thr;
+    const bool ok = finite && X <= 1e15 && X >= 1e-10 && Rm <= 1e15 && W <= 1e30 && fabs(R1[a]) >= 0.5 &&
+                    dev <= 1e-11 * scale && E <= 0.25 * T && T > 1e-15 && T <= 1e15;
+    for (int j = 0; j < 3; j++) {
+      f[j] = (float)c0[j];
+      f[3 + j] = (float)c1[j];
+      f[6 + j] = (float)t3[j];
+      f[9 + j] = (float)R1[j];
+    }
+    f[12] = (float)sp[2];
+    f[13] = 0.0f;
+    f[14] = ok ? PlaneModel<3>::round_down_f32(T - E) : -INFINITY;
+    f[15] = ok ? PlaneModel<3>::round_up_f32(T + E) : INFINITY;
+    if (!finite) f[14] = f[15] = __builtin_nanf("");  // NaN model: never agrees
+  }
+#if defined(__HIPCC__)
+  // xs: 14 packed fields of two frames (R2 0..8, t2 9..11, u 12, v 13); f as above (scalars) -> |err|
+  static __device__ inline v2f filter_value_f32(const v2f *xs, const float *f) {
+    v2f p[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      v2f t = {f[6 + j], f[6 + j]};
+      t = __builtin_elementwise_fma(xs[13], (v2f){f[3 + j], f[3 + j]}, t);
+      p[j] = __builtin_elementwise_fma(xs[12], (v2f){f[j], f[j]}, t);
+    }
+    v2f e = {f[12], f[12]};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      v2f q = __builtin_elementwise_fma(xs[3 * i + 2], p[2], xs[9 + i]);
+      q = __builtin_elementwise_fma(xs[3 * i + 1], p[1], q);
+      q = __builtin_elementwise_fma(xs[3 * i], p[0], q);
+      e = __builtin_elementwise_fma(q, (v2f){f[9 + i], f[9 + i]}, e);
+    }
+    return __builtin_elementwise_abs(e);
+  }
+#endif
   // the generic moment / solve templates are instantiated for every model; the phantom fit never
   // goes through them (run_fit branches on IS_PHANTOM)
   static LSQR_HD void accumulate(const double *, const double *, double *) {}
@@ -316,6 +401,68 @@ inline void phantom_lm_block(const double *G, const double *x, double *blk) {
     for (int i = 0; i < 31; i++) t += e[i].d[p] * Ge[i];
     blk[k++] = t;
   }
+}
+
+
+struct PhantomFit {
+  int ok, lm_info, lm_nfev;
+  double cost;  // sum of squared residuals at the result
+  double params[41];
+};
+
+inline void phantom_unpack(const double *blk, double *G) {  // upper triangle, row-major -> full 31 x 31
+  for (int i = 0; i < 31; i++)
+    for (int j = i; j < 31; j++) G[i * 31 + j] = G[j * 31 + i] = blk[i * 31 - i * (i - 1) / 2 + (j - i)];
+}
+
+// PlanePhantom...Estimator.cxx:357-453: Levenberg-Marquardt on the 11 minimal parameters, every
+// evaluation a function of the Gram matrix G (31 x 31, full); s: initialised by lm_init
+inline void phantom_lm(const double *G, LmState &s, PhantomFit *out) {
+  double blk78[LM_MOM_MAX], par[41];
+  for (;;) {
+    phantom_lm_block(G, s.xtrial, blk78);
+    if (!lm_advance(s, blk78)) break;
+  }
+  const bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
+  for (int j = 0; j < 11; j++) par[j] = s.x[j];
+  PhantomModel::expand(par);
+  out->ok = ok ? 1 : 0;
+  out->lm_info = s.info;
+  out->lm_nfev = s.nfev;
+  out->cost = s.fnorm * s.fnorm;
+  for (int j = 0; j < 41; j++) out->params[j] = par[j];
+}
+
+// leastSquaresEstimate() from the Gram block {upper triangle of G (496), number of frames}
+inline void phantom_fit_block(const double *blk, bool iterative, PhantomFit *out) {
+  memset(out, 0, sizeof *out);
+  const int N = 31;
+  if (!(blk[496] >= 31.0)) return;  // .cxx:139-141: fewer than 31 frames
+  double G[N * N], a[N * N], w[N], v[N * N], x[N], par[41];
+  phantom_unpack(blk, G);
+  for (int i = 0; i < N * N; i++) {
+    if (!(fabs(G[i]) <= 1e300)) return;  // non-finite data: no estimate
+    a[i] = G[i];
+  }
+  sym_eig(N, a, w, v);  // ascending: column 0 belongs to the smallest singular value of the row matrix
+  for (int j = 0; j < N; j++) x[j] = v[j * N];
+  if (!PhantomModel::finish(x, par)) return;
+  if (!iterative) {
+    // cost at the RETURNED parameters (their derived products are rebuilt from the extracted angles and
+    // scales, so they are not the scaled singular vector)
+    double e[N], cost = 0;
+    for (int j = 0; j < 30; j++) e[j] = par[11 + j];
+    e[30] = par[2];
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) cost += e[i] * G[i * N + j] * e[j];
+    out->ok = 1;
+    out->cost = cost > 0 ? cost : 0.0;
+    for (int j = 0; j < 41; j++) out->params[j] = par[j];
+    return;
+  }
+  LmState s;
+  lm_init(s, 11, par, 10e-16, 10e-16, 10e-16, 5000, 100.0);
+  phantom_lm(G, s, out);
 }
 
 }  // namespace lsqr

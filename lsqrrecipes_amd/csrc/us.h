@@ -140,6 +140,8 @@ struct USModel {
   // of the reference's; frames beyond evaluate above 3 delta^2 as long as Ee32 + Ee64 <= delta / 8.
   // With E = 1.01 Ed (required <= delta^2 / 4):  v < delta^2 - E => agrees,  v >= delta^2 + E => does not.
   enum { SPF = 16 };  // c0(3) c1(3) t3(3) t1(3) tin tout 0 0
+  // k_scan_us_f32: fp32 scalars fetched per hypothesis, index of tin (tout follows), fp32 record fields
+  enum { NF32 = 14, TIN = 12, NFLD = SINGLE ? 14 : 17 };
   static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
     const double X = c.absmax, Rm = c.absmax_rot, u = 5.9604644775390625e-08,
                  u64 = 1.1102230246251565e-16, d2 = c.delta_sq;

@@ -54,10 +54,9 @@ __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ d
 }
 
 // fp32 filter block of every hypothesis (after k_estimate_us)
-template <bool SINGLE>
+template <class M>
 __global__ __launch_bounds__(256) void k_prepare_f32_us(const double *__restrict__ hparams, uint32_t H,
                                                         ModelConsts mc, float *__restrict__ spf) {
-  typedef USModel<SINGLE> M;
   const uint32_t h = blockIdx.x * 256 + threadIdx.x;
   if (h >= H) return;
   double sp[M::SP];
@@ -67,18 +66,18 @@ __global__ __launch_bounds__(256) void k_prepare_f32_us(const double *__restrict
   for (int j = 0; j < M::SPF; j++) spf[(size_t)h * M::SPF + j] = f[j];
 }
 
-// K2 for the US estimators with the packed fp32 pre-filter: every lane keeps NP pairs of frames as
-// fp32 fields in registers, the hypotheses' 14 fp32 parameters arrive through the scalar cache; a
+// K2 for the US estimators (cross-wire, pointer, plane phantom: M = USModel<>, PhantomModel) with the
+// packed fp32 pre-filter: every lane keeps NP pairs of frames as
+// fp32 fields in registers, the hypotheses' M::NF32 fp32 parameters arrive through the scalar cache; a
 // v_min over the lane's values gives the one-compare "any candidate in this tile?" test; tiles with a
 // candidate take the inlier ballots, tiles with an observation inside the error band re-read the fp64
 // records and evaluate the exact predicate (bit-identical votes; same counting scheme as k_scan).
-template <bool SINGLE, int NP>
+template <class M, int NP>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_scan_us_f32(const double *__restrict__ data, size_t stride,
                                                         size_t n, const double *__restrict__ sp,
                                                         const float *__restrict__ spf, uint32_t H,
                                                         ModelConsts mc, uint32_t *__restrict__ votes) {
-  typedef USModel<SINGLE> M;
-  constexpr int NFLD = SINGLE ? 14 : 17;
+  constexpr int NFLD = M::NFLD, NF = M::NF32;
   extern __shared__ uint32_t s_cnt[];
   // blockIdx.y selects a segment of the hypothesis range: more resident waves when the observations
   // alone give fewer tiles than the chip has wave slots
@@ -107,19 +106,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         xs[q][k].y = i1 < n ? (float)p1[slot] : __builtin_nanf("");
       }
     }
-    float nx[14];  // the next hypothesis' block is fetched (scalar loads) while the current one is used
+    float nx[NF];  // the next hypothesis' block is fetched (scalar loads) while the current one is used
 #pragma unroll
-    for (int k = 0; k < 14; k++) nx[k] = spf[k];
+    for (int k = 0; k < NF; k++) nx[k] = spf[k];
     for (uint32_t h = 0; h < H; h++) {
-      float fl[14];
+      float fl[NF];
 #pragma unroll
-      for (int k = 0; k < 14; k++) fl[k] = nx[k];
+      for (int k = 0; k < NF; k++) fl[k] = nx[k];
       {
         const float *f = spf + (size_t)(h + 1 < H ? h + 1 : h) * M::SPF;  // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 14; k++) nx[k] = f[k];
+        for (int k = 0; k < NF; k++) nx[k] = f[k];
       }
-      const float tin = fl[12], tout = fl[13];
+      const float tin = fl[M::TIN], tout = fl[M::TIN + 1];
       v2f v[NP];
       float m = __builtin_inff();
 #pragma unroll

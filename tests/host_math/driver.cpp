@@ -1,5 +1,5 @@
 // Host-compiled unit-test driver for the PRODUCT's LSQR_HD math headers
-// (lsqrrecipes_amd/csrc/{models,lm_core,small_linalg,sampler}.h).  Built by tests/test_host_math.py
+// (lsqrrecipes_amd/csrc/{models,lm_core,small_linalg,sampler,us,phantom}.h).  Built by tests/test_host_math.py
 // with g++ -ffp-contract=off; lets the CPU suite check the product's per-model arithmetic, small
 // solvers and LM state machine against the oracle before anything runs on a GPU.  Test-only: the
 // product never executes this path.
@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "models.h"
+#include "phantom.h"
 #include "sampler.h"
 #include "us.h"
 
@@ -150,5 +151,45 @@ int hm_pinv_solve(int m, int n, double *a, const double *b, double tol, double *
   std::vector<double> s(n), v((size_t)n * n);
   return pinv_solve(m, n, a, n, b, tol, x, s.data(), v.data());
 }
+
+
+// ---- plane phantom (phantom.h): rows, agree(), parameter extraction, both fits from the Gram matrix ----
+void hm_phantom_rows(const double *rec, size_t n, double *rows31) {
+  for (size_t i = 0; i < n; i++) {
+    double x[PhantomModel::ND];
+    PhantomModel::load(rec + i * 15, ModelConsts(), x);
+    for (int c = 0; c < 31; c++) rows31[i * 31 + c] = PhantomModel::row_entry(x, c);
+  }
+}
+void hm_phantom_agree(const double *par, double delta, const double *rec, size_t n, uint8_t *mask,
+                      double *resid) {
+  ModelConsts mc = consts(0, delta, 1);
+  for (size_t i = 0; i < n; i++) {
+    double x[PhantomModel::ND];
+    PhantomModel::load(rec + i * 15, mc, x);
+    mask[i] = PhantomModel::agree(par, x, mc) ? 1 : 0;
+    resid[i] = PhantomModel::residual(par, x, mc);
+  }
+}
+int hm_phantom_finish(const double *x31, double *par41) { return PhantomModel::finish(x31, par41) ? 41 : 0; }
+// block: upper triangle of sum a a^T (496) + count; -> 41 parameters or 0
+int hm_phantom_fit(const double *block, int iterative, double *par41, int *info, int *nfev, double *cost) {
+  PhantomFit f;
+  phantom_fit_block(block, iterative != 0, &f);
+  *info = f.lm_info;
+  *nfev = f.lm_nfev;
+  *cost = f.cost;
+  for (int j = 0; j < 41; j++) par41[j] = f.params[j];
+  return f.ok ? 41 : 0;
+}
+// fp32 filter block of a hypothesis: f[16] = c0 c1 t3 R1 t1_z 0 tin tout (phantom.h prepare_f32)
+void hm_phantom_prepare_f32(const double *par41, double delta, double absmax, double absmax_rot, float *f16) {
+  ModelConsts mc = consts(0, delta, 1);
+  mc.absmax = absmax;
+  mc.absmax_rot = absmax_rot;
+  PhantomModel::prepare_f32(par41, mc, f16);
+}
+// LM block {cost, J^T J upper, J^T f} at x from the full Gram matrix
+void hm_phantom_lm_block(const double *G, const double *x11, double *blk78) { phantom_lm_block(G, x11, blk78); }
 
 }  // extern "C"

@@ -1592,3 +1592,50 @@ def test_plane_phantom_sharded_step(ctx):
     assert np.allclose(blk, whole, rtol=1e-12, atol=1e-9)
     fit, _ = ctx.solve_moments(blk, np.zeros(3))
     _phantom_close(fit, b["params"], rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [31, 1000, 300_001])
+def test_plane_phantom_filter_scan_equals_exact_scan(ctx, n):
+    """the packed fp32 pre-filter of the phantom scan (factored evaluation + rigorous band + exact re-check)
+    against the plain fp64 kernel, with frames pushed onto the agree() threshold to a few ulp"""
+    g = np.random.default_rng(7)
+    rec, truth, lab = synth.plane_phantom_fast(n, 0.3, seed=90 + n % 7, pixel_sigma=0.3)
+    clean = synth.plane_phantom_fast(max(n, 64), 0.0, seed=90 + n % 7, pixel_sigma=0.0)[0]
+    delta = 2.0
+    oc = O.cfg(O.PHANTOM, 0, delta, 1)
+    # hypotheses from clean frames (near the truth) so that many frames sit near the threshold after the push
+    ctx.set_model(L.PHANTOM, 0, delta, L.LS_ITERATIVE).upload(clean)
+    subs = O.ctr_subsets(5, 0, 64, len(clean), 31)
+    ctx.hypotheses_from_subsets(subs)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    assert valid.all()
+    evec = np.r_[par[0][11:41], par[0][2]]
+    k = min(n, 2000)
+    idx = g.choice(n, k, replace=False)
+    uu, vv = rec[idx, 13:14], rec[idx, 14:15]
+    rows = np.hstack([uu * rec[idx, :9], vv * rec[idx, :9], rec[idx, :9], rec[idx, 9:12], np.ones((k, 1))])
+    target = delta * g.choice([-1.0, 1.0], k) * (1.0 + g.choice([-1, 1], k) * 10.0 ** g.uniform(-15, -5, k))
+    rec[idx, 9:12] += np.outer(target - rows @ evec, par[0][38:41])
+    # scan the pushed frames with the same 64 models: subsets index the CLEAN upload, so keep the models and
+    # swap the data underneath by uploading rec with the clean minimal frames in front
+    both = np.vstack([clean[:64], rec]) if n >= 64 else np.vstack([clean, rec])
+    ctx.upload(both)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.set_option("scan_filter", 0)
+    ctx.scan()
+    par0, _, exact = ctx.hypotheses()
+    ctx.set_option("scan_filter", 1)
+    ctx.scan()
+    par1, _, filt = ctx.hypotheses()
+    assert np.array_equal(exact, filt) and np.array_equal(par0, par1)
+    for h in (0, 17, 63):
+        assert exact[h] == O.scan(oc, par0[h], both)[0]
+    # NaN / huge records never agree and do not disturb the filter
+    both[64 + 5, 9] = np.nan         # (past the clean frames the subsets index)
+    both[64 + 7, 13] = 1e300
+    ctx.upload(both)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    _, _, v = ctx.hypotheses()
+    for h in (0, 31):
+        assert v[h] == O.scan(oc, par0[h], both)[0]

@@ -265,3 +265,135 @@ def test_sphere_interval_thresholds_are_exact(hm):
         for d2 in cand:
             lit = abs(np.sqrt(np.float64(d2)) - r) < delta
             assert lit == (dlo <= d2 <= dhi), (r, delta, d2, dlo, dhi)
+
+
+def _phantom_gram_block(rows, mask=None):
+    r = rows if mask is None else rows[mask.astype(bool)]
+    G = r.T @ r
+    iu = np.triu_indices(31)
+    return np.ascontiguousarray(np.r_[G[iu], float(len(r))]), G
+
+
+def test_plane_phantom_host_math(hm):
+    """PhantomModel (lsqrrecipes_amd/csrc/phantom.h) on the host: data rows and agree() bit-identical to
+    the oracle's literal restatement, parameter extraction from a null vector, the LM block from the Gram
+    matrix against explicit residuals / finite differences, and both fits from the Gram block against the
+    oracle's SVD / lmdif fits on the frames."""
+    oc = O.cfg(O.PHANTOM, 0, 3.0, 1)
+    clean, truth, _ = synth.plane_phantom(90, 0.0, seed=71, pixel_sigma=0.0)
+    noisy, _, lab = synth.plane_phantom(90, 0.2, seed=71, pixel_sigma=1.0)
+    rows = np.zeros((90, 31))
+    hm.hm_phantom_rows(_p(noisy), 90, _p(rows))
+    u, v = noisy[:, 13:14], noisy[:, 14:15]
+    want_rows = np.hstack([u * noisy[:, :9], v * noisy[:, :9], noisy[:, :9], noisy[:, 9:12], np.ones((90, 1))])
+    assert np.array_equal(rows, want_rows)
+    # agree() / residual on a minimal model: bit-identical to the oracle
+    par = O.estimate(oc, clean[:31])
+    for d in (3.0, 0.05, 60.0):
+        mask, res = np.zeros(90, dtype=np.uint8), np.zeros(90)
+        hm.hm_phantom_agree(_p(par), C.c_double(d), _p(noisy), 90, _p(mask), _p(res))
+        cnt, om = O.scan(O.cfg(O.PHANTOM, 0, d, 1), par, noisy)
+        assert np.array_equal(mask, om)
+    st = O.stats(oc, par, noisy)
+    assert res.min() == st[0] and res.max() == st[1]
+    # parameter extraction: the truth's own 31-vector (and its negative) gives back T3
+    e = np.r_[truth[11:41], truth[2]]
+    for sgn in (1.0, -1.0):
+        out = np.zeros(41)
+        assert hm.hm_phantom_finish(_p(np.ascontiguousarray(sgn * e / np.linalg.norm(e))), _p(out)) == 41
+        assert synth.phantom_check(out, truth)
+        assert np.allclose(out[3:6], truth[3:6], rtol=1e-10) and np.allclose(out[9:11], truth[9:11], rtol=1e-10)
+    # LM block from G == explicit sums over the frames (forward differences for the Jacobian)
+    blk, G = _phantom_gram_block(rows)
+    x = truth[:11] + 0.01
+    got = np.zeros(78)
+    hm.hm_phantom_lm_block(_p(np.ascontiguousarray(G)), _p(np.ascontiguousarray(x)), _p(got))
+
+    def fvec(xx):
+        cy, sy, cx, sx = np.cos(xx[0]), np.sin(xx[0]), np.cos(xx[1]), np.sin(xx[1])
+        R1 = np.array([-sy, cy * sx, cy * cx])
+        R3 = synth.euler_zyx(xx[6], xx[7], xx[8])
+        e = np.r_[np.outer(R1, xx[9] * R3[:, 0]).ravel(), np.outer(R1, xx[10] * R3[:, 1]).ravel(),
+                  np.outer(R1, xx[3:6]).ravel(), R1, xx[2]]
+        return rows @ e
+    f0 = fvec(x)
+    J = np.zeros((90, 11))
+    for j in range(11):
+        h = 1e-6
+        xp, xm = x.copy(), x.copy()
+        xp[j] += h
+        xm[j] -= h
+        J[:, j] = (fvec(xp) - fvec(xm)) / (2 * h)
+    JtJ, Jtf = J.T @ J, J.T @ f0
+    assert np.isclose(got[0], f0 @ f0, rtol=1e-9)
+    assert np.allclose(got[1:67], JtJ[np.triu_indices(11)], rtol=1e-5, atol=1e-5 * np.abs(JtJ).max())
+    assert np.allclose(got[67:78], Jtf, rtol=1e-5, atol=1e-5 * np.abs(Jtf).max())
+    # fits from the Gram block == the oracle's fits on the frames (inliers only, as after RANSAC)
+    inl = np.ascontiguousarray(noisy[lab])
+    blk, _ = _phantom_gram_block(rows, lab)
+    out, info, nfev, cost = np.zeros(41), C.c_int(0), C.c_int(0), C.c_double(0)
+    for iterative in (0, 1):
+        n = hm.hm_phantom_fit(_p(blk), iterative, _p(out), C.byref(info), C.byref(nfev), C.byref(cost))
+        want = O.ls(O.cfg(O.PHANTOM, 0, 3.0, iterative), inl)
+        assert n == 41 == len(want)
+        s = 1.0 if np.dot(out[38:41], want[38:41]) >= 0 else -1.0     # singular-vector sign (phantom.h)
+        tol = 1e-5 if iterative else 1e-6
+        assert np.allclose(out[3:11], want[3:11], rtol=tol, atol=tol)
+        assert np.allclose(s * out[11:41], want[11:41], rtol=tol, atol=tol)
+        assert np.isclose(cost.value, O.stats(oc, want, inl)[3], rtol=1e-6)
+        assert synth.phantom_check(out, truth)
+    assert 1 <= info.value <= 4
+    # fewer than 31 frames / non-finite sums: no estimate
+    few, _ = _phantom_gram_block(rows[:30])
+    assert hm.hm_phantom_fit(_p(few), 1, _p(out), C.byref(info), C.byref(nfev), C.byref(cost)) == 0
+    bad = blk.copy()
+    bad[5] = np.nan
+    assert hm.hm_phantom_fit(_p(bad), 0, _p(out), C.byref(info), C.byref(nfev), C.byref(cost)) == 0
+
+
+def test_plane_phantom_fp32_filter_band_is_conservative(hm):
+    """phantom.h prepare_f32: the factored fp32 evaluation |R1 . (R2 (u c0 + v c1 + t3) + t2) + t1_z| (emulated
+    here in float32 WITHOUT fused operations, i.e. with more rounding than the kernel's fma chain) must
+    decide like the reference's fp64 31-term sum outside [tin, tout): v < tin => agrees, v >= tout =>
+    does not; frames pushed onto the threshold must land inside the band (exact re-check)."""
+    g = np.random.default_rng(5)
+    noisy, truth, lab = synth.plane_phantom_fast(20000, 0.3, seed=81, pixel_sigma=1.0)
+    clean = synth.plane_phantom_fast(64, 0.0, seed=81, pixel_sigma=0.0)[0]
+    X = np.abs(np.delete(noisy, 12, axis=1)).max()
+    Rm = np.abs(noisy[:, :9]).max()
+    f32 = np.float32
+    checked_band = 0
+    for delta in (2.0, 0.01, 50.0):
+        oc = O.cfg(O.PHANTOM, 0, delta, 1)
+        for s in O.ctr_subsets(9, 0, 6, 64, 31):
+            par = O.estimate(oc, clean[s])
+            par[:] = par  # minimal model of clean frames == the truth up to rounding
+            f = np.zeros(16, dtype=np.float32)
+            hm.hm_phantom_prepare_f32(_p(par), C.c_double(delta), C.c_double(X), C.c_double(Rm), _p(f))
+            tin, tout = f[14], f[15]
+            assert np.isfinite(tin) and np.isfinite(tout) and tin < tout
+            rec = noisy.copy()
+            # push 300 frames onto the threshold: err is linear in t2 with gradient R1 (unit), so shifting
+            # t2 along R1 sets err = +-delta (1 +- eps) for eps down to a few ulp
+            R1, evec = par[38:41], np.r_[par[11:41], par[2]]
+            idx = g.choice(len(rec), 300, replace=False)
+            uu, vv = rec[idx, 13:14], rec[idx, 14:15]
+            rows = np.hstack([uu * rec[idx, :9], vv * rec[idx, :9], rec[idx, :9], rec[idx, 9:12], np.ones((300, 1))])
+            target = delta * g.choice([-1.0, 1.0], 300) * (1.0 + g.choice([-1, 1], 300) * 10.0 ** g.uniform(-15, -6, 300))
+            rec[idx, 9:12] += np.outer(target - rows @ evec, R1)
+            r32 = rec.astype(f32)
+            u, v = r32[:, 13], r32[:, 14]
+            p = [u * f[j] + (v * f[3 + j] + f[6 + j]) for j in range(3)]
+            e = np.full(len(rec), f[12], dtype=f32)
+            for i in range(3):
+                q = r32[:, 3 * i] * p[0] + (r32[:, 3 * i + 1] * p[1] + (r32[:, 3 * i + 2] * p[2] + r32[:, 9 + i]))
+                e = q * f[9 + i] + e
+            val = np.abs(e)
+            cnt, m = O.scan(oc, par, rec)
+            m = m.astype(bool)
+            assert m[val < tin].all()
+            assert not m[val >= tout].any()
+            checked_band += int(((val >= tin) & (val < tout)).sum())
+            # the band is narrow: a few parts in 1e3 of delta at these magnitudes
+            assert (tout - tin) < max(0.02, 0.01 * delta) + 2e-2
+    assert checked_band >= 3 * 6 * 250   # the pushed frames sit inside the band
