@@ -248,8 +248,10 @@ struct PhantomModel {
 };
 
 #if defined(__HIPCC__)
-// K1: one 256-thread workgroup per hypothesis; the 31 x 31 system and V in LDS (2 x 31 x 31 x 8 B)
-__global__ __launch_bounds__(256) void k_estimate_phantom(const double *__restrict__ data, size_t stride,
+// K1: one workgroup of T threads (default: one wave) per hypothesis; the 31 x 31 system and V in LDS
+// (2 x 31 x 31 x 8 B)
+template <int T>
+__global__ __launch_bounds__(T) void k_estimate_phantom(const double *__restrict__ data, size_t stride,
                                                           size_t nobs,
                                                           const uint32_t *__restrict__ subsets,
                                                           uint32_t H, double *__restrict__ hparams,
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void k_estimate_phantom(const double *__restri
   const uint32_t h = blockIdx.x;
   if (tid == 0) s_bad = 0;
   __syncthreads();
-  for (int idx = tid; idx < N * M::ND; idx += 256) {
+  for (int idx = tid; idx < N * M::ND; idx += T) {
     int l = idx / M::ND, c = idx % M::ND;
     size_t i = subsets[(size_t)h * N + l];
     if (i >= nobs) {
@@ -272,13 +274,13 @@ __global__ __launch_bounds__(256) void k_estimate_phantom(const double *__restri
     recs[l][c] = (c == 12) ? 0.0 : data[i * stride + c];
   }
   __syncthreads();
-  for (int idx = tid; idx < N * N; idx += 256) {
+  for (int idx = tid; idx < N * N; idx += T) {
     int l = idx / N, c = idx % N;  // row (frame) l, column c
     A[c * LDA + l] = M::row_entry(recs[l], c);
   }
   __syncthreads();
   int npos = 0;
-  block_null_vector<256>(N, N, A, LDA, V, LDA, x, &npos);
+  block_null_vector<T, N, N>(N, N, A, LDA, V, LDA, x, &npos);
   if (tid == 0) s_npos = npos;
   __syncthreads();
   if (tid == 0) {

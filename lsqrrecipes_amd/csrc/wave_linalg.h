@@ -34,7 +34,7 @@ __device__ inline double wave_max(double v) {
 // One-sided Jacobi sweeps (see block_pinv_solve): A (m x n, column-major) becomes U*S, V (n x n)
 // accumulates the rotations.
 template <int T>
-__device__ inline void block_jacobi_svd(int m, int n, double *A, int lda, double *V, int ldv) {
+__device__ inline int block_jacobi_svd(int m, int n, double *A, int lda, double *V, int ldv) {
   constexpr int LPP = T / 32;  // lanes per pair
   const int tid = threadIdx.x;
   for (int idx = tid; idx < n * n; idx += T) {
@@ -44,7 +44,8 @@ __device__ inline void block_jacobi_svd(int m, int n, double *A, int lda, double
   __syncthreads();
   const int nn = (n + 1) & ~1;  // even number of players; index n is a dummy when n is odd
   const int p = tid / LPP, sub = tid % LPP;
-  for (int sweep = 0; sweep < 60; sweep++) {
+  int sweep = 0;
+  for (; sweep < 60; sweep++) {
     int any_rot = 0;
     for (int r = 0; r < nn - 1; r++) {
       int i = 0, j = 0;
@@ -100,6 +101,103 @@ __device__ inline void block_jacobi_svd(int m, int n, double *A, int lda, double
     }
     if (!any_rot) break;
   }
+  return sweep;
+}
+
+// The same sweeps for compile-time sizes: both columns of a pair (and of V) are fetched into registers in
+// one batch of LDS reads, the rotation works on the registers and writes back -- one LDS round trip per
+// round instead of one per element (the generic loops above wait for every dependent read).  Same
+// arithmetic in the same order as block_jacobi_svd.
+template <int T, int M, int N>
+__device__ inline int block_jacobi_svd_fixed(double *A, int lda, double *V, int ldv) {
+  constexpr int LPP = T / 32, RA = (M + LPP - 1) / LPP, RV = (N + LPP - 1) / LPP;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < N * N; idx += T) {
+    int r = idx % N, c = idx / N;
+    V[c * ldv + r] = (r == c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  constexpr int nn = (N + 1) & ~1;
+  const int p = tid / LPP, sub = tid % LPP;
+  int sweep = 0;
+  for (; sweep < 60; sweep++) {
+    int any_rot = 0;
+    for (int r = 0; r < nn - 1; r++) {
+      int i = 0, j = 0;
+      bool active = p < nn / 2;
+      if (active) {
+        if (p == 0) {
+          i = nn - 1;
+          j = r;
+        } else {
+          i = (r + p) % (nn - 1);
+          j = (r - p + (nn - 1)) % (nn - 1);
+        }
+        if (i > j) {
+          int t = i;
+          i = j;
+          j = t;
+        }
+        active = j < N;
+      }
+      const double *ai = A + (active ? i : 0) * lda, *aj = A + (active ? j : 0) * lda;
+      const double *vi = V + (active ? i : 0) * ldv, *vj = V + (active ? j : 0) * ldv;
+      double ui[RA], uj[RA], wi[RV], wj[RV];
+#pragma unroll
+      for (int q = 0; q < RA; q++) {
+        const int k = sub + q * LPP;
+        const bool ok = active && k < M;
+        ui[q] = ok ? ai[k] : 0.0;
+        uj[q] = ok ? aj[k] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < RV; q++) {
+        const int k = sub + q * LPP;
+        const bool ok = active && k < N;
+        wi[q] = ok ? vi[k] : 0.0;
+        wj[q] = ok ? vj[k] : 0.0;
+      }
+      double al = 0, be = 0, ga = 0;
+#pragma unroll
+      for (int q = 0; q < RA; q++) {
+        al = fma(ui[q], ui[q], al);
+        be = fma(uj[q], uj[q], be);
+        ga = fma(ui[q], uj[q], ga);
+      }
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) {
+        al += __shfl_xor(al, o);
+        be += __shfl_xor(be, o);
+        ga += __shfl_xor(ga, o);
+      }
+      const bool rot = active && ga != 0.0 && fabs(ga) > 4e-15 * sqrt(al * be);
+      if (rot) {
+        double zeta = (be - al) / (2.0 * ga);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        double *bi = A + i * lda, *bj = A + j * lda, *xi = V + i * ldv, *xj = V + j * ldv;
+#pragma unroll
+        for (int q = 0; q < RA; q++) {
+          const int k = sub + q * LPP;
+          if (k < M) {
+            bi[k] = c * ui[q] - sn * uj[q];
+            bj[k] = sn * ui[q] + c * uj[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < RV; q++) {
+          const int k = sub + q * LPP;
+          if (k < N) {
+            xi[k] = c * wi[q] - sn * wj[q];
+            xj[k] = sn * wi[q] + c * wj[q];
+          }
+        }
+      }
+      any_rot |= __syncthreads_or(rot ? 1 : 0);  // also the barrier between rounds
+    }
+    if (!any_rot) break;
+  }
+  return sweep;
 }
 
 template <int T>
@@ -145,12 +243,13 @@ __device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double 
 // Right singular vector of the smallest singular value of A (m x n, n <= 64; destroyed) -> x (n),
 // unit length; *n_positive = number of singular values > 0 (vnl_svd's default rank: only exact zeros
 // are dropped).  All T threads call it.
-template <int T>
+template <int T, int M = 0, int N = 0>
 __device__ inline void block_null_vector(int m, int n, double *A, int lda, double *V, int ldv,
                                          double *x, int *n_positive) {
   __shared__ int s_jmin, s_npos;
   const int tid = threadIdx.x;
-  block_jacobi_svd<T>(m, n, A, lda, V, ldv);
+  if constexpr (M > 0) block_jacobi_svd_fixed<T, M, N>(A, lda, V, ldv);
+  else block_jacobi_svd<T>(m, n, A, lda, V, ldv);
   double s2 = 0;
   if (tid < n)
     for (int k = 0; k < m; k++) {
