@@ -247,6 +247,17 @@ def main():
                 traffic = t.get(key)
             except Exception:
                 traffic = None
+        issue = None   # measured instruction-issue utilisation of the scan kernel (profiles/, SQ counters)
+        sfile = os.path.join(ROOT, "profiles", "r01g_plane_scan_sq_counters.json")
+        if a.workload == "plane" and a.points == 10_000_000 and H == 4096 and idx["built"] and os.path.exists(sfile):
+            try:
+                d = json.load(open(sfile))["derived"]
+                issue = {"valu_issue_busy": d["valu_issue_busy"], "salu_issue_busy_per_cu": d["salu_issue_busy_per_cu"],
+                         "lanes_active": d["lanes_active"],
+                         "source": "profiles/r01g_plane_scan_sq_counters.json (rocprofv3 --pmc SQ_* passes of this kernel "
+                                   "and shape; not collected live)"}
+            except Exception:
+                issue = None
         out = {
             "metric": METRIC,
             "value": value, "unit": "hypotheses/s", "n_gpus": a.gpus, "steps": a.steps,
@@ -282,6 +293,7 @@ def main():
                                   "fp64_issue_measured_gops": FP64_VALU_MEASURED_GOPS,
                                   "frac_of_peak": eq_gops / FP64_VALU_PEAK_GOPS,
                                   "frac_of_measured_issue_rate": eq_gops / FP64_VALU_MEASURED_GOPS,
+                                  "issue_utilisation": issue,
                                   "note": ("culling and the pre-filter decide most pairs without "
                                            "the exact fp64 formula, so the exact-equivalent rate "
                                            "exceeds the fp64 issue roof") if filtered else
