@@ -153,6 +153,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(device))
         else:
             dist.init_process_group(backend)
+            if os.environ.get("LSQR_STEP") == "device":
+                torch.cuda.init()      # torch's HIP runtime has to come up before the library's
+                torch.cuda.set_device(local)
     from lsqrrecipes_amd import _lib as L
     from lsqrrecipes_amd.context import Context
     from lsqrrecipes_amd.distributed import Comm, ShardedRansac
@@ -170,6 +173,8 @@ def main():
         ctx.set_option("scan_index", 0)
     comm = Comm(dist, device)
     eng = ShardedRansac(ctx, comm)
+    step_on_device = dist is not None and os.environ.get(
+        "LSQR_STEP", "device" if backend == "nccl" else "host") == "device"
     H = a.batch
     seed = 0xC0FFEE
 
@@ -180,7 +185,9 @@ def main():
             if r["info"].best_votes == 0:
                 return None
             return int(r["info"].best_votes), r["params"], int(r["info"].fit.n_used)
-        r = eng.step(seed, i, H)
+        # multi-GPU: exchanges on device buffers, one host synchronisation per step (step_device);
+        # LSQR_STEP=host keeps the staged-through-the-host variant (the gloo rehearsal's default)
+        r = eng.step_device(seed, i, H) if step_on_device else eng.step(seed, i, H)
         if r is None:
             return None
         votes, gidx, par, fit, cnt, info = r
@@ -270,7 +277,10 @@ def main():
                            a.workload, a.points),
                        "points": a.points, "hypotheses_per_gpu_per_step": H,
                        "record_bytes": rec, "parallelism": "hypotheses sharded over %d GPU(s), "
-                       "observations replicated" % a.gpus},
+                       "observations replicated" % a.gpus,
+                       "step": ("lsqr_batch_fit (one chain, one sync)" if comm.world == 1 and not force_dist
+                                else "step_device (collectives on device buffers, one sync)" if step_on_device
+                                else "step (exchanges staged through the host)")},
             "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),
                           "params": [float(x) for x in fit],
                           "abs_dot_true_normal": float(abs(np.dot(fit[:3], truth[:3])))

@@ -222,6 +222,30 @@ LSQR_API int lsqr_ransac(lsqr_ctx *ctx, double p, uint64_t seed, const uint32_t 
  * stream index of the winner.  Returns LSQR_EMPTY when no hypothesis was valid or the fit failed. */
 LSQR_API int lsqr_batch_fit(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H,
                             double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info);
+/* ---- multi-GPU step with device-resident exchange buffers ------------------------------------------
+ * One rank's part of a step of `world` x H hypotheses, all device work chained on the context's stream and
+ * ONE host synchronisation (lsqr_step_finish); the two exchanges are collectives on the caller's device
+ * buffers between the calls (RCCL: all-reduce MAX of packed_dev[0] as int64, all-reduce SUM of block_dev):
+ *   lsqr_step_scan    hypotheses [first, first + H) of the stream: sample, solve, scan; packed_dev[0] =
+ *                     (votes << 32) | (0xFFFFFFFF - (index_base + index)) of the first best one, 0 if none
+ *   lsqr_step_winner  the winner (stream index batch_first + in-batch index taken from packed_dev) is
+ *                     re-derived on the device, its consensus mask taken over observations [begin, end)
+ *                     and block_dev[0 .. len) = phase-0 moment block of the slice, block_dev[len] = its
+ *                     inlier count (len = lsqr_moments_len(cfg, 0))
+ *   lsqr_step_finish  final fit from the (summed) block; winner_out: the winner's lsqr_num_params
+ *                     parameters; info->best_votes / best_index (in-batch index) from packed_dev,
+ *                     info->evaluated = 1 when the batch had a valid hypothesis (else 0),
+ *                     info->fit.n_used = the summed count.  LSQR_EMPTY: no valid hypothesis / fit failed.
+ * lsqr_set_stream(external = 1) makes the context enqueue on the caller's HIP stream (the stream the
+ * collectives are ordered with, e.g. torch's current stream; NULL = the default stream); external = 0
+ * restores the context's own (non-blocking) stream. */
+LSQR_API int lsqr_set_stream(lsqr_ctx *ctx, void *hip_stream, int external);
+LSQR_API int lsqr_step_scan(lsqr_ctx *ctx, uint64_t seed, uint64_t first, size_t H, uint32_t index_base,
+                            uint64_t *packed_dev);
+LSQR_API int lsqr_step_winner(lsqr_ctx *ctx, uint64_t seed, uint64_t batch_first,
+                              const uint64_t *packed_dev, size_t begin, size_t end, double *block_dev);
+LSQR_API int lsqr_step_finish(lsqr_ctx *ctx, const uint64_t *packed_dev, const double *block_dev,
+                              double *winner_out, double *params_out, lsqr_ransac_info *info);
 /* Exhaustive overload (RANSAC.h:111-113): all C(N,k) subsets in lexicographic order. */
 LSQR_API int lsqr_ransac_exhaustive(lsqr_ctx *ctx, double *params_out, uint8_t *consensus_out,
                                     lsqr_ransac_info *info);

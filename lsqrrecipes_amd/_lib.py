@@ -85,6 +85,12 @@ SIGNATURES = {
                                C.POINTER(FitInfo)]),
     "lsqr_stats": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     "lsqr_residuals": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "lsqr_set_stream": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
+    "lsqr_step_scan": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint32, C.c_void_p]),
+    "lsqr_step_winner": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t,
+                                   C.c_void_p]),
+    "lsqr_step_finish": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(RansacInfo)]),
     "lsqr_ransac": (C.c_int, [_ctx, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p,
                               C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_batch_fit": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p,

@@ -180,6 +180,32 @@ class Context:
         self._chk(self._lib.lsqr_stats(self._h, L.ptr(p), int(use_mask), L.ptr(out)))
         return out
 
+    # ---- multi-GPU step with device-resident exchange buffers ---------------------------
+    def set_stream(self, hip_stream):
+        """enqueue on the caller's HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream;
+        0 is the default stream); None restores the context's own stream"""
+        if hip_stream is None:
+            self._chk(self._lib.lsqr_set_stream(self._h, None, 0))
+        else:
+            self._chk(self._lib.lsqr_set_stream(self._h, C.c_void_p(int(hip_stream) or None), 1))
+
+    def step_scan(self, seed, first, H, index_base, packed_ptr):
+        self._chk(self._lib.lsqr_step_scan(self._h, seed, first, H, index_base, C.c_void_p(packed_ptr)))
+
+    def step_winner(self, seed, batch_first, packed_ptr, begin, end, block_ptr):
+        self._chk(self._lib.lsqr_step_winner(self._h, seed, batch_first, C.c_void_p(packed_ptr), begin, end,
+                                             C.c_void_p(block_ptr)))
+
+    def step_finish(self, packed_ptr, block_ptr):
+        """-> (status, winner params, fitted params (possibly empty), RansacInfo)"""
+        win = np.zeros(max(self.P, 1))
+        out = np.zeros(max(self.P, 64))
+        info = L.RansacInfo()
+        st = self._chk(self._lib.lsqr_step_finish(self._h, C.c_void_p(packed_ptr), C.c_void_p(block_ptr),
+                                                  L.ptr(win), L.ptr(out), C.byref(info)), allow_empty=True)
+        fit = out[:info.n_params].copy() if st == L.OK else np.zeros(0)
+        return st, win, fit, info
+
     def residuals(self, params, begin=0, end=None):
         """the model's residual of every record in [begin, end) (lsqr_residuals)"""
         end = self.n if end is None else end

@@ -479,14 +479,16 @@ __global__ __launch_bounds__(64) void k_lm_advance(LmState *st, const double *__
 }
 
 // first-max winner of a vote array: (votes << 32) | (0xFFFFFFFF - index)
+// `base`: offset of this rank's hypotheses inside a multi-GPU batch (the packed values of all ranks are
+// then comparable: one all-reduce MAX picks the earliest best hypothesis of the whole batch)
 __global__ __launch_bounds__(kBlock) void k_best(const uint32_t *__restrict__ votes,
                                                  const uint8_t *__restrict__ valid, uint32_t H,
-                                                 unsigned long long *__restrict__ out) {
+                                                 unsigned long long *__restrict__ out, uint32_t base = 0) {
   __shared__ unsigned long long s_b[kBlock / 64];
   unsigned long long best = 0;
   for (uint32_t h = threadIdx.x; h < H; h += kBlock) {
     if (!valid[h]) continue;
-    unsigned long long p = ((unsigned long long)votes[h] << 32) | (0xFFFFFFFFu - h);
+    unsigned long long p = ((unsigned long long)votes[h] << 32) | (0xFFFFFFFFu - (base + h));
     best = p > best ? p : best;
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -499,6 +501,27 @@ __global__ __launch_bounds__(kBlock) void k_best(const uint32_t *__restrict__ vo
     for (int w = 1; w < kBlock / 64; w++) best = s_b[w] > best ? s_b[w] : best;
     *out = best;
   }
+}
+
+// the winner's subset from the packed winner in device memory (multi-GPU step: no host round trip between
+// the all-reduce and the re-derivation of the winning hypothesis); same draw rule as k_sample / k_sample_wave
+__global__ __launch_bounds__(64) void k_winner_subset(uint64_t seed, uint64_t batch_first,
+                                                      const unsigned long long *__restrict__ packed,
+                                                      uint64_t n, int K, uint32_t *__restrict__ subsets) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long pk = *packed;
+  const uint64_t in_batch = pk ? 0xFFFFFFFFull - (pk & 0xFFFFFFFFull) : 0;
+  uint32_t idx[64], sorted[64];
+  ctr_subset(seed, batch_first + in_batch, n, K, idx, sorted);
+  for (int l = 0; l < K; l++) subsets[l] = idx[l];
+}
+
+// {moment block, inlier count of the slice} -> the exchange buffer of the multi-GPU step
+__global__ __launch_bounds__(256) void k_pack_block(const double *__restrict__ mom, int nmom,
+                                                    const unsigned long long *__restrict__ count,
+                                                    double *__restrict__ out) {
+  for (int i = threadIdx.x; i < nmom; i += 256) out[i] = mom[i];
+  if (threadIdx.x == 0) out[nmom] = (double)*count;
 }
 
 // residual statistics {min, max, sum, sumsq, count} per block

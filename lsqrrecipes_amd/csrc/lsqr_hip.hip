@@ -27,7 +27,8 @@ using namespace lsqr;
 // ------------------------------------------------------------------------------------------------
 struct lsqr_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream all work is enqueued on
+  hipStream_t own_stream = nullptr;  // created with the context (stream == own_stream unless lsqr_set_stream)
   lsqr_model_cfg cfg{};
   ModelConsts mc{};
   bool has_model = false;
@@ -58,6 +59,7 @@ struct lsqr_ctx {
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   bool scanned = false;
+  bool external_stream = false;
 
   double *d_rows = nullptr;  // plane phantom: the data rows a_i as an n x 32 matrix (phantom.h)
   size_t rows_cap = 0;
@@ -1101,7 +1103,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
   if (hipSetDevice(device) != hipSuccess) return LSQR_ERR_NO_DEVICE;
   lsqr_ctx *c = new lsqr_ctx();
   c->device = device;
-  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+  bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipMalloc((void **)&c->d_partials, sizeof(double) * kDenseBlocks * 2160) == hipSuccess &&
             hipMalloc((void **)&c->d_mom, sizeof(double) * 4096) == hipSuccess &&
@@ -1111,6 +1113,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
             hipMalloc((void **)&c->d_out, sizeof(SolveOut)) == hipSuccess &&
             hipMalloc((void **)&c->d_counter, 64) == hipSuccess &&
             hipHostMalloc(&c->h_pin, 1 << 16) == hipSuccess;
+  c->stream = c->own_stream;
   if (!ok) {
     lsqr_ctx_destroy(c);
     return LSQR_ERR_HIP;
@@ -1122,7 +1125,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
 void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);
   drop_index(c);
   void *bufs[] = {c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
@@ -1132,7 +1135,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -1992,6 +1995,131 @@ int lsqr_winner_moments(lsqr_ctx *c, uint64_t seed, uint64_t stream_index, size_
   if (count_out) memcpy(count_out, pin + 1, sizeof(uint64_t));
   if (params_out) memcpy(params_out, pin + 2, sizeof(double) * c->P);
   if (origin_out) memcpy(origin_out, pin + 66, sizeof(double) * 32);
+  return LSQR_OK;
+}
+
+// ---- multi-GPU step with device-resident exchange buffers (lsqr_hip.h) ----------------------------------
+int lsqr_set_stream(lsqr_ctx *c, void *hip_stream, int external) {
+  if (!c) return LSQR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of ours may still be in flight on the old stream
+  // profiling events recorded on the old stream stay valid (events are not bound to a stream)
+  // external: the caller's stream as given -- NULL is the (legacy) default stream, which torch uses unless
+  // told otherwise
+  c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
+  c->external_stream = external != 0;
+  return LSQR_OK;
+}
+
+int lsqr_step_scan(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, uint32_t index_base,
+                   uint64_t *packed_dev) {
+  if (!packed_dev) return c ? fail(c, LSQR_ERR_INVALID, "null exchange buffer") : LSQR_ERR_INVALID;
+  int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
+  if (st != LSQR_OK) return st;
+  if ((st = run_scan(c)) != LSQR_OK) return st;
+  c->scanned = true;
+  hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
+                     (uint32_t)c->H, (unsigned long long *)packed_dev, index_base);
+  HIPCHK(c, hipGetLastError());
+  return LSQR_OK;
+}
+
+int lsqr_step_winner(lsqr_ctx *c, uint64_t seed, uint64_t batch_first, const uint64_t *packed_dev,
+                     size_t begin, size_t end, double *block_dev) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!packed_dev || !block_dev || begin > end || end > c->n) return fail(c, LSQR_ERR_INVALID, "bad argument");
+  if ((st = ensure_hyp(c, 1)) != LSQR_OK) return st;
+  c->H = 1;
+  c->scanned = false;
+  {
+    ProfScope ps(c, KID_SAMPLE);
+    hipLaunchKernelGGL(k_winner_subset, dim3(1), dim3(64), 0, c->stream, seed, batch_first,
+                       (const unsigned long long *)packed_dev, (uint64_t)c->n, c->K, c->d_subsets);
+    HIPCHK(c, hipGetLastError());
+  }
+  if ((st = run_estimate(c)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams, sizeof(double) * c->HS, hipMemcpyDeviceToDevice,
+                           c->stream));
+  if ((st = launch_mask(c, begin, end)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemsetAsync(c->d_vec, 0, sizeof(double) * 32, c->stream));
+  const int m = c->cfg.model;
+  if (m == LSQR_MODEL_PLANE || m == LSQR_MODEL_LINE || m == LSQR_MODEL_SPHERE)
+    HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (m == LSQR_MODEL_SPHERE ? 0 : c->ND),
+                             sizeof(double) * c->ND, hipMemcpyDeviceToDevice, c->stream));
+  int nmom = 0;
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    return launch_moments<M>(c, 1, begin, end, 0, &nmom);
+  });
+  if (st != LSQR_OK) return st;
+  hipLaunchKernelGGL(k_pack_block, dim3(1), dim3(256), 0, c->stream, c->d_mom, nmom, c->d_counter,
+                     block_dev);
+  HIPCHK(c, hipGetLastError());
+  return LSQR_OK;
+}
+
+int lsqr_step_finish(lsqr_ctx *c, const uint64_t *packed_dev, const double *block_dev,
+                     double *winner_out, double *params_out, lsqr_ransac_info *info) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!packed_dev || !block_dev) return fail(c, LSQR_ERR_INVALID, "null exchange buffer");
+  const int nmom = lsqr_moments_len(&c->cfg, 0);
+  // staging: {packed, count, valid, winner params[64]} behind the SolveOut / the phantom's block
+  char *pin = (char *)c->h_pin;
+  unsigned long long *p_packed = (unsigned long long *)(pin + 32768);
+  double *p_count = (double *)(pin + 32768 + 8);
+  uint8_t *p_valid = (uint8_t *)(pin + 32768 + 16);
+  double *p_win = (double *)(pin + 32768 + 64);
+  HIPCHK(c, hipMemcpyAsync(p_packed, packed_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p_count, block_dev + nmom, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p_valid, c->d_valid, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p_win, c->d_hparams, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
+  SolveOut out;
+  memset(&out, 0, sizeof out);
+  if (c->cfg.model == LSQR_MODEL_PHANTOM) {  // solved on the host from the Gram block
+    double *blk = (double *)(pin + 40960);
+    HIPCHK(c, hipMemcpyAsync(blk, block_dev, sizeof(double) * nmom, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    phantom_solve_block(c->cfg, blk, &out);
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->d_mom, block_dev, sizeof(double) * nmom, hipMemcpyDeviceToDevice,
+                             c->stream));
+    st = dispatch(c->cfg, [&](auto tag) -> int {
+      typedef typename decltype(tag)::type M;
+      if constexpr (M::IS_DENSE) {
+        return launch_solve_dense(c);
+      } else {
+        ProfScope ps(c, KID_SOLVE);
+        hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
+                           c->d_out);
+        HIPCHK(c, hipGetLastError());
+        return LSQR_OK;
+      }
+    });
+    if (st != LSQR_OK) return st;
+    if ((st = read_out(c, &out)) != LSQR_OK) return st;  // the one synchronisation of the step
+  }
+  const unsigned long long pk = *p_packed;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->evaluated = pk != 0;  // a winner exists
+    info->best_votes = (uint32_t)(pk >> 32);
+    info->best_index = pk ? 0xFFFFFFFFull - (pk & 0xFFFFFFFFull) : 0;
+    info->n_params = out.ok ? out.n_params : 0;
+    info->fit.n_params = info->n_params;
+    info->fit.lm_info = out.lm_info;
+    info->fit.lm_nfev = out.lm_nfev;
+    info->fit.cost = out.cost;
+    info->fit.n_used = (uint64_t)(*p_count + 0.5);
+    info->fraction = c->n ? *p_count / (double)c->n : 0.0;
+  }
+  if (pk == 0 || !*p_valid) return LSQR_EMPTY;
+  if (winner_out) memcpy(winner_out, p_win, sizeof(double) * c->P);
+  if (!out.ok) return LSQR_EMPTY;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
   return LSQR_OK;
 }
 

@@ -83,6 +83,8 @@ class ShardedRansac:
     def __init__(self, engine, comm):
         self.e = engine
         self.c = comm
+        self._xbuf = None     # (packed int64[1], block float64[nmom + 1]) device tensors of step_device
+        self._stream = None
 
     def batch(self, seed, batch_index, H):
         """One batch of world*H hypotheses: sample+solve+scan own slice, pick the global winner.
@@ -137,6 +139,41 @@ class ShardedRansac:
         fit, info = e.solve_moments(blk[:-1], origin)
         fit, info = self._refine(fit, info, lo, hi)
         return int(win >> 32), gidx, par, fit, int(round(blk[-1])), info
+
+    def step_device(self, seed, batch_index, H):
+        """The same step with the two exchanges as collectives on DEVICE buffers and one host
+        synchronisation (lsqr_step_scan / _winner / _finish): scan -> k_best into `packed` ->
+        all-reduce MAX -> winner re-derived on the device from `packed` -> mask + moment block of the
+        rank's slice into `block` -> all-reduce SUM -> solve.  The context enqueues on torch's current
+        stream, which the process group orders its collectives with.  Same return value as step().
+        torch bundles its own HIP runtime: call torch.cuda.init() before the first Context is created in a
+        process that uses both (two runtimes initialised in the other order do not see the devices)."""
+        import torch
+        e, c = self.e, self.c
+        if self._xbuf is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            nmom = e.moments_len(0)
+            self._xbuf = (torch.zeros(1, dtype=torch.int64, device=dev),
+                          torch.zeros(nmom + 1, dtype=torch.float64, device=dev))
+        stream = int(torch.cuda.current_stream().cuda_stream)   # 0: the default stream
+        if stream != self._stream:
+            e.set_stream(stream)
+            self._stream = stream
+        packed, block = self._xbuf
+        first = (batch_index * c.world + c.rank) * H
+        e.step_scan(seed, first, H, c.rank * H, packed.data_ptr())
+        if c.dist is not None:
+            c.dist.all_reduce(packed, op=c.dist.ReduceOp.MAX)
+        lo, hi = slice_bounds(e.n, c.rank, c.world)
+        e.step_winner(seed, batch_index * c.world * H, packed.data_ptr(), lo, hi, block.data_ptr())
+        if c.dist is not None:
+            c.dist.all_reduce(block, op=c.dist.ReduceOp.SUM)
+        st, par, fit, info = e.step_finish(packed.data_ptr(), block.data_ptr())
+        if not info.evaluated:   # no valid hypothesis in the whole batch
+            return None
+        gidx = batch_index * c.world * H + int(info.best_index)
+        fit, finfo = self._refine(fit, info.fit, lo, hi)
+        return int(info.best_votes), gidx, par, fit, int(info.fit.n_used), finfo
 
     def _refine(self, fit, info, lo, hi):
         """LM refinement over the sharded observation range (sphere geometric / US iterative)."""

@@ -1,0 +1,47 @@
+"""Helper of test_gpu_parity.py::test_step_device_world2_equals_world1 -- run under torch.distributed.run
+with 2 ranks (gloo, both ranks on GPU 0): ShardedRansac.step_device() with the exchanges as collectives on
+device tensors must pick the same winner and consensus count as one process scanning the whole batch."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+torch.cuda.init()  # torch's HIP runtime has to come up before the library's
+torch.cuda.set_device(0)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lsqrrecipes_amd import _lib as L, synth  # noqa: E402
+from lsqrrecipes_amd.context import Context  # noqa: E402
+from lsqrrecipes_amd.distributed import Comm, ShardedRansac  # noqa: E402
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ok = True
+for model, dim, ls, H in ((L.PLANE, 3, 0, 1024), (L.SPHERE, 3, L.LS_GEOMETRIC, 1024), (L.DENSE, 8, 0, 128),
+                          (L.PHANTOM, 0, L.LS_ITERATIVE, 128)):
+    if model == L.DENSE:
+        data, delta = synth.dense(40_000, 8, 0.3, seed=5)[0], 0.1
+    elif model == L.PHANTOM:
+        data, delta = synth.plane_phantom_fast(20_000, 0.05, seed=5, pixel_sigma=0.02)[0], 2.0
+    else:
+        gen = {L.PLANE: synth.plane, L.SPHERE: synth.sphere}[model]
+        data, delta = gen(120_000, 0.5, seed=77, dim=dim)[0], 0.5
+    with Context(0) as c:
+        c.set_model(model, dim, delta, ls).upload(data)
+        got = ShardedRansac(c, Comm(dist, "cpu")).step_device(11, 2, H)
+        if rank == 0:
+            with Context(0) as c1:
+                c1.set_model(model, dim, delta, ls).upload(data)
+                want = ShardedRansac(c1, Comm(None)).step(11, 2, H * world)
+            same = (got[0], got[1], got[4]) == (want[0], want[1], want[4]) and np.array_equal(got[2], want[2]) \
+                and np.allclose(got[3], want[3], rtol=1e-9, atol=1e-9)
+            if not same:
+                print("MISMATCH", model, got[:2], want[:2], got[4], want[4], got[3], want[3])
+            ok = ok and same
+        c.set_stream(None)
+    dist.barrier()
+if rank == 0:
+    print("world2 step_device ok" if ok else "world2 step_device FAILED")
+dist.destroy_process_group()

@@ -1639,3 +1639,68 @@ def test_plane_phantom_filter_scan_equals_exact_scan(ctx, n):
     _, _, v = ctx.hypotheses()
     for h in (0, 31):
         assert v[h] == O.scan(oc, par0[h], both)[0]
+
+
+STEP_DEVICE_SCRIPT = r"""
+import sys, numpy as np, torch
+torch.cuda.init()                      # torch's HIP runtime must come up before the library's
+sys.path.insert(0, %r)
+from lsqrrecipes_amd import _lib as L, synth
+from lsqrrecipes_amd.context import Context
+from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+cases = [(L.PLANE, 3, 0), (L.SPHERE, 3, L.LS_GEOMETRIC), (L.LINE, 3, 0), (L.DENSE, 8, 0),
+         (L.US_SINGLE, 0, L.LS_ANALYTIC), (L.US_SINGLE, 0, L.LS_ITERATIVE), (L.PHANTOM, 0, L.LS_ITERATIVE)]
+for model, dim, ls in cases:
+    if model == L.DENSE:
+        data, delta = synth.dense(60_000, 8, 0.3, seed=5)[0], 0.1
+    elif model == L.US_SINGLE:
+        data, delta = synth.us_single_fast(50_000, 0.3, seed=5)[0], 3.0
+    elif model == L.PHANTOM:
+        data, delta = synth.plane_phantom_fast(30_000, 0.05, seed=5, pixel_sigma=0.02)[0], 2.0
+    else:
+        gen = {L.PLANE: synth.plane, L.SPHERE: synth.sphere, L.LINE: synth.line}[model]
+        data, delta = gen(150_000, 0.5, seed=998, dim=dim)[0], 0.5
+    with Context(0) as c1, Context(0) as c2:
+        c1.set_model(model, dim, delta, ls).upload(data)
+        c2.set_model(model, dim, delta, ls).upload(data)
+        H = 256 if model in (L.DENSE, L.PHANTOM) else 2500
+        want = ShardedRansac(c1, Comm(None)).step(7, 3, H)
+        sr = ShardedRansac(c2, Comm(None))
+        for stream in (None, torch.cuda.Stream()):       # torch's default stream, then a side stream
+            with torch.cuda.stream(stream):
+                got = sr.step_device(7, 3, H)
+            assert (got[0], got[1], got[4]) == (want[0], want[1], want[4]), (model, got[:2], want[:2])
+            assert np.array_equal(got[2], want[2])
+            assert np.allclose(got[3], want[3], rtol=1e-12, atol=1e-12), (model, got[3], want[3])
+        if model == L.PLANE:   # a batch without any valid hypothesis: None, like step()
+            c2.upload(np.zeros((1000, 3)))
+            assert sr.step_device(7, 0, 64) is None
+        c2.set_stream(None)
+print("step_device ok")
+"""
+
+
+def test_sharded_step_with_device_exchange_buffers():
+    """ShardedRansac.step_device(): packed winner and moment block stay in device tensors between the
+    calls (where the collectives act) and the host synchronises once; same result as step() for every
+    model family.  Own process: torch's HIP runtime has to initialise before the library's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", STEP_DEVICE_SCRIPT % root], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "step_device ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_step_device_world2_equals_world1():
+    """two ranks (gloo, sharing the box's one GPU) run step_device(): all-reduce MAX / SUM on the device
+    exchange tensors; winner, consensus count and fit equal one process scanning the whole batch"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547",
+                        os.path.join(root, "tests", "dist_step_device.py")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "world2 step_device ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
