@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-index", action="store_true", help="exhaustive scan (no spatial index)")
     ap.add_argument("--outliers", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="single GPU: one blocking lsqr_batch_fit per step instead of pipelined batches")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the adaptive RANSAC::compute() timing after the steps (profiling runs: "
                          "keeps one launch shape per kernel)")
@@ -200,16 +202,35 @@ def main():
             torch.cuda.synchronize()
         comm.barrier()
 
+    # single GPU, closed-form fit: batches are pipelined -- batch i + 1 is enqueued before batch i is read
+    # (lsqr_batch_fit_enqueue / _wait), so the host's latency between steps hides behind the device's work;
+    # every step still runs the whole chain.  --no-pipeline keeps one blocking call per step.
+    pipelined = (comm.world == 1 and not force_dist and not a.no_pipeline
+                 and not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC))
+
+    def run_steps(first_step, count):
+        last = None
+        if not pipelined:
+            for i in range(count):
+                last = step(first_step + i)
+            return last
+        for i in range(count):
+            ctx.batch_fit_enqueue(seed, (first_step + i) * H, H, slot=i & 1)
+            if i:
+                last = ctx.batch_fit_wait((i - 1) & 1)
+        if count:
+            last = ctx.batch_fit_wait((count - 1) & 1)
+        if last is None or last["info"].best_votes == 0:
+            return None
+        return int(last["info"].best_votes), last["params"], int(last["info"].fit.n_used)
+
     ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
-    for i in range(a.warmup):
-        step(i)
+    run_steps(0, a.warmup)
     n_idx, ms_idx = ctx.profile_get("index")
     ctx.profile(True)
     sync()
     t0 = time.perf_counter()
-    last = None
-    for i in range(a.steps):
-        last = step(a.warmup + i)
+    last = run_steps(a.warmup, a.steps)
     sync()
     dt = time.perf_counter() - t0
     dt = comm.allreduce_max_f64(dt)
@@ -278,7 +299,9 @@ def main():
                        "points": a.points, "hypotheses_per_gpu_per_step": H,
                        "record_bytes": rec, "parallelism": "hypotheses sharded over %d GPU(s), "
                        "observations replicated" % a.gpus,
-                       "step": ("lsqr_batch_fit (one chain, one sync)" if comm.world == 1 and not force_dist
+                       "step": ("lsqr_batch_fit_enqueue/_wait (one chain per step, next step enqueued before "
+                                "the previous one is read)" if pipelined
+                                else "lsqr_batch_fit (one chain, one sync)" if comm.world == 1 and not force_dist
                                 else "step_device (collectives on device buffers, one sync)" if step_on_device
                                 else "step (exchanges staged through the host)")},
             "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),

@@ -222,6 +222,15 @@ LSQR_API int lsqr_ransac(lsqr_ctx *ctx, double p, uint64_t seed, const uint32_t 
  * stream index of the winner.  Returns LSQR_EMPTY when no hypothesis was valid or the fit failed. */
 LSQR_API int lsqr_batch_fit(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H,
                             double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info);
+/* lsqr_batch_fit split in two for pipelining: _enqueue chains the whole batch (sample .. fit and the copies
+ * of the results into pinned slot `slot`, 0 or 1) on the stream and returns without waiting; _wait blocks on
+ * that slot's event and returns what lsqr_batch_fit returns (no consensus copy: read it with lsqr_mask_*
+ * before the next batch is enqueued if it is needed).  Batches execute in order on the one stream, so the
+ * next batch can be enqueued before the previous one is read: the host's latency between steps disappears
+ * behind the device's work.  Closed-form fits only (LSQR_ERR_INVALID for the iterative fits and the plane
+ * phantom, whose final fit keeps the host in the loop). */
+LSQR_API int lsqr_batch_fit_enqueue(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H, int slot);
+LSQR_API int lsqr_batch_fit_wait(lsqr_ctx *ctx, int slot, double *params_out, lsqr_ransac_info *info);
 /* ---- multi-GPU step with device-resident exchange buffers ------------------------------------------
  * One rank's part of a step of `world` x H hypotheses, all device work chained on the context's stream and
  * ONE host synchronisation (lsqr_step_finish); the two exchanges are collectives on the caller's device

@@ -95,6 +95,8 @@ SIGNATURES = {
                               C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_batch_fit": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p,
                                  C.POINTER(RansacInfo)]),
+    "lsqr_batch_fit_enqueue": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]),
+    "lsqr_batch_fit_wait": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_ransac_exhaustive": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_replay_init": (C.c_int, [C.c_size_t, C.c_int, C.c_double, _u64p]),
     "lsqr_replay": (C.c_size_t, [C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_void_p,

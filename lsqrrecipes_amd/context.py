@@ -246,6 +246,20 @@ class Context:
                     params=out[:info.n_params].copy() if st == L.OK else np.zeros(0),
                     consensus=cons[:self.n] if cons is not None else None, info=info)
 
+    def batch_fit_enqueue(self, seed, first, H, slot=0):
+        """chain a whole batch on the stream and return (lsqr_batch_fit_enqueue); closed-form fits only"""
+        self._chk(self._lib.lsqr_batch_fit_enqueue(self._h, seed, first, H, slot))
+
+    def batch_fit_wait(self, slot=0):
+        """-> the dict of batch_fit() (without consensus) for the batch enqueued in `slot`"""
+        out = np.zeros(max(self.P, 32))
+        info = L.RansacInfo()
+        st = self._chk(self._lib.lsqr_batch_fit_wait(self._h, slot, L.ptr(out), C.byref(info)),
+                       allow_empty=True)
+        return dict(status=st, fraction=info.fraction,
+                    params=out[:info.n_params].copy() if st == L.OK else np.zeros(0), consensus=None,
+                    info=info)
+
     def ransac_exhaustive(self, want_consensus=True):
         out = np.zeros(max(self.P, 32))
         cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None

@@ -60,6 +60,9 @@ struct lsqr_ctx {
   uint32_t *d_votes = nullptr;
   bool scanned = false;
   bool external_stream = false;
+  hipEvent_t slot_ev[2] = {nullptr, nullptr};  // lsqr_batch_fit_enqueue / _wait
+  uint64_t slot_first[2] = {0, 0}, slot_H[2] = {0, 0};
+  bool slot_busy[2] = {false, false};
 
   double *d_rows = nullptr;  // plane phantom: the data rows a_i as an n x 32 matrix (phantom.h)
   size_t rows_cap = 0;
@@ -883,6 +886,37 @@ void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, 
   }
 }
 
+// the closed-form part of run_fit without the read-back: moments + solve chained on the stream, result in
+// d_out.  Models whose fit needs the host in the loop (LM, the phantom's Gram solve) are refused.
+int enqueue_fit(lsqr_ctx *c, int use_mask) {
+  if (wants_lm(c->cfg) || c->cfg.model == LSQR_MODEL_PHANTOM)
+    return fail(c, LSQR_ERR_INVALID, "this fit needs the host between device passes");
+  return dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    int nmom = 0, st;
+    if constexpr (M::IS_DENSE) {
+      if ((st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
+      return launch_solve_dense(c);
+    } else {
+      bool first_datum = !c->origin_valid;
+      if constexpr (requires { M::ORIGIN_FIRST; }) first_datum = true;
+      if (first_datum) {
+        HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND, hipMemcpyDeviceToDevice,
+                                 c->stream));
+      } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (c->cfg.model == LSQR_MODEL_SPHERE ? 0 : M::ND),
+                                 sizeof(double) * M::ND, hipMemcpyDeviceToDevice, c->stream));
+      }
+      if ((st = launch_moments<M>(c, use_mask, 0, c->n, 0, &nmom)) != LSQR_OK) return st;
+      ProfScope ps(c, KID_SOLVE);
+      hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
+                         c->d_out);
+      HIPCHK(c, hipGetLastError());
+      return LSQR_OK;
+    }
+  });
+}
+
 // leastSquaresEstimate over [0,n) (single device).  Leaves the result in d_out.
 int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
   return dispatch(c->cfg, [&](auto tag) -> int {
@@ -1135,6 +1169,8 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->slot_ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1995,6 +2031,69 @@ int lsqr_winner_moments(lsqr_ctx *c, uint64_t seed, uint64_t stream_index, size_
   if (count_out) memcpy(count_out, pin + 1, sizeof(uint64_t));
   if (params_out) memcpy(params_out, pin + 2, sizeof(double) * c->P);
   if (origin_out) memcpy(origin_out, pin + 66, sizeof(double) * 32);
+  return LSQR_OK;
+}
+
+// ---- pipelined batches: enqueue now, read later ------------------------------------------------------------
+static char *slot_pin(lsqr_ctx *c, int slot) { return (char *)c->h_pin + 49152 + slot * 2048; }
+
+int lsqr_batch_fit_enqueue(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, int slot) {
+  if (!c || slot < 0 || slot > 1) return LSQR_ERR_INVALID;
+  if (c->slot_busy[slot]) return fail(c, LSQR_ERR_STATE, "slot %d holds an unread result", slot);
+  if (c->has_model && (wants_lm(c->cfg) || c->cfg.model == LSQR_MODEL_PHANTOM))
+    return fail(c, LSQR_ERR_INVALID, "this model's fit needs the host between device passes");
+  int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
+  if (st != LSQR_OK) return st;
+  if ((st = run_scan(c)) != LSQR_OK) return st;
+  c->scanned = true;
+  hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
+                     (uint32_t)c->H, c->d_counter + 1, 0u);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
+  hipLaunchKernelGGL(k_take_best, dim3(1), dim3(64), 0, c->stream, c->d_counter + 1, c->d_hparams,
+                     c->HS, c->d_par);
+  HIPCHK(c, hipGetLastError());
+  if ((st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
+  char *pin = slot_pin(c, slot);
+  HIPCHK(c, hipMemcpyAsync(pin, c->d_counter, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           c->stream));  // {inliers, packed winner}
+  if ((st = enqueue_fit(c, 1)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(pin + 64, c->d_out, sizeof(SolveOut), hipMemcpyDeviceToHost, c->stream));
+  if (!c->slot_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->slot_ev[slot], hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->slot_ev[slot], c->stream));
+  c->slot_first[slot] = first;
+  c->slot_H[slot] = H;
+  c->slot_busy[slot] = true;
+  return LSQR_OK;
+}
+
+int lsqr_batch_fit_wait(lsqr_ctx *c, int slot, double *params_out, lsqr_ransac_info *info) {
+  if (!c || slot < 0 || slot > 1) return LSQR_ERR_INVALID;
+  if (!c->slot_busy[slot]) return fail(c, LSQR_ERR_STATE, "slot %d has nothing in flight", slot);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->slot_ev[slot]));
+  c->slot_busy[slot] = false;
+  const char *pin = slot_pin(c, slot);
+  unsigned long long head[2];
+  SolveOut out;
+  memcpy(head, pin, sizeof head);
+  memcpy(&out, pin + 64, sizeof out);
+  const unsigned long long cnt = head[0], pk = head[1];
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->fraction = c->n ? (double)cnt / (double)c->n : 0.0;
+    info->iterations = c->slot_H[slot];
+    info->evaluated = c->slot_H[slot];
+    info->best_votes = (uint32_t)(pk >> 32);
+    info->best_index = pk ? c->slot_first[slot] + (0xFFFFFFFFull - (pk & 0xFFFFFFFFull)) : 0;
+    info->n_params = out.ok ? out.n_params : 0;
+    info->fit.n_params = info->n_params;
+    info->fit.n_used = cnt;
+    info->fit.cost = out.cost;
+  }
+  if (pk == 0 || !out.ok) return LSQR_EMPTY;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
   return LSQR_OK;
 }
 

@@ -1704,3 +1704,46 @@ def test_step_device_world2_equals_world1():
                         os.path.join(root, "tests", "dist_step_device.py")],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "world2 step_device ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("model,dim,ls", [(L.PLANE, 3, 0), (L.SPHERE, 3, L.LS_ALGEBRAIC), (L.LINE, 2, 0),
+                                          (L.DENSE, 8, 0), (L.US_SINGLE, 0, L.LS_ANALYTIC), (L.PIVOT, 3, 0)])
+def test_pipelined_batches_equal_blocking_batches(ctx, model, dim, ls):
+    """lsqr_batch_fit_enqueue / _wait: the next batch is enqueued before the previous one is read; results
+    equal lsqr_batch_fit's for the same stream ranges"""
+    if model == L.DENSE:
+        data, delta = synth.dense(60_000, 8, 0.3, seed=5)[0], 0.1
+    elif model == L.US_SINGLE:
+        data, delta = synth.us_single_fast(50_000, 0.3, seed=5)[0], 3.0
+    elif model == L.PIVOT:
+        data, delta = synth.pivot(40_000, 0.3, seed=5)[0], 1.0
+    else:
+        data, delta = _data(model, dim, 150_000, 997, outliers=0.5), 0.5
+    ctx.set_model(model, dim, delta, ls).upload(data)
+    H = 512
+    want = [ctx.batch_fit(21, i * H, H) for i in range(5)]
+    got = []
+    ctx.batch_fit_enqueue(21, 0, H, slot=0)
+    for i in range(1, 5):
+        ctx.batch_fit_enqueue(21, i * H, H, slot=i & 1)
+        got.append(ctx.batch_fit_wait((i - 1) & 1))
+    got.append(ctx.batch_fit_wait(4 & 1))
+    for w, g in zip(want, got):
+        assert g["status"] == w["status"]
+        assert (g["info"].best_votes, g["info"].best_index, g["info"].fit.n_used) == \
+               (w["info"].best_votes, w["info"].best_index, w["info"].fit.n_used)
+        assert np.array_equal(g["params"], w["params"])
+    # slot discipline
+    with pytest.raises(L.LsqrError):
+        ctx.batch_fit_wait(0)                         # nothing in flight
+    ctx.batch_fit_enqueue(21, 0, H, slot=1)
+    with pytest.raises(L.LsqrError):
+        ctx.batch_fit_enqueue(21, H, H, slot=1)      # unread result
+    ctx.batch_fit_wait(1)
+
+
+def test_pipelined_batches_refuse_host_in_the_loop_fits(ctx):
+    ctx.set_model(L.SPHERE, 3, 0.5, L.LS_GEOMETRIC).upload(_data(L.SPHERE, 3, 5000, 1))
+    with pytest.raises(L.LsqrError) as e:
+        ctx.batch_fit_enqueue(1, 0, 64)
+    assert e.value.status == L.ERR_INVALID
