@@ -392,6 +392,61 @@ __global__ __launch_bounds__(kBlock) void k_moments(const double *__restrict__ d
   }
 }
 
+// K3 + K4 in one pass over the records: consensus mask of the (prepared) model `par` and the phase-0
+// moment block of the agreeing records about `ctxv`.  Same chunking, same per-thread order and the same
+// partial sums as k_mask followed by k_moments<M, AccLs<M>, true> -- the block is bit-identical -- but the
+// records are read once (the winner's mask + fit at 10 M points: 0.115 -> 0.07 ms).
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_mask_moments(const double *__restrict__ data, size_t stride,
+                                                         size_t begin, size_t end, size_t chunk,
+                                                         const double *__restrict__ par,
+                                                         const double *__restrict__ ctxv, ModelConsts mc,
+                                                         uint8_t *__restrict__ mask,
+                                                         unsigned long long *__restrict__ counter,
+                                                         double *__restrict__ partials) {
+  typedef AccLs<M> A;
+  __shared__ double s_m[kBlock / 64][A::N];
+  __shared__ uint32_t s_c[kBlock / 64];
+  double acc[A::N];
+#pragma unroll
+  for (int k = 0; k < A::N; k++) acc[k] = 0.0;
+  double sp[M::SP];
+  for (int j = 0; j < M::SP; j++) sp[j] = par[j];  // prepared by k_prepare
+  double cv[M::P > M::REC ? M::P : M::REC];
+  for (int k = 0; k < (M::P > M::REC ? M::P : M::REC); k++) cv[k] = ctxv[k];
+  uint32_t local = 0;
+  size_t lo = begin + (size_t)blockIdx.x * chunk;
+  size_t hi = lo + chunk < end ? lo + chunk : end;
+  for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    double x[M::REC];
+    M::load(data + i * stride, mc, x);
+    const bool a = M::agree(sp, x, mc);
+    mask[i] = a ? 1 : 0;
+    if (!a) continue;
+    local++;
+    A::acc(x, cv, acc);
+  }
+#pragma unroll
+  for (int k = 0; k < A::N; k++) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x < A::N) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) t += s_m[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kBlock / 64; w++) t += s_c[w];
+    if (t) atomicAdd(counter, t);
+  }
+}
+
 // fixed-order sum of the per-block partials -> mom[0..nmom): one wave per moment, lane-strided
 // partial sums then a shuffle tree (the order depends only on nblocks).
 __global__ __launch_bounds__(64) void k_reduce(const double *__restrict__ partials, int nblocks,

@@ -81,6 +81,7 @@ struct lsqr_ctx {
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
   int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1, opt_syrk_diag = 0;
+  int opt_fuse_mask = 1;  // winner's mask + moment block in one pass (0: two kernels, for A/B runs)
   long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
 
@@ -888,7 +889,7 @@ void lm_settings(const lsqr_model_cfg &cfg, int *n, double *ftol, double *xtol, 
 
 // the closed-form part of run_fit without the read-back: moments + solve chained on the stream, result in
 // d_out.  Models whose fit needs the host in the loop (LM, the phantom's Gram solve) are refused.
-int enqueue_fit(lsqr_ctx *c, int use_mask) {
+int enqueue_fit(lsqr_ctx *c, int use_mask, bool have_moments = false) {
   if (wants_lm(c->cfg) || c->cfg.model == LSQR_MODEL_PHANTOM)
     return fail(c, LSQR_ERR_INVALID, "this fit needs the host between device passes");
   return dispatch(c->cfg, [&](auto tag) -> int {
@@ -898,16 +899,18 @@ int enqueue_fit(lsqr_ctx *c, int use_mask) {
       if ((st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
       return launch_solve_dense(c);
     } else {
-      bool first_datum = !c->origin_valid;
-      if constexpr (requires { M::ORIGIN_FIRST; }) first_datum = true;
-      if (first_datum) {
-        HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND, hipMemcpyDeviceToDevice,
-                                 c->stream));
-      } else {
-        HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (c->cfg.model == LSQR_MODEL_SPHERE ? 0 : M::ND),
-                                 sizeof(double) * M::ND, hipMemcpyDeviceToDevice, c->stream));
+      if (!have_moments) {
+        bool first_datum = !c->origin_valid;
+        if constexpr (requires { M::ORIGIN_FIRST; }) first_datum = true;
+        if (first_datum) {
+          HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND, hipMemcpyDeviceToDevice,
+                                   c->stream));
+        } else {
+          HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (c->cfg.model == LSQR_MODEL_SPHERE ? 0 : M::ND),
+                                   sizeof(double) * M::ND, hipMemcpyDeviceToDevice, c->stream));
+        }
+        if ((st = launch_moments<M>(c, use_mask, 0, c->n, 0, &nmom)) != LSQR_OK) return st;
       }
-      if ((st = launch_moments<M>(c, use_mask, 0, c->n, 0, &nmom)) != LSQR_OK) return st;
       ProfScope ps(c, KID_SOLVE);
       hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
                          c->d_out);
@@ -918,7 +921,8 @@ int enqueue_fit(lsqr_ctx *c, int use_mask) {
 }
 
 // leastSquaresEstimate over [0,n) (single device).  Leaves the result in d_out.
-int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
+// have_moments: d_mom already holds the phase-0 block about d_vec (launch_mask_moments)
+int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     int nmom = 0, st;
@@ -934,6 +938,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
       if ((st = launch_solve_dense(c)) != LSQR_OK) return st;
       return read_out(c, out);
     } else {
+    if (!have_moments) {
     bool first_datum = !c->origin_valid;  // default origin: the first observation
     if constexpr (requires { M::ORIGIN_FIRST; }) first_datum = true;  // parameters hold no point
     if (first_datum) {
@@ -944,6 +949,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out) {
                                sizeof(double) * M::ND, hipMemcpyDeviceToDevice, c->stream));
     }
     if ((st = launch_moments<M>(c, use_mask, 0, c->n, 0, &nmom)) != LSQR_OK) return st;
+    }
     {
       ProfScope ps(c, KID_SOLVE);
       hipLaunchKernelGGL((k_solve<M>), dim3(1), dim3(64), 0, c->stream, c->d_mom, c->d_vec, c->mc,
@@ -1050,6 +1056,75 @@ int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (count_out) *count_out = *(unsigned long long *)c->h_pin;
   return LSQR_OK;
+}
+
+// mask of d_par over [begin, end) and the phase-0 moment block of the agreeing records about d_vec (set by the
+// caller) in ONE pass; -> d_mask, d_counter[0], d_mom.  *fused = false (nothing launched) for the models
+// whose moments are not a per-record accumulate (dense: SYRK on the matrix cores; phantom: Gram of the rows).
+int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *fused) {
+  *fused = false;
+  if (c->cfg.model == LSQR_MODEL_DENSE || c->cfg.model == LSQR_MODEL_PHANTOM || !c->opt_fuse_mask)
+    return LSQR_OK;
+  int st = ensure(c, &c->d_mask, &c->mask_cap, c->n);
+  if (st != LSQR_OK) return st;
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if constexpr (M::IS_DENSE || requires { M::IS_PHANTOM; }) {
+      return LSQR_ERR_INVALID;
+    } else {
+      HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+      if constexpr (M::SP > M::P) {
+        hipLaunchKernelGGL((k_prepare<M>), dim3(1), dim3(64), 0, c->stream, c->d_par, c->mc);
+        HIPCHK(c, hipGetLastError());
+      }
+      size_t cnt = end - begin;
+      int nb = grid_for(cnt, kBlock * 16, kMaxPartials);  // the chunking of launch_moments
+      size_t chunk = (cnt + nb - 1) / nb;
+      chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+      nb = (int)((cnt + chunk - 1) / chunk);
+      if (nb < 1) nb = 1;
+      *nmom = M::NMOM;
+      {
+        ProfScope ps(c, KID_MASK);
+        hipLaunchKernelGGL((k_mask_moments<M>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
+                           begin, end, chunk, c->d_par, c->d_vec, c->mc, c->d_mask, c->d_counter,
+                           c->d_partials);
+        HIPCHK(c, hipGetLastError());
+      }
+      ProfScope ps(c, KID_SOLVE);
+      hipLaunchKernelGGL(k_reduce, dim3(*nmom), dim3(64), 0, c->stream, c->d_partials, nb, (int)MOM_MAX,
+                         *nmom, c->d_mom);
+      HIPCHK(c, hipGetLastError());
+      return LSQR_OK;
+    }
+  });
+  if (st != LSQR_OK) return st;
+  c->mask_valid = true;
+  c->origin_valid = true;
+  *fused = true;
+  return LSQR_OK;
+}
+
+// origin of a masked fit as run_fit chooses it: the model's own point (d_par) once a mask exists, the first
+// record for the models whose parameters hold no point
+int set_fit_origin(lsqr_ctx *c, bool from_model) {
+  return dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if constexpr (M::IS_DENSE || requires { M::IS_PHANTOM; }) {
+      return LSQR_OK;
+    } else {
+      bool first_datum = !from_model;
+      if constexpr (requires { M::ORIGIN_FIRST; }) first_datum = true;
+      if (first_datum) {
+        HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_data, sizeof(double) * M::ND, hipMemcpyDeviceToDevice,
+                                 c->stream));
+      } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (c->cfg.model == LSQR_MODEL_SPHERE ? 0 : M::ND),
+                                 sizeof(double) * M::ND, hipMemcpyDeviceToDevice, c->stream));
+      }
+      return LSQR_OK;
+    }
+  });
 }
 
 // the winner's scan parameters -> d_par, on the device (no host round trip between scan and mask)
@@ -1961,7 +2036,11 @@ int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double 
   hipLaunchKernelGGL(k_take_best, dim3(1), dim3(64), 0, c->stream, c->d_counter + 1, c->d_hparams,
                      c->HS, c->d_par);
   HIPCHK(c, hipGetLastError());
-  if ((st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
+  bool fused = false;
+  int nm = 0;
+  if ((st = set_fit_origin(c, true)) != LSQR_OK) return st;
+  if ((st = launch_mask_moments(c, 0, c->n, &nm, &fused)) != LSQR_OK) return st;
+  if (!fused && (st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
   unsigned long long *pin2 = (unsigned long long *)((char *)c->h_pin + 8192);
   HIPCHK(c, hipMemcpyAsync(pin2, c->d_counter, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));  // {inliers, packed winner}
@@ -1969,7 +2048,7 @@ int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double 
     HIPCHK(c, hipMemcpyAsync(consensus_out, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
   SolveOut out;
   memset(&out, 0, sizeof out);
-  if ((st = run_fit(c, 1, &out)) != LSQR_OK) return st;  // synchronises the stream
+  if ((st = run_fit(c, 1, &out, fused)) != LSQR_OK) return st;  // synchronises the stream
   const unsigned long long cnt = pin2[0], pk = pin2[1];
   if (info) {
     memset(info, 0, sizeof *info);
@@ -2004,18 +2083,22 @@ int lsqr_winner_moments(lsqr_ctx *c, uint64_t seed, uint64_t stream_index, size_
   HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams, sizeof(double) * c->HS, hipMemcpyDeviceToDevice,
                            c->stream));
-  if ((st = launch_mask(c, begin, end)) != LSQR_OK) return st;
   HIPCHK(c, hipMemsetAsync(c->d_vec, 0, sizeof(double) * 32, c->stream));
   const int m = c->cfg.model;
   if (m == LSQR_MODEL_PLANE || m == LSQR_MODEL_LINE || m == LSQR_MODEL_SPHERE)
     HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (m == LSQR_MODEL_SPHERE ? 0 : c->ND),
                              sizeof(double) * c->ND, hipMemcpyDeviceToDevice, c->stream));
   int nmom = 0;
-  st = dispatch(c->cfg, [&](auto tag) -> int {
-    typedef typename decltype(tag)::type M;
-    return launch_moments<M>(c, 1, begin, end, 0, &nmom);
-  });
-  if (st != LSQR_OK) return st;
+  bool fused = false;
+  if ((st = launch_mask_moments(c, begin, end, &nmom, &fused)) != LSQR_OK) return st;
+  if (!fused) {
+    if ((st = launch_mask(c, begin, end)) != LSQR_OK) return st;
+    st = dispatch(c->cfg, [&](auto tag) -> int {
+      typedef typename decltype(tag)::type M;
+      return launch_moments<M>(c, 1, begin, end, 0, &nmom);
+    });
+    if (st != LSQR_OK) return st;
+  }
   double *pin = (double *)((char *)c->h_pin + 16384);  // {valid, count, params[64], origin[32]}
   HIPCHK(c, hipMemcpyAsync(pin, c->d_valid, 1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(pin + 1, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -2053,11 +2136,15 @@ int lsqr_batch_fit_enqueue(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
   hipLaunchKernelGGL(k_take_best, dim3(1), dim3(64), 0, c->stream, c->d_counter + 1, c->d_hparams,
                      c->HS, c->d_par);
   HIPCHK(c, hipGetLastError());
-  if ((st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
+  bool fused = false;
+  int nm = 0;
+  if ((st = set_fit_origin(c, true)) != LSQR_OK) return st;
+  if ((st = launch_mask_moments(c, 0, c->n, &nm, &fused)) != LSQR_OK) return st;
+  if (!fused && (st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
   char *pin = slot_pin(c, slot);
   HIPCHK(c, hipMemcpyAsync(pin, c->d_counter, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            c->stream));  // {inliers, packed winner}
-  if ((st = enqueue_fit(c, 1)) != LSQR_OK) return st;
+  if ((st = enqueue_fit(c, 1, fused)) != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(pin + 64, c->d_out, sizeof(SolveOut), hipMemcpyDeviceToHost, c->stream));
   if (!c->slot_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->slot_ev[slot], hipEventDisableTiming));
   HIPCHK(c, hipEventRecord(c->slot_ev[slot], c->stream));
@@ -2141,18 +2228,22 @@ int lsqr_step_winner(lsqr_ctx *c, uint64_t seed, uint64_t batch_first, const uin
   HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_hparams, sizeof(double) * c->HS, hipMemcpyDeviceToDevice,
                            c->stream));
-  if ((st = launch_mask(c, begin, end)) != LSQR_OK) return st;
   HIPCHK(c, hipMemsetAsync(c->d_vec, 0, sizeof(double) * 32, c->stream));
   const int m = c->cfg.model;
   if (m == LSQR_MODEL_PLANE || m == LSQR_MODEL_LINE || m == LSQR_MODEL_SPHERE)
     HIPCHK(c, hipMemcpyAsync(c->d_vec, c->d_par + (m == LSQR_MODEL_SPHERE ? 0 : c->ND),
                              sizeof(double) * c->ND, hipMemcpyDeviceToDevice, c->stream));
   int nmom = 0;
-  st = dispatch(c->cfg, [&](auto tag) -> int {
-    typedef typename decltype(tag)::type M;
-    return launch_moments<M>(c, 1, begin, end, 0, &nmom);
-  });
-  if (st != LSQR_OK) return st;
+  bool fused = false;
+  if ((st = launch_mask_moments(c, begin, end, &nmom, &fused)) != LSQR_OK) return st;
+  if (!fused) {
+    if ((st = launch_mask(c, begin, end)) != LSQR_OK) return st;
+    st = dispatch(c->cfg, [&](auto tag) -> int {
+      typedef typename decltype(tag)::type M;
+      return launch_moments<M>(c, 1, begin, end, 0, &nmom);
+    });
+    if (st != LSQR_OK) return st;
+  }
   hipLaunchKernelGGL(k_pack_block, dim3(1), dim3(256), 0, c->stream, c->d_mom, nmom, c->d_counter,
                      block_dev);
   HIPCHK(c, hipGetLastError());
@@ -2260,6 +2351,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   if (!strcmp(name, "scan_hsplit")) {  // hypothesis segments per tile of the two-level scan (0 = auto)
     if (value < 0 || value > 128) return fail(c, LSQR_ERR_INVALID, "scan_hsplit must be 0..128");
     c->opt_hsplit = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "fuse_mask")) {  // winner's mask + moment block in one pass (default) or two kernels
+    c->opt_fuse_mask = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_block")) {  // workgroup size of the two-level scan

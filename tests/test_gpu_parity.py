@@ -1747,3 +1747,31 @@ def test_pipelined_batches_refuse_host_in_the_loop_fits(ctx):
     with pytest.raises(L.LsqrError) as e:
         ctx.batch_fit_enqueue(1, 0, 64)
     assert e.value.status == L.ERR_INVALID
+
+
+@pytest.mark.parametrize("model,dim,ls", [(L.PLANE, 3, 0), (L.PLANE, 2, 0), (L.SPHERE, 3, L.LS_GEOMETRIC),
+                                          (L.LINE, 3, 0), (L.US_SINGLE, 0, L.LS_ANALYTIC), (L.ABSOR, 3, 0),
+                                          (L.RAY, 3, 0)])
+def test_fused_mask_and_moments_equal_two_kernels(ctx, model, dim, ls):
+    """k_mask_moments (the winner's consensus mask and its moment block in one pass over the records) gives
+    the same mask, count and bit-identical fit as k_mask followed by k_moments"""
+    aux = 0.0
+    if model == L.US_SINGLE:
+        data, delta = synth.us_single_fast(70_001, 0.3, seed=6)[0], 3.0
+    elif model == L.ABSOR:
+        data, delta = synth.absolute_orientation(50_003, 0.3, seed=6)[0], 1.0
+    elif model == L.RAY:
+        data, delta, aux = synth.rays(50_003, 0.3, seed=6)[0], 1.0, 0.017453292519943295
+    else:
+        data, delta = _data(model, dim, 130_003, 996, outliers=0.5), 0.5
+    ctx.set_model(model, dim, delta, ls, aux=aux).upload(data)
+    ctx.set_option("fuse_mask", 0)
+    two = ctx.batch_fit(31, 0, 700, want_consensus=True)
+    ctx.set_option("fuse_mask", 1)
+    one = ctx.batch_fit(31, 0, 700, want_consensus=True)
+    assert one["status"] == two["status"] == L.OK
+    assert np.array_equal(one["consensus"], two["consensus"])
+    assert (one["info"].best_votes, one["info"].best_index, one["info"].fit.n_used) == \
+           (two["info"].best_votes, two["info"].best_index, two["info"].fit.n_used)
+    assert np.array_equal(one["params"], two["params"])
+    assert one["consensus"].sum() == one["info"].fit.n_used
