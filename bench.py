@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="hypotheses per GPU per step (0 = 4096; "
                     "1024 for the dense system)")
     ap.add_argument("--workload", default="plane",
-                    choices=["plane", "sphere", "line", "dense", "us"])
+                    choices=["plane", "sphere", "line", "dense", "us", "phantom"])
     ap.add_argument("--no-filter", action="store_true", help="plain fp64 scan (no fp32 pre-filter)")
     ap.add_argument("--no-index", action="store_true", help="exhaustive scan (no spatial index)")
     ap.add_argument("--outliers", type=float, default=0.5)
@@ -73,11 +73,13 @@ def make_data(workload, n, outliers):
         return synth.line(n, outliers)
     if workload == "dense":
         return synth.dense(n, 64, 0.05)
+    if workload == "phantom":  # k = 31: an all-inlier subset needs few off-plane frames
+        return synth.plane_phantom_fast(n, min(outliers, 0.05), pixel_sigma=0.05)
     return synth.us_single_fast(n, outliers)
 
 
 # fp64 VALU instructions of the exact agree() per (hypothesis, observation) pair: arithmetic + compares
-OPS_PER_PAIR = {"plane": 9, "sphere": 10, "line": 20, "dense": 130, "us": 69}
+OPS_PER_PAIR = {"plane": 9, "sphere": 10, "line": 20, "dense": 130, "us": 69, "phantom": 64}
 
 
 def cpu_baseline(workload, data, delta):
@@ -86,15 +88,16 @@ def cpu_baseline(workload, data, delta):
     container) driving the restated estimator; falls back to the oracle's C port of the loop."""
     from oracle import pyoracle as O
     model = {"plane": O.PLANE, "sphere": O.SPHERE, "line": O.LINE, "dense": O.DENSE,
-             "us": O.US_SINGLE}[workload]
+             "us": O.US_SINGLE, "phantom": O.PHANTOM}[workload]
     c = O.cfg(model, 64 if workload == "dense" else 3, delta, O.LS_ALGEBRAIC)
     cores = 1
     t0 = time.perf_counter()
-    if workload == "dense":
-        # the adaptive bound never closes for k = 64 (w^64 underflows), so the CPU leg is a bounded
-        # sample of the metric's unit itself: minimal-subset solve + one full agree() pass
+    if workload in ("dense", "phantom"):
+        # the adaptive bound never closes for k = 64 / hardly for k = 31 (w^k underflows), so the CPU leg is
+        # a bounded sample of the metric's unit itself: minimal-subset solve + one full agree() pass
         n = len(data)
-        subs = O.ctr_subsets(20261003, 0, 64, n, 64)
+        k = 64 if workload == "dense" else 31
+        subs = O.ctr_subsets(20261003, 0, 64 if workload == "dense" else 4096, n, k)
         hyp = 0
         while hyp < len(subs) and (hyp < 4 or time.perf_counter() - t0 < 12.0):
             par = O.estimate(c, data[subs[hyp]])
@@ -103,9 +106,10 @@ def cpu_baseline(workload, data, delta):
             hyp += 1
         dt = time.perf_counter() - t0
         return {"value": hyp / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
-                "sample": "oracle C port of DenseLinearEquationSystemParametersEstimator: %d hypotheses "
-                          "(64x64 minimal solve + full agree() pass over N=%d rows, no early exit) "
-                          "in %.2f s; 1 thread" % (hyp, n, dt)}
+                "sample": "oracle C port of %s: %d hypotheses "
+                          "(%dx%d minimal solve + full agree() pass over N=%d records, no early exit) "
+                          "in %.2f s; 1 thread" % ("DenseLinearEquationSystemParametersEstimator" if k == 64 else
+                                                   "PlanePhantomUSCalibrationParametersEstimator", hyp, k, k, n, dt)}
     if O.ref_available():
         r = O.ref_ransac(c, data, 0.999, seed=20261003)
         hyp = r["estimate_calls"]
@@ -126,7 +130,7 @@ def cpu_baseline(workload, data, delta):
 def main():
     a = parse()
     if a.points <= 0:
-        a.points = {"dense": 2_000_000, "us": 1_000_000}.get(a.workload, 10_000_000)
+        a.points = {"dense": 2_000_000, "us": 1_000_000, "phantom": 1_000_000}.get(a.workload, 10_000_000)
     if a.batch <= 0:
         a.batch = 1024 if a.workload == "dense" else 4096
     rank = int(os.environ.get("RANK", "0"))
@@ -162,10 +166,10 @@ def main():
     from lsqrrecipes_amd.context import Context
     from lsqrrecipes_amd.distributed import Comm, ShardedRansac
 
-    delta = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0}[a.workload]
+    delta = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}[a.workload]
     model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE, "dense": L.DENSE,
-             "us": L.US_SINGLE}[a.workload]
-    ls_type = L.LS_ANALYTIC if a.workload == "us" else L.LS_GEOMETRIC
+             "us": L.US_SINGLE, "phantom": L.PHANTOM}[a.workload]
+    ls_type = L.LS_ANALYTIC if a.workload == "us" else L.LS_GEOMETRIC   # GEOMETRIC == ITERATIVE == 1
     data, truth, lab = make_data(a.workload, a.points, a.outliers)
     ctx = Context(local)
     ctx.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
@@ -206,7 +210,7 @@ def main():
     # (lsqr_batch_fit_enqueue / _wait), so the host's latency between steps hides behind the device's work;
     # every step still runs the whole chain.  --no-pipeline keeps one blocking call per step.
     pipelined = (comm.world == 1 and not force_dist and not a.no_pipeline
-                 and not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC))
+                 and not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom")
 
     def run_steps(first_step, count):
         last = None
@@ -254,7 +258,7 @@ def main():
         alg_bytes = float(H) * a.points * rec          # N*sizeof(T) per hypothesis
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs_per_s = float(H) * a.points / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
-        filtered = a.workload in ("plane", "sphere", "line", "us", "dense") and not a.no_filter
+        filtered = not a.no_filter
         if idx["built"] and not a.no_filter:
             kname = ("k_scan_cells<%s> (two-level: fp32 cell-box culling over a Morton-sorted copy, "
                      "packed fp32 filter + exact fp64 re-check in surviving cells)" % a.workload)
@@ -262,8 +266,9 @@ def main():
             kname = {"plane": "k_scan_f32<plane> (fp32 pre-filter + exact fp64 re-check)",
                      "sphere": "k_scan_f32<sphere> (fp32 pre-filter + exact fp64 re-check)",
                      "line": "k_scan_f32<line> (fp32 pre-filter + exact fp64 re-check)",
-                     "us": "k_scan<us> (fused fp64 pre-filter + exact fp64 re-check)",
-                     "dense": "k_scan_dense_mfma (fp64 MFMA filter + exact re-check worklist)"}.get(
+                     "us": "k_scan_us_f32<us> (packed fp32 pre-filter + exact fp64 re-check)",
+                     "phantom": "k_scan_us_f32<phantom> (factored packed fp32 pre-filter + exact fp64 re-check)",
+                     "dense": "k_scan_dense_mfma2 (fp64 MFMA filter + exact re-check worklist)"}.get(
                          a.workload)
         eq_gops = pairs_per_s * OPS_PER_PAIR[a.workload] / 1e9
         traffic = None
