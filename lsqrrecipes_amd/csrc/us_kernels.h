@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ d
     for (int c = 0; c < NC; c++) A[c * LDA + lane] = a[c];
   }
   __syncthreads();
-  int rank = wave_pinv_solve(MR, NC, A, LDA, V, LDA, b, kUsSvEps, 0.0, x, cw);
+  int rank = block_pinv_solve<64, MR, NC>(MR, NC, A, LDA, V, LDA, b, kUsSvEps, 0.0, x, cw);
   bool ok = (rank == NC) && !__any(!in_range);
   if (lane == 0) {
     double par[M::SP];

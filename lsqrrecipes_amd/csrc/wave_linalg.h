@@ -200,14 +200,16 @@ __device__ inline int block_jacobi_svd_fixed(double *A, int lda, double *V, int 
   return sweep;
 }
 
-template <int T>
+// M, N > 0: compile-time sizes (m == M, n == N), register-batched rounds (block_jacobi_svd_fixed)
+template <int T, int M = 0, int N = 0>
 __device__ inline int block_pinv_solve(int m, int n, double *A, int lda, double *V, int ldv,
                                        const double *b, double tol_abs, double tol_rel, double *x,
                                        double *cwork) {
   __shared__ int s_rank;
   __shared__ double s_smax;
   const int tid = threadIdx.x;
-  block_jacobi_svd<T>(m, n, A, lda, V, ldv);
+  if constexpr (M > 0) block_jacobi_svd_fixed<T, M, N>(A, lda, V, ldv);
+  else block_jacobi_svd<T>(m, n, A, lda, V, ldv);
   // singular values and projections of b
   double s2 = 0, d = 0;
   if (tid < n)
