@@ -319,7 +319,7 @@ template <int D>
 struct PlaneCell {
   typedef PlaneModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 0, ROW2_OFF = 0 };  // row = fp64 scan parameters
-  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0 };  // measured best (tools/ab_cells.py)
+  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0, MIN_WAVES = 6 };  // measured best (tools/ab_cells.py)
   struct Hyp {
     double n[3], c;
     float nf[3], e0;
@@ -406,6 +406,7 @@ template <int D>
 struct SphereCell {
   typedef SphereModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
+  enum { MIN_WAVES = 4 };
   enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // absolute coordinates: wider band, whole-cell re-checks
                                                     // cost more; LDS broadcast measured 5 % faster here
   struct Hyp {
@@ -471,7 +472,7 @@ template <int D>
 struct LineCell {
   typedef LineModel<D> M;
   enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
-  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0 };
+  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0, MIN_WAVES = 4 };
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;
@@ -553,7 +554,9 @@ inline CellConsts cell_consts(const LineCell<D> *, const ModelConsts &mc) {
 // current 64 are processed.  Votes of the 64 hypotheses of a group are collected in one VGPR
 // (lane b = hypothesis h0 + b, v_readlane / v_writelane) and flushed with one LDS atomic per group.
 template <class CM, int PP, int CPT, int BS, bool LDSB = false>
-__global__ __launch_bounds__(BS) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
+// CM::MIN_WAVES (default tile shape only): the register budget that buys the occupancy measured best -- plane
+// 80 VGPRs = 6 waves per SIMD (98 VGPRs / 4 waves without the hint: 1.44 -> 1.31 ms; 7 waves spill: 1.40 ms)
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? CM::MIN_WAVES : 1, 8))) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
                                                     const CellBox *__restrict__ boxes,
                                                     uint32_t ncells, const double *__restrict__ sp,
                                                     const float *__restrict__ rows,
