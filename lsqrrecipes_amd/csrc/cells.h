@@ -472,7 +472,7 @@ template <int D>
 struct LineCell {
   typedef LineModel<D> M;
   enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
-  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0, MIN_WAVES = 4 };
+  enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1, MIN_WAVES = 4 };  // measured (tools/ab_cells.py): 2.17 ms against 2.34 ms with 512 / v_readlane
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;

@@ -11,7 +11,7 @@ model = {'plane': L.PLANE, 'sphere': L.SPHERE, 'line': L.LINE}[wl]
 data = gen(N, 0.5)[0]
 ctx = Context(0); ctx.set_model(model, 3, 0.5).upload(data)
 ctx.hypotheses_sample(1, 0, H)
-variants = [(0, 0, 0, 0), (2, 0, 1, 256), (2, 0, 1, 257), (2, 256, 1, 257), (2, 512, 1, 257)]
+variants = [(2, 0, 1, 0), (2, 128, 1, 256), (2, 256, 1, 256), (2, 512, 1, 256), (2, 256, 1, 257), (2, 512, 1, 257), (2, 512, 1, 1024)]
 ref = None
 res = {v: [] for v in variants}
 ctx.profile(True)
