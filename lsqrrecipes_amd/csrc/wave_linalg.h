@@ -108,9 +108,16 @@ __device__ inline int block_jacobi_svd(int m, int n, double *A, int lda, double 
 // one batch of LDS reads, the rotation works on the registers and writes back -- one LDS round trip per
 // round instead of one per element (the generic loops above wait for every dependent read).  Same
 // arithmetic in the same order as block_jacobi_svd.
+constexpr int pow2_floor(int x) { return x < 2 ? 1 : 2 * pow2_floor(x / 2); }
+
 template <int T, int M, int N>
 __device__ inline int block_jacobi_svd_fixed(double *A, int lda, double *V, int ldv) {
-  constexpr int LPP = T / 32, RA = (M + LPP - 1) / LPP, RV = (N + LPP - 1) / LPP;
+  // lanes per column pair: as many as the workgroup affords for the (N + 1) / 2 pairs of a round (a power of
+  // two <= 64, so that a pair's lanes are consecutive inside one wave and combine with shuffles); 31 columns
+  // on one wave: 16 pairs x 4 lanes, 8 rows per lane
+  constexpr int NPAIR = ((N + 1) & ~1) / 2;
+  constexpr int LPP = pow2_floor(T / NPAIR) > 64 ? 64 : pow2_floor(T / NPAIR);
+  constexpr int RA = (M + LPP - 1) / LPP, RV = (N + LPP - 1) / LPP;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < N * N; idx += T) {
     int r = idx % N, c = idx / N;
@@ -170,7 +177,9 @@ __device__ inline int block_jacobi_svd_fixed(double *A, int lda, double *V, int 
         be += __shfl_xor(be, o);
         ga += __shfl_xor(ga, o);
       }
-      const bool rot = active && ga != 0.0 && fabs(ga) > 4e-15 * sqrt(al * be);
+      // |ga| > 4e-15 sqrt(al be), squared (no square root on the critical path; al be <= 1e300 for any
+      // system the callers accept)
+      const bool rot = active && ga != 0.0 && ga * ga > 1.6e-29 * (al * be);
       if (rot) {
         double zeta = (be - al) / (2.0 * ga);
         double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -193,7 +202,12 @@ __device__ inline int block_jacobi_svd_fixed(double *A, int lda, double *V, int 
           }
         }
       }
-      any_rot |= __syncthreads_or(rot ? 1 : 0);  // also the barrier between rounds
+      if constexpr (T == 64) {  // one wave: a ballot instead of the workgroup reduction
+        __syncthreads();
+        any_rot |= __any(rot) ? 1 : 0;
+      } else {
+        any_rot |= __syncthreads_or(rot ? 1 : 0);  // also the barrier between rounds
+      }
     }
     if (!any_rot) break;
   }
