@@ -212,8 +212,21 @@ def main():
     pipelined = (comm.world == 1 and not force_dist and not a.no_pipeline
                  and not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom")
 
+    closed_form = not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
+    pipelined_dist = step_on_device and closed_form and not a.no_pipeline
+
     def run_steps(first_step, count):
         last = None
+        if pipelined_dist:   # multi-GPU: step i + 1 is enqueued (collectives included) before step i is read
+            for i in range(count):
+                eng.step_device(seed, first_step + i, H, slot=i & 1)
+                if i:
+                    last = eng.step_device_wait((i - 1) & 1)
+            if count:
+                last = eng.step_device_wait((count - 1) & 1)
+            if last is None:
+                return None
+            return last[0], last[3], last[4]
         if not pipelined:
             for i in range(count):
                 last = step(first_step + i)
@@ -307,6 +320,8 @@ def main():
                        "step": ("lsqr_batch_fit_enqueue/_wait (one chain per step, next step enqueued before "
                                 "the previous one is read)" if pipelined
                                 else "lsqr_batch_fit (one chain, one sync)" if comm.world == 1 and not force_dist
+                                else "step_device, pipelined (collectives on device buffers; step i + 1 enqueued "
+                                "before step i is read)" if pipelined_dist
                                 else "step_device (collectives on device buffers, one sync)" if step_on_device
                                 else "step (exchanges staged through the host)")},
             "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),

@@ -255,6 +255,14 @@ LSQR_API int lsqr_step_winner(lsqr_ctx *ctx, uint64_t seed, uint64_t batch_first
                               const uint64_t *packed_dev, size_t begin, size_t end, double *block_dev);
 LSQR_API int lsqr_step_finish(lsqr_ctx *ctx, const uint64_t *packed_dev, const double *block_dev,
                               double *winner_out, double *params_out, lsqr_ransac_info *info);
+/* lsqr_step_finish in two halves (as lsqr_batch_fit_enqueue / _wait): the solve and the copies of the step's
+ * results into pinned slot `slot` (0 or 1) are enqueued, the next step can be enqueued on the same exchange
+ * buffers (stream order keeps this step's copies ahead of the next step's writes), and _wait blocks on the
+ * slot's event.  The phantom's host-side solve runs in _wait and uses one staging area: do not pipeline it. */
+LSQR_API int lsqr_step_finish_enqueue(lsqr_ctx *ctx, const uint64_t *packed_dev, const double *block_dev,
+                                      int slot);
+LSQR_API int lsqr_step_finish_wait(lsqr_ctx *ctx, int slot, double *winner_out, double *params_out,
+                                   lsqr_ransac_info *info);
 /* Exhaustive overload (RANSAC.h:111-113): all C(N,k) subsets in lexicographic order. */
 LSQR_API int lsqr_ransac_exhaustive(lsqr_ctx *ctx, double *params_out, uint8_t *consensus_out,
                                     lsqr_ransac_info *info);

@@ -91,6 +91,8 @@ SIGNATURES = {
                                    C.c_void_p]),
     "lsqr_step_finish": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(RansacInfo)]),
+    "lsqr_step_finish_enqueue": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
+    "lsqr_step_finish_wait": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_ransac": (C.c_int, [_ctx, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p,
                               C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_batch_fit": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p,

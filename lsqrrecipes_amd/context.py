@@ -206,6 +206,18 @@ class Context:
         fit = out[:info.n_params].copy() if st == L.OK else np.zeros(0)
         return st, win, fit, info
 
+    def step_finish_enqueue(self, packed_ptr, block_ptr, slot=0):
+        self._chk(self._lib.lsqr_step_finish_enqueue(self._h, C.c_void_p(packed_ptr), C.c_void_p(block_ptr), slot))
+
+    def step_finish_wait(self, slot=0):
+        win = np.zeros(max(self.P, 1))
+        out = np.zeros(max(self.P, 64))
+        info = L.RansacInfo()
+        st = self._chk(self._lib.lsqr_step_finish_wait(self._h, slot, L.ptr(win), L.ptr(out), C.byref(info)),
+                       allow_empty=True)
+        fit = out[:info.n_params].copy() if st == L.OK else np.zeros(0)
+        return st, win, fit, info
+
     def residuals(self, params, begin=0, end=None):
         """the model's residual of every record in [begin, end) (lsqr_residuals)"""
         end = self.n if end is None else end

@@ -63,6 +63,8 @@ struct lsqr_ctx {
   hipEvent_t slot_ev[2] = {nullptr, nullptr};  // lsqr_batch_fit_enqueue / _wait
   uint64_t slot_first[2] = {0, 0}, slot_H[2] = {0, 0};
   bool slot_busy[2] = {false, false};
+  hipEvent_t step_ev[2] = {nullptr, nullptr};  // lsqr_step_finish_enqueue / _wait
+  bool step_busy[2] = {false, false};
 
   double *d_rows = nullptr;  // plane phantom: the data rows a_i as an n x 32 matrix (phantom.h)
   size_t rows_cap = 0;
@@ -1246,6 +1248,8 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->slot_ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->step_ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -2250,29 +2254,23 @@ int lsqr_step_winner(lsqr_ctx *c, uint64_t seed, uint64_t batch_first, const uin
   return LSQR_OK;
 }
 
-int lsqr_step_finish(lsqr_ctx *c, const uint64_t *packed_dev, const double *block_dev,
-                     double *winner_out, double *params_out, lsqr_ransac_info *info) {
+// results of a step are staged per slot: {packed, count, valid, winner params[64], SolveOut, phantom block}
+static char *step_pin(lsqr_ctx *c, int slot) { return (char *)c->h_pin + 53248 + slot * 2048; }
+
+int lsqr_step_finish_enqueue(lsqr_ctx *c, const uint64_t *packed_dev, const double *block_dev, int slot) {
   int st = need_ready(c, true);
   if (st != LSQR_OK) return st;
-  if (!packed_dev || !block_dev) return fail(c, LSQR_ERR_INVALID, "null exchange buffer");
+  if (!packed_dev || !block_dev || slot < 0 || slot > 1) return fail(c, LSQR_ERR_INVALID, "bad argument");
+  if (c->step_busy[slot]) return fail(c, LSQR_ERR_STATE, "step slot %d holds an unread result", slot);
   const int nmom = lsqr_moments_len(&c->cfg, 0);
-  // staging: {packed, count, valid, winner params[64]} behind the SolveOut / the phantom's block
-  char *pin = (char *)c->h_pin;
-  unsigned long long *p_packed = (unsigned long long *)(pin + 32768);
-  double *p_count = (double *)(pin + 32768 + 8);
-  uint8_t *p_valid = (uint8_t *)(pin + 32768 + 16);
-  double *p_win = (double *)(pin + 32768 + 64);
-  HIPCHK(c, hipMemcpyAsync(p_packed, packed_dev, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(p_count, block_dev + nmom, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(p_valid, c->d_valid, 1, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(p_win, c->d_hparams, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
-  SolveOut out;
-  memset(&out, 0, sizeof out);
-  if (c->cfg.model == LSQR_MODEL_PHANTOM) {  // solved on the host from the Gram block
-    double *blk = (double *)(pin + 40960);
+  char *pin = step_pin(c, slot);
+  HIPCHK(c, hipMemcpyAsync(pin, packed_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 8, block_dev + nmom, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 16, c->d_valid, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 64, c->d_hparams, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
+  if (c->cfg.model == LSQR_MODEL_PHANTOM) {  // solved on the host from the Gram block (in _wait)
+    double *blk = (double *)((char *)c->h_pin + 40960);  // one block area: phantom steps are not pipelined
     HIPCHK(c, hipMemcpyAsync(blk, block_dev, sizeof(double) * nmom, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    phantom_solve_block(c->cfg, blk, &out);
   } else {
     HIPCHK(c, hipMemcpyAsync(c->d_mom, block_dev, sizeof(double) * nmom, hipMemcpyDeviceToDevice,
                              c->stream));
@@ -2289,9 +2287,33 @@ int lsqr_step_finish(lsqr_ctx *c, const uint64_t *packed_dev, const double *bloc
       }
     });
     if (st != LSQR_OK) return st;
-    if ((st = read_out(c, &out)) != LSQR_OK) return st;  // the one synchronisation of the step
+    HIPCHK(c, hipMemcpyAsync(pin + 1024, c->d_out, sizeof(SolveOut), hipMemcpyDeviceToHost, c->stream));
   }
-  const unsigned long long pk = *p_packed;
+  if (!c->step_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->step_ev[slot], hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->step_ev[slot], c->stream));
+  c->step_busy[slot] = true;
+  return LSQR_OK;
+}
+
+int lsqr_step_finish_wait(lsqr_ctx *c, int slot, double *winner_out, double *params_out,
+                          lsqr_ransac_info *info) {
+  if (!c || slot < 0 || slot > 1) return LSQR_ERR_INVALID;
+  if (!c->step_busy[slot]) return fail(c, LSQR_ERR_STATE, "step slot %d has nothing in flight", slot);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->step_ev[slot]));  // the one synchronisation of the step
+  c->step_busy[slot] = false;
+  const char *pin = step_pin(c, slot);
+  unsigned long long pk;
+  double count;
+  memcpy(&pk, pin, 8);
+  memcpy(&count, pin + 8, 8);
+  const uint8_t valid = *(const uint8_t *)(pin + 16);
+  SolveOut out;
+  memset(&out, 0, sizeof out);
+  if (c->cfg.model == LSQR_MODEL_PHANTOM)
+    phantom_solve_block(c->cfg, (const double *)((const char *)c->h_pin + 40960), &out);
+  else
+    memcpy(&out, pin + 1024, sizeof out);
   if (info) {
     memset(info, 0, sizeof *info);
     info->evaluated = pk != 0;  // a winner exists
@@ -2302,15 +2324,23 @@ int lsqr_step_finish(lsqr_ctx *c, const uint64_t *packed_dev, const double *bloc
     info->fit.lm_info = out.lm_info;
     info->fit.lm_nfev = out.lm_nfev;
     info->fit.cost = out.cost;
-    info->fit.n_used = (uint64_t)(*p_count + 0.5);
-    info->fraction = c->n ? *p_count / (double)c->n : 0.0;
+    info->fit.n_used = (uint64_t)(count + 0.5);
+    info->fraction = c->n ? count / (double)c->n : 0.0;
   }
-  if (pk == 0 || !*p_valid) return LSQR_EMPTY;
-  if (winner_out) memcpy(winner_out, p_win, sizeof(double) * c->P);
+  if (pk == 0 || !valid) return LSQR_EMPTY;
+  if (winner_out) memcpy(winner_out, pin + 64, sizeof(double) * c->P);
   if (!out.ok) return LSQR_EMPTY;
   if (params_out)
     for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
   return LSQR_OK;
+}
+
+int lsqr_step_finish(lsqr_ctx *c, const uint64_t *packed_dev, const double *block_dev,
+                     double *winner_out, double *params_out, lsqr_ransac_info *info) {
+  if (c && c->step_busy[0]) return fail(c, LSQR_ERR_STATE, "step slot 0 holds an unread result");
+  int st = lsqr_step_finish_enqueue(c, packed_dev, block_dev, 0);
+  if (st != LSQR_OK) return st;
+  return lsqr_step_finish_wait(c, 0, winner_out, params_out, info);
 }
 
 int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {

@@ -85,6 +85,7 @@ class ShardedRansac:
         self.c = comm
         self._xbuf = None     # (packed int64[1], block float64[nmom + 1]) device tensors of step_device
         self._stream = None
+        self._pending = {}
 
     def batch(self, seed, batch_index, H):
         """One batch of world*H hypotheses: sample+solve+scan own slice, pick the global winner.
@@ -140,7 +141,7 @@ class ShardedRansac:
         fit, info = self._refine(fit, info, lo, hi)
         return int(win >> 32), gidx, par, fit, int(round(blk[-1])), info
 
-    def step_device(self, seed, batch_index, H):
+    def step_device(self, seed, batch_index, H, slot=None):
         """The same step with the two exchanges as collectives on DEVICE buffers and one host
         synchronisation (lsqr_step_scan / _winner / _finish): scan -> k_best into `packed` ->
         all-reduce MAX -> winner re-derived on the device from `packed` -> mask + moment block of the
@@ -168,12 +169,26 @@ class ShardedRansac:
         e.step_winner(seed, batch_index * c.world * H, packed.data_ptr(), lo, hi, block.data_ptr())
         if c.dist is not None:
             c.dist.all_reduce(block, op=c.dist.ReduceOp.SUM)
+        if slot is not None:     # pipelined: results are fetched later with step_device_wait(slot)
+            e.step_finish_enqueue(packed.data_ptr(), block.data_ptr(), slot)
+            self._pending[slot] = (batch_index, H, lo, hi)
+            return None
         st, par, fit, info = e.step_finish(packed.data_ptr(), block.data_ptr())
+        return self._step_result(info, par, fit, batch_index, H, lo, hi)
+
+    def _step_result(self, info, par, fit, batch_index, H, lo, hi):
         if not info.evaluated:   # no valid hypothesis in the whole batch
             return None
-        gidx = batch_index * c.world * H + int(info.best_index)
+        gidx = batch_index * self.c.world * H + int(info.best_index)
         fit, finfo = self._refine(fit, info.fit, lo, hi)
         return int(info.best_votes), gidx, par, fit, int(info.fit.n_used), finfo
+
+    def step_device_wait(self, slot):
+        """Result of the step enqueued with step_device(..., slot=slot) (closed-form fits only: an LM
+        refinement needs further device passes and belongs to the blocking form)."""
+        batch_index, H, lo, hi = self._pending.pop(slot)
+        st, par, fit, info = self.e.step_finish_wait(slot)
+        return self._step_result(info, par, fit, batch_index, H, lo, hi)
 
     def _refine(self, fit, info, lo, hi):
         """LM refinement over the sharded observation range (sphere geometric / US iterative)."""

@@ -40,6 +40,18 @@ for model, dim, ls, H in ((L.PLANE, 3, 0, 1024), (L.SPHERE, 3, L.LS_GEOMETRIC, 1
             if not same:
                 print("MISMATCH", model, got[:2], want[:2], got[4], want[4], got[3], want[3])
             ok = ok and same
+        if model == L.PLANE:   # pipelined steps over the collectives
+            sr = ShardedRansac(c, Comm(dist, "cpu"))
+            blocking = [sr.step_device(11, b, H) for b in range(3)]
+            sr.step_device(11, 0, H, slot=0)
+            sr.step_device(11, 1, H, slot=1)
+            piped = [sr.step_device_wait(0)]
+            sr.step_device(11, 2, H, slot=0)
+            piped += [sr.step_device_wait(1), sr.step_device_wait(0)]
+            for g, w in zip(piped, blocking):
+                if not ((g[0], g[1], g[4]) == (w[0], w[1], w[4]) and np.array_equal(g[3], w[3])):
+                    print("PIPELINE MISMATCH", g[:2], w[:2])
+                    ok = False
         c.set_stream(None)
     dist.barrier()
 if rank == 0:

@@ -1672,6 +1672,16 @@ for model, dim, ls in cases:
             assert (got[0], got[1], got[4]) == (want[0], want[1], want[4]), (model, got[:2], want[:2])
             assert np.array_equal(got[2], want[2])
             assert np.allclose(got[3], want[3], rtol=1e-12, atol=1e-12), (model, got[3], want[3])
+        if ls == 0 and model != L.PHANTOM:   # closed-form fits: pipelined steps (enqueue i + 1 before reading i)
+            blocking = [sr.step_device(7, b, H) for b in range(4)]
+            piped = []
+            sr.step_device(7, 0, H, slot=0)
+            for b in range(1, 4):
+                sr.step_device(7, b, H, slot=b & 1)
+                piped.append(sr.step_device_wait((b - 1) & 1))
+            piped.append(sr.step_device_wait(3 & 1))
+            for g, w in zip(piped, blocking):
+                assert (g[0], g[1], g[4]) == (w[0], w[1], w[4]) and np.array_equal(g[3], w[3])
         if model == L.PLANE:   # a batch without any valid hypothesis: None, like step()
             c2.upload(np.zeros((1000, 3)))
             assert sr.step_device(7, 0, 64) is None
