@@ -294,13 +294,13 @@ def main():
             except Exception:
                 traffic = None
         issue = None   # measured instruction-issue utilisation of the scan kernel (profiles/, SQ counters)
-        sfile = os.path.join(ROOT, "profiles", "r01g_plane_scan_sq_counters.json")
+        sfile = os.path.join(ROOT, "profiles", "r01h_plane_scan_sq_counters.json")
         if a.workload == "plane" and a.points == 10_000_000 and H == 4096 and idx["built"] and os.path.exists(sfile):
             try:
                 d = json.load(open(sfile))["derived"]
                 issue = {"valu_issue_busy": d["valu_issue_busy"], "salu_issue_busy_per_cu": d["salu_issue_busy_per_cu"],
                          "lanes_active": d["lanes_active"],
-                         "source": "profiles/r01g_plane_scan_sq_counters.json (rocprofv3 --pmc SQ_* passes of this kernel "
+                         "source": "profiles/r01h_plane_scan_sq_counters.json (rocprofv3 --pmc SQ_* passes of this kernel "
                                    "and shape; not collected live)"}
             except Exception:
                 issue = None
