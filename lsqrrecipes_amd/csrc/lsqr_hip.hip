@@ -507,6 +507,14 @@ int launch_scan_cells(lsqr_ctx *c) {
     uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
     size_t lds = (size_t)((hc + 3) & ~3u) * sizeof(uint32_t) + (LDSB ? (size_t)wpb * 2048 : 0);
     int per_cu = (int)std::min<size_t>(32 / wpb, (160 * 1024) / std::max<size_t>(lds, 1));
+    {  // persistent waves pulling tiles from the queues: launch exactly what is resident at once
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_scan_cells<CM, PP, CPT, BS, LDSB>, BS, lds) ==
+              hipSuccess && occ >= 1)
+        per_cu = std::min(per_cu, occ);
+      else
+        (void)hipGetLastError();
+    }
     if (per_cu < 1) per_cu = 1;
     size_t blocks = std::min<size_t>((wtiles + wpb - 1) / wpb, (size_t)256 * per_cu);
     // a unit is a whole tile by default: splitting the hypothesis range of a tile into segments
