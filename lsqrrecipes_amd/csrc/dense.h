@@ -61,10 +61,28 @@ __global__ __launch_bounds__(256) void k_mask_dense(const double *__restrict__ d
   for (size_t base = begin + ((size_t)blockIdx.x * 4 + wave) * ROWS; base < end; base += nw * ROWS) {
     const int rows = (int)(end - base < (size_t)ROWS ? end - base : (size_t)ROWS);
     const int total = rows * (n + 1);
-    // stride == n + 1 doubles is the tight layout; any stride is handled row by row
-    for (int idx = lane; idx < total; idx += 64) {
-      const int r = idx / (n + 1), c = idx - r * (n + 1);
-      tile[r * pitch + c] = data[(base + r) * stride + c];
+    // stride == n + 1 doubles is the tight layout; any stride is handled row by row.  Eight loads per lane
+    // are in flight before the first LDS store (two waves per SIMD fit beside the 66 KB tiles: nothing else
+    // hides the HBM latency); (r, c) advance incrementally instead of dividing per element
+    {
+      constexpr int U = 8;
+      const int w = n + 1;
+      int r = lane / w, c = lane - r * w;
+      const int dr = 64 / w, dc = 64 - dr * w;  // one step of 64 elements
+      for (int idx = lane; idx < total; idx += 64 * U) {
+        double v[U];
+        int rr[U], cc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          rr[u] = r, cc[u] = c;
+          v[u] = idx + 64 * u < total ? data[(base + r) * stride + c] : 0.0;
+          r += dr, c += dc;
+          if (c >= w) c -= w, r++;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (idx + 64 * u < total) tile[rr[u] * pitch + cc[u]] = v[u];
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < rows) {
