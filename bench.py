@@ -53,6 +53,11 @@ def parse():
     ap.add_argument("--no-index", action="store_true", help="exhaustive scan (no spatial index)")
     ap.add_argument("--outliers", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--us-fit", default="analytic", choices=["iterative", "analytic"],
+                    help="final fit of the US workload: the analytic estimate (default) or Levenberg-Marquardt "
+                         "from it with the reference's 1e-15 tolerances -- at 1 M noisy frames MINPACK then "
+                         "wanders inside rounding noise until its 5000-evaluation limit (90 us per evaluation: "
+                         "0.45 s per step) and reports failure, exactly as the reference's settings make it")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single GPU: one blocking lsqr_batch_fit per step instead of pipelined batches")
     ap.add_argument("--no-end-to-end", action="store_true",
@@ -169,7 +174,9 @@ def main():
     delta = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}[a.workload]
     model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE, "dense": L.DENSE,
              "us": L.US_SINGLE, "phantom": L.PHANTOM}[a.workload]
-    ls_type = L.LS_ANALYTIC if a.workload == "us" else L.LS_GEOMETRIC   # GEOMETRIC == ITERATIVE == 1
+    # GEOMETRIC == ITERATIVE == 1: the sphere's geometric fit, the US calibrations' and the phantom's LM fit
+    # (BASELINE.json configs[2], configs[4]); --us-fit analytic keeps the closed-form US fit
+    ls_type = L.LS_ANALYTIC if (a.workload == "us" and a.us_fit == "analytic") else L.LS_GEOMETRIC
     data, truth, lab = make_data(a.workload, a.points, a.outliers)
     ctx = Context(local)
     ctx.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
@@ -210,9 +217,10 @@ def main():
     # (lsqr_batch_fit_enqueue / _wait), so the host's latency between steps hides behind the device's work;
     # every step still runs the whole chain.  --no-pipeline keeps one blocking call per step.
     pipelined = (comm.world == 1 and not force_dist and not a.no_pipeline
-                 and not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom")
+                 and not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC)
+                 and a.workload != "phantom")
 
-    closed_form = not (a.workload == "sphere" and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
+    closed_form = not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
     pipelined_dist = step_on_device and closed_form and not a.no_pipeline
 
     def run_steps(first_step, count):
