@@ -184,6 +184,10 @@ LSQR_API int lsqr_solve_moments(lsqr_ctx *ctx, const double *block, const double
 LSQR_API int lsqr_winner_moments(lsqr_ctx *ctx, uint64_t seed, uint64_t stream_index, size_t begin,
                                  size_t end, double *params_out, double *origin_out,
                                  double *block_out, uint64_t *count_out);
+/* lsqr_moments with the block left in device memory and no synchronisation (the caller all-reduces it in
+ * place on the context's stream, see lsqr_set_stream, and reads it back once). */
+LSQR_API int lsqr_moments_dev(lsqr_ctx *ctx, int use_mask, size_t begin, size_t end, int phase,
+                              const double *x, double *block_dev);
 /* Levenberg-Marquardt over summed phase-1 blocks (MINPACK lmder control flow on the device):
  *   lsqr_lm_begin(x0) -> x_trial;  repeat { block = sum over ranks of lsqr_moments(phase 1,
  *   x_trial);  lsqr_lm_step(block) -> cont, x_trial }  until !cont.  On the last step params_out

@@ -76,6 +76,8 @@ SIGNATURES = {
     "lsqr_moments_len": (C.c_int, [C.POINTER(ModelCfg), C.c_int]),
     "lsqr_moments": (C.c_int, [_ctx, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                C.c_void_p]),
+    "lsqr_moments_dev": (C.c_int, [_ctx, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+                               C.c_void_p]),
     "lsqr_solve_moments": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.POINTER(FitInfo)]),
     "lsqr_winner_moments": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t,

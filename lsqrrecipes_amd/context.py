@@ -135,6 +135,15 @@ class Context:
                                          L.ptr(blk)))
         return blk
 
+    def moments_dev(self, x, block_ptr, begin=0, end=None, phase=0, use_mask=False):
+        """moments() with the block left at device address block_ptr, no synchronisation"""
+        end = self.n if end is None else end
+        xv = np.zeros(32)
+        x = np.asarray(x, dtype=np.float64)
+        xv[:len(x)] = x
+        self._chk(self._lib.lsqr_moments_dev(self._h, int(use_mask), begin, end, phase, L.ptr(xv),
+                                             C.c_void_p(block_ptr)))
+
     def winner_moments(self, seed, stream_index, begin=0, end=None):
         """-> (params, origin(32), block, count): lsqr_winner_moments, one host synchronisation"""
         end = self.n if end is None else end

@@ -1595,6 +1595,28 @@ int lsqr_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase,
   return LSQR_OK;
 }
 
+// lsqr_moments with the block left in DEVICE memory (no synchronisation): the multi-GPU LM loop all-reduces
+// it in place and reads it back once
+int lsqr_moments_dev(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase, const double *x,
+                     double *block_dev) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (begin > end || end > c->n || !block_dev) return fail(c, LSQR_ERR_INVALID, "bad range");
+  if (use_mask && !c->mask_valid) return fail(c, LSQR_ERR_STATE, "no mask on the device");
+  if (!x) return fail(c, LSQR_ERR_INVALID, "moments need an origin / evaluation point");
+  double *pin = (double *)((char *)c->h_pin + 57344);  // x staged in pinned memory: the copy stays asynchronous
+  memcpy(pin, x, sizeof(double) * 32);
+  HIPCHK(c, hipMemcpyAsync(c->d_vec, pin, sizeof(double) * 32, hipMemcpyHostToDevice, c->stream));
+  int nmom = 0;
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    return launch_moments<M>(c, use_mask, begin, end, phase, &nmom);
+  });
+  if (st != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(block_dev, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToDevice, c->stream));
+  return LSQR_OK;
+}
+
 static void fill_info(const SolveOut &out, lsqr_fit_info *info) {
   if (!info) return;
   memset(info, 0, sizeof *info);

@@ -86,6 +86,7 @@ class ShardedRansac:
         self._xbuf = None     # (packed int64[1], block float64[nmom + 1]) device tensors of step_device
         self._stream = None
         self._pending = {}
+        self._lmbuf = None
 
     def batch(self, seed, batch_index, H):
         """One batch of world*H hypotheses: sample+solve+scan own slice, pick the global winner.
@@ -197,7 +198,22 @@ class ShardedRansac:
         model = e.cfg.model
         iterative = (model == L.SPHERE and e.cfg.ls_type == L.LS_GEOMETRIC) or (
             model in (L.US_SINGLE, L.US_POINTER) and e.cfg.ls_type == L.LS_ITERATIVE)
-        if len(fit) and iterative:
+        if len(fit) and iterative and self._stream is not None and hasattr(e, "moments_dev"):
+            # device path (step_device): the LM block is all-reduced in device memory, one read-back per
+            # evaluation
+            import torch
+            n1 = e.moments_len(1)
+            if self._lmbuf is None or self._lmbuf.numel() != n1:
+                self._lmbuf = torch.zeros(n1, dtype=torch.float64, device=self._xbuf[1].device)
+            xt = e.lm_begin(fit)
+            while True:
+                e.moments_dev(xt[:e.P], self._lmbuf.data_ptr(), lo, hi, phase=1, use_mask=True)
+                if c.dist is not None:
+                    c.dist.all_reduce(self._lmbuf, op=c.dist.ReduceOp.SUM)
+                cont, xt, fit, info = e.lm_step(self._lmbuf.cpu().numpy())
+                if not cont:
+                    break
+        elif len(fit) and iterative:
             xt = e.lm_begin(fit)
             while True:
                 blk = c.allreduce_sum_f64(e.moments(xt[:e.P], lo, hi, phase=1, use_mask=True))
