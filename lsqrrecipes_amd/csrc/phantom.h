@@ -14,7 +14,7 @@
 //     sum f^2 = e^T G e,  J^T J = E^T G E,  J^T f = E^T G e  with E = de/dx (forward-mode derivatives),
 //     fed to the same MINPACK control flow (lm_core.h) as the other LM fits.
 // The minimal solve (exactly 31 frames, .cxx:16-24) takes the null vector of the 31 x 31 system by a
-// workgroup-parallel one-sided Jacobi SVD in LDS.  The sign of a singular vector is arbitrary: the
+// one-sided Jacobi SVD in LDS (one wave per hypothesis).  The sign of a singular vector is arbitrary: the
 // reference fixes the scale factor's sign arbitrarily too (.cxx:215-218), it flips T1 and leaves
 // agree() -- a squared quantity -- unchanged.
 #pragma once
