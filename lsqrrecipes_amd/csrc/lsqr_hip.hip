@@ -78,6 +78,7 @@ struct lsqr_ctx {
   double *d_mom = nullptr;       // MOM_MAX
   double *d_vec = nullptr;       // 32 doubles: origin / parameter vector handed to kernels
   double *d_par = nullptr;       // 32 doubles: model parameters for mask/stats
+  double *d_best = nullptr;      // scan-parameter row of the best hypothesis so far (lsqr_ransac*)
   LmState *d_lm = nullptr;
   SolveOut *d_out = nullptr;
   unsigned long long *d_counter = nullptr;
@@ -1228,6 +1229,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
             hipMalloc((void **)&c->d_mom, sizeof(double) * 4096) == hipSuccess &&
             hipMalloc((void **)&c->d_vec, sizeof(double) * 128) == hipSuccess &&
             hipMalloc((void **)&c->d_par, sizeof(double) * 128) == hipSuccess &&
+            hipMalloc((void **)&c->d_best, sizeof(double) * 128) == hipSuccess &&
             hipMalloc((void **)&c->d_lm, sizeof(LmState)) == hipSuccess &&
             hipMalloc((void **)&c->d_out, sizeof(SolveOut)) == hipSuccess &&
             hipMalloc((void **)&c->d_counter, 64) == hipSuccess &&
@@ -1247,7 +1249,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   drop_index(c);
   void *bufs[] = {c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
-                  c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_lm, c->d_out, c->d_counter};
+                  c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1912,22 +1914,43 @@ size_t lsqr_replay(size_t n, int k, double p, const uint32_t *subsets, const uin
 }
 
 // ---- RANSAC<T,S>::compute ------------------------------------------------------------------------------
-static int finish_ransac(lsqr_ctx *c, bool has_best, const double *best_params, uint32_t best_votes,
-                         double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info) {
+// RANSAC.hxx:129-139 for the winner stashed in d_best (its full scan-parameter row): consensus mask + the
+// moment block of its least squares fit in one pass, the fit, one host synchronisation (LM fits: one more per
+// evaluation).  The mask count must reproduce the scan's vote count.
+static int finish_ransac(lsqr_ctx *c, bool has_best, uint32_t best_votes, double *params_out,
+                         uint8_t *consensus_out, lsqr_ransac_info *info) {
   info->best_votes = best_votes;
   info->fraction = (double)best_votes / (double)c->n;
   info->n_params = 0;
   if (!has_best || best_votes == 0) return LSQR_EMPTY;  // RANSAC.hxx:129: nothing written
-  uint64_t cnt = 0;
-  int st = lsqr_mask(c, best_params, 0, c->n, consensus_out, &cnt);
-  if (st != LSQR_OK) return st;
+  int st;
+  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_par, c->d_best, sizeof(double) * c->HS, hipMemcpyDeviceToDevice, c->stream));
+  bool fused = false;
+  int nm = 0;
+  if ((st = set_fit_origin(c, true)) != LSQR_OK) return st;
+  if ((st = launch_mask_moments(c, 0, c->n, &nm, &fused)) != LSQR_OK) return st;
+  if (!fused && (st = launch_mask(c, 0, c->n)) != LSQR_OK) return st;
+  unsigned long long *pin2 = (unsigned long long *)((char *)c->h_pin + 8192);
+  HIPCHK(c, hipMemcpyAsync(pin2, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  if (consensus_out)
+    HIPCHK(c, hipMemcpyAsync(consensus_out, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
+  SolveOut out;
+  memset(&out, 0, sizeof out);
+  if ((st = run_fit(c, 1, &out, fused)) != LSQR_OK) return st;  // synchronises the stream
+  const unsigned long long cnt = pin2[0];
   if (cnt != best_votes)
-    return fail(c, LSQR_ERR_HIP, "consensus mask count %llu != scan votes %u",
-                (unsigned long long)cnt, best_votes);
-  st = lsqr_ls_fit(c, 1, params_out, &info->fit);
+    return fail(c, LSQR_ERR_HIP, "consensus mask count %llu != scan votes %u", cnt, best_votes);
+  info->fit.n_params = out.ok ? out.n_params : 0;
+  info->fit.lm_info = out.lm_info;
+  info->fit.lm_nfev = out.lm_nfev;
+  info->fit.cost = out.cost;
   info->fit.n_used = cnt;
-  if (st == LSQR_OK) info->n_params = info->fit.n_params;
-  return st;
+  if (!out.ok) return LSQR_EMPTY;
+  info->n_params = out.n_params;
+  if (params_out)
+    for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
+  return LSQR_OK;
 }
 
 int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, size_t n_subsets,
@@ -1946,7 +1969,6 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
   DedupSet dedup;
   std::vector<uint32_t> sub, votes;
   std::vector<uint8_t> valid;
-  std::vector<double> best_params((size_t)c->P, 0.0);
   uint64_t base = 0;
   size_t batch = 256;
   while (!rs[RS_DONE]) {
@@ -1977,9 +1999,9 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     info->evaluated += H;
     if (rs[RS_HAS] && (!had || rs[RS_BEST_IDX] != prev_best_idx)) {
       size_t e = (size_t)(rs[RS_BEST_IDX] - base);
-      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + e * c->HS,
-                               sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      // the winner's row stays on the device (the next batch overwrites d_hparams): no host round trip
+      HIPCHK(c, hipMemcpyAsync(c->d_best, c->d_hparams + e * c->HS, sizeof(double) * c->HS,
+                               hipMemcpyDeviceToDevice, c->stream));
     }
     base += used;
     if (used < H) break;
@@ -1991,7 +2013,7 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
   }
   info->iterations = rs[RS_I];
   info->best_index = rs[RS_BEST_IDX];
-  return finish_ransac(c, rs[RS_HAS] != 0, best_params.data(), (uint32_t)rs[RS_BEST], params_out,
+  return finish_ransac(c, rs[RS_HAS] != 0, (uint32_t)rs[RS_BEST], params_out,
                        consensus_out, info);
 }
 
@@ -2008,7 +2030,6 @@ int lsqr_ransac_exhaustive(lsqr_ctx *c, double *params_out, uint8_t *consensus_o
   // all C(N,k) tuples in lexicographic order (RANSAC.hxx:197-213), in batches
   std::vector<uint32_t> comb((size_t)k), sub, votes;
   std::vector<uint8_t> valid;
-  std::vector<double> best_params((size_t)c->P, 0.0);
   for (int l = 0; l < k; l++) comb[l] = (uint32_t)l;
   bool more = true, has = false;
   uint32_t best = 0;
@@ -2042,16 +2063,15 @@ int lsqr_ransac_exhaustive(lsqr_ctx *c, double *params_out, uint8_t *consensus_o
         has = true;
       }
     if (winner >= 0) {
-      HIPCHK(c, hipMemcpyAsync(best_params.data(), c->d_hparams + (size_t)winner * c->HS,
-                               sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_best, c->d_hparams + (size_t)winner * c->HS, sizeof(double) * c->HS,
+                               hipMemcpyDeviceToDevice, c->stream));
     }
     index += H;
     info->evaluated += H;
   }
   info->iterations = index;
   info->best_index = best_idx;
-  return finish_ransac(c, has, best_params.data(), best, params_out, consensus_out, info);
+  return finish_ransac(c, has, best, params_out, consensus_out, info);
 }
 
 // One fixed-size batch end to end, everything chained on the stream: sample -> solve -> scan ->
