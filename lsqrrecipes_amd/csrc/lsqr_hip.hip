@@ -89,6 +89,8 @@ struct lsqr_ctx {
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
 
   void *h_pin = nullptr;  // pinned staging (64 KiB)
+  void *h_batch = nullptr;  // pinned results of a lsqr_ransac batch (grown on demand)
+  size_t batch_pin_cap = 0;
 
   bool prof = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1253,6 +1255,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->h_batch) (void)hipHostFree(c->h_batch);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1967,8 +1970,6 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
   uint64_t rs[6];
   lsqr_replay_init(c->n, k, p, rs);
   DedupSet dedup;
-  std::vector<uint32_t> sub, votes;
-  std::vector<uint8_t> valid;
   uint64_t base = 0;
   size_t batch = 256;
   while (!rs[RS_DONE]) {
@@ -1980,22 +1981,32 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     uint64_t remaining = rs[RS_TRIES] - base;
     if (remaining < H) H = (size_t)remaining;
     if (H == 0) break;
-    sub.resize(H * k);
+    // batch results land in pinned memory with one synchronisation: {votes[H], subsets[H*k], valid[H]}
+    const size_t need = H * sizeof(uint32_t) * (1 + (size_t)k) + H;
+    if (need > c->batch_pin_cap) {
+      if (c->h_batch) (void)hipHostFree(c->h_batch);
+      c->h_batch = nullptr;
+      c->batch_pin_cap = 0;
+      HIPCHK(c, hipHostMalloc(&c->h_batch, std::max<size_t>(need, 1 << 16)));
+      c->batch_pin_cap = std::max<size_t>(need, 1 << 16);
+    }
+    uint32_t *p_votes = (uint32_t *)c->h_batch, *p_sub = p_votes + H;
+    uint8_t *p_valid = (uint8_t *)(p_sub + H * k);
     if (subsets) {
-      memcpy(sub.data(), subsets + base * k, H * k * sizeof(uint32_t));
-      st = lsqr_hypotheses_from_subsets(c, sub.data(), H);
+      memcpy(p_sub, subsets + base * k, H * k * sizeof(uint32_t));
+      st = lsqr_hypotheses_from_subsets(c, p_sub, H);
     } else {
-      st = lsqr_hypotheses_sample(c, seed, base, H, sub.data());
+      st = lsqr_hypotheses_sample(c, seed, base, H, nullptr);
     }
     if (st != LSQR_OK) return st;
     if ((st = lsqr_scan(c)) != LSQR_OK) return st;
-    votes.resize(H);
-    valid.resize(H);
-    if ((st = lsqr_get_hypotheses(c, nullptr, valid.data(), votes.data())) != LSQR_OK) return st;
+    if (!subsets)
+      HIPCHK(c, hipMemcpyAsync(p_sub, c->d_subsets, H * k * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               c->stream));
+    if ((st = lsqr_get_hypotheses(c, nullptr, p_valid, p_votes)) != LSQR_OK) return st;  // synchronises
     uint64_t prev_best_idx = rs[RS_BEST_IDX];
     bool had = rs[RS_HAS] != 0;
-    size_t used = lsqr_replay(c->n, k, p, sub.data(), valid.data(), votes.data(), H, base, &dedup,
-                              rs);
+    size_t used = lsqr_replay(c->n, k, p, p_sub, p_valid, p_votes, H, base, &dedup, rs);
     info->evaluated += H;
     if (rs[RS_HAS] && (!had || rs[RS_BEST_IDX] != prev_best_idx)) {
       size_t e = (size_t)(rs[RS_BEST_IDX] - base);
