@@ -390,66 +390,92 @@ inline CellConsts cell_consts(const PlaneCell<D> *, const ModelConsts &mc) {
   return cc;
 }
 
-// Sphere.  Observations stay in absolute coordinates; the second level is SphereModel's packed fp32
-// measure t = sum (x32_i - c32_i)^2 - mid with its (tin, tout) of prepare_f32 (models.h), whose bound
-// already holds for every observation with |x_i| <= X.  Level 1 bounds the squared distance from the
-// sphere centre over the box:  g_i = |ctr_i - c_i|, lo_i = max(g_i - hh_i, 0), hi_i = g_i + hh_i with
-// hh_i = h_i + e, e = 1.01 * 2u(X + C)(1 + u) >= the fp32 error of g_i (|ctr_i| <= X, |c_i| <= C), so
-// for every observation of the box  sum lo_i^2 (1 - 8u) <= D* <= sum hi_i^2 (1 + 8u)  (the factors
-// cover the fp32 evaluation of the two sums).  The reference agrees only for D_ref in [dlo, dhi]
-// (SphereModel::prepare; D_ref within 1e-12 relative of D*), so with f[10] = fl32_down(dlo (1 - 1e-9)),
-// f[11] = fl32_up(dhi (1 + 1e-9)):  dmax2 (1 + 8u) < f[10]  or  dmin2 (1 - 8u) > f[11]  proves that no
-// observation of the cell agrees.  Hypotheses whose filter is switched off (tout = +inf: literal
-// formula, magnitudes outside the validated range) keep every cell and take the exact path for
-// every observation; a NaN model fails both comparisons' complements and never survives.
+// Sphere.  Like the plane and the line, observations relative to the cell centre: x = ctr + y, x' = fl32(y), and
+// with w = ctr - c (fp64, per hypothesis and cell)
+//   D* = |x - c|^2 = |w|^2 + 2 w.y + |y|^2,      T* = D* - mid = k0 + sum (2 w_i + y_i) y_i,   k0 = |w|^2 - mid,
+// so the fp32 arithmetic sees 2 r R-sized numbers instead of r^2-sized ones (r radius, R cell radius):
+//   t32 = fma chain  s = fl32(k0);  s = fma(fl32(x'_i + fl32(2 w_i)), x'_i, s)
+// Error of t32 against T* (u = 2^-24, Y_i = |y_i| <= h_i, W_i = |w_i|): x' rounding u Y_i (2W_i + 2Y_i), rounding
+// of 2w_i: 2u W_i Y_i, of the sum: u (2W_i + Y_i) Y_i, three fma results and fl32(k0): u (3S + |k0|) with
+// S <= |k0| + sum (2W_i + Y_i) Y_i, in total <= u (12 sum W_i Y_i + 6 sum Y_i^2 + 4 |k0|)
+//   <= u (12 |w| R + 6 R^2 + 4 |k0|).
+// A cell that can hold a candidate has |k0| <= K := half + 2|w|R + R^2 + slack (else level 1 drops it), and the
+// reference's fp64 D_ref, the fp64 evaluation of w and k0 are within eta = 1e-12 ((|w| + R)^2 + mid) of the
+// exact values.  With E = 1.01 u (12 |w| R + 6 R^2 + 4 K) + eta (evaluated in fp32 with |w| rounded up):
+//   |t32| < (half - E)(1 - 2^-21) => D_ref in [dlo, dhi] (agrees);   |t32| >= (half + E)(1 + 2^-21) => does not.
+// Level 1: T* over the box lies in [k0 - 2 rr, k0 + 2 rr + R^2], rr = sum W_i h_i; the cell is dropped when that
+// range (widened by E and 1e-5 relative for the fp32 evaluation of the bounds) misses [-tout, tout].
+// Hypotheses whose filter is off (literal formula / magnitudes outside the validated range: f[21] = 0) keep every
+// cell and send every observation the exact way (tin = -inf, tout = +inf); a NaN model never survives.
 template <int D>
 struct SphereCell {
   typedef SphereModel<D> M;
-  enum { NB = 6, NV = 4, RELATIVE = 0, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
-  enum { MIN_WAVES = 4 };
-  enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // absolute coordinates: wider band, whole-cell re-checks
-                                                    // cost more; LDS broadcast measured 5 % faster here
+  enum { NB = 6, NV = 4, RELATIVE = 1, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
+  enum { MIN_WAVES = 4 };  // 72 VGPRs = 7 waves per SIMD as compiled
+  enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // measured (tools/ab_cells.py): 1.9 ms; 512 / v_readlane 2.1 ms
   struct Hyp {
-    float nc[3], nmid, tin, tout, dlo, dhi;
+    double c[3], mid;
+    float half;
+    bool off, nan;
   };
   static __device__ inline void load(const float *row, const float *, bool valid,
                                      const CellConsts &, Hyp &h) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) h.nc[i] = row[2 * i];
-    h.nmid = row[6];
-    h.tin = row[8];
-    h.tout = valid ? row[9] : __builtin_nanf("");
-    h.dlo = valid ? row[10] : __builtin_nanf("");
-    h.dhi = row[11];
+    for (int i = 0; i < 3; i++) h.c[i] = i < D ? f64_from(row + 12 + 2 * i) : 0.0;
+    h.mid = f64_from(row + 18);
+    h.half = row[20];
+    const float flag = row[21];
+    h.nan = !valid || !(flag == flag);
+    h.off = valid && flag == 0.0f;
   }
-  static __device__ inline bool level1(const Hyp &h, const CellBox &b, const double *,
+  static __device__ inline bool level1(const Hyp &h, const CellBox &b, const double *ctr,
                                        const CellConsts &cc, float *bc) {
-    float dmin2 = 0.0f, dmax2 = 0.0f;
+    double w[3], k0 = -h.mid;
+    float rr = 0.0f;
 #pragma unroll
-    for (int i = 0; i < D; i++) {
-      const float g = __builtin_fabsf(b.c[i] + h.nc[i]);
-      const float e = (cc.f[0] + __builtin_fabsf(h.nc[i])) * cc.f[1];  // 1.01 * 2u (X + |c_i|)(1 + u)
-      const float hh = b.h[i] + e;
-      const float lo = __builtin_fmaxf(g - hh, 0.0f), hi = g + hh;
-      dmin2 = __builtin_fmaf(lo, lo, dmin2);
-      dmax2 = __builtin_fmaf(hi, hi, dmax2);
+    for (int i = D - 1; i >= 0; i--) {
+      w[i] = ctr[i] - h.c[i];
+      k0 = fma(w[i], w[i], k0);
     }
-    bc[0] = h.nc[0], bc[1] = h.nc[1], bc[2] = h.nc[2], bc[3] = h.nmid, bc[4] = h.tin, bc[5] = h.tout;
-    const bool off = h.tout == __builtin_inff();  // filter disabled: everything goes the exact way
-    const bool hit = (dmax2 * 1.000001f >= h.dlo) & (dmin2 * 0.999999f <= h.dhi);
-    return off | hit;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float wf = i < D ? (float)w[i] : 0.0f;
+      bc[i] = 2.0f * wf;
+      if (i < D) rr = __builtin_fmaf(__builtin_fabsf(wf), b.h[i], rr);
+    }
+    const float k0f = (float)k0;
+    const float R = b.pad[0];
+    // |w| rounded up: |w|^2 = k0 + mid
+    const float wn = __builtin_sqrtf(__builtin_fmaxf((float)(k0 + h.mid), 0.0f)) * 1.000001f;
+    const float wr = wn * R, r2 = R * R;
+    const float K = (h.half + 2.0f * wr + r2) * 1.0001f;
+    // cc.f: 0 = 1.01 u, 1 = 1e-12 (both rounded up)
+    float E = cc.f[0] * (12.0f * wr + 6.0f * r2 + 4.0f * K) * 1.00001f +
+              cc.f[1] * ((wn + R) * (wn + R) + (float)h.mid) * 1.00001f;
+    // K's 1e-4 head room has to cover E and the level-1 slack (see the bound on |k0| of a surviving cell)
+    if (h.off || !(E <= 5e-5f * K)) E = __builtin_inff();
+    const float tin = (h.half - E) * 0.9999995f;
+    const float tout = (h.half + E) * 1.0000005f;
+    bc[3] = k0f, bc[4] = tin, bc[5] = tout;
+    // range of T* over the box, widened for the fp32 evaluation of its end points
+    const float span = 2.0f * rr * 1.00001f, mag = (__builtin_fabsf(k0f) + span + r2) * 1e-5f;
+    const bool miss = (k0f - span - mag > tout) | (k0f + span + r2 * 1.00001f + mag < -tout);
+    return !h.nan & (h.off | !miss);
   }
   static __device__ inline v2f value(const v2f *xs, const v2f *fp) {
-    return M::filter_value(xs, fp);
+    v2f s = fp[3];
+#pragma unroll
+    for (int i = D - 1; i >= 0; i--) s = __builtin_elementwise_fma(xs[i] + fp[i], xs[i], s);
+    return s;
   }
 };
 template <int D>
-inline CellConsts cell_consts(const SphereCell<D> *, const ModelConsts &mc) {
+inline CellConsts cell_consts(const SphereCell<D> *, const ModelConsts &) {
   const double u = 5.9604644775390625e-08;
   CellConsts cc;
   memset(&cc, 0, sizeof cc);
-  cc.f[0] = f32_up_host(mc.absmax);
-  cc.f[1] = f32_up_host(1.01 * 2.0 * u * (1.0 + 1e-6));
+  cc.f[0] = f32_up_host(1.01 * u * (1.0 + 1e-6));
+  cc.f[1] = f32_up_host(1e-12 * (1.0 + 1e-6));
   return cc;
 }
 

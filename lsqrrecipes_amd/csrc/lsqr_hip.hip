@@ -236,7 +236,7 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   c->H_cap = 0;
   HIPCHK(c, hipMalloc((void **)&c->d_subsets, cap * 64 * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc((void **)&c->d_hparams, cap * 64 * sizeof(double)));
-  HIPCHK(c, hipMalloc((void **)&c->d_hparams_f32, cap * 16 * sizeof(float)));
+  HIPCHK(c, hipMalloc((void **)&c->d_hparams_f32, cap * 32 * sizeof(float)));  // M::SPF <= 32
   HIPCHK(c, hipMalloc((void **)&c->d_valid, cap));
   HIPCHK(c, hipMalloc((void **)&c->d_votes, cap * sizeof(uint32_t)));
   c->H_cap = cap;

@@ -480,10 +480,12 @@ struct SphereModel {
   // its rounding) + 1e-12 Dcap (fp64 vs exact):
   //   |t| <  half - Ecap  =>  D_ref in [Dlo, Dhi]  (certainly agrees)
   //   |t| >= half + Ecap  =>  certainly does not;   in between: exact fp64 predicate.
-  enum { NF = 4, SPF = 12, FGRAN = 0 };
+  // f[12..19]: centre (3 doubles) and mid (1 double) as pairs of 32-bit words, f[20] = half, f[21] = 1 when the
+  // filter is usable: the cell-relative evaluation of the two-level scan (cells.h: SphereCell)
+  enum { NF = 4, SPF = 24, FGRAN = 0 };
   static LSQR_HD void prepare_f32(const double *sp, const ModelConsts &c, float *f) {
     const double X = c.absmax, u = 5.9604644775390625e-08;
-    for (int i = 0; i < 12; i++) f[i] = 0.0f;
+    for (int i = 0; i < 24; i++) f[i] = 0.0f;
     double C = 0.0;
     for (int i = 0; i < D; i++) {
       f[2 * i] = f[2 * i + 1] = -(float)sp[i];  // x + (-c)
@@ -505,6 +507,19 @@ struct SphereModel {
     f[10] = ok ? PlaneModel<3>::round_down_f32(dlo * (1.0 - 1e-9)) : 0.0f;
     f[11] = ok ? PlaneModel<3>::round_up_f32(dhi * (1.0 + 1e-9)) : INFINITY;
     if (!(sp[0] == sp[0]) || (dlo != dlo)) f[8] = f[9] = f[10] = f[11] = __builtin_nanf("");  // never agrees
+    {
+      double w[4] = {D > 0 ? sp[0] : 0.0, D > 1 ? sp[1] : 0.0, D > 2 ? sp[D > 2 ? 2 : 0] : 0.0, mid};
+      for (int i = 0; i < 4; i++) {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &w[i], 8);
+        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+        __builtin_memcpy(&f[12 + 2 * i], &lo, 4);
+        __builtin_memcpy(&f[13 + 2 * i], &hi, 4);
+      }
+      f[20] = (float)half;  // rounding is covered by the cell model's slack
+      f[21] = ok ? 1.0f : 0.0f;
+      if (!(sp[0] == sp[0]) || (dlo != dlo)) f[21] = __builtin_nanf("");
+    }
   }
 #if defined(__HIPCC__)
   static __device__ inline v2f filter_value(const v2f *xs, const v2f *f) {
