@@ -1162,24 +1162,19 @@ struct TupleLess {
 };
 typedef std::set<std::vector<uint32_t>, TupleLess> DedupSet;
 
-// RANSAC.hxx:254-280
+// C(n, m), the cap on numTries (RANSAC.hxx:41,110).  The reference evaluates it in double (:254-280): the
+// running product over the shorter of the two factor ranges, ascending, one division, saturation to UINT_MAX
+// when a product overflowed or the quotient does not fit.  The cap has to come out identical, so the same
+// products are formed in the same order here.
 unsigned int choose_sat(unsigned int n, unsigned int m) {
-  double denominatorEnd, numeratorStart, numerator, denominator, i, result;
-  if ((n - m) > m) {
-    numeratorStart = n - m + 1;
-    denominatorEnd = m;
-  } else {
-    numeratorStart = m + 1;
-    denominatorEnd = n - m;
-  }
-  for (i = numeratorStart, numerator = 1; i <= n; i++) numerator *= i;
-  for (i = 1, denominator = 1; i <= denominatorEnd; i++) denominator *= i;
-  result = numerator / denominator;
-  if (denominator > std::numeric_limits<double>::max() ||
-      numerator > std::numeric_limits<double>::max() ||
-      static_cast<double>(std::numeric_limits<unsigned int>::max()) < result)
-    return std::numeric_limits<unsigned int>::max();
-  return static_cast<unsigned int>(result);
+  if (m > n) return 0;
+  const unsigned int shorter = std::min(m, n - m);
+  double top = 1.0, bottom = 1.0;
+  for (double f = (double)(n - shorter) + 1.0; f <= (double)n; f += 1.0) top *= f;
+  for (double f = 1.0; f <= (double)shorter; f += 1.0) bottom *= f;
+  const double c = top / bottom;
+  const bool saturated = std::isinf(top) || std::isinf(bottom) || !(c <= 4294967295.0);
+  return saturated ? 0xFFFFFFFFu : (unsigned int)c;
 }
 
 // (int) cast at RANSAC.hxx:108 made explicit: out-of-range / NaN -> 0x80000000 as cvttsd2si does

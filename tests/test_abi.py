@@ -98,3 +98,16 @@ def test_replay_first_max_wins():
     votes = np.array([10, 500, 500, 499, 500, 3], dtype=np.uint32)
     r = ctx_mod.replay(n, 3, 0.5, subs, np.ones(6, np.uint8), votes)
     assert r["best_index"] == 1 and r["best_votes"] == 500
+
+
+def test_tries_cap_equals_reference_choose():
+    """lsqr_replay_init's initial numTries is C(N, k) as RANSAC.hxx:254-280 evaluates it (double products,
+    saturation to UINT_MAX): same value as the oracle's restatement over a grid incl. the saturating cases."""
+    lib = L.load()
+    st = (C.c_uint64 * 6)()
+    for n in (3, 4, 10, 64, 65, 100, 129, 1000, 1625, 1626, 2000, 2954, 2955, 65536, 10_000_000, 0xFFFFFFF0):
+        for k in (1, 2, 3, 4, 31, 64):
+            if k > n:
+                continue
+            assert lib.lsqr_replay_init(n, k, 0.99, st) == L.OK
+            assert st[1] == O.lib().orc_choose(n, k), (n, k)
