@@ -25,6 +25,7 @@
  *                                                                common/Frame.h:30-31,41
  *   CalibratedPointer DataType 18 slots (+ Point3D p)            .../SinglePointTarget...h:335-339
  *   pair<Point3D,Point3D>      6 doubles (first, second)         .../AbsoluteOrientation...h:14-15
+ *                              (ls_type 1 = weightedLeastSquaresEstimate, .h:86: 7 doubles, slot 6 = weight)
  *   Frame                      13 slots (104 B)                  common/Frame.h:30-31,41
  *   Ray3D                      6 doubles (Point3D p, Vector3D n) common/Ray3D.h:23-24
  * A caller's std::vector<T> is passed as (pointer, count, stride in bytes) without repacking.
@@ -77,7 +78,7 @@ typedef struct {
   int32_t model;   /* lsqr_model */
   int32_t dim;     /* point dimension (plane/sphere/line: 2 or 3), n for DENSE (1..64) */
   double delta;    /* constructor argument, NOT squared (PlaneParametersEstimator.hxx:13-17) */
-  int32_t ls_type; /* sphere / US only */
+  int32_t ls_type; /* sphere / US; ABSOR: 1 = records carry a weight in slot 6 (weighted fit) */
   int32_t reserved;
   double aux;      /* RAY: minimalAngularDeviation in radians (RayIntersection...Estimator.h:34-35);
                       unused by the other models */
@@ -141,6 +142,12 @@ LSQR_API int lsqr_hypotheses_from_subsets(lsqr_ctx *ctx, const uint32_t *subsets
  * subsets_out (nullable) receives the H*k indices. */
 LSQR_API int lsqr_hypotheses_sample(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H,
                                     uint32_t *subsets_out);
+/* The same sampler stream evaluated on the HOST (no context, no device): subsets_out receives hypotheses
+ * [first_index, first_index + H) of stream `seed` for n observations and subsets of k (1..64) indices, draw
+ * order.  Used by RANSAC<T,S>::compute() for user-defined estimators without a device model (the plugin path
+ * of lsqrrecipes_amd/include/RANSAC.h), so that host and device paths walk one subset stream. */
+LSQR_API int lsqr_sample_subsets(uint64_t seed, uint64_t first_index, size_t H, uint64_t n, int k,
+                                 uint32_t *subsets_out);
 /* ---- agree() scan over all observations (RANSAC.hxx:94-99, without the early exit) ---------- */
 LSQR_API int lsqr_scan(lsqr_ctx *ctx);
 /* Results of the current batch: any pointer may be NULL.  params: H*P doubles; valid: H bytes

@@ -64,6 +64,7 @@ SIGNATURES = {
     "lsqr_count": (C.c_size_t, [_ctx]),
     "lsqr_hypotheses_from_subsets": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "lsqr_hypotheses_sample": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p]),
+    "lsqr_sample_subsets": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint64, C.c_int, C.c_void_p]),
     "lsqr_scan": (C.c_int, [_ctx]),
     "lsqr_get_hypotheses": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lsqr_num_hypotheses": (C.c_size_t, [_ctx]),

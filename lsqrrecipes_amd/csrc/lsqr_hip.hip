@@ -16,6 +16,7 @@
 
 #include "../../include/lsqr_hip.h"
 #include "kernels.h"
+#include "models_nd.h"
 #include "dense.h"
 #include "us_kernels.h"
 #include "cells.h"
@@ -176,14 +177,29 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
     case LSQR_MODEL_PLANE:
       if (cfg.dim == 3) return f(Tag<PlaneModel<3>>{});
       if (cfg.dim == 2) return f(Tag<PlaneModel<2>>{});
+      if (cfg.dim == 4) return f(Tag<PlaneModelN<4>>{});  // general dimension: models_nd.h
+      if (cfg.dim == 5) return f(Tag<PlaneModelN<5>>{});
+      if (cfg.dim == 6) return f(Tag<PlaneModelN<6>>{});
+      if (cfg.dim == 7) return f(Tag<PlaneModelN<7>>{});
+      if (cfg.dim == 8) return f(Tag<PlaneModelN<8>>{});
       break;
     case LSQR_MODEL_SPHERE:
       if (cfg.dim == 3) return f(Tag<SphereModel<3>>{});
       if (cfg.dim == 2) return f(Tag<SphereModel<2>>{});
+      if (cfg.dim == 4) return f(Tag<SphereModelN<4>>{});
+      if (cfg.dim == 5) return f(Tag<SphereModelN<5>>{});
+      if (cfg.dim == 6) return f(Tag<SphereModelN<6>>{});
+      if (cfg.dim == 7) return f(Tag<SphereModelN<7>>{});
+      if (cfg.dim == 8) return f(Tag<SphereModelN<8>>{});
       break;
     case LSQR_MODEL_LINE:
       if (cfg.dim == 3) return f(Tag<LineModel<3>>{});
       if (cfg.dim == 2) return f(Tag<LineModel<2>>{});
+      if (cfg.dim == 4) return f(Tag<LineModelN<4>>{});
+      if (cfg.dim == 5) return f(Tag<LineModelN<5>>{});
+      if (cfg.dim == 6) return f(Tag<LineModelN<6>>{});
+      if (cfg.dim == 7) return f(Tag<LineModelN<7>>{});
+      if (cfg.dim == 8) return f(Tag<LineModelN<8>>{});
       break;
     case LSQR_MODEL_US_SINGLE: return f(Tag<USModel<true>>{});
     case LSQR_MODEL_US_POINTER: return f(Tag<USModel<false>>{});
@@ -543,12 +559,11 @@ int launch_scan_cells(lsqr_ctx *c) {
 }
 template <class CM, int PP, int CPT>
 int run_scan_cells(lsqr_ctx *c) {
-  if (c->opt_block == 1024) return launch_scan_cells<CM, PP, CPT, 1024>(c);
   // hypothesis broadcast to the survivors: v_readlane, or (scan_block 257 / the model's choice)
-  // uniform-address LDS reads
+  // uniform-address LDS reads.  (1024-thread workgroups measured 3-5 % slower and are no longer built.)
   if (c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST))
     return launch_scan_cells<CM, PP, CPT, 256, true>(c);
-  return launch_scan_cells<CM, PP, CPT, 256>(c);  // measured: 256 is 3-5 % faster than 1024
+  return launch_scan_cells<CM, PP, CPT, 256>(c);
 }
 
 int run_scan(lsqr_ctx *c) {
@@ -680,20 +695,11 @@ int run_scan(lsqr_ctx *c) {
               usable = false;
             }
           }
-          const int cpt = c->opt_cpt ? c->opt_cpt : 1;
+          // one cell per wave tile; several cells per tile and 128-record cells were measured dead ends
+          //  and are no longer instantiated
           if (usable) {
-            if (cell_pts == 128) {
-              if (cpt == 1) return run_scan_cells<CM, 1, 1>(c);
-              if (cpt == 2) return run_scan_cells<CM, 1, 2>(c);
-              return run_scan_cells<CM, 1, 4>(c);
-            }
-            if (cell_pts == 512) {
-              if (cpt == 1) return run_scan_cells<CM, 4, 1>(c);
-              return run_scan_cells<CM, 4, 2>(c);
-            }
-            if (cpt == 1) return run_scan_cells<CM, 2, 1>(c);
-            if (cpt == 2) return run_scan_cells<CM, 2, 2>(c);
-            return run_scan_cells<CM, 2, 4>(c);
+            if (cell_pts == 512) return run_scan_cells<CM, 4, 1>(c);
+            return run_scan_cells<CM, 2, 1>(c);
           }
         }
       }
@@ -1314,7 +1320,7 @@ int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_DENSE: return cfg->dim + 1;
     case LSQR_MODEL_US_SINGLE: return 15;
     case LSQR_MODEL_US_POINTER: return 18;
-    case LSQR_MODEL_ABSOR: return 6;
+    case LSQR_MODEL_ABSOR: return cfg->ls_type == 1 ? 7 : 6;  // weighted fit: [first, second, weight]
     case LSQR_MODEL_PIVOT: return 13;
     case LSQR_MODEL_RAY: return 6;
     case LSQR_MODEL_LINE2D: return 2;
@@ -1443,6 +1449,13 @@ int lsqr_hypotheses_sample(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return LSQR_OK;
+}
+
+int lsqr_sample_subsets(uint64_t seed, uint64_t first, size_t H, uint64_t n, int k, uint32_t *out) {
+  if (!out || k < 1 || k > 64 || n < (uint64_t)k || n > 0xFFFFFFF0ull) return LSQR_ERR_INVALID;
+  uint32_t sorted[64];
+  for (size_t h = 0; h < H; h++) ctr_subset(seed, first + h, n, k, out + h * (size_t)k, sorted);
   return LSQR_OK;
 }
 
@@ -2429,8 +2442,7 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_cpt")) {  // cells per wave tile of the two-level scan
-    if (value != 0 && value != 1 && value != 2 && value != 4)
-      return fail(c, LSQR_ERR_INVALID, "scan_cpt must be 0, 1, 2 or 4");
+    if (value != 0 && value != 1) return fail(c, LSQR_ERR_INVALID, "scan_cpt must be 0 or 1");
     c->opt_cpt = value;
     return LSQR_OK;
   }
@@ -2444,14 +2456,14 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_block")) {  // workgroup size of the two-level scan
-    if (value != 0 && value != 256 && value != 257 && value != 1024)
-      return fail(c, LSQR_ERR_INVALID, "scan_block must be 0, 256, 257 (256 + LDS broadcast) or 1024");
+    if (value != 0 && value != 256 && value != 257)
+      return fail(c, LSQR_ERR_INVALID, "scan_block must be 0, 256 or 257 (256 + LDS broadcast)");
     c->opt_block = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_cell")) {  // observations per cell of the spatial index
-    if (value != 0 && value != 128 && value != 256 && value != 512)
-      return fail(c, LSQR_ERR_INVALID, "scan_cell must be 0, 128, 256 or 512");
+    if (value != 0 && value != 256 && value != 512)
+      return fail(c, LSQR_ERR_INVALID, "scan_cell must be 0, 256 or 512");
     c->opt_cell = value;
     return LSQR_OK;
   }

@@ -60,10 +60,13 @@ LSQR_HD void frame_quaternion(const double *R, double *q) {
 // scan parameters: the 7 + the 9 rotation entries agree() would rebuild per datum
 // (Frame ctor, Frame.cxx:174-198, no normalisation).
 struct AbsOrModel {
-  enum { ND = 6, K = 3, P = 7, SP = 16, REC = 6, PPL = 4, IS_DENSE = 0, IS_US = 0, ORIGIN_FIRST = 1 };
+  // REC = 7: slot 6 is the pair's weight -- read from the record when ls_type == 1 (weighted fit,
+  // AbsoluteOrientation...cxx:208-291; records of 7 doubles), 1.0 otherwise (records of 6 doubles)
+  enum { ND = 6, K = 3, P = 7, SP = 16, REC = 7, PPL = 4, IS_DENSE = 0, IS_US = 0, ORIGIN_FIRST = 1 };
   enum { NMOM = 1 + 3 + 3 + 9 };
-  static LSQR_HD void load(const double *p, const ModelConsts &, double *rec) {
+  static LSQR_HD void load(const double *p, const ModelConsts &c, double *rec) {
     for (int i = 0; i < 6; i++) rec[i] = p[i];
+    rec[6] = c.ls_type == 1 ? p[6] : 1.0;
   }
   // vnl_vector::normalize(): multiply by 1/sqrt(sum of squares) unless the sum is zero
   static LSQR_HD void normalize3(double *v) {
@@ -139,25 +142,29 @@ struct AbsOrModel {
     frame_from_quaternion(sp[0], sp[1], sp[2], sp[3], false, sp + 7);
     return sqrt(dist_sq(sp, x));
   }
-  // moments about org = (first, second) of the first datum: {N, sum l', sum r', sum l' r'^T}
-  // (AbsoluteOrientation...cxx:133-168 accumulates the same sums un-shifted)
+  // moments about org = (first, second) of the first datum: {sum w, sum w l', sum w r', sum w l' r'^T}
+  // (AbsoluteOrientation...cxx:133-168 accumulates the same sums un-shifted with w = 1, :223-258 with the
+  // caller's weights; multiplying by w = 1.0 is exact, so the unweighted block is unchanged)
   static LSQR_HD void accumulate(const double *x, const double *org, double *m) {
     double l[3], r[3];
+    const double w = x[6];
     for (int i = 0; i < 3; i++) {
       l[i] = x[i] - org[i];
       r[i] = x[3 + i] - org[3 + i];
     }
-    m[0] += 1.0;
+    m[0] += w;
     for (int i = 0; i < 3; i++) {
-      m[1 + i] += l[i];
-      m[4 + i] += r[i];
-      for (int j = 0; j < 3; j++) m[7 + 3 * i + j] = fma(l[i], r[j], m[7 + 3 * i + j]);
+      const double wl = w * l[i];
+      m[1 + i] += wl;
+      m[4 + i] += w * r[i];
+      for (int j = 0; j < 3; j++) m[7 + 3 * i + j] = fma(wl, r[j], m[7 + 3 * i + j]);
     }
   }
   // Horn's closed form (AbsoluteOrientation...cxx:170-198): largest eigenvector of the 4x4 N
-  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &, double *par) {
+  // (weighted: n = sum of the weights; the caller has checked the pair count, :213-216)
+  static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &c, double *par) {
     const double n = m[0];
-    if (n < 3.0) return false;  // :129
+    if (c.ls_type == 1 ? !(n > 0.0) : n < 3.0) return false;  // :129
     double ml[3], mr[3], M[9], Nm[16], w[4], V[16], R[9];
     for (int i = 0; i < 3; i++) {
       ml[i] = m[1 + i] / n;

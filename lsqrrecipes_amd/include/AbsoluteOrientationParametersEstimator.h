@@ -46,6 +46,26 @@ class AbsoluteOrientationParametersEstimator
     if (data.size() < this->minForEstimate) return;
     detail::lsFit(cfg(), &data[0], data.size(), parameters);
   }
+  // AbsoluteOrientationParametersEstimator.h:86 / .cxx:208-291: Horn's closed form with per-pair weights
+  // (`weights` holds at least data.size() non-negative entries).  The device reduces the weighted sums
+  // {sum w, sum w l, sum w r, sum w l r^T} of records [first, second, weight].
+  void weightedLeastSquaresEstimate(std::vector<DataT *> &data, std::vector<double> &weights,
+                                    std::vector<double> &parameters) {
+    parameters.clear();
+    if (data.size() < this->minForEstimate) return;
+    if (weights.size() < data.size()) throw std::out_of_range("lsqrRecipes: fewer weights than point pairs");
+    std::vector<double> rec(7 * data.size());
+    for (size_t i = 0; i < data.size(); i++) {
+      for (int j = 0; j < 3; j++) {
+        rec[7 * i + j] = data[i]->first[j];
+        rec[7 * i + 3 + j] = data[i]->second[j];
+      }
+      rec[7 * i + 6] = weights[i];
+    }
+    lsqr_model_cfg c = cfg();
+    c.ls_type = 1;
+    detail::lsFitRaw(c, &rec[0], data.size(), 7 * sizeof(double), parameters);
+  }
   virtual bool agree(std::vector<double> &parameters, DataT &data) {
     return detail::agreeOne(cfg(), parameters, data);
   }

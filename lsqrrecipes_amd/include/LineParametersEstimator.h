@@ -1,6 +1,6 @@
 // LineParametersEstimator.h -- drop-in for parametersEstimators/LineParametersEstimator.{h,hxx}:
 // line [direction, a] through a.  Same constructor / setDelta / virtuals; every method
-// runs on the device through the C ABI.  Device models exist for dimension 2 and 3.
+// runs on the device through the C ABI.  Device models exist for dimensions 2 to 8.
 #ifndef _LINE_PARAMETERS_ESTIMATOR_H_
 #define _LINE_PARAMETERS_ESTIMATOR_H_
 
@@ -45,7 +45,7 @@ class LineParametersEstimator : public ParametersEstimator<Point<double, dimensi
 
   virtual bool deviceModel(lsqr_model_cfg &c) const {
     c = cfg();
-    return dimension == 2 || dimension == 3;
+    return dimension >= 2 && dimension <= 8;  // device models: 2, 3 (models.h) and 4..8 (models_nd.h)
   }
 
  private:

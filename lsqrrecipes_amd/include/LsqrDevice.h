@@ -93,6 +93,19 @@ inline void lsFit(const lsqr_model_cfg &cfg, const T *recs, size_t count,
   if (info) *info = fi;
 }
 
+// leastSquaresEstimate() over records the caller has laid out itself (pointer, count, stride in bytes)
+inline void lsFitRaw(const lsqr_model_cfg &cfg, const void *recs, size_t count, size_t stride_bytes,
+                     std::vector<double> &parameters) {
+  parameters.clear();
+  if (count == 0) return;
+  Device &d = Device::instance();
+  d.model(cfg);
+  d.check(lsqr_upload(d.ctx(), recs, count, stride_bytes));
+  std::vector<double> p(64);
+  lsqr_fit_info fi;
+  if (d.check(lsqr_ls_fit(d.ctx(), 0, &p[0], &fi))) parameters.assign(p.begin(), p.begin() + fi.n_params);
+}
+
 template <class T>
 inline bool agreeOne(const lsqr_model_cfg &cfg, const std::vector<double> &parameters, const T &rec) {
   Device &d = Device::instance();

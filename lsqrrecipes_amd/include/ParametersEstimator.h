@@ -1,9 +1,10 @@
 // ParametersEstimator.h -- the reference's plugin interface
 // (parametersEstimators/ParametersEstimator.h:26-64), unchanged in names, argument meaning and the
 // "empty parameters vector == failure" convention, plus ONE addition: deviceModel(), through which
-// an estimator tells RANSAC<T,S>::compute() which device model evaluates it.  The five hot-path
-// estimators of this drop-in implement it; the hot path has no CPU fallback, so handing an
-// estimator without a device model to RANSAC::compute() throws (see RANSAC.h).
+// an estimator tells RANSAC<T,S>::compute() which device model evaluates it.  Every estimator this
+// library ships implements it and runs on the MI355X only.  A user-defined subclass keeps the default
+// (false): RANSAC<T,S>::compute() then drives its virtuals with the reference's serial loop (RANSAC.h,
+// "plugin path"), as the reference's readme.txt:40-72 promises for user estimators.
 #ifndef _PARAMETERS_ESTIMATOR_H_
 #define _PARAMETERS_ESTIMATOR_H_
 
@@ -27,7 +28,7 @@ class ParametersEstimator {
 
   unsigned int numForEstimate() { return this->minForEstimate; }
 
-  // false: no device implementation (RANSAC::compute will refuse it)
+  // false: no device implementation (RANSAC::compute drives the virtuals on the host: plugin path)
   virtual bool deviceModel(lsqr_model_cfg &) const { return false; }
 
  protected:

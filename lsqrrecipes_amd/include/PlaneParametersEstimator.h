@@ -1,6 +1,6 @@
 // PlaneParametersEstimator.h -- drop-in for parametersEstimators/PlaneParametersEstimator.{h,hxx}:
 // (hyper)plane [n, a], dot(n, p - a) = 0.  Same constructor / setDelta / virtuals; every method
-// runs on the device through the C ABI.  Device models exist for dimension 2 and 3.
+// runs on the device through the C ABI.  Device models exist for dimensions 2 to 8.
 #ifndef _PLANE_PARAMETERS_ESTIMATOR_H_
 #define _PLANE_PARAMETERS_ESTIMATOR_H_
 
@@ -45,7 +45,7 @@ class PlaneParametersEstimator : public ParametersEstimator<Point<double, dimens
 
   virtual bool deviceModel(lsqr_model_cfg &c) const {
     c = cfg();
-    return dimension == 2 || dimension == 3;
+    return dimension >= 2 && dimension <= 8;  // device models: 2, 3 (models.h) and 4..8 (models_nd.h)
   }
 
  private:

@@ -1,7 +1,7 @@
 // SphereParametersEstimator.h -- drop-in for parametersEstimators/SphereParametersEstimator.{h,hxx}:
 // (hyper)sphere [c, r].  Same constructor (delta, LeastSquaresType = GEOMETRIC), setters and public
 // helpers (algebraic / geometric least squares, getDistanceStatistics); device models for
-// dimension 2 (circle) and 3 (sphere).
+// dimensions 2 (circle), 3 (sphere) and 4 to 8 (hyperspheres).
 #ifndef _SPHERE_PARAMETERS_ESTIMATOR_H_
 #define _SPHERE_PARAMETERS_ESTIMATOR_H_
 
@@ -80,9 +80,23 @@ class SphereParametersEstimator : public ParametersEstimator<Point<double, dimen
     detail::distanceStats(c, parameters, &data[0], data.size(), min, max, mean);
   }
 
+  // the reference's signature (SphereParametersEstimator.h:156-159, .hxx:341-377): the distance of every
+  // point is appended to `distances` (push_back: earlier entries stay, as in the reference)
+  static void getDistanceStatistics(std::vector<double> &parameters, std::vector<PointT> &data,
+                                    std::vector<double> &distances, double &min, double &max,
+                                    double &mean) {
+    if (parameters.size() < dimension + 1) throw std::exception();
+    lsqr_model_cfg c = {LSQR_MODEL_SPHERE, (int32_t)dimension, 1.0, GEOMETRIC, 0};
+    detail::distanceStats(c, parameters, &data[0], data.size(), min, max, mean);
+    const size_t at = distances.size();
+    distances.resize(at + data.size());
+    detail::Device &d = detail::Device::instance();
+    d.check(lsqr_residuals(d.ctx(), &parameters[0], 0, data.size(), &distances[at]));
+  }
+
   virtual bool deviceModel(lsqr_model_cfg &c) const {
     c = cfg(lsType);
-    return dimension == 2 || dimension == 3;
+    return dimension >= 2 && dimension <= 8;  // device models: 2, 3 (models.h) and 4..8 (models_nd.h)
   }
 
  private:

@@ -90,42 +90,37 @@ static int plane_estimate(int d, const double *const *p, size_t n, double *out) 
     out[1] = ny / norm;
     out[2] = nz / norm;
   } else {
-    /* :70-104 null vector of the d x (d+1) matrix [p,-1] via SVD.  Restated through the
-     * (d+1)x(d+1) Gram matrix's eigen decomposition: same null space, rank test on
-     * sqrt(eigenvalue) <= EPS.  (VNL absent: parity unpinned for this branch.) */
+    /* :70-104 null vector of the d x (d+1) matrix [p,-1] via SVD, rank decided on the singular values at
+     * EPS (zero_out_absolute).  The matrix is padded with a zero row to (d+1) x (d+1): same null space,
+     * same non-zero singular values, and d+1 singular values in all -- what vnl_svd reports for a
+     * d x (d+1) matrix (LINPACK dsvdc yields min(m+1, n) of them).  nullvector() is the right singular
+     * vector of the smallest one.  (VNL absent: bit-level parity of this branch is unpinned.) */
     int m = d + 1;
-    double *G = (double *)calloc((size_t)m * m, sizeof(double));
+    double *A = (double *)calloc((size_t)m * m, sizeof(double));
+    double *U = (double *)malloc(sizeof(double) * m * m);
     double *w = (double *)malloc(sizeof(double) * m);
     double *V = (double *)malloc(sizeof(double) * m * m);
     double norm = 0;
     int rank = 0;
     for (i = 0; i < d; i++) {
-      double row[65];
-      for (j = 0; j < d; j++) row[j] = p[i][j];
-      row[d] = -1;
-      for (j = 0; j < m; j++) {
-        int k;
-        for (k = 0; k < m; k++) G[j * m + k] += row[j] * row[k];
-      }
+      for (j = 0; j < d; j++) A[i * m + j] = p[i][j];
+      A[i * m + d] = -1;
     }
-    orc_sym_eig(m, G, w, V);
+    orc_svd(m, m, A, U, w, V); /* singular values descending */
     for (i = 0; i < m; i++)
-      if (w[i] > 0 && sqrt(w[i]) > EPS) rank++;
-    if (rank < d) {
-      free(G);
-      free(w);
-      free(V);
-      return 0;
-    }
-    for (i = 0; i < d; i++) {
-      out[i] = V[i * m + 0];
-      norm += out[i] * out[i];
-    }
-    norm = 1.0 / sqrt(norm);
-    for (i = 0; i < d; i++) out[i] *= norm;
-    free(G);
+      if (w[i] > EPS) rank++;
+    if (rank >= d)
+      for (i = 0; i < d; i++) {
+        out[i] = V[i * m + (m - 1)];
+        norm += out[i] * out[i];
+      }
+    free(A);
+    free(U);
     free(w);
     free(V);
+    if (rank < d || !(norm > 0)) return 0;
+    norm = 1.0 / sqrt(norm);
+    for (i = 0; i < d; i++) out[i] *= norm;
   }
   for (i = 0; i < d; i++) out[d + i] = p[0][i]; /* :107-108 */
   return 2 * d;
@@ -554,6 +549,49 @@ static int absor_ls(const double *const *p, size_t n, double *out) {
     for (b = 0; b < 3; b++)
       N[(a + 1) * 4 + (b + 1)] = (a == b ? -traceM : 0.0) + (M[a][b] + M[b][a]);
   orc_sym_eig(4, N, w, V); /* ascending: column 3 = largest (:187-195) */
+  for (a = 0; a < 4; a++) q[a] = V[a * 4 + 3];
+  for (a = 0; a < 4; a++) out[a] = q[a];
+  frame_from_quaternion(q[0], q[1], q[2], q[3], 1, R);
+  for (a = 0; a < 3; a++) mf[a] = R[a][0] * m1[0] + R[a][1] * m1[1] + R[a][2] * m1[2] + 0.0;
+  for (a = 0; a < 3; a++) out[4 + a] = m2[a] - mf[a];
+  return 7;
+}
+
+/* AbsoluteOrientationParametersEstimator.cxx:208-291 weightedLeastSquaresEstimate: Horn's closed form with
+ * weighted means and a weighted correlation matrix.  Records: [first(3), second(3)]; w: one weight each. */
+int orc_absor_weighted_ls(const double *const *p, const double *wt, size_t n, double *out) {
+  double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0}, M[3][3], N[16], w[4], V[16], R[3][3], q[4];
+  double traceM, A12, A20, A01, mf[3], sumWeights = 0.0;
+  size_t i;
+  int a, b;
+  if (n < 3) return 0;
+  for (i = 0; i < n; i++) sumWeights += wt[i];
+  for (i = 0; i < n; i++)
+    for (a = 0; a < 3; a++) {
+      m1[a] += p[i][a] * wt[i];
+      m2[a] += p[i][3 + a] * wt[i];
+    }
+  for (a = 0; a < 3; a++) {
+    m1[a] /= sumWeights;
+    m2[a] /= sumWeights;
+  }
+  memset(M, 0, sizeof M);
+  for (i = 0; i < n; i++)
+    for (a = 0; a < 3; a++)
+      for (b = 0; b < 3; b++) M[a][b] += (p[i][a] * p[i][3 + b]) * wt[i];
+  for (a = 0; a < 3; a++)
+    for (b = 0; b < 3; b++) M[a][b] += (m1[a] * m2[b]) * (-sumWeights);
+  traceM = 0.0;
+  for (a = 0; a < 3; a++) traceM += M[a][a];
+  A12 = M[1][2] - M[2][1];
+  A20 = M[2][0] - M[0][2];
+  A01 = M[0][1] - M[1][0];
+  N[0] = traceM; N[1] = A12; N[2] = A20; N[3] = A01;
+  N[4] = A12; N[8] = A20; N[12] = A01;
+  for (a = 0; a < 3; a++)
+    for (b = 0; b < 3; b++)
+      N[(a + 1) * 4 + (b + 1)] = (a == b ? -traceM : 0.0) + (M[a][b] + M[b][a]);
+  orc_sym_eig(4, N, w, V);
   for (a = 0; a < 4; a++) q[a] = V[a * 4 + 3];
   for (a = 0; a < 4; a++) out[a] = q[a];
   frame_from_quaternion(q[0], q[1], q[2], q[3], 1, R);

@@ -93,6 +93,7 @@ def lib():
         L.orc_sphere_geometric.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp, _dp,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_us_analytic.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp]
+        L.orc_absor_weighted_ls.argtypes = [C.POINTER(_dp), _dp, C.c_size_t, _dp]
         L.orc_us_iterative.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp, _dp,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return _lib
@@ -319,6 +320,16 @@ def sphere_geometric(dim, pts, init):
     n = lib().orc_sphere_geometric(dim, _ptrs(rows), len(rows), _d(init), _d(out),
                                    C.byref(info), C.byref(nfev))
     return out[:n].copy(), info.value, nfev.value
+
+
+def absor_weighted_ls(pairs, weights):
+    """AbsoluteOrientationParametersEstimator::weightedLeastSquaresEstimate (.cxx:208-291)"""
+    a = np.ascontiguousarray(pairs, dtype=np.float64).reshape(-1, 6)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    rows = [np.ascontiguousarray(a[i]) for i in range(a.shape[0])]
+    out = np.zeros(7)
+    n = lib().orc_absor_weighted_ls(_ptrs(rows), _d(w), len(rows), _d(out))
+    return out[:n].copy()
 
 
 def us_analytic(model, recs):

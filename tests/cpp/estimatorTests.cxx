@@ -451,22 +451,258 @@ static void ransacTest() {
   double fe = RANSAC<P, double>::compute(params, &est, small, &consensus);
   CHECK(fe >= 3.0 / 16 && params.size() == 6);
   CHECK((RANSAC<P, double>::lastInfo().iterations == 560));  // C(16,3)
-  // an estimator without a device model is refused loudly
-  struct Foreign : public ParametersEstimator<P, double> {
-    Foreign() : ParametersEstimator<P, double>(3) {}
-    void estimate(std::vector<P *> &, std::vector<double> &) {}
-    void estimate(std::vector<P> &, std::vector<double> &) {}
-    void leastSquaresEstimate(std::vector<P *> &, std::vector<double> &) {}
-    void leastSquaresEstimate(std::vector<P> &, std::vector<double> &) {}
-    bool agree(std::vector<double> &, P &) { return false; }
-  } foreign;
-  bool threw = false;
-  try {
-    RANSAC<P, double>::compute(params, &foreign, data, 0.9);
-  } catch (std::runtime_error &) {
-    threw = true;
+}
+
+// ---- plugin path: a user-defined estimator (the reference's advertised use, readme.txt:40-72) --------------
+// The readme's example: a 2-D line [n, a] estimator written by the user against ParametersEstimator<T,S>.
+// It has no device model, so RANSAC<T,S>::compute() drives its virtuals with the serial loop; because that
+// loop shares the subset stream and the stopping rule with the device path, it must reproduce what the
+// built-in Line2DParametersEstimator computes on the device for the same seed.
+struct UserPoint2D {
+  double x, y;
+};
+class UserLine2D : public ParametersEstimator<UserPoint2D, double> {
+ public:
+  UserLine2D(double delta) : ParametersEstimator<UserPoint2D, double>(2), d2(delta * delta), calls(0) {}
+  virtual void estimate(std::vector<UserPoint2D *> &data, std::vector<double> &p) {
+    p.clear();
+    if (data.size() < 2) return;
+    double nx = data[1]->y - data[0]->y, ny = data[0]->x - data[1]->x;
+    double norm = std::sqrt(nx * nx + ny * ny);
+    if (norm < 2.220446049250313e-16) return;
+    p.push_back(nx / norm);
+    p.push_back(ny / norm);
+    p.push_back(data[0]->x);
+    p.push_back(data[0]->y);
   }
-  CHECK(threw);
+  virtual void estimate(std::vector<UserPoint2D> &data, std::vector<double> &p) {
+    std::vector<UserPoint2D *> q;
+    for (size_t i = 0; i < data.size(); i++) q.push_back(&data[i]);
+    estimate(q, p);
+  }
+  virtual void leastSquaresEstimate(std::vector<UserPoint2D *> &data, std::vector<double> &p) {
+    p.clear();
+    if (data.size() < 2) return;
+    double mx = 0, my = 0, sxx = 0, sxy = 0, syy = 0;
+    for (size_t i = 0; i < data.size(); i++) mx += data[i]->x, my += data[i]->y;
+    mx /= data.size(), my /= data.size();
+    for (size_t i = 0; i < data.size(); i++) {
+      double dx = data[i]->x - mx, dy = data[i]->y - my;
+      sxx += dx * dx, sxy += dx * dy, syy += dy * dy;
+    }
+    double th = 0.5 * std::atan2(2 * sxy, sxx - syy);  // direction of largest spread
+    p.push_back(-std::sin(th));
+    p.push_back(std::cos(th));
+    p.push_back(mx);
+    p.push_back(my);
+  }
+  virtual void leastSquaresEstimate(std::vector<UserPoint2D> &data, std::vector<double> &p) {
+    std::vector<UserPoint2D *> q;
+    for (size_t i = 0; i < data.size(); i++) q.push_back(&data[i]);
+    leastSquaresEstimate(q, p);
+  }
+  virtual bool agree(std::vector<double> &p, UserPoint2D &d) {
+    calls++;
+    double s = p[0] * (d.x - p[2]) + p[1] * (d.y - p[3]);
+    return s * s < d2;
+  }
+  double d2;
+  size_t calls;
+};
+
+static void pluginTest() {
+  std::vector<UserPoint2D> data;
+  std::vector<Point2D> same;
+  const double n[2] = {0.6, 0.8}, a[2] = {5, -7};
+  for (int i = 0; i < 3000; i++) {
+    double x = U(-500, 500), y = U(-500, 500);
+    if (i % 5 < 3) {  // 60 % inliers
+      double d = (x - a[0]) * n[0] + (y - a[1]) * n[1];
+      x += -d * n[0] + N(0.2), y += -d * n[1] + N(0.2);
+    }
+    UserPoint2D u = {x, y};
+    Point2D q;
+    q[0] = x, q[1] = y;
+    data.push_back(u);
+    same.push_back(q);
+  }
+  UserLine2D user(0.5);
+  lsqr_model_cfg none;
+  CHECK(!user.deviceModel(none));
+  std::vector<double> pu, pd;
+  std::vector<bool> cu, cd;
+  RANSAC<UserPoint2D, double>::seed() = 77;
+  double fu = RANSAC<UserPoint2D, double>::compute(pu, &user, data, 0.999, &cu);
+  lsqr_ransac_info iu = RANSAC<UserPoint2D, double>::lastInfo();
+  CHECK(pu.size() == 4 && cu.size() == data.size());
+  CHECK(fu > 0.55 && fu < 0.65);
+  CHECK(user.calls > 0);
+  if (pu.size() == 4) CHECK(std::fabs(std::fabs(pu[0] * n[0] + pu[1] * n[1]) - 1) < 1e-5);
+  // the built-in estimator of the same model on the device, same stream
+  Line2DParametersEstimator builtin(0.5);
+  RANSAC<Point2D, double>::seed() = 77;
+  double fd = RANSAC<Point2D, double>::compute(pd, &builtin, same, 0.999, &cd);
+  lsqr_ransac_info id = RANSAC<Point2D, double>::lastInfo();
+  CHECK(fd == fu && cd == cu);
+  CHECK(id.iterations == iu.iterations && id.best_index == iu.best_index && id.best_votes == iu.best_votes);
+  if (pd.size() == 4 && pu.size() == 4) {
+    double dot = pd[0] * pu[0] + pd[1] * pu[1];
+    CHECK(std::fabs(std::fabs(dot) - 1) < 1e-9);
+  }
+  // a built-in estimator forced through the plugin loop (virtuals evaluated one call at a time on the device)
+  // gives what the batched device path gives: small set, or the per-datum calls take minutes
+  typedef Point<double, 3> P;
+  std::vector<P> pts;
+  for (int i = 0; i < 60; i++) {
+    P p;
+    for (int j = 0; j < 3; j++) p[j] = U(-100, 100);
+    if (i % 3) p[2] = 0.25 * p[0] - 0.5 * p[1] + 3 + N(0.05);
+    pts.push_back(p);
+  }
+  PlaneParametersEstimator<3> plane(0.3);
+  std::vector<double> a1, a2;
+  std::vector<bool> c1, c2;
+  RANSAC<P, double>::seed() = 5;
+  double f1 = RANSAC<P, double>::compute(a1, &plane, pts, 0.99, &c1);
+  lsqr_ransac_info i1 = RANSAC<P, double>::lastInfo();
+  RANSAC<P, double>::forceHostLoop() = true;
+  double f2 = RANSAC<P, double>::compute(a2, &plane, pts, 0.99, &c2);
+  lsqr_ransac_info i2 = RANSAC<P, double>::lastInfo();
+  CHECK(f1 == f2 && c1 == c2 && a1.size() == 6 && a2.size() == 6);
+  CHECK(i1.iterations == i2.iterations && i1.best_index == i2.best_index);
+  // exhaustive overload through the plugin loop == device
+  std::vector<P> few(pts.begin(), pts.begin() + 9);
+  double e2 = RANSAC<P, double>::compute(a2, &plane, few, &c2);
+  RANSAC<P, double>::forceHostLoop() = false;
+  double e1 = RANSAC<P, double>::compute(a1, &plane, few, &c1);
+  CHECK((e1 == e2 && c1 == c2 && RANSAC<P, double>::lastInfo().iterations == 84));  // C(9,3)
+  RANSAC<P, double>::seed() = 1;
+  // degenerate user estimator (never produces a model): no consensus, parameters empty, return 0
+  struct Mute : public UserLine2D {
+    Mute() : UserLine2D(0.5) {}
+    void estimate(std::vector<UserPoint2D *> &, std::vector<double> &p) { p.clear(); }
+  } mute;
+  std::vector<UserPoint2D> tiny(data.begin(), data.begin() + 6);
+  std::vector<double> pm(2, 1.0);
+  CHECK((RANSAC<UserPoint2D, double>::compute(pm, &mute, tiny, 0.9) == 0));
+  CHECK(pm.empty());
+}
+
+// ---- dimensions above 3 (the reference's templates take any dimension; its sphere test runs 4-D) -----------
+template <unsigned int D>
+static void sphereNdTest() {  // testing/SphereParametersEstimatorTest.cxx:379-431 (testnD), data :432-468
+  typedef Point<double, D> P;
+  const double sigma = 1.0;
+  std::vector<double> truth, params;
+  for (unsigned i = 0; i < D; i++) truth.push_back(U(-1000, 1000));
+  truth.push_back(U(0, 1000));
+  std::vector<P> data, clean;
+  for (unsigned i = 0; i < 10 * (D + 1); i++) {
+    double t[D], nn = 0;
+    for (unsigned j = 0; j < D; j++) t[j] = U(-1, 1), nn += t[j] * t[j];
+    nn = std::sqrt(nn);
+    P c, p;
+    for (unsigned j = 0; j < D; j++) {
+      c[j] = truth[j] + truth[D] * t[j] / nn;
+      p[j] = c[j] + N(sigma);
+    }
+    clean.push_back(c);
+    data.push_back(p);
+  }
+  SphereParametersEstimator<D> est(0.5);
+  auto close = [&](const std::vector<double> &e) {
+    if (e.size() != D + 1) return false;
+    double d = 0;
+    for (unsigned j = 0; j < D; j++) d += (e[j] - truth[j]) * (e[j] - truth[j]);
+    return std::sqrt(d) <= 3 * sigma && (e[D] - truth[D]) <= 3 * sigma;
+  };
+  est.estimate(clean, params);
+  CHECK(close(params));
+  est.setLeastSquaresType(SphereParametersEstimator<D>::ALGEBRAIC);
+  est.leastSquaresEstimate(data, params);
+  CHECK(close(params));
+  est.setLeastSquaresType(SphereParametersEstimator<D>::GEOMETRIC);
+  est.leastSquaresEstimate(data, params);
+  CHECK(close(params));
+  CHECK(est.agree(truth, clean[3]));
+  P off = clean[3];
+  off[0] += 2.0;
+  CHECK(!est.agree(truth, off) || std::fabs(off[0] - truth[0]) < 1.0);
+  // distances vector of getDistanceStatistics (SphereParametersEstimator.h:156-159): appended
+  std::vector<double> dist(2, -1.0);
+  double mn, mx, mean;
+  SphereParametersEstimator<D>::getDistanceStatistics(truth, clean, dist, mn, mx, mean);
+  CHECK(dist.size() == 2 + clean.size() && dist[0] == -1.0 && dist[1] == -1.0);
+  double sum = 0, big = 0;
+  for (size_t i = 2; i < dist.size(); i++) sum += dist[i], big = std::max(big, dist[i]);
+  CHECK(mx == big && std::fabs(mean - sum / clean.size()) < 1e-12 && mx < 1e-9);
+  // RANSAC in D dimensions with gross outliers
+  std::vector<P> mixed(data);
+  for (unsigned i = 0; i < 4 * (D + 1); i++) {
+    P p;
+    for (unsigned j = 0; j < D; j++) p[j] = U(-2000, 2000);
+    mixed.push_back(p);
+  }
+  SphereParametersEstimator<D> rest(4.0);
+  std::vector<bool> cons;
+  double frac = RANSAC<P, double>::compute(params, &rest, mixed, 0.99, &cons);
+  CHECK(params.size() == D + 1 && frac > 0.5);
+  CHECK(close(params));
+}
+
+template <unsigned int D>
+static void planeLineNdTest() {
+  typedef Point<double, D> P;
+  double n[D], a[D], nn = 0;
+  for (unsigned j = 0; j < D; j++) n[j] = U(-1, 1), a[j] = U(-100, 100), nn += n[j] * n[j];
+  for (unsigned j = 0; j < D; j++) n[j] /= std::sqrt(nn);
+  std::vector<P> onPlane, onLine;
+  for (unsigned i = 0; i < 40 * D; i++) {
+    P p, q;
+    double d = 0, t = U(-300, 300);
+    for (unsigned j = 0; j < D; j++) p[j] = U(-500, 500), d += (p[j] - a[j]) * n[j];
+    for (unsigned j = 0; j < D; j++) {
+      p[j] += -d * n[j] + N(0.05);
+      q[j] = a[j] + t * n[j] + N(0.05);
+    }
+    if (i % 4 == 3)
+      for (unsigned j = 0; j < D; j++) p[j] = U(-500, 500), q[j] = U(-500, 500);
+    onPlane.push_back(p);
+    onLine.push_back(q);
+  }
+  std::vector<double> params;
+  std::vector<bool> cons;
+  PlaneParametersEstimator<D> pe(0.3);
+  std::vector<P> minimal;
+  for (unsigned i = 0; minimal.size() < D; i++)
+    if (i % 4 != 3) minimal.push_back(onPlane[i]);
+  pe.estimate(minimal, params);   // SVD null-vector branch (PlaneParametersEstimator.hxx:70-104)
+  CHECK(params.size() == 2 * D);
+  if (params.size() == 2 * D) {
+    double dot = 0;
+    for (unsigned j = 0; j < D; j++) dot += params[j] * n[j];
+    CHECK(std::fabs(dot) > 0.999);
+    for (unsigned j = 0; j < D; j++) CHECK(params[D + j] == minimal[0][j]);
+  }
+  std::vector<P> repeated(D, minimal[0]);  // rank-deficient minimal set -> empty
+  pe.estimate(repeated, params);
+  CHECK(params.empty());
+  double frac = RANSAC<P, double>::compute(params, &pe, onPlane, 0.99, &cons);
+  CHECK(params.size() == 2 * D && frac > 0.7 && frac < 0.8);
+  if (params.size() == 2 * D) {
+    double dot = 0, off = 0;
+    for (unsigned j = 0; j < D; j++) dot += params[j] * n[j], off += (params[D + j] - a[j]) * n[j];
+    CHECK(std::fabs(std::fabs(dot) - 1) < 1e-6 && std::fabs(off) < 0.1);
+    CHECK(pe.agree(params, onPlane[0]));
+  }
+  LineParametersEstimator<D> le(0.5);
+  frac = RANSAC<P, double>::compute(params, &le, onLine, 0.99, &cons);
+  CHECK(params.size() == 2 * D && frac > 0.7 && frac < 0.8);
+  if (params.size() == 2 * D) {
+    double dot = 0;
+    for (unsigned j = 0; j < D; j++) dot += params[j] * n[j];
+    CHECK(std::fabs(std::fabs(dot) - 1) < 1e-6);
+  }
 }
 
 static void absoluteOrientationTest() {  // testing/AbsoluteOrientationParametersEstimatorTest.cxx:19-118
@@ -576,6 +812,51 @@ static void pivotTest(const char *file) {  // testing/PivotCalibrationParameters
   for (size_t i = 0; i < est.size(); i++) CHECK(std::fabs(est[i] - knownLS[i]) < maxError);
 }
 
+static void weightedAbsoluteOrientationTest() {  // AbsoluteOrientationParametersEstimator.h:86, .cxx:208-291
+  typedef std::pair<Point3D, Point3D> Pair;
+  // ground truth: rotation about (1,2,3)/|.| by 0.7 rad, translation (5,-3,2)
+  const double ax[3] = {1 / std::sqrt(14.0), 2 / std::sqrt(14.0), 3 / std::sqrt(14.0)}, ang = 0.7;
+  const double q[4] = {std::cos(ang / 2), ax[0] * std::sin(ang / 2), ax[1] * std::sin(ang / 2),
+                       ax[2] * std::sin(ang / 2)};
+  Frame f(5, -3, 2, q[0], q[1], q[2], q[3]);
+  std::vector<Pair> pairs;
+  for (int i = 0; i < 12; i++) {
+    Pair pr;
+    for (int j = 0; j < 3; j++) pr.first[j] = U(-100, 100);
+    f.apply(pr.first, pr.second);
+    pairs.push_back(pr);
+  }
+  for (int j = 0; j < 3; j++) pairs[2].second[j] += 40;   // two corrupted pairs ...
+  for (int j = 0; j < 3; j++) pairs[7].second[j] -= 25;
+  std::vector<Pair *> ptrs;
+  for (size_t i = 0; i < pairs.size(); i++) ptrs.push_back(&pairs[i]);
+  std::vector<double> w(pairs.size(), 1.0), pw, pu, pz;
+  AbsoluteOrientationParametersEstimator est(0.5);
+  est.weightedLeastSquaresEstimate(ptrs, w, pw);   // unit weights == the plain fit
+  est.leastSquaresEstimate(ptrs, pu);
+  CHECK(pw.size() == 7 && pu.size() == 7);
+  for (size_t i = 0; i < 7 && pw.size() == 7 && pu.size() == 7; i++) CHECK(std::fabs(pw[i] - pu[i]) < 1e-12);
+  w[2] = w[7] = 0.0;                                // ... weighted out: the exact transformation
+  est.weightedLeastSquaresEstimate(ptrs, w, pz);
+  CHECK(pz.size() == 7);
+  if (pz.size() == 7) {
+    double s = pz[0] * q[0] < 0 ? -1.0 : 1.0;
+    for (int i = 0; i < 4; i++) CHECK(std::fabs(s * pz[i] - q[i]) < 1e-9);
+    CHECK(std::fabs(pz[4] - 5) < 1e-7 && std::fabs(pz[5] + 3) < 1e-7 && std::fabs(pz[6] - 2) < 1e-7);
+  }
+  if (pu.size() == 7) CHECK(std::fabs(pu[4] - 5) > 0.5 || std::fabs(pu[5] + 3) > 0.5 || std::fabs(pu[6] - 2) > 0.5);
+  for (size_t i = 0; i < w.size(); i++) w[i] = U(0.1, 3.0);   // non-uniform weights halved: same answer
+  std::vector<double> h(w), p1, p2;
+  for (size_t i = 0; i < h.size(); i++) h[i] *= 0.5;
+  est.weightedLeastSquaresEstimate(ptrs, w, p1);
+  est.weightedLeastSquaresEstimate(ptrs, h, p2);
+  CHECK(p1.size() == 7 && p2.size() == 7);
+  for (size_t i = 0; i < 7 && p1.size() == 7 && p2.size() == 7; i++) CHECK(std::fabs(p1[i] - p2[i]) < 1e-9);
+  std::vector<Pair *> two(ptrs.begin(), ptrs.begin() + 2);
+  est.weightedLeastSquaresEstimate(two, w, p1);
+  CHECK(p1.empty());
+}
+
 int main(int argc, char *argv[]) {
   try {
     planeTest();
@@ -588,6 +869,13 @@ int main(int argc, char *argv[]) {
     rayIntersectionTest();
     pivotTest(argc > 2 ? argv[2] : 0);
     ransacTest();
+    pluginTest();
+    sphereNdTest<4>();
+    sphereNdTest<6>();
+    planeLineNdTest<4>();
+    planeLineNdTest<5>();
+    planeLineNdTest<8>();
+    weightedAbsoluteOrientationTest();
   } catch (std::exception &e) {
     std::printf("EXCEPTION: %s\n", e.what());
     return EXIT_FAILURE;

@@ -1,0 +1,151 @@
+"""GPU parity in dimensions above 3 (csrc/models_nd.h): the reference's plane / sphere / line templates
+take any dimension (PlaneParametersEstimator.hxx:70-104 SVD null vector, SphereParametersEstimator.hxx:169-202
+pseudo-inverse, LineParametersEstimator.hxx any d), its own sphere test runs a 4-D case.  agree() scans and
+masks are BIT-EXACT against the oracle evaluated on the device's models; the SVD-based minimal solves (VNL,
+unpinned) and the fits within 1e-6 relative.  Also: weightedLeastSquaresEstimate of the absolute
+orientation estimator (AbsoluteOrientationParametersEstimator.cxx:208-291)."""
+import numpy as np
+import pytest
+
+from lsqrrecipes_amd import _lib as L
+from lsqrrecipes_amd import synth
+from lsqrrecipes_amd.context import Context
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+GEN = {L.PLANE: synth.plane, L.SPHERE: synth.sphere, L.LINE: synth.line}
+CASES = [(L.PLANE, 4), (L.PLANE, 5), (L.PLANE, 8), (L.SPHERE, 4), (L.SPHERE, 6), (L.SPHERE, 8),
+         (L.LINE, 4), (L.LINE, 7)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _align(model, dim, got, want):
+    if model in (L.PLANE, L.LINE):
+        s = np.sign(got[:dim] @ want[:dim])
+        return np.concatenate([s * got[:dim], got[dim:]])
+    return got
+
+
+@pytest.mark.parametrize("model,dim", CASES)
+def test_nd_minimal_solves_scan_mask(ctx, model, dim):
+    n = 20_011
+    data, truth, lab = GEN[model](n, 0.4, seed=300 + 7 * dim + model, dim=dim)
+    oc = O.cfg(model, dim, 0.5)
+    k = O.lib().orc_min_subset(oc)
+    ctx.set_model(model, dim, 0.5).upload(data)
+    assert ctx.K == k and ctx.ND == dim
+    H = 96
+    subs = O.ctr_subsets(17, 0, H, n, k)
+    subs[5] = subs[5][0]            # one datum repeated: rank deficient -> degenerate
+    # a subset of inliers only, so that one hypothesis collects a real consensus set
+    subs[9] = np.flatnonzero(lab)[:k]
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    assert not valid[5] and votes[5] == 0
+    for h in range(H):
+        want = O.estimate(oc, data[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0), h
+        if not valid[h]:
+            continue
+        if model == L.LINE:
+            assert np.array_equal(par[h], want)                 # closed form: bit-exact
+        else:
+            g = _align(model, dim, par[h], want)
+            assert np.allclose(g, want, rtol=REL, atol=REL * max(1.0, np.abs(want).max())), h
+        cnt, _ = O.scan(oc, par[h], data)                       # agree() on the device's model: bit-exact
+        assert votes[h] == cnt, h
+    assert votes[9] > 0.4 * n
+    _, bv, bi = ctx.best()
+    vv = np.where(valid > 0, votes, 0)
+    assert bv == vv.max() and bi == int(np.argmax(vv))
+    m, cnt = ctx.mask_from_hypothesis(bi)
+    wcnt, wmask = O.scan(oc, par[bi], data)
+    assert cnt == wcnt == bv and np.array_equal(m, wmask)
+    st = ctx.stats(par[bi], use_mask=True)
+    assert np.allclose(st, O.stats(oc, par[bi], data, wmask), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("model,dim", CASES)
+def test_nd_least_squares_and_ransac(ctx, model, dim):
+    n = 12_007
+    data, truth, lab = GEN[model](n, 0.3, seed=900 + dim + model, dim=dim)
+    mask = lab.astype(np.uint8)
+    for ls_type in ((L.LS_ALGEBRAIC, L.LS_GEOMETRIC) if model == L.SPHERE else (0,)):
+        oc = O.cfg(model, dim, 0.5, ls_type)
+        ctx.set_model(model, dim, 0.5, ls_type).upload(data)
+        ctx.set_mask(mask)
+        got, info = ctx.ls_fit(use_mask=True)
+        want = O.ls(oc, data, mask)
+        assert len(got) == len(want) > 0
+        g = _align(model, dim, got, want)
+        if model == L.PLANE:   # the point is free inside the plane: compare its offset along the normal
+            assert np.allclose(g[:dim], want[:dim], rtol=REL, atol=REL)
+            assert abs((g[dim:] - want[dim:]) @ want[:dim]) < REL * max(1.0, np.abs(want[dim:]).max())
+        else:
+            assert np.allclose(g, want, rtol=REL, atol=REL * max(1.0, np.abs(want).max()))
+        # whole RANSAC<T,S>::compute(): consensus == oracle scan of the device's winner, fit == oracle fit of it
+        r = ctx.ransac(0.99, seed=3)
+        assert r["status"] == L.OK
+        k = ctx.K
+        sub = O.ctr_subsets(3, int(r["info"].best_index), 1, n, k)
+        ctx.hypotheses_from_subsets(sub)
+        wpar, ok = ctx.hypothesis(0)
+        assert ok
+        wcnt, wmask = O.scan(oc, wpar, data)
+        assert wcnt == r["info"].best_votes and np.array_equal(r["consensus"], wmask)
+        want = O.ls(oc, data, wmask)
+        g = _align(model, dim, r["params"], want)
+        if model == L.PLANE:
+            assert np.allclose(g[:dim], want[:dim], rtol=REL, atol=REL)
+        else:
+            assert np.allclose(g, want, rtol=REL, atol=REL * max(1.0, np.abs(want).max()))
+        assert (wmask.astype(bool) & ~lab).sum() <= 0.02 * n
+
+
+def test_unsupported_dimension_fails_loudly(ctx):
+    with pytest.raises(L.LsqrError):
+        ctx.set_model(L.PLANE, 9, 0.5)
+    with pytest.raises(L.LsqrError):
+        ctx.set_model(L.SPHERE, 1, 0.5)
+
+
+def test_absolute_orientation_weighted_fit(ctx):
+    pairs, truth, lab = synth.absolute_orientation(400, 0.2, seed=11)
+    g = np.random.default_rng(4)
+    w = g.uniform(0.0, 3.0, len(pairs))
+    w[~lab] = 0.0                                   # outliers weighted out
+    rec = np.hstack([pairs, w[:, None]])
+    ctx.set_model(L.ABSOR, 3, 0.5, 1).upload(rec)   # ls_type 1: records carry a weight
+    assert ctx.ND == 7
+    got, _ = ctx.ls_fit()
+    want = O.absor_weighted_ls(pairs, w)
+    assert len(got) == len(want) == 7
+    s = np.sign(got[:4] @ want[:4])
+    assert np.allclose(s * got[:4], want[:4], rtol=REL, atol=REL)
+    assert np.allclose(got[4:], want[4:], rtol=REL, atol=REL * max(1.0, np.abs(want[4:]).max()))
+    # unit weights reproduce the plain fit
+    ctx.upload(np.hstack([pairs, np.ones((len(pairs), 1))]))
+    got1, _ = ctx.ls_fit()
+    ctx.set_model(L.ABSOR, 3, 0.5, 0).upload(pairs)
+    got0, _ = ctx.ls_fit()
+    assert np.array_equal(got1, got0)
+    # the minimal solve and agree() ignore the weight slot
+    ctx.set_model(L.ABSOR, 3, 0.5, 1).upload(rec)
+    subs = O.ctr_subsets(2, 0, 32, len(rec), 3)
+    ctx.hypotheses_from_subsets(subs)
+    ctx.scan()
+    par, valid, votes = ctx.hypotheses()
+    oc = O.cfg(O.ABSOR, 3, 0.5)
+    for h in range(32):
+        want = O.estimate(oc, pairs[subs[h]])
+        assert bool(valid[h]) == (len(want) > 0)
+        if valid[h]:
+            assert votes[h] == O.scan(oc, par[h], pairs)[0]

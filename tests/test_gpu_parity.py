@@ -911,9 +911,9 @@ def test_cell_scan_matches_exhaustive_and_oracle(ctx, model, dim, n):
     ctx.set_model(model, dim, 0.5).upload(data)
     ctx.hypotheses_sample(21, 0, H)
     plain = _scan_votes(ctx, 0)
-    for cell, cpt in ((0, 0), (128, 1), (128, 4), (256, 2), (512, 1), (512, 2)):
+    for cell, cpt in ((0, 0), (256, 1), (512, 1)):
         assert np.array_equal(_scan_votes(ctx, 2, cell, cpt), plain), (cell, cpt)
-    for block in (256, 257, 1024):      # v_readlane / LDS broadcast of the hypothesis, 16-wave workgroups
+    for block in (256, 257):      # v_readlane / LDS broadcast of the hypothesis
         ctx.set_option("scan_block", block)
         v = _scan_votes(ctx, 2)
         ctx.set_option("scan_block", 0)

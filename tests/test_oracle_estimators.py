@@ -356,3 +356,58 @@ def test_plane_phantom_ransac_rejects_off_plane_frames():
     assert len(r["params"]) == 41
     assert synth.phantom_check(r["params"], truth)
     assert not r["consensus"][~lab].any() and r["consensus"][lab].mean() > 0.9
+
+
+# ---- round 2 additions -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [2, 4, 5, 8])
+def test_plane_nd_minimal_solve_is_the_svd_null_vector(dim):
+    """PlaneParametersEstimator.hxx:70-104: normal = null vector of [p_i, -1] (LAPACK SVD as the independent
+    reference), point = first datum; a repeated datum is rank deficient -> empty."""
+    g = np.random.default_rng(dim)
+    oc = O.cfg(O.PLANE, dim, 0.5)
+    for _ in range(20):
+        p = g.uniform(-1000, 1000, (dim, dim))
+        par = O.estimate(oc, p)
+        assert len(par) == 2 * dim
+        v = np.linalg.svd(np.hstack([p, -np.ones((dim, 1))]))[2][-1]
+        n = v[:dim] / np.linalg.norm(v[:dim])
+        assert abs(abs(n @ par[:dim]) - 1) < 1e-12
+        assert np.array_equal(par[dim:], p[0])
+        assert all(O.agree(oc, par, q) for q in p)
+    p[1] = p[0]
+    assert len(O.estimate(oc, p)) == 0
+
+
+@pytest.mark.parametrize("dim", [4, 6])
+def test_sphere_nd_minimal_solve(dim):
+    """SphereParametersEstimator.hxx:169-202: the d+1 points lie on the estimated hypersphere."""
+    g = np.random.default_rng(10 + dim)
+    oc = O.cfg(O.SPHERE, dim, 0.5)
+    c = g.uniform(-1000, 1000, dim)
+    r = 321.5
+    u = g.normal(size=(dim + 1, dim))
+    p = c + r * u / np.linalg.norm(u, axis=1)[:, None]
+    par = O.estimate(oc, p)
+    assert np.allclose(par, np.concatenate([c, [r]]), rtol=1e-9, atol=1e-7)
+    p[2] = p[1]
+    assert len(O.estimate(oc, p)) == 0
+
+
+def test_absor_weighted_ls_against_numpy():
+    """AbsoluteOrientationParametersEstimator.cxx:208-291 against an independent weighted Kabsch (SVD) solution."""
+    from lsqrrecipes_amd import synth
+    pairs, truth, lab = synth.absolute_orientation(60, 0.0, seed=3, sigma=0.3)
+    g = np.random.default_rng(8)
+    w = g.uniform(0.1, 2.0, len(pairs))
+    got = O.absor_weighted_ls(pairs, w)
+    assert len(got) == 7
+    a, b = pairs[:, :3], pairs[:, 3:]
+    ma, mb = (w[:, None] * a).sum(0) / w.sum(), (w[:, None] * b).sum(0) / w.sum()
+    Hm = ((a - ma) * w[:, None]).T @ (b - mb)
+    U, _, Vt = np.linalg.svd(Hm)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    Rg = synth.quat_to_matrix(got[:4])
+    assert np.allclose(Rg, R, atol=1e-9)
+    assert np.allclose(got[4:], mb - R @ ma, atol=1e-8)
+    assert np.allclose(O.absor_weighted_ls(pairs, np.ones(len(pairs))), O.ls(O.cfg(O.ABSOR, 3, 0.5), pairs), atol=1e-12)
