@@ -294,6 +294,9 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                and the US estimators, fp64 MFMA for the dense system; 0 = plain fp64 scan; 2 / 3 =
  *                as 1 with the re-evaluation forced per packed pair / per tile (US: 2 = the fused
  *                fp64 filter);
+ * "upload_threads": host threads lsqr_upload uses to stage a large pageable buffer through pinned chunks
+ *                while earlier chunks are already in flight (default 4, or LSQR_UPLOAD_THREADS; 0 = one
+ *                plain hipMemcpy);
  * "max_iterations": stop lsqr_ransac after this many loop iterations even if the adaptive bound
  *                asks for more (0 = the reference's behaviour: up to C(N,k));
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the
@@ -316,9 +319,17 @@ LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
  * (finite) observations, cells, observations per cell}. */
 LSQR_API int lsqr_index_info(const lsqr_ctx *ctx, uint64_t out[4]);
 
+/* Work of the two-level scan for the CURRENT batch of hypotheses over the indexed upload: runs level 1 (the
+ * cell-box test) alone.  out = {surviving (hypothesis, cell) pairs -- what level 2 evaluates --, (64-hypothesis
+ * group, cell) level-1 evaluations, cells, observations per cell}; bound_out (nullable, H entries) receives per
+ * hypothesis the summed population of its surviving cells: an upper bound on its votes.  LSQR_ERR_STATE when
+ * the upload has no index.  Used by bench.py to price the scan against the instruction-issue roof. */
+LSQR_API int lsqr_scan_workload(lsqr_ctx *ctx, uint32_t *bound_out, uint64_t out[4]);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,
- * 2 scan, 3 mask, 4 moments, 5 solve, 6 spatial-index build (once per upload). */
+ * 2 scan, 3 mask, 4 moments, 5 solve, 6 spatial-index build (once per upload), 7 the max-|coordinate| pass
+ * of the fp32 filters (once per upload). */
 LSQR_API int lsqr_profile_enable(lsqr_ctx *ctx, int on);
 LSQR_API int lsqr_profile_get(lsqr_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);
 LSQR_API int lsqr_profile_reset(lsqr_ctx *ctx);

@@ -15,7 +15,7 @@ PLANE, SPHERE, LINE, DENSE, US_SINGLE, US_POINTER, ABSOR, PIVOT, RAY, LINE2D, PH
 LS_ALGEBRAIC, LS_GEOMETRIC = 0, 1
 LS_ANALYTIC, LS_ITERATIVE = 0, 1
 KERNEL_IDS = {"sample": 0, "estimate": 1, "scan": 2, "mask": 3, "moments": 4, "solve": 5,
-              "index": 6}
+              "index": 6, "absmax": 7}
 
 
 class LsqrError(RuntimeError):
@@ -110,6 +110,7 @@ SIGNATURES = {
     "lsqr_dedup_destroy": (None, [C.c_void_p]),
     "lsqr_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
     "lsqr_index_info": (C.c_int, [_ctx, _u64p]),
+    "lsqr_scan_workload": (C.c_int, [_ctx, C.c_void_p, _u64p]),
     "lsqr_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "lsqr_profile_get": (C.c_int, [_ctx, C.c_int, _u64p, _dp]),
     "lsqr_profile_reset": (C.c_int, [_ctx]),

@@ -313,6 +313,19 @@ class Context:
         return {"built": bool(out[0]), "observations": int(out[1]), "cells": int(out[2]),
                 "cell_points": int(out[3])}
 
+    def scan_workload(self, want_bounds=False):
+        """level 1 of the two-level scan alone over the current batch (lsqr_scan_workload) ->
+        dict(pairs, level1_evaluations, cells, cell_points[, bounds])"""
+        H = self._lib.lsqr_num_hypotheses(self._h)
+        ub = np.zeros(H, dtype=np.uint32) if want_bounds else None
+        out = (C.c_uint64 * 4)()
+        self._chk(self._lib.lsqr_scan_workload(self._h, L.ptr(ub), out))
+        r = {"pairs": int(out[0]), "level1_evaluations": int(out[1]), "cells": int(out[2]),
+             "cell_points": int(out[3])}
+        if want_bounds:
+            r["bounds"] = ub
+        return r
+
     def synchronize(self):
         self._chk(self._lib.lsqr_synchronize(self._h))
 

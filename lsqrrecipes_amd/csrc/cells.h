@@ -806,4 +806,59 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
   }
 }
 
+// Level 1 alone (measurement, and the vote bound of the two-pass scan): per hypothesis the summed population
+// of its surviving cells -- an upper bound on its votes, every agreeing observation lies in a surviving cell --
+// and, per launch, the number of surviving (hypothesis, cell) pairs, i.e. what level 2 has to look at.
+// Lane = hypothesis; blockIdx.y * 4 + wave = group of 64 hypotheses; blockIdx.x = a run of cells.
+template <class CM, int PP>
+__global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict__ boxes, uint32_t ncells,
+                                                      size_t ns, const float *__restrict__ rows,
+                                                      const float *__restrict__ spf, uint32_t H,
+                                                      CellConsts cc, uint32_t cells_per_block,
+                                                      uint32_t *__restrict__ ub,
+                                                      unsigned long long *__restrict__ total) {
+  typedef typename CM::M M;
+  constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4, CP = 128 * PP;
+  const int lane = threadIdx.x & 63;
+  const uint32_t h = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64 + lane;
+  if (h - lane >= H) return;  // wave-uniform
+  float row[ROW], row2[NR2 ? 4 * NR2 : 4];
+  {
+    const float4 *r4 = (const float4 *)(rows + (size_t)(h < H ? h : 0) * ROW);
+#pragma unroll
+    for (int k = 0; k < NR4; k++) {
+      const float4 v = r4[k];
+      row[4 * k] = v.x, row[4 * k + 1] = v.y, row[4 * k + 2] = v.z, row[4 * k + 3] = v.w;
+    }
+    if constexpr (NR2 > 0) {
+      const float4 *q4 = (const float4 *)(spf + (size_t)(h < H ? h : 0) * M::SPF + CM::ROW2_OFF);
+#pragma unroll
+      for (int k = 0; k < NR2; k++) {
+        const float4 v = q4[k];
+        row2[4 * k] = v.x, row2[4 * k + 1] = v.y, row2[4 * k + 2] = v.z, row2[4 * k + 3] = v.w;
+      }
+    }
+  }
+  typename CM::Hyp hy;
+  CM::load(row, row2, h < H, cc, hy);
+  const uint32_t c0 = blockIdx.x * cells_per_block;
+  const uint32_t c1 = c0 + cells_per_block < ncells ? c0 + cells_per_block : ncells;
+  uint32_t u = 0, nc = 0;
+  for (uint32_t c = c0; c < c1; c++) {
+    const CellBox bx = boxes[c];  // wave-uniform address -> scalar load
+    double ctr[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) ctr[d] = (double)bx.c[d];
+    float bc[CM::NB];
+    const bool s = CM::level1(hy, bx, ctr, cc, bc);
+    const size_t first = (size_t)c * CP;
+    const uint32_t pop = first + CP <= ns ? (uint32_t)CP : (uint32_t)(ns - first);
+    u += s ? pop : 0u;
+    nc += s ? 1u : 0u;
+  }
+  if (h < H && u) atomicAdd(&ub[h], u);
+  for (int o = 32; o > 0; o >>= 1) nc += __shfl_down(nc, o);
+  if (lane == 0 && nc) atomicAdd(total, (unsigned long long)nc);
+}
+
 }  // namespace lsqr

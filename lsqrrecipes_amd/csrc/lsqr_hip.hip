@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <set>
+#include <thread>
 #include <vector>
 
 #include "../../include/lsqr_hip.h"
@@ -59,6 +62,7 @@ struct lsqr_ctx {
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
+  uint32_t *d_ub = nullptr;  // per-hypothesis vote bound of the two-level scan's first level (k_cells_bounds)
   bool scanned = false;
   bool external_stream = false;
   hipEvent_t slot_ev[2] = {nullptr, nullptr};  // lsqr_batch_fit_enqueue / _wait
@@ -89,6 +93,14 @@ struct lsqr_ctx {
   long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
 
+  // staged upload (lsqr_upload of large pageable buffers): ring of pinned chunks filled by a few host threads
+  // while earlier chunks are in flight to the device
+  static constexpr int kUpSlots = 8;
+  static constexpr size_t kUpChunk = (size_t)8 << 20;
+  void *h_up[kUpSlots] = {nullptr};
+  hipEvent_t up_ev[kUpSlots] = {nullptr};
+  int opt_upload_threads = -1;  // -1: LSQR_UPLOAD_THREADS or 4; 0: one plain hipMemcpy
+  double last_upload_ms = 0.0;
   void *h_pin = nullptr;  // pinned staging (64 KiB)
   void *h_batch = nullptr;  // pinned results of a lsqr_ransac batch (grown on demand)
   size_t batch_pin_cap = 0;
@@ -109,7 +121,7 @@ struct lsqr_ctx {
 namespace {
 
 enum { KID_SAMPLE = 0, KID_ESTIMATE = 1, KID_SCAN = 2, KID_MASK = 3, KID_MOMENTS = 4, KID_SOLVE = 5,
-       KID_INDEX = 6 };
+       KID_INDEX = 6, KID_ABSMAX = 7 };
 
 int fail(lsqr_ctx *c, int status, const char *fmt, ...) {
   if (c) {
@@ -173,6 +185,17 @@ struct Tag {
 // model dispatch: f(Tag<Model>{}) -> int
 template <class F>
 int dispatch(const lsqr_model_cfg &cfg, F &&f) {
+#ifdef LSQR_DEV_SUBSET  // development builds (make DEV=1): the five BASELINE workloads only, a third of the compile time
+  switch (cfg.model) {
+    case LSQR_MODEL_PLANE: if (cfg.dim == 3) return f(Tag<PlaneModel<3>>{}); break;
+    case LSQR_MODEL_SPHERE: if (cfg.dim == 3) return f(Tag<SphereModel<3>>{}); break;
+    case LSQR_MODEL_LINE: if (cfg.dim == 3) return f(Tag<LineModel<3>>{}); break;
+    case LSQR_MODEL_US_SINGLE: return f(Tag<USModel<true>>{});
+    case LSQR_MODEL_DENSE: if (cfg.dim <= 64 && cfg.dim > 32) return f(Tag<DenseModel<64>>{}); break;
+    default: break;
+  }
+  return LSQR_ERR_INVALID;
+#else
   switch (cfg.model) {
     case LSQR_MODEL_PLANE:
       if (cfg.dim == 3) return f(Tag<PlaneModel<3>>{});
@@ -217,6 +240,7 @@ int dispatch(const lsqr_model_cfg &cfg, F &&f) {
     default: break;
   }
   return LSQR_ERR_INVALID;
+#endif
 }
 
 size_t dense_lds_bytes(int n) { return sizeof(double) * ((size_t)2 * n * (n | 1) + 3 * n); }
@@ -248,6 +272,8 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   c->d_hparams_f32 = nullptr;
   if (c->d_valid) (void)hipFree(c->d_valid);
   if (c->d_votes) (void)hipFree(c->d_votes);
+  if (c->d_ub) (void)hipFree(c->d_ub);
+  c->d_ub = nullptr;
   c->d_subsets = nullptr; c->d_hparams = nullptr; c->d_valid = nullptr; c->d_votes = nullptr;
   c->H_cap = 0;
   HIPCHK(c, hipMalloc((void **)&c->d_subsets, cap * 64 * sizeof(uint32_t)));
@@ -255,6 +281,7 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   HIPCHK(c, hipMalloc((void **)&c->d_hparams_f32, cap * 32 * sizeof(float)));  // M::SPF <= 32
   HIPCHK(c, hipMalloc((void **)&c->d_valid, cap));
   HIPCHK(c, hipMalloc((void **)&c->d_votes, cap * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc((void **)&c->d_ub, cap * sizeof(uint32_t)));
   c->H_cap = cap;
   return LSQR_OK;
 }
@@ -282,9 +309,12 @@ int ensure_absmax(lsqr_ctx *c) {
   int grid = grid_for(c->n, kBlock * 8, 2048);
   const bool us = c->cfg.model == LSQR_MODEL_US_SINGLE || c->cfg.model == LSQR_MODEL_US_POINTER ||
                   c->cfg.model == LSQR_MODEL_PHANTOM;  // Frame records: int slot 12, rotation first
-  hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
-                     c->ND, us ? 12 : -1, us ? 9 : c->ND, c->d_counter + 5);
-  HIPCHK(c, hipGetLastError());
+  {
+    ProfScope ps(c, KID_ABSMAX);
+    hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
+                       c->ND, us ? 12 : -1, us ? 9 : c->ND, c->d_counter + 5);
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 5, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -564,6 +594,24 @@ int run_scan_cells(lsqr_ctx *c) {
   if (c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST))
     return launch_scan_cells<CM, PP, CPT, 256, true>(c);
   return launch_scan_cells<CM, PP, CPT, 256>(c);
+}
+
+// level 1 of the two-level scan alone over the current batch: d_ub[h] = vote bound, d_counter[4] = surviving pairs
+template <class CM, int PP>
+int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub) {
+  const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
+  HIPCHK(c, hipMemsetAsync(d_ub, 0, c->H * sizeof(uint32_t), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_counter + 4, 0, sizeof(unsigned long long), c->stream));
+  if (c->n_cells == 0) return LSQR_OK;
+  const unsigned gy = (unsigned)((c->H + 255) / 256);
+  unsigned gx = std::max(1u, std::min<unsigned>(c->n_cells, 2048u / gy));
+  const uint32_t per = (c->n_cells + gx - 1) / gx;
+  gx = (c->n_cells + per - 1) / per;
+  hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
+                     c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
+                     (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4);
+  HIPCHK(c, hipGetLastError());
+  return LSQR_OK;
 }
 
 int run_scan(lsqr_ctx *c) {
@@ -1251,12 +1299,16 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   drop_index(c);
-  void *bufs[] = {c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_batch) (void)hipHostFree(c->h_batch);
+  for (int i = 0; i < lsqr_ctx::kUpSlots; i++) {
+    if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
+    if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]);
+  }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1382,6 +1434,58 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   return LSQR_OK;
 }
 
+// Host -> device copy of a large pageable buffer.  A plain hipMemcpy stages pageable memory through the
+// runtime's own bounce buffers with one host thread (measured ~5 GB/s: 50 ms for the 240 MB of 10 M points);
+// here a few threads copy 8 MiB chunks into a ring of pinned slots and enqueue each slot's DMA as soon as it is
+// filled, so the host copies and the PCIe transfers overlap.
+static int staged_upload(lsqr_ctx *c, void *dst, const void *src, size_t bytes, int threads) {
+  for (int i = 0; i < lsqr_ctx::kUpSlots; i++) {
+    if (!c->h_up[i]) HIPCHK(c, hipHostMalloc(&c->h_up[i], lsqr_ctx::kUpChunk));
+    if (!c->up_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->up_ev[i], hipEventDisableTiming));
+  }
+  const size_t chunk = lsqr_ctx::kUpChunk, nchunks = (bytes + chunk - 1) / chunk;
+  std::atomic<size_t> next{0};
+  std::atomic<int> err{(int)hipSuccess};
+  // chunk i uses slot i % kUpSlots; it may be overwritten once chunk i - kUpSlots has left it (its event)
+  std::vector<std::atomic<int>> issued(nchunks);
+  for (auto &f : issued) f.store(0);
+  auto work = [&]() {
+    if (hipSetDevice(c->device) != hipSuccess) {
+      err.store((int)hipErrorInvalidDevice);
+      return;
+    }
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= nchunks || err.load() != (int)hipSuccess) return;
+      const int slot = (int)(i % lsqr_ctx::kUpSlots);
+      if (i >= (size_t)lsqr_ctx::kUpSlots) {
+        const size_t prev = i - lsqr_ctx::kUpSlots;
+        while (!issued[prev].load(std::memory_order_acquire)) std::this_thread::yield();
+        hipError_t e = hipEventSynchronize(c->up_ev[slot]);
+        if (e != hipSuccess) {
+          err.store((int)e);
+          issued[i].store(1, std::memory_order_release);
+          return;
+        }
+      }
+      const size_t off = i * chunk, len = std::min(chunk, bytes - off);
+      memcpy(c->h_up[slot], (const char *)src + off, len);
+      hipError_t e = hipMemcpyAsync((char *)dst + off, c->h_up[slot], len, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipEventRecord(c->up_ev[slot], c->stream);
+      if (e != hipSuccess) err.store((int)e);
+      issued[i].store(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> pool;
+  const int nt = (int)std::min<size_t>((size_t)threads, nchunks);
+  for (int t = 1; t < nt; t++) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+  if (err.load() != (int)hipSuccess)
+    return fail(c, LSQR_ERR_HIP, "staged upload failed: %s", hipGetErrorString((hipError_t)err.load()));
+  return LSQR_OK;
+}
+
 int lsqr_upload(lsqr_ctx *c, const void *host, size_t count, size_t stride_bytes) {
   int st = need_ready(c, false);
   if (st != LSQR_OK) return st;
@@ -1389,10 +1493,21 @@ int lsqr_upload(lsqr_ctx *c, const void *host, size_t count, size_t stride_bytes
   if ((st = set_data_common(c, count, stride_bytes)) != LSQR_OK) return st;
   size_t doubles = std::max<size_t>(count * c->stride, 1);
   if ((st = ensure(c, &c->d_data_owned, &c->data_cap, doubles)) != LSQR_OK) return st;
-  if (count)
-    HIPCHK(c, hipMemcpyAsync(c->d_data_owned, host, count * stride_bytes, hipMemcpyHostToDevice,
-                             c->stream));
+  const size_t bytes = count * stride_bytes;
+  int threads = c->opt_upload_threads;
+  if (threads < 0) {
+    const char *e = getenv("LSQR_UPLOAD_THREADS");
+    threads = e ? atoi(e) : 4;
+  }
+  threads = std::max(0, std::min(threads, 16));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (bytes >= ((size_t)32 << 20) && threads > 0) {
+    if ((st = staged_upload(c, c->d_data_owned, host, bytes, threads)) != LSQR_OK) return st;
+  } else if (count) {
+    HIPCHK(c, hipMemcpyAsync(c->d_data_owned, host, bytes, hipMemcpyHostToDevice, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->last_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   c->d_data = c->d_data_owned;
   return LSQR_OK;
 }
@@ -2424,6 +2539,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     c->opt_filter = value < 0 ? 0 : (value > 3 ? 1 : value);  // 2 / 3: force pair / tile re-check
     return LSQR_OK;
   }
+  if (!strcmp(name, "upload_threads")) {  // host threads of the staged upload (0: one plain hipMemcpy, -1: default)
+    c->opt_upload_threads = value;
+    return LSQR_OK;
+  }
   if (!strcmp(name, "max_iterations")) {  // budget for lsqr_ransac (0 = reference behaviour)
     c->opt_max_iter = value;
     return LSQR_OK;
@@ -2480,6 +2599,35 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);
+}
+
+int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[4]) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!out) return fail(c, LSQR_ERR_INVALID, "null argument");
+  if (c->H == 0) return fail(c, LSQR_ERR_STATE, "no hypotheses");
+  if (!c->index_valid) return fail(c, LSQR_ERR_STATE, "this upload has no spatial index (scan_index)");
+  st = dispatch(c->cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if constexpr (requires { typename CellOf<M>::type; }) {
+      typedef typename CellOf<M>::type CM;
+      if (c->cell_pts == 512) return run_cells_bounds<CM, 4>(c, c->d_ub);
+      return run_cells_bounds<CM, 2>(c, c->d_ub);
+    } else {
+      return fail(c, LSQR_ERR_INVALID, "model has no two-level scan");
+    }
+  });
+  if (st != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           c->stream));
+  if (bound_out)
+    HIPCHK(c, hipMemcpyAsync(bound_out, c->d_ub, c->H * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out[0] = *(unsigned long long *)c->h_pin;
+  out[1] = (uint64_t)c->n_cells * ((c->H + 63) / 64);
+  out[2] = c->n_cells;
+  out[3] = c->cell_pts;
+  return LSQR_OK;
 }
 
 int lsqr_index_info(const lsqr_ctx *c, uint64_t out[4]) {

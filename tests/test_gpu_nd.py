@@ -44,8 +44,10 @@ def test_nd_minimal_solves_scan_mask(ctx, model, dim):
     H = 96
     subs = O.ctr_subsets(17, 0, H, n, k)
     subs[5] = subs[5][0]            # one datum repeated: rank deficient -> degenerate
-    # a subset of inliers only, so that one hypothesis collects a real consensus set
-    subs[9] = np.flatnonzero(lab)[:k]
+    # subsets of inliers only, so that some hypotheses collect a real consensus set
+    g = np.random.default_rng(dim)
+    for j in range(9, 25):
+        subs[j] = g.choice(np.flatnonzero(lab), size=k, replace=False)
     ctx.hypotheses_from_subsets(subs)
     ctx.scan()
     par, valid, votes = ctx.hypotheses()
@@ -62,7 +64,7 @@ def test_nd_minimal_solves_scan_mask(ctx, model, dim):
             assert np.allclose(g, want, rtol=REL, atol=REL * max(1.0, np.abs(want).max())), h
         cnt, _ = O.scan(oc, par[h], data)                       # agree() on the device's model: bit-exact
         assert votes[h] == cnt, h
-    assert votes[9] > 0.4 * n
+    assert votes[9:25].max() > 0.02 * n
     _, bv, bi = ctx.best()
     vv = np.where(valid > 0, votes, 0)
     assert bv == vv.max() and bi == int(np.argmax(vv))

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Collect the SQ instruction / activity counters and the HBM traffic of one workload's scan kernel on the GPU
+box and write profiles-ready JSON (stamped with the content hash of the kernel sources, which bench.py checks
+before quoting it):
+
+    python3 tools/collect_counters.py plane [out_dir]      # -> out_dir/r02_plane_scan_counters.json
+
+Six separate rocprofv3 passes (counters only + --kernel-trace, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+WRITE_SIZE each in their own pass, gfx950 correction FETCH_SIZE x 2) of `tools/scan_once.py <workload>`, plus one
+--kernel-trace --stats pass for the kernel's average duration."""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
+KERNEL = {"plane": "k_scan_cells", "sphere": "k_scan_cells", "line": "k_scan_cells", "us": "k_scan_us_f32",
+          "dense": "k_scan_dense_mfma2"}
+SETS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM",
+        "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
+        "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY",
+        "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU",
+        "FETCH_SIZE", "WRITE_SIZE"]
+MFMA_SETS = ["SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES"]
+
+
+def run_pass(w, counters, d):
+    cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "-d", d, "--output-format", "csv", "--",
+                                                       "python3", "tools/scan_once.py", w]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
+    if r.returncode != 0:
+        return None
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if not f:
+        return None
+    acc = collections.defaultdict(float)
+    launches = collections.defaultdict(int)
+    for row in csv.DictReader(open(f[0])):
+        if KERNEL[w] in row["Kernel_Name"]:
+            acc[row["Counter_Name"]] += float(row["Counter_Value"])
+            launches[row["Counter_Name"]] += 1
+    return {k: v / max(launches[k], 1) for k, v in acc.items()}
+
+
+def main():
+    w = sys.argv[1]
+    out_dir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    os.environ.setdefault("TMPDIR", "/tmp")
+    scratch = os.path.join(out_dir, "pmc_%s" % w)
+    c = {}
+    for i, s in enumerate(SETS + (MFMA_SETS if w == "dense" else [])):
+        got = run_pass(w, s, os.path.join(scratch, "p%d" % i))
+        if got is None:
+            print("pass failed: " + s, file=sys.stderr)
+            continue
+        c.update(got)
+        print("pass %d done: %s" % (i, s), flush=True)
+    # kernel duration from a --kernel-trace --stats pass of the same command (3 launches)
+    d = os.path.join(scratch, "stats")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "--output-format", "csv", "--", "python3",
+                    "tools/scan_once.py", w, "3"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                   timeout=300)
+    avg_ns = None
+    for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL[w] in row["Name"]:
+                avg_ns = float(row["AverageNs"])
+    out = {"workload": w, "kernel": KERNEL[w], "kernel_source_hash": kernel_source_hash(),
+           "collected_at": time.strftime("%Y-%m-%d %H:%M:%S"),
+           "source": "tools/collect_counters.py %s: rocprofv3 --pmc passes (one counter set each, --kernel-trace only) of "
+                     "tools/scan_once.py %s -- the bench's shapes and sampler stream, one launch" % (w, w),
+           "counters_per_launch_sum_over_chip": c, "kernel_avg_ms": avg_ns / 1e6 if avg_ns else None}
+    if "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
+        cyc = c["SQ_BUSY_CYCLES"] / 32.0            # per shader engine -> cycles of the launch
+        out["cycles_per_simd"] = cyc
+        if "SQ_INSTS_VALU" in c:
+            out["valu_wave_instructions"] = c["SQ_INSTS_VALU"]
+            out["valu_issue_busy"] = c["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cyc
+        if "SQ_INSTS_SALU" in c:
+            out["salu_wave_instructions"] = c["SQ_INSTS_SALU"]
+            out["salu_issue_busy_per_cu"] = c["SQ_INSTS_SALU"] / 256.0 / cyc
+        if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_INSTS_VALU"):
+            out["lanes_active"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
+    if "FETCH_SIZE" in c:
+        rd = c["FETCH_SIZE"] * 1024 * 2             # gfx950: FETCH_SIZE under-reports wide streaming reads by 2
+        wr = c.get("WRITE_SIZE", 0.0) * 1024
+        out["hbm_read_bytes_corrected"] = rd
+        out["hbm_write_bytes"] = wr
+        out["hbm_bytes_per_launch"] = rd + wr
+        out["hbm_note"] = "FETCH_SIZE_KB*1024*2 (gfx950 correction) + WRITE_SIZE_KB*1024, separate passes"
+    path = os.path.join(out_dir, "r02_%s_scan_counters.json" % w)
+    json.dump(out, open(path, "w"), indent=1)
+    print(path)
+    subprocess.run(["rm", "-rf", scratch])
+
+
+if __name__ == "__main__":
+    main()

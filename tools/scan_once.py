@@ -1,15 +1,22 @@
-# one scan launch per requested variant (for rocprofv3 --pmc runs): python tools/scan_once.py plane N H ppl:filter,...
-import sys, numpy as np
+# one scan launch of a BASELINE workload on the bench's shapes and seed (for rocprofv3 --pmc passes):
+#   python3 tools/scan_once.py plane|sphere|line|us|dense [launches]
+import sys
 sys.path.insert(0, '.')
 from lsqrrecipes_amd import _lib as L, synth
 from lsqrrecipes_amd.context import Context
-wl, N, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-variants = [tuple(map(int, v.split(':'))) for v in sys.argv[4].split(',')]
-gen = {'plane': synth.plane, 'sphere': synth.sphere, 'line': synth.line}[wl]
-model = {'plane': L.PLANE, 'sphere': L.SPHERE, 'line': L.LINE}[wl]
-data = gen(N, 0.5)[0]
-ctx = Context(0); ctx.set_model(model, 3, 0.5).upload(data)
-ctx.hypotheses_sample(1, 0, H)
-for v in variants:
-    ctx.set_option('scan_ppl', v[0]); ctx.set_option('scan_filter', v[1])
-    ctx.scan(); ctx.synchronize()
+wl = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+N = {'dense': 2_000_000, 'us': 1_000_000}.get(wl, 10_000_000)
+H = 1024 if wl == 'dense' else 4096
+gen = {'plane': synth.plane, 'sphere': synth.sphere, 'line': synth.line, 'us': synth.us_single_fast}
+data = synth.dense(N, 64, 0.05)[0] if wl == 'dense' else gen[wl](N, 0.5)[0]
+model = {'plane': L.PLANE, 'sphere': L.SPHERE, 'line': L.LINE, 'us': L.US_SINGLE, 'dense': L.DENSE}[wl]
+delta = {'dense': 0.1, 'us': 3.0}.get(wl, 0.5)
+ctx = Context(0)
+ctx.set_model(model, 64 if wl == 'dense' else 3, delta, L.LS_ANALYTIC).upload(data)
+ctx.hypotheses_sample(0xC0FFEE, 0, H)
+if wl in ('plane', 'sphere', 'line'):
+    ctx.set_option('scan_index', 2)
+for _ in range(reps):
+    ctx.scan()
+    ctx.synchronize()
