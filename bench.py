@@ -406,7 +406,7 @@ def cold_call(a, L, Context, data, model, delta, ls_type, cpu):
     """What a caller of RANSAC<T,S>::compute() (RANSAC.h:75-79) sees on data that is NOT yet on the device:
     lsqr_upload of the caller's pageable buffer + lsqr_ransac (adaptive, p = 0.999) + the consensus copy."""
     res = {}
-    for label, threads in (("staged_upload", -1), ("plain_hipMemcpy", 0)):
+    for label, threads in (("plain_hipMemcpy", 0), ("staged_upload_4_threads", 4)):
         c2 = Context(0)
         try:
             c2.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type)
@@ -434,7 +434,7 @@ def cold_call(a, L, Context, data, model, delta, ls_type, cpu):
             c2.close()
     out = {"what": "lsqr_upload (host, pageable) + lsqr_ransac (p = 0.999) + consensus copy, %d records of %d B; "
                    "best of 2 calls after the first" % (len(data), data.shape[1] * 8),
-           "ms": res["staged_upload"]["total_ms"], "detail": res}
+           "ms": res["plain_hipMemcpy"]["total_ms"], "detail": res}
     if cpu and "compute_call_s" in cpu:
         out["reference_cpu_call_s"] = cpu["compute_call_s"]
         out["speedup_vs_reference_call"] = cpu["compute_call_s"] * 1e3 / out["ms"]

@@ -1244,7 +1244,13 @@ enum { RS_I = 0, RS_TRIES = 1, RS_BEST = 2, RS_BEST_IDX = 3, RS_HAS = 4, RS_DONE
 // =================================================================================================
 extern "C" {
 
-const char *lsqr_version(void) { return "lsqrrecipes_amd 0.1 (gfx950)"; }
+const char *lsqr_version(void) {
+#ifdef LSQR_DEV_SUBSET
+  return "lsqrrecipes_amd 0.2 (gfx950) DEVELOPMENT SUBSET BUILD";
+#else
+  return "lsqrrecipes_amd 0.2 (gfx950)";
+#endif
+}
 
 const char *lsqr_status_string(int s) {
   switch (s) {
@@ -1494,10 +1500,13 @@ int lsqr_upload(lsqr_ctx *c, const void *host, size_t count, size_t stride_bytes
   size_t doubles = std::max<size_t>(count * c->stride, 1);
   if ((st = ensure(c, &c->d_data_owned, &c->data_cap, doubles)) != LSQR_OK) return st;
   const size_t bytes = count * stride_bytes;
+  // measured on the MI355X box (bench.py cold_call, 240 MB from a pageable numpy buffer): one plain
+  // hipMemcpy 4.3 ms = 56 GB/s, the staged ring with 4 threads 5.1 ms -- so the plain copy is the default and
+  // the staged path stays an option for hosts whose runtime stages pageable memory slowly
   int threads = c->opt_upload_threads;
   if (threads < 0) {
     const char *e = getenv("LSQR_UPLOAD_THREADS");
-    threads = e ? atoi(e) : 4;
+    threads = e ? atoi(e) : 0;
   }
   threads = std::max(0, std::min(threads, 16));
   const auto t0 = std::chrono::steady_clock::now();

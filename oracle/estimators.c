@@ -1220,6 +1220,17 @@ static void us_lm_fcn(void *vctx, int m, int n, const double *x, double *fvec, d
   }
 }
 
+/* the residual vector (iflag 1 -> fvec[n]) or the Jacobian (iflag 2 -> fjac[n x np], row-major) of the US
+ * calibration at x, for callers that drive their own minimiser (tests/golden/make_golden.py hands them to
+ * SciPy's MINPACK to pin lmder's behaviour at the reference's tolerances) */
+void orc_us_fcn(int model, const double *const *recs, size_t n, const double *x, double *fvec, double *fjac,
+                int iflag) {
+  us_lm_ctx c;
+  c.model = model;
+  c.recs = recs;
+  us_lm_fcn(&c, (int)n, model == ORC_US_SINGLE ? 11 : 8, x, fvec, fjac, iflag);
+}
+
 /* SinglePointTarget...cxx:272-329 (tolerances 10e-16, 5000 evals) and :919-973 (10e-8) */
 int orc_us_iterative(int model, const double *const *recs, size_t n, const double *init,
                      double *out, int *info_out, int *nfev_out) {

@@ -134,6 +134,8 @@ int orc_lcg_rand(void *ctx);
 /* symmetric eigen: A (n*n row-major, destroyed), w ascending, V columns = eigenvectors */
 /* AbsoluteOrientation...cxx:208-291; p[i] = [first(3), second(3)], wt[i] >= 0 */
 int orc_absor_weighted_ls(const double *const *p, const double *wt, size_t n, double *out);
+void orc_us_fcn(int model, const double *const *recs, size_t n, const double *x, double *fvec, double *fjac,
+                int iflag);
 void orc_sym_eig(int n, double *A, double *w, double *V);
 /* thin SVD by one-sided Jacobi: A m*n row-major (m>=n) -> U m*n, s n (descending), V n*n */
 void orc_svd(int m, int n, const double *A, double *U, double *s, double *V);

@@ -93,6 +93,8 @@ def lib():
         L.orc_sphere_geometric.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp, _dp,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_us_analytic.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp]
+        L.orc_us_fcn.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp, _dp, _dp, C.c_int]
+        L.orc_us_fcn.restype = None
         L.orc_absor_weighted_ls.argtypes = [C.POINTER(_dp), _dp, C.c_size_t, _dp]
         L.orc_us_iterative.argtypes = [C.c_int, C.POINTER(_dp), C.c_size_t, _dp, _dp,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -352,6 +354,32 @@ def us_iterative(model, recs, init):
                            C.byref(info), C.byref(nfev))
     # the last iterate is returned even when the reference would report failure (info not in 1..4)
     return out[:(20 if model == US_SINGLE else 17)].copy(), info.value, nfev.value
+
+
+class UsFunction:
+    """residual vector f(x) and Jacobian J(x) of the US calibration (SinglePointTarget...cxx:415-658 / :1059-1286)
+    over a fixed set of frames, for an external minimiser"""
+
+    def __init__(self, model, recs):
+        nd = 15 if model == US_SINGLE else 18
+        self.model = model
+        self.a = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, nd)
+        self.rows = [self.a[i] for i in range(self.a.shape[0])]
+        self.ptrs = _ptrs(self.rows)
+        self.m = self.a.shape[0]
+        self.np = 11 if model == US_SINGLE else 8
+
+    def f(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(self.m)
+        lib().orc_us_fcn(self.model, self.ptrs, self.m, _d(x), _d(out), None, 1)
+        return out
+
+    def jac(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros((self.m, self.np))
+        lib().orc_us_fcn(self.model, self.ptrs, self.m, _d(x), None, _d(out), 2)
+        return out
 
 
 def phantom_analytic(recs):

@@ -11,6 +11,8 @@ Outputs (all data, no reference source text):
                             seeded data and seeded rand() streams
   numerics_vectors.npz      NumPy/SciPy results (eigh, svd, lstsq, MINPACK lmder through
                             scipy.optimize.leastsq) on seeded inputs
+  us_lm_vectors.npz         SciPy MINPACK on the US calibration at the reference's 1e-15 tolerances, 1 k / 20 k /
+                            100 k frames: stopping code, evaluation count, minimiser (BASELINE config 5)
 """
 import os
 import shutil
@@ -105,8 +107,40 @@ def numerics_vectors():
     np.savez_compressed(os.path.join(HERE, "numerics_vectors.npz"), **out)
 
 
+def us_lm_vectors(sizes=(1000, 20000, 100000)):
+    """BASELINE config 5 (SingleUnknownPointTarget, Levenberg-Marquardt with the reference's settings,
+    SinglePointTarget...Estimator.cxx:287-295: f/x/g tolerances 1e-15, 5000 evaluations): what MINPACK itself
+    (scipy.optimize.leastsq = lmder) does on 1 k / 20 k / 100 k noisy frames, started from the analytic estimate --
+    the stopping code, the number of function evaluations and the final iterate.  f and J are the restated
+    formulae of the oracle (oracle/estimators.c us_lm_fcn, .cxx:415-658).  The frames are NOT stored: they are
+    regenerated from (generator, size, seed), which are."""
+    from scipy.optimize import leastsq
+    out = {}
+    for m in sizes:
+        seed = 4100 + m
+        rec = synth.us_single_fast(m, 0.0, seed=seed)[0]
+        init = O.us_analytic(O.US_SINGLE, rec)[:11]
+        F = O.UsFunction(O.US_SINGLE, rec)
+        r = leastsq(F.f, init, Dfun=F.jac, ftol=1e-15, xtol=1e-15, gtol=1e-15, maxfev=5000, full_output=True)
+        w, info, nfev = O.us_iterative(O.US_SINGLE, rec, init)
+        key = "us_lm_%d_" % m
+        out[key + "seed"] = np.array([seed])
+        out[key + "init"] = init
+        out[key + "scipy_x"] = r[0]
+        out[key + "scipy_nfev_ier"] = np.array([r[2]["nfev"], r[4]])
+        out[key + "scipy_cost"] = np.array([(r[2]["fvec"] ** 2).sum()])
+        out[key + "oracle_x"] = w[:11]
+        out[key + "oracle_nfev_info"] = np.array([nfev, info])
+        print(m, "scipy", r[2]["nfev"], r[4], "oracle", nfev, info, np.abs(w[:11] - r[0]).max(), flush=True)
+    np.savez_compressed(os.path.join(HERE, "us_lm_vectors.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "us_lm":
+        us_lm_vectors()
+        sys.exit(0)
     copy_data()
     ransac_vectors()
     numerics_vectors()
+    us_lm_vectors()
     print("golden fixtures written to", HERE)

@@ -34,6 +34,7 @@ def test_header_symbols_exported_and_bound():
 def test_version_and_status_strings():
     lib = L.load()
     assert b"gfx950" in lib.lsqr_version()
+    assert b"SUBSET" not in lib.lsqr_version(), "liblsqr_hip.so is a development subset build (make DEV=1)"
     assert lib.lsqr_status_string(L.EMPTY) != lib.lsqr_status_string(L.OK)
 
 
