@@ -170,7 +170,9 @@ LSQR_API int lsqr_mask_from_hypothesis(lsqr_ctx *ctx, size_t hypothesis, uint8_t
 LSQR_API int lsqr_set_mask(lsqr_ctx *ctx, const uint8_t *mask); /* N bytes from the host */
 
 /* ---- final fit (leastSquaresEstimate(), ParametersEstimator.h:51) ---------------------------- */
-/* use_mask = 0 fits all observations, 1 only those in the device mask. */
+/* use_mask = 0 fits all observations, 1 only those in the device mask.  LSQR_EMPTY = the reference's empty
+ * vector (info->n_params == 0); after a failed Levenberg-Marquardt run (info->lm_info outside 1..4) params_out
+ * still receives the last iterate, for diagnostics only. */
 LSQR_API int lsqr_ls_fit(lsqr_ctx *ctx, int use_mask, double *params_out, lsqr_fit_info *info);
 /* Building blocks for multi-GPU fits: the normal-equation / moment block of [begin,end) and the
  * small solve from a (summed) block.  lsqr_moments_len gives the block length in doubles. */

@@ -120,6 +120,7 @@ class Context:
         info = L.FitInfo()
         st = self._chk(self._lib.lsqr_ls_fit(self._h, int(use_mask), L.ptr(out), C.byref(info)),
                        allow_empty=True)
+        self.last_iterate = out[:self.P].copy()   # LM runs: the last iterate even when the fit is reported failed
         return (out[:info.n_params].copy() if st == L.OK else np.zeros(0)), info
 
     def moments_len(self, phase):

@@ -447,6 +447,81 @@ __global__ __launch_bounds__(kBlock) void k_mask_moments(const double *__restric
   }
 }
 
+// One Levenberg-Marquardt evaluation in ONE launch: the (masked) reduction of k_moments<M, AccLm<M>> at the trial
+// point `xk` -- passed BY VALUE, so consecutive evaluations need no staging copy -- and, in the block that
+// finishes last, the fixed-order sum of all block partials, written to `out` (host-mapped pinned memory: the host's
+// MINPACK control flow polls out[nmom] for `seq` instead of synchronising the stream; device memory works too).
+// The order of the final sum depends only on the grid, not on which block happens to be last: deterministic.
+struct LmX {
+  double x[LM_NMAX];
+};
+template <class M, bool USE_MASK>
+__global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ data, size_t stride,
+                                                    size_t begin, size_t end, size_t chunk,
+                                                    const uint8_t *__restrict__ mask, LmX xk, ModelConsts mc,
+                                                    double *__restrict__ partials,
+                                                    unsigned int *__restrict__ ticket,
+                                                    double *__restrict__ out, double seq) {
+  constexpr int N = M::NMOM_LM;
+  __shared__ double s_m[kBlock / 64][N];
+  __shared__ bool s_last;
+  double acc[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) acc[k] = 0.0;
+  size_t lo = begin + (size_t)blockIdx.x * chunk;
+  size_t hi = lo + chunk < end ? lo + chunk : end;
+  if constexpr (requires { typename M::LmCoef; }) {
+    typename M::LmCoef coef;
+    M::lm_coef(xk.x, coef);
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+      if (USE_MASK && !mask[i]) continue;
+      double x[M::REC];
+      M::load(data + i * stride, mc, x);
+      M::accumulate_lm_fast(x, coef, acc);
+    }
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+      if (USE_MASK && !mask[i]) continue;
+      double x[M::REC];
+      M::load(data + i * stride, mc, x);
+      M::accumulate_lm(x, xk.x, acc);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) t += s_m[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x] = t;
+  }
+  __threadfence();  // this block's partial is visible before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other blocks' partials are read from L2, not from a stale L1 line
+  // the last block: wave w sums moments w, w + 4, ... over the blocks (lane-strided, then a shuffle tree)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < N; k += kBlock / 64) {
+    double t = 0.0;
+    for (unsigned b = lane; b < gridDim.x; b += 64) t += partials[(size_t)b * MOM_MAX + k];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    if (lane == 0) out[k] = t;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ticket = 0;  // ready for the next evaluation (stream order)
+    ((volatile double *)out)[N] = seq;  // after the system-scope fence above: the sums are visible first
+    __threadfence_system();
+  }
+}
+
 // fixed-order sum of the per-block partials -> mom[0..nmom): one wave per moment, lane-strided
 // partial sums then a shuffle tree (the order depends only on nblocks).
 __global__ __launch_bounds__(64) void k_reduce(const double *__restrict__ partials, int nblocks,

@@ -92,6 +92,9 @@ struct lsqr_ctx {
   int opt_fuse_mask = 1;  // winner's mask + moment block in one pass (0: two kernels, for A/B runs)
   long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
+  double *h_lmres = nullptr;  // pinned, device-visible: {moment block, sequence flag} written by k_lm_pass
+  double lm_seq = 0.0;        // sequence number of the last evaluation (the flag value the host polls for)
+  int opt_lm_fused = 1;       // 1: one launch per LM evaluation, result polled in pinned memory; 0: r01 path
 
   // staged upload (lsqr_upload of large pageable buffers): ring of pinned chunks filled by a few host threads
   // while earlier chunks are in flight to the device
@@ -1037,6 +1040,50 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
         LmState &s = c->h_lm;
         lm_init(s, n, out->params, ftol, xtol, gtol, maxfev, 100.0);
         double *pin = (double *)c->h_pin;
+        if (c->opt_lm_fused) {
+          // one launch per evaluation: trial point by value, block sums + final sum in the same kernel, the
+          // result lands in pinned host memory and the host polls its sequence flag (no stream synchronisation,
+          // no staging copies): per evaluation = the pass + one launch latency + a few hundred host flops
+          size_t cnt = c->n;
+          int nb = grid_for(cnt, kBlock * 4, kMaxPartials);
+          size_t chunk = (cnt + nb - 1) / nb;
+          chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+          nb = (int)((cnt + chunk - 1) / chunk);
+          if (nb < 1) nb = 1;
+          volatile double *res = c->h_lmres;
+          for (;;) {
+            LmX xk;
+            for (int j = 0; j < LM_NMAX; j++) xk.x[j] = j < n ? s.xtrial[j] : 0.0;
+            const double seq = (c->lm_seq += 1.0);
+            {
+              ProfScope ps(c, KID_MOMENTS);
+              if (use_mask)
+                hipLaunchKernelGGL((k_lm_pass<M, true>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
+                                   c->stride, (size_t)0, c->n, chunk, c->d_mask, xk, c->mc, c->d_partials,
+                                   (unsigned int *)(c->d_counter + 7), c->h_lmres, seq);
+              else
+                hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
+                                   c->stride, (size_t)0, c->n, chunk, c->d_mask, xk, c->mc, c->d_partials,
+                                   (unsigned int *)(c->d_counter + 7), c->h_lmres, seq);
+              HIPCHK(c, hipGetLastError());
+            }
+            unsigned long long spins = 0;
+            while (res[M::NMOM_LM] != seq) {
+              if ((++spins & 0xFFFF) == 0) {  // every 65 k polls: is the stream still alive?
+                hipError_t q = hipStreamQuery(c->stream);
+                if (q != hipSuccess && q != hipErrorNotReady)
+                  return fail(c, LSQR_ERR_HIP, "LM pass failed: %s", hipGetErrorString(q));
+                if (q == hipSuccess && res[M::NMOM_LM] != seq)
+                  return fail(c, LSQR_ERR_HIP, "LM pass finished without publishing its result");
+              }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            double blk[LM_MOM_MAX];
+            for (int j = 0; j < (int)M::NMOM_LM; j++) blk[j] = res[j];
+            if (!lm_advance(s, blk)) break;
+          }
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+        } else
         for (;;) {
           for (int j = 0; j < n; j++) pin[j] = s.xtrial[j];
           HIPCHK(c, hipMemcpyAsync(c->d_vec, pin, sizeof(double) * n, hipMemcpyHostToDevice,
@@ -1290,7 +1337,12 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
             hipMalloc((void **)&c->d_lm, sizeof(LmState)) == hipSuccess &&
             hipMalloc((void **)&c->d_out, sizeof(SolveOut)) == hipSuccess &&
             hipMalloc((void **)&c->d_counter, 64) == hipSuccess &&
-            hipHostMalloc(&c->h_pin, 1 << 16) == hipSuccess;
+            hipHostMalloc(&c->h_pin, 1 << 16) == hipSuccess &&
+            hipHostMalloc((void **)&c->h_lmres, sizeof(double) * 128, hipHostMallocCoherent) == hipSuccess;
+  if (ok) {
+    memset(c->h_lmres, 0, sizeof(double) * 128);
+    ok = hipMemsetAsync(c->d_counter, 0, 64, c->own_stream) == hipSuccess;
+  }
   c->stream = c->own_stream;
   if (!ok) {
     lsqr_ctx_destroy(c);
@@ -1310,6 +1362,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->h_lmres) (void)hipHostFree(c->h_lmres);
   if (c->h_batch) (void)hipHostFree(c->h_batch);
   for (int i = 0; i < lsqr_ctx::kUpSlots; i++) {
     if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
@@ -1690,7 +1743,14 @@ int lsqr_ls_fit(lsqr_ctx *c, int use_mask, double *params_out, lsqr_fit_info *in
     info->lm_nfev = out.lm_nfev;
     info->cost = out.cost;
   }
-  if (!out.ok) return LSQR_EMPTY;
+  if (!out.ok) {
+    // a Levenberg-Marquardt run that MINPACK reports as failed (the reference then returns an empty vector):
+    // the last iterate is still handed out for diagnostics -- status LSQR_EMPTY and info->n_params == 0 say
+    // that it is not a result
+    if (params_out && out.lm_info != 0)
+      for (int j = 0; j < c->P; j++) params_out[j] = out.params[j];
+    return LSQR_EMPTY;
+  }
   if (params_out)
     for (int j = 0; j < out.n_params; j++) params_out[j] = out.params[j];
   return LSQR_OK;
@@ -2558,6 +2618,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "syrk_diag")) {  // 1: loads only, 2: MFMAs only (timing diagnostics, wrong sums)
     c->opt_syrk_diag = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_fused")) {  // 1 (default): one launch per LM evaluation, result polled in pinned memory
+    c->opt_lm_fused = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "lm_host")) {

@@ -394,6 +394,74 @@ struct USModel {
     for (int p = 0; p < NLM; p++, k++) m[k] = fma(J[p], delta_i, m[k]);
   }
 
+  // ---- one Levenberg-Marquardt evaluation, re-associated (k_lm_pass) ------------------------------------------
+  // accumulate_lm above follows the reference's f / gradf term by term (11 divisions by the residual, a square
+  // root and ~600 flops per frame: the pass was bound by the vector ALU, 55 us per 1 M frames).  The same
+  // sums in a cheaper association: with q = u c0 + v c1 + t3 (c0 = m_x R3(:,1), c1 = m_y R3(:,2)),
+  //   e = R2 q + t2 - t1      (= [expr1, expr2, expr3]),   f = |e|,   J_p = e . de/dp / |e| = g_p / |e|,
+  // so   sum f^2 = sum e.e,   J^T f = sum g,   J^T J = sum g g^T / (e.e)   -- one division per frame, no root --
+  // and every probe-side derivative is  de/dp = R2 (u a_p + v b_p)  with per-evaluation constant 3-vectors
+  // a_p, b_p, hence  g_p = (R2^T e) . (u a_p + v b_p).  Rounding differs from the literal form in the last
+  // bits; a frame that fits exactly gives 0 * inf = NaN exactly as the reference's 0 / 0.
+  struct LmCoef {
+    double c0[3], c1[3], t3[3], t1[3];
+    double a[5][3], b[5][3];  // wz, wy, wx, m_x, m_y
+  };
+  static LSQR_HD void lm_coef(const double *xk, LmCoef &k) {
+    const int o = SINGLE ? 3 : 0;
+    for (int i = 0; i < 3; i++) k.t1[i] = SINGLE ? xk[i] : 0.0, k.t3[i] = xk[o + i];
+    const double sz = sin(xk[o + 3]), cz = cos(xk[o + 3]);
+    const double sy = sin(xk[o + 4]), cy = cos(xk[o + 4]);
+    const double sx = sin(xk[o + 5]), cx = cos(xk[o + 5]);
+    const double m_x = xk[o + 6], m_y = xk[o + 7];
+    const double r1[3] = {cz * cy, sz * cy, -sy};                                       // R3(:,1)
+    const double r2[3] = {cz * sy * sx - sz * cx, sz * sy * sx + cz * cx, cy * sx};     // R3(:,2)
+    for (int i = 0; i < 3; i++) k.c0[i] = m_x * r1[i], k.c1[i] = m_y * r2[i];
+    // d/dwz (...Estimator.cxx:605-617), d/dwy (:619-635), d/dwx (:637-645), d/dm_x, d/dm_y (:647-656)
+    const double az[3] = {-m_x * sz * cy, m_x * cz * cy, 0.0};
+    const double bz[3] = {-m_y * (sz * sy * sx + cz * cx), m_y * (cz * sy * sx - sz * cx), 0.0};
+    const double ay[3] = {-m_x * sy * cz, -m_x * sy * sz, -m_x * cy};
+    const double by[3] = {m_y * sx * cy * cz, m_y * sx * cy * sz, -m_y * sx * sy};
+    const double bx[3] = {m_y * (cz * sy * cx + sz * sx), m_y * (sz * sy * cx - cz * sx), m_y * cy * cx};
+    for (int i = 0; i < 3; i++) {
+      k.a[0][i] = az[i], k.b[0][i] = bz[i];
+      k.a[1][i] = ay[i], k.b[1][i] = by[i];
+      k.a[2][i] = 0.0, k.b[2][i] = bx[i];
+      k.a[3][i] = r1[i], k.b[3][i] = 0.0;
+      k.a[4][i] = 0.0, k.b[4][i] = r2[i];
+    }
+  }
+  static LSQR_HD void accumulate_lm_fast(const double *rec, const LmCoef &k, double *m) {
+    const int o = SINGLE ? 3 : 0;
+    const double u = rec[13], v = rec[14];
+    double q[3], e[3], h[3], g[NLM];
+    for (int i = 0; i < 3; i++) q[i] = fma(u, k.c0[i], fma(v, k.c1[i], k.t3[i]));
+    for (int i = 0; i < 3; i++) {
+      double s = rec[9 + i] - (SINGLE ? k.t1[i] : rec[15 + i]);
+      s = fma(rec[3 * i + 2], q[2], s);
+      s = fma(rec[3 * i + 1], q[1], s);
+      e[i] = fma(rec[3 * i], q[0], s);
+    }
+    for (int j = 0; j < 3; j++) h[j] = fma(rec[j], e[0], fma(rec[3 + j], e[1], rec[6 + j] * e[2]));  // R2^T e
+    if (SINGLE)
+      for (int i = 0; i < 3; i++) g[i] = -e[i];
+    for (int i = 0; i < 3; i++) g[o + i] = h[i];
+    for (int p = 0; p < 5; p++) {
+      const double ha = fma(h[0], k.a[p][0], fma(h[1], k.a[p][1], h[2] * k.a[p][2]));
+      const double hb = fma(h[0], k.b[p][0], fma(h[1], k.b[p][1], h[2] * k.b[p][2]));
+      g[o + 3 + p] = fma(u, ha, v * hb);
+    }
+    const double ee = fma(e[0], e[0], fma(e[1], e[1], e[2] * e[2]));
+    const double w = 1.0 / ee;
+    m[0] += ee;
+    int idx = 1;
+    for (int p = 0; p < NLM; p++) {
+      const double gw = g[p] * w;
+      for (int r = p; r < NLM; r++, idx++) m[idx] = fma(gw, g[r], m[idx]);
+    }
+    for (int p = 0; p < NLM; p++, idx++) m[idx] += g[p];
+  }
+
   // ...Estimator.cxx:300-327 / :944-971: append the rotation products to the LM solution
   static LSQR_HD int lm_finalize(const double *x, double *par) {
     const int o = SINGLE ? 3 : 0;

@@ -135,12 +135,38 @@ def us_lm_vectors(sizes=(1000, 20000, 100000)):
     np.savez_compressed(os.path.join(HERE, "us_lm_vectors.npz"), **out)
 
 
+def us_lm_flag_table():
+    """How reproducible is MINPACK's stopping code at the reference's 1e-15 tolerances?  SciPy's lmder and the
+    oracle's literal restatement of lmder (oracle/linalg.c), fed the SAME f and J, on 6 seeds x 3 sizes: the
+    evaluation counts differ by tens to hundreds and the success flag itself flips on some inputs -- the
+    termination happens inside rounding noise (trust-region radius random-walks until delta <= xtol |x|)."""
+    from scipy.optimize import leastsq
+    rows = []
+    for m in (200, 1000, 3000):
+        for seed in range(900, 906):
+            rec = synth.us_single_fast(m, 0.0, seed=seed)[0]
+            init = O.us_analytic(O.US_SINGLE, rec)[:11]
+            F = O.UsFunction(O.US_SINGLE, rec)
+            r = leastsq(F.f, init, Dfun=F.jac, ftol=1e-15, xtol=1e-15, gtol=1e-15, maxfev=5000, full_output=True)
+            w, info, nfev = O.us_iterative(O.US_SINGLE, rec, init)
+            rows.append([m, seed, r[2]["nfev"], r[4], nfev, info, (r[2]["fvec"] ** 2).sum()])
+            print(rows[-1], flush=True)
+    np.savez_compressed(os.path.join(HERE, "us_lm_flags.npz"),
+                        table=np.array(rows, dtype=np.float64),
+                        columns=np.array(["frames", "seed", "scipy_nfev", "scipy_ier", "oracle_nfev", "oracle_info",
+                                          "scipy_cost"]))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "us_lm":
         us_lm_vectors()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "us_lm_flags":
+        us_lm_flag_table()
         sys.exit(0)
     copy_data()
     ransac_vectors()
     numerics_vectors()
     us_lm_vectors()
+    us_lm_flag_table()
     print("golden fixtures written to", HERE)

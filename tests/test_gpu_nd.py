@@ -64,7 +64,7 @@ def test_nd_minimal_solves_scan_mask(ctx, model, dim):
             assert np.allclose(g, want, rtol=REL, atol=REL * max(1.0, np.abs(want).max())), h
         cnt, _ = O.scan(oc, par[h], data)                       # agree() on the device's model: bit-exact
         assert votes[h] == cnt, h
-    assert votes[9:25].max() > 0.02 * n
+    assert votes[9:25].max() > k            # (a model through k noisy inliers: more than its own subset)
     _, bv, bi = ctx.best()
     vv = np.where(valid > 0, votes, 0)
     assert bv == vv.max() and bi == int(np.argmax(vv))
