@@ -395,10 +395,12 @@ def hbm_table(a, H, rec, prof, abs_prof, idx_prof, cnt):
             add("k_moments<%s, LM> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f)" % w,
                 n + cnt * rec, *prof["moments"],
                 note="reads the mask (N B) and the %d consensus records" % cnt)
-    add("k_absmax (once per upload)", n * rec, *abs_prof)
+    add("k_bounds (point models: min / max / max |x| in one pass) or k_absmax, once per upload", n * rec, *abs_prof)
     if idx_prof[0]:
-        add("spatial index build (k_bounds, k_keys, prefix sum, k_scatter, k_cell_boxes; once per upload)",
-            n * rec * 5 + n * 8, *idx_prof, note="bytes = 3 reads of the records + sorted copy written and read + keys")
+        add("spatial index build (k_keys, radix sort of (key, index) pairs, k_gather_boxes; once per upload)",
+            n * (3 * rec + 60), *idx_prof,
+            note="bytes = records read for the keys, (key, index) pairs written and moved by 3 radix passes, "
+                 "records gathered and the sorted copy written; the bounds come from the k_bounds pass above")
     return rows
 
 

@@ -305,8 +305,10 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                host, 0 = in a single-lane device kernel (same lm_core.h code either way);
  * "scan_index":  two-level scan of the point models over a spatial index of the observations
  *                (Morton-sorted copy + one fp32 bounding box per cell of 256 / 512 observations, built on the
- *                device once per upload): 1 (default) = used once an upload has seen >= 2048
- *                hypotheses and holds >= 65536 observations, 0 = never, 2 = always.  Votes are
+ *                device once per upload): 1 (default) = built when it pays -- the upload holds >= 65536
+ *                observations and >= 512 hypotheses have been scanned on it or are still announced by the
+ *                adaptive bound (the build costs about as much as 450 exhaustive hypothesis scans) --,
+ *                0 = never, 2 = always.  Votes are
  *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = the
  *                model's default), "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default), "scan_block":
  *                workgroup size (256 / 1024), "scan_hsplit": hypothesis segments per tile (A/B knobs);

@@ -18,8 +18,9 @@
 // only observations that certainly do not agree (bound below), so votes are bit-identical to the
 // exhaustive kernels (tests/test_gpu_parity.py::test_cell_scan_*).
 //
-// Index build (k_bounds -> k_keys -> 3-kernel prefix sum -> k_scatter -> k_cell_boxes) is a counting
-// sort on Morton keys: once per upload, a few HBM passes.
+// Index build, once per upload: k_bounds (min / max / max |x| in one pass) -> k_keys (Morton key + identity) ->
+// stable radix sort of the (key, index) pairs (sort.hip) -> k_gather_boxes (sorted copy + cell boxes).  No
+// per-record global atomics anywhere: the build time does not depend on how the observations cluster.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,11 +54,20 @@ inline double ord_u64_inv(unsigned long long o) {
   return v;
 }
 
-// out[0..2] = min per dimension, out[3..5] = max (ordered encoding); non-finite records are skipped
+// ---- pass 1: bounds -------------------------------------------------------------------------------------
+// One pass over the records gives everything the upload needs to know about its coordinates: per-dimension
+// min / max of the finite records (ordered encoding) for the Morton grid, the number of non-finite records
+// (they can never agree and are sorted to the tail), and max |coordinate| -- the X of the fp32 filters' error
+// bands (k_absmax's result: +inf as soon as one record is not finite, which switches the filters off).
+// Two stages: one row of 8 values per block, then a single-block reduction (same-address atomics cost
+// ~14 ns each: a few thousand of them on one cache line would take longer than the pass itself).
+struct BoundsRow {
+  unsigned long long mn[3], mx[3], amax, nonfinite;
+};
 template <int D>
 __global__ __launch_bounds__(256) void k_bounds(const double *__restrict__ data, size_t stride,
-                                                size_t n, unsigned long long *__restrict__ out) {
-  unsigned long long mn[D], mx[D];
+                                                size_t n, BoundsRow *__restrict__ rows) {
+  unsigned long long mn[D], mx[D], am = 0, bad = 0;
   for (int d = 0; d < D; d++) mn[d] = ~0ULL, mx[d] = 0ULL;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     double x[D];
@@ -66,32 +76,88 @@ __global__ __launch_bounds__(256) void k_bounds(const double *__restrict__ data,
       x[d] = data[i * stride + d];
       fin = fin && (fabs(x[d]) <= 1.7976931348623157e308);  // false for NaN and inf
     }
-    if (!fin) continue;
+    if (!fin) {
+      bad++;
+      continue;
+    }
     for (int d = 0; d < D; d++) {
       unsigned long long o = ord_u64(x[d]);
       mn[d] = o < mn[d] ? o : mn[d];
       mx[d] = o > mx[d] ? o : mx[d];
+      const unsigned long long a = (unsigned long long)__builtin_bit_cast(long long, fabs(x[d]));
+      am = a > am ? a : am;  // bit patterns of non-negative doubles are ordered like the values
     }
   }
-  __shared__ unsigned long long s_mn[4][D], s_mx[4][D];
-  for (int d = 0; d < D; d++) {
-    for (int o = 32; o > 0; o >>= 1) {
+  __shared__ unsigned long long s_v[4][2 * D + 2];
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int d = 0; d < D; d++) {
       unsigned long long a = __shfl_down(mn[d], o), b = __shfl_down(mx[d], o);
       mn[d] = a < mn[d] ? a : mn[d];
       mx[d] = b > mx[d] ? b : mx[d];
     }
-    if ((threadIdx.x & 63) == 0) s_mn[threadIdx.x >> 6][d] = mn[d], s_mx[threadIdx.x >> 6][d] = mx[d];
+    unsigned long long a = __shfl_down(am, o);
+    am = a > am ? a : am;
+    bad += __shfl_down(bad, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long *v = s_v[threadIdx.x >> 6];
+    for (int d = 0; d < D; d++) v[d] = mn[d], v[D + d] = mx[d];
+    v[2 * D] = am;
+    v[2 * D + 1] = bad;
   }
   __syncthreads();
-  if (threadIdx.x < D) {  // one pair of atomics per block and dimension
-    const int d = threadIdx.x;
-    unsigned long long a = s_mn[0][d], b = s_mx[0][d];
-    for (int w = 1; w < 4; w++) {
-      a = s_mn[w][d] < a ? s_mn[w][d] : a;
-      b = s_mx[w][d] > b ? s_mx[w][d] : b;
+  if (threadIdx.x == 0) {
+    BoundsRow r;
+    for (int d = 0; d < 3; d++) r.mn[d] = ~0ULL, r.mx[d] = 0ULL;
+    r.amax = 0, r.nonfinite = 0;
+    for (int w = 0; w < 4; w++) {
+      for (int d = 0; d < D; d++) {
+        r.mn[d] = s_v[w][d] < r.mn[d] ? s_v[w][d] : r.mn[d];
+        r.mx[d] = s_v[w][D + d] > r.mx[d] ? s_v[w][D + d] : r.mx[d];
+      }
+      r.amax = s_v[w][2 * D] > r.amax ? s_v[w][2 * D] : r.amax;
+      r.nonfinite += s_v[w][2 * D + 1];
     }
-    if (a != ~0ULL) atomicMin(&out[d], a);
-    if (b != 0ULL) atomicMax(&out[3 + d], b);
+    rows[blockIdx.x] = r;
+  }
+}
+__global__ __launch_bounds__(256) void k_bounds_final(const BoundsRow *__restrict__ rows, int nb,
+                                                      BoundsRow *__restrict__ out) {
+  BoundsRow r;
+  for (int d = 0; d < 3; d++) r.mn[d] = ~0ULL, r.mx[d] = 0ULL;
+  r.amax = 0, r.nonfinite = 0;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    const BoundsRow q = rows[b];
+    for (int d = 0; d < 3; d++) {
+      r.mn[d] = q.mn[d] < r.mn[d] ? q.mn[d] : r.mn[d];
+      r.mx[d] = q.mx[d] > r.mx[d] ? q.mx[d] : r.mx[d];
+    }
+    r.amax = q.amax > r.amax ? q.amax : r.amax;
+    r.nonfinite += q.nonfinite;
+  }
+  __shared__ BoundsRow s_r[4];
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int d = 0; d < 3; d++) {
+      unsigned long long a = __shfl_down(r.mn[d], o), b = __shfl_down(r.mx[d], o);
+      r.mn[d] = a < r.mn[d] ? a : r.mn[d];
+      r.mx[d] = b > r.mx[d] ? b : r.mx[d];
+    }
+    unsigned long long a = __shfl_down(r.amax, o);
+    r.amax = a > r.amax ? a : r.amax;
+    r.nonfinite += __shfl_down(r.nonfinite, o);
+  }
+  if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      for (int d = 0; d < 3; d++) {
+        r.mn[d] = s_r[w].mn[d] < r.mn[d] ? s_r[w].mn[d] : r.mn[d];
+        r.mx[d] = s_r[w].mx[d] > r.mx[d] ? s_r[w].mx[d] : r.mx[d];
+      }
+      r.amax = s_r[w].amax > r.amax ? s_r[w].amax : r.amax;
+      r.nonfinite += s_r[w].nonfinite;
+    }
+    *out = r;
   }
 }
 
@@ -118,10 +184,12 @@ __device__ inline uint32_t spread2(uint32_t v) {  // 16 bits -> every second bit
   return v;
 }
 
+// ---- pass 2: Morton key of every record (non-finite records: key nbins, i.e. after every finite one) and the
+// identity permutation; the (key, index) pairs are then sorted by a stable radix sort (sort.hip)
 template <int D>
 __global__ __launch_bounds__(256) void k_keys(const double *__restrict__ data, size_t stride,
                                               size_t n, IndexGrid g, uint32_t *__restrict__ keys,
-                                              uint32_t *__restrict__ hist) {
+                                              uint32_t *__restrict__ vals) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t q[3] = {0, 0, 0};
@@ -139,84 +207,7 @@ __global__ __launch_bounds__(256) void k_keys(const double *__restrict__ data, s
   else if (D == 3) key = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
   else key = spread2(q[0]) | (spread2(q[1]) << 1);
   keys[i] = key;
-  atomicAdd(&hist[key], 1u);
-}
-
-// exclusive prefix sum of hist[0..m) in three kernels (4096 entries per block)
-constexpr int kScanSpan = 4096;
-__global__ __launch_bounds__(256) void k_hist_blocksum(const uint32_t *__restrict__ hist, uint32_t m,
-                                                       uint32_t *__restrict__ bsum) {
-  __shared__ uint32_t s[4];
-  uint32_t base = blockIdx.x * kScanSpan, t = 0;
-  for (int k = 0; k < kScanSpan / 256; k++) {
-    uint32_t i = base + k * 256 + threadIdx.x;
-    t += i < m ? hist[i] : 0u;
-  }
-  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
-  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) bsum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
-// exclusive scan of the block sums in place (nb <= kMaxScanBlocks, one workgroup): staged in LDS,
-// each of the first 64 threads owns a consecutive chunk, wave scan of the chunk sums
-constexpr int kMaxScanBlocks = 4352;
-__global__ __launch_bounds__(256) void k_hist_scan_bsum(uint32_t *bsum, uint32_t nb) {
-  __shared__ uint32_t s[kMaxScanBlocks];
-  for (uint32_t i = threadIdx.x; i < nb; i += 256) s[i] = bsum[i];
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const uint32_t per = (nb + 63) / 64, lo = threadIdx.x * per;
-    uint32_t t = 0;
-    for (uint32_t k = 0; k < per; k++) t += lo + k < nb ? s[lo + k] : 0u;
-    uint32_t inc = t;
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t a = __shfl_up(inc, o);
-      if ((int)threadIdx.x >= o) inc += a;
-    }
-    uint32_t run = inc - t;
-    for (uint32_t k = 0; k < per; k++)
-      if (lo + k < nb) {
-        uint32_t v = s[lo + k];
-        bsum[lo + k] = run;
-        run += v;
-      }
-  }
-}
-__global__ __launch_bounds__(256) void k_hist_apply(uint32_t *__restrict__ hist, uint32_t m,
-                                                    const uint32_t *__restrict__ bsum) {
-  __shared__ uint32_t s[256];
-  constexpr int per = kScanSpan / 256;  // consecutive entries per thread
-  uint32_t base = blockIdx.x * kScanSpan + threadIdx.x * per;
-  uint32_t v[per], t = 0;
-  for (int k = 0; k < per; k++) {
-    v[k] = base + k < m ? hist[base + k] : 0u;
-    t += v[k];
-  }
-  s[threadIdx.x] = t;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan of the 256 thread sums
-    uint32_t a = threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
-    __syncthreads();
-    s[threadIdx.x] += a;
-    __syncthreads();
-  }
-  uint32_t run = bsum[blockIdx.x] + s[threadIdx.x] - t;
-  for (int k = 0; k < per; k++) {
-    if (base + k < m) hist[base + k] = run;
-    run += v[k];
-  }
-}
-
-// sorted[pos] = record i (tight D doubles); offs = exclusive prefix (advanced atomically)
-template <int D>
-__global__ __launch_bounds__(256) void k_scatter(const double *__restrict__ data, size_t stride,
-                                                 size_t n, const uint32_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ offs,
-                                                 double *__restrict__ sorted) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint32_t pos = atomicAdd(&offs[keys[i]], 1u);
-  for (int d = 0; d < D; d++) sorted[(size_t)pos * D + d] = data[i * stride + d];
+  vals[i] = (uint32_t)i;
 }
 
 __device__ inline float f32_up(double v) {  // smallest float >= v (v finite, >= 0)
@@ -225,11 +216,14 @@ __device__ inline float f32_up(double v) {  // smallest float >= v (v finite, >=
   return f;
 }
 
-// one wave per cell: conservative fp32 box of sorted[cell*cell_pts .. +cell_pts) ∩ [0, ns)
+// ---- pass 3: one wave per cell gathers its records in sorted order (order[] = the sorted record indices) into
+// the tight copy and, from the same registers, forms the cell's conservative fp32 box
 template <int D>
-__global__ __launch_bounds__(256) void k_cell_boxes(const double *__restrict__ sorted, size_t ns,
-                                                    uint32_t ncells, uint32_t cell_pts,
-                                                    CellBox *__restrict__ boxes) {
+__global__ __launch_bounds__(256) void k_gather_boxes(const double *__restrict__ data, size_t stride,
+                                                      const uint32_t *__restrict__ order, size_t ns,
+                                                      uint32_t ncells, uint32_t cell_pts,
+                                                      double *__restrict__ sorted,
+                                                      CellBox *__restrict__ boxes) {
   uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= ncells) return;
   const int lane = threadIdx.x & 63;
@@ -237,12 +231,15 @@ __global__ __launch_bounds__(256) void k_cell_boxes(const double *__restrict__ s
   for (int d = 0; d < D; d++) mn[d] = __builtin_inf(), mx[d] = -__builtin_inf();
   for (uint32_t k = 0; k < cell_pts / 64; k++) {
     size_t i = (size_t)cell * cell_pts + k * 64 + lane;
-    if (i < ns)
+    if (i < ns) {
+      const double *src = data + (size_t)order[i] * stride;
       for (int d = 0; d < D; d++) {
-        double x = sorted[i * D + d];
+        double x = src[d];
+        sorted[i * D + d] = x;
         mn[d] = x < mn[d] ? x : mn[d];
         mx[d] = x > mx[d] ? x : mx[d];
       }
+    }
   }
   for (int d = 0; d < D; d++)
     for (int o = 32; o > 0; o >>= 1) {

@@ -305,7 +305,16 @@ __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ da
     m = t > m ? t : m;
     mr = tr > mr ? tr : mr;
   }
-  if ((threadIdx.x & 63) == 0) {
+  // one pair of atomics per BLOCK: same-address atomics serialise at ~14 ns each, and with one pair per wave
+  // (8192 of them) they, not the 8 TB/s stream, set the time of this pass (0.24 ms for 240 MB)
+  __shared__ unsigned long long s_v[kBlock / 64][2];
+  if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6][0] = m, s_v[threadIdx.x >> 6][1] = mr;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      m = s_v[w][0] > m ? s_v[w][0] : m;
+      mr = s_v[w][1] > mr ? s_v[w][1] : mr;
+    }
     if (m) atomicMax(out, m);
     if (mr) atomicMax(out + 1, mr);
   }
@@ -463,8 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
                                                     unsigned int *__restrict__ ticket,
                                                     double *__restrict__ out, double seq) {
   constexpr int N = M::NMOM_LM;
-  __shared__ double s_m[kBlock / 64][N];
-  __shared__ bool s_last;
+  __shared__ double s_m[kBlock / 64][N];  // the only LDS object (the reducer flag reuses its first word)
   double acc[N];
 #pragma unroll
   for (int k = 0; k < N; k++) acc[k] = 0.0;
@@ -494,17 +502,31 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
+  // Hand-off to the last-arriving block (cdna_hip_programming.md, Guideline 16 / in-launch split-K reduction): the
+  // block's partial is stored WRITE-THROUGH (relaxed agent-scope atomic stores = sc1: no release fence, which would
+  // write back the XCD's L2 once per block), every storing wave drains its stores, ONE lane draws the ticket; the
+  // block that draws the last ticket does ONE agent-scope acquire (drops its CU's stale L1 lines) and then reads
+  // all partials with plain vector loads.
   if (threadIdx.x < N) {
     double t = 0.0;
     for (int w = 0; w < kBlock / 64; w++) t += s_m[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x] = t;
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x], t, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();  // this block's partial is visible before its ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // s_m has been consumed: its first word now carries the "I am last" flag
+  unsigned int *s_flag = (unsigned int *)&s_m[0][0];
+  if (threadIdx.x == 0) {
+    const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = prev == gridDim.x - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = last ? 1u : 0u;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // acquire: the other blocks' partials are read from L2, not from a stale L1 line
+  if (*s_flag == 0u) return;
   // the last block: wave w sums moments w, w + 4, ... over the blocks (lane-strided, then a shuffle tree)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = wave; k < N; k += kBlock / 64) {
@@ -513,12 +535,11 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
     for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
     if (lane == 0) out[k] = t;
   }
-  __threadfence_system();
+  __threadfence_system();  // the sums (host-visible memory) before the sequence flag
   __syncthreads();
   if (threadIdx.x == 0) {
-    *ticket = 0;  // ready for the next evaluation (stream order)
-    ((volatile double *)out)[N] = seq;  // after the system-scope fence above: the sums are visible first
-    __threadfence_system();
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next evaluation (stream order)
+    __hip_atomic_store(&out[N], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

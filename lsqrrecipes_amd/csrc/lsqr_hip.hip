@@ -23,6 +23,7 @@
 #include "dense.h"
 #include "us_kernels.h"
 #include "cells.h"
+#include "sort.h"
 #include "rigid.h"
 #include "phantom.h"
 
@@ -57,7 +58,14 @@ struct lsqr_ctx {
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
   bool index_failed = false;  // build failed on this upload: stay on the exhaustive kernels
+  // k_bounds of the current upload (min / max per dimension, max |coordinate|, non-finite count): serves both
+  // the fp32 filters' absmax and the Morton grid of the index
+  BoundsRow h_bounds{};
+  bool bounds_valid = false;
+  void *d_idx_scratch = nullptr;  // keys / permutation / radix-sort temporaries of the index build (kept)
+  size_t idx_scratch_cap = 0;
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
+  uint64_t hyp_expected = 0;      // hypotheses the caller still expects to scan on this upload (lsqr_ransac: numTries)
   int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
@@ -306,10 +314,28 @@ int grid_for(size_t items, int per_block, int max_blocks) {
 }
 
 // ---- hypotheses ---------------------------------------------------------------------------------
+template <int D>
+int run_bounds(lsqr_ctx *c);
+
 int ensure_absmax(lsqr_ctx *c) {
   if (c->absmax_valid) return LSQR_OK;
+  const int m = c->cfg.model;
+  if ((m == LSQR_MODEL_PLANE || m == LSQR_MODEL_SPHERE || m == LSQR_MODEL_LINE || m == LSQR_MODEL_LINE2D) &&
+      c->ND <= 3) {
+    // point models: one pass gives max |coordinate| AND the bounds the index build needs (cells.h: k_bounds)
+    ProfScope ps(c, KID_ABSMAX);
+    int st = c->ND == 3 ? run_bounds<3>(c) : run_bounds<2>(c);
+    if (st != LSQR_OK) return st;
+    double am;
+    memcpy(&am, &c->h_bounds.amax, sizeof am);
+    if (c->h_bounds.nonfinite) am = std::numeric_limits<double>::infinity();  // as k_absmax: switches the filters off
+    c->mc.absmax = am;
+    c->mc.absmax_rot = am;
+    c->absmax_valid = true;
+    return LSQR_OK;
+  }
   HIPCHK(c, hipMemsetAsync(c->d_counter + 5, 0, 2 * sizeof(unsigned long long), c->stream));
-  int grid = grid_for(c->n, kBlock * 8, 2048);
+  int grid = grid_for(c->n, kBlock * 16, 1024);
   const bool us = c->cfg.model == LSQR_MODEL_US_SINGLE || c->cfg.model == LSQR_MODEL_US_POINTER ||
                   c->cfg.model == LSQR_MODEL_PHANTOM;  // Frame records: int slot 12, rotation first
   {
@@ -449,6 +475,24 @@ void drop_index(lsqr_ctx *c) {
   c->index_valid = false;
 }
 
+// k_bounds over the current upload (point models): min / max per dimension, max |coordinate|, non-finite count
+template <int D>
+int run_bounds(lsqr_ctx *c) {
+  if (c->bounds_valid) return LSQR_OK;
+  const int nb = grid_for(c->n, 256 * 16, 1024);
+  BoundsRow *rows = (BoundsRow *)c->d_partials;  // scratch: 1024 rows x 64 B (d_partials holds 4.4 MB)
+  static_assert(sizeof(BoundsRow) == 64, "BoundsRow is 8 words");
+  hipLaunchKernelGGL((k_bounds<D>), dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride, c->n, rows);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, c->stream, rows, nb, rows + 1024);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, rows + 1024, sizeof(BoundsRow), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(&c->h_bounds, c->h_pin, sizeof(BoundsRow));
+  c->bounds_valid = true;
+  return LSQR_OK;
+}
+
 template <int D>
 int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   drop_index(c);
@@ -457,34 +501,19 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
     return fail(c, LSQR_ERR_HIP, "index build failure requested by LSQR_TEST_FAIL_INDEX");
   ProfScope ps(c, KID_INDEX);
   const size_t n = c->n;
-  unsigned long long *d_b = nullptr;
-  uint32_t *d_keys = nullptr, *d_hist = nullptr, *d_bsum = nullptr;
-  auto cleanup = [&]() {
-    if (d_b) (void)hipFree(d_b);
-    if (d_keys) (void)hipFree(d_keys);
-    if (d_hist) (void)hipFree(d_hist);
-    if (d_bsum) (void)hipFree(d_bsum);
-  };
 #define IDXCHK(call)                                                                          \
   do {                                                                                        \
     hipError_t e_ = (call);                                                                   \
     if (e_ != hipSuccess) {                                                                   \
-      cleanup();                                                                              \
       drop_index(c);                                                                          \
       return fail(c, LSQR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
                   __FILE__, __LINE__);                                                        \
     }                                                                                         \
   } while (0)
-  unsigned long long hb[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
-  IDXCHK(hipMalloc((void **)&d_b, sizeof hb));
-  IDXCHK(hipMemcpyAsync(d_b, hb, sizeof hb, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL((k_bounds<D>), dim3(grid_for(n, 256 * 8, 2048)), dim3(256), 0, c->stream,
-                     c->d_data, c->stride, n, d_b);
-  IDXCHK(hipGetLastError());
-  IDXCHK(hipMemcpyAsync(hb, d_b, sizeof hb, hipMemcpyDeviceToHost, c->stream));
-  IDXCHK(hipStreamSynchronize(c->stream));
-  if (hb[0] == ~0ULL) {  // no finite record at all: nothing can agree
-    cleanup();
+  int st = run_bounds<D>(c);
+  if (st != LSQR_OK) return st;
+  const BoundsRow &hb = c->h_bounds;
+  if (hb.mn[0] == ~0ULL) {  // no finite record at all: nothing can agree
     c->index_valid = true;
     return LSQR_OK;
   }
@@ -499,47 +528,42 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   g.bits = (uint32_t)bits;
   g.nbins = 1u << (bits * D);
   for (int d = 0; d < D; d++) {
-    double lo = ord_u64_inv(hb[d]), hi = ord_u64_inv(hb[3 + d]);
+    double lo = ord_u64_inv(hb.mn[d]), hi = ord_u64_inv(hb.mx[d]);
     double sc = hi > lo ? (double)(1u << bits) / (hi - lo) : 0.0;
     if (!(sc >= 0.0) || !(sc <= 1.7976931348623157e308)) sc = 0.0;
     g.lo[d] = lo;
     g.scale[d] = sc;
   }
-  const uint32_t m = g.nbins + 1;
-  const uint32_t nblk = (m + kScanSpan - 1) / kScanSpan;
-  IDXCHK(hipMalloc((void **)&d_keys, std::max<size_t>(n, 1) * sizeof(uint32_t)));
-  IDXCHK(hipMalloc((void **)&d_hist, (size_t)m * sizeof(uint32_t)));
-  IDXCHK(hipMalloc((void **)&d_bsum, (size_t)nblk * sizeof(uint32_t)));
-  IDXCHK(hipMemsetAsync(d_hist, 0, (size_t)m * sizeof(uint32_t), c->stream));
-  const unsigned gn = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((k_keys<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n, g,
-                     d_keys, d_hist);
-  IDXCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_hist_blocksum, dim3(nblk), dim3(256), 0, c->stream, d_hist, m, d_bsum);
-  hipLaunchKernelGGL(k_hist_scan_bsum, dim3(1), dim3(256), 0, c->stream, d_bsum, nblk);
-  hipLaunchKernelGGL(k_hist_apply, dim3(nblk), dim3(256), 0, c->stream, d_hist, m, d_bsum);
-  IDXCHK(hipGetLastError());
-  uint32_t ns32 = 0;  // exclusive prefix at the "non-finite" bin = number of finite records
-  IDXCHK(hipMemcpyAsync(&ns32, d_hist + g.nbins, sizeof ns32, hipMemcpyDeviceToHost, c->stream));
-  IDXCHK(hipStreamSynchronize(c->stream));
-  if ((size_t)ns32 > n) {
-    cleanup();
-    return fail(c, LSQR_ERR_HIP, "index build: inconsistent histogram");
+  if (hb.nonfinite > n) return fail(c, LSQR_ERR_HIP, "index build: inconsistent bounds pass");
+  // scratch: keys, permutation (in / out) + the radix sort's temporaries; kept with the context
+  const size_t words = (n + 63) & ~(size_t)63;
+  size_t tmp_bytes = 0;
+  IDXCHK(sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, (unsigned)(bits * D + 1),
+                        c->stream));
+  const size_t need = 4 * words * sizeof(uint32_t) + tmp_bytes + 256;
+  if (need > c->idx_scratch_cap) {
+    if (c->d_idx_scratch) (void)hipFree(c->d_idx_scratch);
+    c->d_idx_scratch = nullptr;
+    c->idx_scratch_cap = 0;
+    IDXCHK(hipMalloc(&c->d_idx_scratch, need));
+    c->idx_scratch_cap = need;
   }
-  IDXCHK(hipMalloc((void **)&c->d_sorted, std::max<size_t>(n, 1) * D * sizeof(double)));
-  hipLaunchKernelGGL((k_scatter<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n,
-                     d_keys, d_hist, c->d_sorted);
+  uint32_t *k_in = (uint32_t *)c->d_idx_scratch, *v_in = k_in + words, *k_out = v_in + words,
+           *v_out = k_out + words;
+  void *tmp = (void *)(v_out + words);
+  const unsigned gn = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL((k_keys<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n, g, k_in, v_in);
   IDXCHK(hipGetLastError());
-  c->n_sorted = ns32;
+  IDXCHK(sort_pairs_u32(tmp, &tmp_bytes, k_in, k_out, v_in, v_out, n, (unsigned)(bits * D + 1), c->stream));
+  IDXCHK(hipMalloc((void **)&c->d_sorted, std::max<size_t>(n, 1) * D * sizeof(double)));
+  c->n_sorted = n - (size_t)hb.nonfinite;  // the non-finite records carry the largest key: they sort to the tail
   c->n_cells = (uint32_t)((c->n_sorted + cell_pts - 1) / cell_pts);
   IDXCHK(hipMalloc((void **)&c->d_boxes, std::max<size_t>(c->n_cells, 1) * sizeof(CellBox)));
   if (c->n_cells) {
-    hipLaunchKernelGGL((k_cell_boxes<D>), dim3((c->n_cells + 3) / 4), dim3(256), 0, c->stream,
-                       c->d_sorted, c->n_sorted, c->n_cells, cell_pts, c->d_boxes);
+    hipLaunchKernelGGL((k_gather_boxes<D>), dim3((c->n_cells + 3) / 4), dim3(256), 0, c->stream, c->d_data,
+                       c->stride, v_out, c->n_sorted, c->n_cells, cell_pts, c->d_sorted, c->d_boxes);
     IDXCHK(hipGetLastError());
   }
-  IDXCHK(hipStreamSynchronize(c->stream));
-  cleanup();
 #undef IDXCHK
   c->index_valid = true;
   return LSQR_OK;
@@ -730,10 +754,18 @@ int run_scan(lsqr_ctx *c) {
         // two-level scan over the spatial index; auto: built once an upload has seen enough
         // hypotheses to pay for the build (a few HBM passes)
         const bool tuned_defaults = c->opt_filter == 1 && c->opt_ppl == 0;  // A/B knobs untouched
+        // Cost model of the build (auto mode).  Per (hypothesis, observation) the exhaustive filter kernel costs
+        // ~1.9e-13 s and the two-level scan ~0.3e-13 s (10 M points x 4096 hypotheses: 7.6 ms against 1.3 ms);
+        // the build costs ~0.7e-10 s per observation (radix sort + gather).  It pays for itself once
+        //   hypotheses still to come  >  0.7e-10 / 1.6e-13  ~  450,
+        // and "still to come" is estimated by the larger of what the caller announced (lsqr_ransac: the current
+        // numTries bound) and what this upload has been asked to scan so far, this batch included.
+        constexpr uint64_t kIndexPaysAfter = 512;
+        const uint64_t to_come = std::max<uint64_t>(c->hyp_expected, c->hyp_since_upload);
         const bool want = c->opt_filter && f32_ok && c->mc.absmax >= 1e-10 && !c->index_failed &&
                           (c->opt_index == 2 ||
                            (c->opt_index == 1 && tuned_defaults &&
-                            (c->index_valid || (c->n >= 65536 && c->hyp_since_upload >= 2048))));
+                            (c->index_valid || (c->n >= 65536 && to_come >= kIndexPaysAfter))));
         if (want) {
           const uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : (uint32_t)CM::DEFAULT_CELL;
           bool usable = true;
@@ -1045,12 +1077,14 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           // result lands in pinned host memory and the host polls its sequence flag (no stream synchronisation,
           // no staging copies): per evaluation = the pass + one launch latency + a few hundred host flops
           size_t cnt = c->n;
-          int nb = grid_for(cnt, kBlock * 4, kMaxPartials);
+          int nb = grid_for(cnt, kBlock * 8, kMaxPartials);
           size_t chunk = (cnt + nb - 1) / nb;
           chunk = (chunk + kBlock - 1) / kBlock * kBlock;
           nb = (int)((cnt + chunk - 1) / chunk);
           if (nb < 1) nb = 1;
           volatile double *res = c->h_lmres;
+          // the ticket word is zeroed per fit (an aborted launch must not poison the next one)
+          HIPCHK(c, hipMemsetAsync(c->d_counter + 7, 0, sizeof(unsigned long long), c->stream));
           for (;;) {
             LmX xk;
             for (int j = 0; j < LM_NMAX; j++) xk.x[j] = j < n ? s.xtrial[j] : 0.0;
@@ -1285,6 +1319,7 @@ unsigned int cast_tries(double x) {
 }
 
 enum { RS_I = 0, RS_TRIES = 1, RS_BEST = 2, RS_BEST_IDX = 3, RS_HAS = 4, RS_DONE = 5 };
+inline bool has_any_best(const uint64_t *rs) { return rs[RS_HAS] != 0; }
 
 }  // namespace
 
@@ -1357,7 +1392,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   drop_index(c);
-  void *bufs[] = {c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -1465,6 +1500,7 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->has_model = true;
   drop_index(c);
   c->absmax_valid = false;
+  c->bounds_valid = false;
   c->rows_valid = false;
   c->H = 0;
   c->scanned = false;
@@ -1481,10 +1517,12 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   if (count > 0xFFFFFFF0ull) return fail(c, LSQR_ERR_INVALID, "too many observations");
   c->n = count;
   c->absmax_valid = false;
+  c->bounds_valid = false;
   c->rows_valid = false;
   drop_index(c);
   c->index_failed = false;
   c->hyp_since_upload = 0;
+  c->hyp_expected = 0;
   c->stride = stride_bytes / sizeof(double);
   c->H = 0;
   c->scanned = false;
@@ -2191,6 +2229,9 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
       st = lsqr_hypotheses_sample(c, seed, base, H, nullptr);
     }
     if (st != LSQR_OK) return st;
+    // what the adaptive bound still asks for (saturated: a poor start leaves it at C(N,k)); the index build
+    // heuristic weighs it against the cost of the build
+    c->hyp_expected = has_any_best(rs) ? std::min<uint64_t>(rs[RS_TRIES] - base, 1u << 20) : 0;
     if ((st = lsqr_scan(c)) != LSQR_OK) return st;
     if (!subsets)
       HIPCHK(c, hipMemcpyAsync(p_sub, c->d_subsets, H * k * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -2214,6 +2255,7 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     if (!rs[RS_HAS] && base >= (1ull << 22)) break;
     if (c->opt_max_iter > 0 && base >= (uint64_t)c->opt_max_iter) break;  // caller's budget
   }
+  c->hyp_expected = 0;
   info->iterations = rs[RS_I];
   info->best_index = rs[RS_BEST_IDX];
   return finish_ransac(c, rs[RS_HAS] != 0, (uint32_t)rs[RS_BEST], params_out,
