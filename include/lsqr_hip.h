@@ -194,7 +194,8 @@ LSQR_API int lsqr_winner_moments(lsqr_ctx *ctx, uint64_t seed, uint64_t stream_i
                                  size_t end, double *params_out, double *origin_out,
                                  double *block_out, uint64_t *count_out);
 /* lsqr_moments with the block left in device memory and no synchronisation (the caller all-reduces it in
- * place on the context's stream, see lsqr_set_stream, and reads it back once). */
+ * place on the context's stream, see lsqr_set_stream, and reads it back once).  x is staged in one of four
+ * pinned slots, each guarded by an event: calls may be issued back to back. */
 LSQR_API int lsqr_moments_dev(lsqr_ctx *ctx, int use_mask, size_t begin, size_t end, int phase,
                               const double *x, double *block_dev);
 /* Levenberg-Marquardt over summed phase-1 blocks (MINPACK lmder control flow on the device):
@@ -276,6 +277,32 @@ LSQR_API int lsqr_step_finish_enqueue(lsqr_ctx *ctx, const uint64_t *packed_dev,
                                       int slot);
 LSQR_API int lsqr_step_finish_wait(lsqr_ctx *ctx, int slot, double *winner_out, double *params_out,
                                    lsqr_ransac_info *info);
+/* ---- several devices from one process ------------------------------------------------------------------
+ * north_star: "hypothesis batches shard trivially across the 8 GPUs of one node".  One lsqr_ctx per entry of
+ * `devices` (an entry may repeat: several contexts on one device -- the tests run two on the box's one GPU).
+ * Observations are uploaded to the first device once and replicated device-to-device (peer copies: xGMI inside a
+ * node); a batch of n * H hypotheses is scanned in n contiguous slices; the earliest best hypothesis is picked by
+ * a max over the packed (votes, ~index) words and its consensus mask + moment block are taken slice-wise and
+ * summed in rank order -- both exchanges are peer copies into the first device's gather area (8 B and <= 17 KB:
+ * latency-bound either way) followed by a reduction kernel there; between PROCESSES (bench.py --gpus N, one rank
+ * per GPU) the same two exchanges are RCCL all-reduces.  Results: winner, consensus set and iteration count equal
+ * the single-device entry points bit for bit; the final fit agrees to rounding (different summation tree). */
+typedef struct lsqr_multi lsqr_multi;
+LSQR_API int lsqr_multi_create(const int *devices, int n, lsqr_multi **out);
+LSQR_API void lsqr_multi_destroy(lsqr_multi *m);
+LSQR_API int lsqr_multi_size(const lsqr_multi *m);
+LSQR_API lsqr_ctx *lsqr_multi_ctx(lsqr_multi *m, int rank); /* per-device options / profiling */
+LSQR_API const char *lsqr_multi_last_error(const lsqr_multi *m);
+LSQR_API int lsqr_multi_set_model(lsqr_multi *m, const lsqr_model_cfg *cfg);
+LSQR_API int lsqr_multi_upload(lsqr_multi *m, const void *host_records, size_t count, size_t stride_bytes);
+/* lsqr_batch_fit over n devices: hypotheses [first, first + n * H_per_device) of the stream; info->best_index is
+ * the stream index of the winner */
+LSQR_API int lsqr_multi_batch_fit(lsqr_multi *m, uint64_t seed, uint64_t first_index, size_t H_per_device,
+                                  double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info);
+/* lsqr_ransac (RANSAC<T,S>::compute, probabilistic overload) over n devices, device sampler stream `seed` */
+LSQR_API int lsqr_multi_ransac(lsqr_multi *m, double p, uint64_t seed, double *params_out,
+                               uint8_t *consensus_out, lsqr_ransac_info *info);
+
 /* Exhaustive overload (RANSAC.h:111-113): all C(N,k) subsets in lexicographic order. */
 LSQR_API int lsqr_ransac_exhaustive(lsqr_ctx *ctx, double *params_out, uint8_t *consensus_out,
                                     lsqr_ransac_info *info);

@@ -102,6 +102,17 @@ SIGNATURES = {
                                  C.POINTER(RansacInfo)]),
     "lsqr_batch_fit_enqueue": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]),
     "lsqr_batch_fit_wait": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.POINTER(RansacInfo)]),
+    "lsqr_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "lsqr_multi_destroy": (None, [C.c_void_p]),
+    "lsqr_multi_size": (C.c_int, [C.c_void_p]),
+    "lsqr_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lsqr_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "lsqr_multi_set_model": (C.c_int, [C.c_void_p, C.POINTER(ModelCfg)]),
+    "lsqr_multi_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lsqr_multi_batch_fit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.POINTER(RansacInfo)]),
+    "lsqr_multi_ransac": (C.c_int, [C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p,
+                                    C.POINTER(RansacInfo)]),
     "lsqr_ransac_exhaustive": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.POINTER(RansacInfo)]),
     "lsqr_replay_init": (C.c_int, [C.c_size_t, C.c_int, C.c_double, _u64p]),
     "lsqr_replay": (C.c_size_t, [C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_void_p,

@@ -331,6 +331,83 @@ class Context:
         self._chk(self._lib.lsqr_synchronize(self._h))
 
 
+class MultiContext:
+    """Several devices from one process (lsqr_multi_*): the hypothesis stream sharded over one lsqr_ctx per entry
+    of `devices`, exchanges by peer copies.  devices=[0, 0] puts two contexts on one GPU (tests)."""
+
+    def __init__(self, devices):
+        self._lib = L.load()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        st = self._lib.lsqr_multi_create(arr, len(devices), C.byref(h))
+        if st != L.OK:
+            raise L.LsqrError(st, "lsqr_multi_create(%s): %s" % (list(devices), self._lib.lsqr_status_string(st).decode()))
+        self._h = h
+        self.size = len(devices)
+        self.cfg = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsqr_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, st, allow_empty=False):
+        if st == L.OK or (allow_empty and st == L.EMPTY):
+            return st
+        raise L.LsqrError(st, "%s (%s)" % (self._lib.lsqr_status_string(st).decode(),
+                                           self._lib.lsqr_multi_last_error(self._h).decode()))
+
+    def set_model(self, model, dim=3, delta=0.5, ls_type=L.LS_GEOMETRIC, aux=0.0):
+        self.cfg = L.ModelCfg(int(model), int(dim), float(delta), int(ls_type), 0, float(aux))
+        self._chk(self._lib.lsqr_multi_set_model(self._h, C.byref(self.cfg)))
+        self.P = self._lib.lsqr_num_params(C.byref(self.cfg))
+        return self
+
+    def upload(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float64)
+        a = a.reshape(-1, a.shape[-1])
+        self._chk(self._lib.lsqr_multi_upload(self._h, L.ptr(a), a.shape[0], a.shape[1] * 8))
+        self.n = a.shape[0]
+        return self
+
+    def set_option(self, name, value):
+        for r in range(self.size):
+            c = self._lib.lsqr_multi_ctx(self._h, r)
+            st = self._lib.lsqr_set_option(C.c_void_p(c), name.encode(), int(value))
+            if st != L.OK:
+                raise L.LsqrError(st, "lsqr_set_option(%s)" % name)
+
+    def batch_fit(self, seed, first, H, want_consensus=False):
+        out = np.zeros(max(self.P, 64))
+        cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None
+        info = L.RansacInfo()
+        st = self._chk(self._lib.lsqr_multi_batch_fit(self._h, seed, first, H, L.ptr(out), L.ptr(cons),
+                                                      C.byref(info)), allow_empty=True)
+        return dict(status=st, fraction=info.fraction,
+                    params=out[:info.n_params].copy() if st == L.OK else np.zeros(0),
+                    consensus=cons[:self.n] if cons is not None else None, info=info)
+
+    def ransac(self, p, seed=1, want_consensus=True):
+        out = np.zeros(max(self.P, 64))
+        cons = np.zeros(max(self.n, 1), dtype=np.uint8) if want_consensus else None
+        info = L.RansacInfo()
+        st = self._lib.lsqr_multi_ransac(self._h, float(p), seed, L.ptr(out), L.ptr(cons), C.byref(info))
+        if st == L.ERR_INVALID and info.iterations == 0:
+            return dict(status=st, fraction=0.0, params=None, consensus=None, info=info)
+        self._chk(st, allow_empty=True)
+        return dict(status=st, fraction=info.fraction,
+                    params=out[:info.n_params].copy() if st == L.OK else np.zeros(0),
+                    consensus=cons[:self.n] if (cons is not None and info.best_votes > 0) else None, info=info)
+
+
 def replay(n, k, p, subsets, valid, votes, dedup=True):
     """Host replay of RANSAC.hxx:49-117 over one batch (exposed for tests)."""
     lib = L.load()

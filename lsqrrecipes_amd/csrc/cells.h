@@ -755,14 +755,23 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
           const float btin = LDSB ? btin_l
                                   : __builtin_bit_cast(float, __builtin_amdgcn_readlane(
                                                                   __builtin_bit_cast(int, bc[NB - 2]), b));
-          unsigned long long in[2 * PP], amb = 0;
+          // Does any observation sit in the band tin <= |v| < tout?  One ballot instead of one per value: the
+          // smallest NON-NEGATIVE difference |v| - tin of the lane, found as the unsigned minimum of the bit patterns
+          // (a negative difference -- a certain inlier -- has its sign bit set and looks huge; a NaN row looks
+          // larger than any finite number), against fl(tout - tin).  Conservative: rounding is monotone, so
+          // tin <= |v| < tout implies fl(|v| - tin) <= fl(tout - tin); flagging |v| == tout too only costs a re-check.
+          unsigned long long in[2 * PP];
+          uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
           for (int p = 0; p < PP; p++) {
-            in[2 * p] = __ballot(__builtin_fabsf(s[p].x) < btin);
-            in[2 * p + 1] = __ballot(__builtin_fabsf(s[p].y) < btin);
-            amb |= (in[2 * p] ^ __ballot(__builtin_fabsf(s[p].x) < btout)) |
-                   (in[2 * p + 1] ^ __ballot(__builtin_fabsf(s[p].y) < btout));
+            const float ax = __builtin_fabsf(s[p].x), ay = __builtin_fabsf(s[p].y);
+            in[2 * p] = __ballot(ax < btin);
+            in[2 * p + 1] = __ballot(ay < btin);
+            const uint32_t dx = __builtin_bit_cast(uint32_t, ax - btin), dy = __builtin_bit_cast(uint32_t, ay - btin);
+            dmin = dx < dmin ? dx : dmin;
+            dmin = dy < dmin ? dy : dmin;
           }
+          const unsigned long long amb = __ballot(dmin <= __builtin_bit_cast(uint32_t, btout - btin));
           if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
             const double *hp = sp + (size_t)(h0 + b) * SPD;  // wave-uniform -> scalar loads
 #pragma unroll

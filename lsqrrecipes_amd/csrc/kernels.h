@@ -456,11 +456,80 @@ __global__ __launch_bounds__(kBlock) void k_mask_moments(const double *__restric
   }
 }
 
-// One Levenberg-Marquardt evaluation in ONE launch: the (masked) reduction of k_moments<M, AccLm<M>> at the trial
-// point `xk` -- passed BY VALUE, so consecutive evaluations need no staging copy -- and, in the block that
-// finishes last, the fixed-order sum of all block partials, written to `out` (host-mapped pinned memory: the host's
-// MINPACK control flow polls out[nmom] for `seq` instead of synchronising the stream; device memory works too).
-// The order of the final sum depends only on the grid, not on which block happens to be last: deterministic.
+// ---- stable compaction of the consensus set (before an iterative fit) ---------------------------------------
+// An iterative fit passes over the SAME consensus set once per evaluation (sphere: ~15 times, the US calibration
+// with the reference's tolerances: up to 5000 times).  Reading it through the mask touches every cache line of the
+// upload (24 B to 144 B records, ~40-50 % of them agreeing: no line is skipped), so the set is first copied, in
+// order, into a tight buffer: every later pass reads n_in * sizeof(record) bytes, coalesced, with all lanes busy.
+//   k_compact_count   block b counts the set bytes of mask[b * chunk, (b + 1) * chunk)
+//   k_compact_scan    exclusive prefix over the (<= 1024) block counts, total -> offs[nb]
+//   k_compact_write   block b writes its agreeing records, in order, from offs[b] on
+__global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restrict__ mask, size_t n, size_t chunk,
+                                                          uint32_t *__restrict__ counts) {
+  __shared__ uint32_t s_c[kBlock / 64];
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  uint32_t c = 0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) c += mask[i] ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+__global__ __launch_bounds__(1024) void k_compact_scan(const uint32_t *__restrict__ counts, int nb,
+                                                       uint32_t *__restrict__ offs) {
+  __shared__ uint32_t s[1024];
+  const int t = threadIdx.x;
+  const uint32_t v = t < nb ? counts[t] : 0u;
+  s[t] = v;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t a = t >= o ? s[t - o] : 0u;
+    __syncthreads();
+    s[t] += a;
+    __syncthreads();
+  }
+  if (t < nb) offs[t] = s[t] - v;
+  if (t == 0) offs[nb] = s[nb > 0 ? nb - 1 : 0];
+}
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_compact_write(const double *__restrict__ data, size_t stride,
+                                                          const uint8_t *__restrict__ mask, size_t n, size_t chunk,
+                                                          const uint32_t *__restrict__ offs,
+                                                          double *__restrict__ dst) {
+  __shared__ uint32_t s_w[kBlock / 64];
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  size_t base = offs[blockIdx.x];
+  for (size_t i0 = lo; i0 < hi; i0 += kBlock) {
+    const size_t i = i0 + threadIdx.x;
+    const bool m = i < hi && mask[i];
+    const unsigned long long b = __ballot(m);
+    const uint32_t before = (uint32_t)__builtin_popcountll(b & ((1ULL << lane) - 1ULL));
+    if (lane == 0) s_w[wave] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+      if (w < wave) woff += s_w[w];
+      tot += s_w[w];
+    }
+    if (m) {
+      const double *src = data + i * stride;
+      double *d = dst + (base + woff + before) * (size_t)ND;
+#pragma unroll
+      for (int k = 0; k < ND; k++) d[k] = src[k];
+    }
+    base += tot;
+    __syncthreads();
+  }
+}
+
+// One Levenberg-Marquardt evaluation without a host synchronisation: k_lm_pass is the (masked) reduction of
+// k_moments<M, AccLm<M>> at the trial point `xk` -- passed BY VALUE, so consecutive evaluations need no staging
+// copy -- and k_lm_publish, next on the stream, sums the block partials (one wave per moment, in parallel across
+// the chip: a few microseconds; summing them in the last-arriving block of the pass itself was measured at
+// 30-40 us of serial tail) and PUBLISHES the block to host-visible pinned memory: the wave that draws the last
+// ticket writes the sequence flag the host's MINPACK control flow polls.  The kernel boundary makes the partials
+// visible; the order of every sum depends only on the grid: deterministic.
 struct LmX {
   double x[LM_NMAX];
 };
@@ -468,11 +537,9 @@ template <class M, bool USE_MASK>
 __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ data, size_t stride,
                                                     size_t begin, size_t end, size_t chunk,
                                                     const uint8_t *__restrict__ mask, LmX xk, ModelConsts mc,
-                                                    double *__restrict__ partials,
-                                                    unsigned int *__restrict__ ticket,
-                                                    double *__restrict__ out, double seq) {
+                                                    double *__restrict__ partials) {
   constexpr int N = M::NMOM_LM;
-  __shared__ double s_m[kBlock / 64][N];  // the only LDS object (the reducer flag reuses its first word)
+  __shared__ double s_m[kBlock / 64][N];
   double acc[N];
 #pragma unroll
   for (int k = 0; k < N; k++) acc[k] = 0.0;
@@ -502,44 +569,29 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
-  // Hand-off to the last-arriving block (cdna_hip_programming.md, Guideline 16 / in-launch split-K reduction): the
-  // block's partial is stored WRITE-THROUGH (relaxed agent-scope atomic stores = sc1: no release fence, which would
-  // write back the XCD's L2 once per block), every storing wave drains its stores, ONE lane draws the ticket; the
-  // block that draws the last ticket does ONE agent-scope acquire (drops its CU's stale L1 lines) and then reads
-  // all partials with plain vector loads.
   if (threadIdx.x < N) {
     double t = 0.0;
     for (int w = 0; w < kBlock / 64; w++) t += s_m[w][threadIdx.x];
-    __hip_atomic_store(&partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x], t, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x] = t;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // s_m has been consumed: its first word now carries the "I am last" flag
-  unsigned int *s_flag = (unsigned int *)&s_m[0][0];
-  if (threadIdx.x == 0) {
-    const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = prev == gridDim.x - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *s_flag = last ? 1u : 0u;
-  }
-  __syncthreads();
-  if (*s_flag == 0u) return;
-  // the last block: wave w sums moments w, w + 4, ... over the blocks (lane-strided, then a shuffle tree)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = wave; k < N; k += kBlock / 64) {
-    double t = 0.0;
-    for (unsigned b = lane; b < gridDim.x; b += 64) t += partials[(size_t)b * MOM_MAX + k];
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
-    if (lane == 0) out[k] = t;
-  }
-  __threadfence_system();  // the sums (host-visible memory) before the sequence flag
-  __syncthreads();
-  if (threadIdx.x == 0) {
+}
+
+// grid = nmom blocks of one wave.  out: host-visible (or device) buffer of nmom + 1 doubles, out[nmom] = seq flag.
+__global__ __launch_bounds__(64) void k_lm_publish(const double *__restrict__ partials, int nblocks, int nmom,
+                                                   unsigned int *__restrict__ ticket, double *__restrict__ out,
+                                                   double seq) {
+  const int k = blockIdx.x;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) t += partials[(size_t)b * MOM_MAX + k];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if (threadIdx.x != 0) return;
+  out[k] = t;
+  __threadfence_system();  // this sum is visible (host memory) before the ticket says so
+  const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev == (unsigned int)nmom - 1u) {
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next evaluation (stream order)
-    __hip_atomic_store(&out[N], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&out[nmom], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

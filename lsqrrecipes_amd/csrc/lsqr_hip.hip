@@ -54,6 +54,7 @@ struct lsqr_ctx {
   double *d_sorted = nullptr;
   uint32_t *d_queues = nullptr;  // work-queue counters of k_scan_cells
   CellBox *d_boxes = nullptr;
+  size_t sorted_cap = 0, boxes_cap = 0;  // doubles / boxes allocated
   size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
@@ -76,6 +77,8 @@ struct lsqr_ctx {
   hipEvent_t slot_ev[2] = {nullptr, nullptr};  // lsqr_batch_fit_enqueue / _wait
   uint64_t slot_first[2] = {0, 0}, slot_H[2] = {0, 0};
   bool slot_busy[2] = {false, false};
+  hipEvent_t mdev_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // lsqr_moments_dev: staging slots of x
+  unsigned mdev_next = 0;
   hipEvent_t step_ev[2] = {nullptr, nullptr};  // lsqr_step_finish_enqueue / _wait
   bool step_busy[2] = {false, false};
 
@@ -100,6 +103,8 @@ struct lsqr_ctx {
   int opt_fuse_mask = 1;  // winner's mask + moment block in one pass (0: two kernels, for A/B runs)
   long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
+  double *d_lmrec = nullptr;  // consensus set copied tight and in order for the iterative fits (k_compact_*)
+  size_t lmrec_cap = 0;
   double *h_lmres = nullptr;  // pinned, device-visible: {moment block, sequence flag} written by k_lm_pass
   double lm_seq = 0.0;        // sequence number of the last evaluation (the flag value the host polls for)
   int opt_lm_fused = 1;       // 1: one launch per LM evaluation, result polled in pinned memory; 0: r01 path
@@ -465,14 +470,20 @@ struct CellOf<LineModel<D>> {
 };
 
 // ---- spatial index (cells.h) ------------------------------------------------------------------------
+// invalidates the index; its buffers are kept (a later upload of similar size rebuilds into them: hipMalloc /
+// hipFree of a few hundred MB cost milliseconds, several times the build's 0.65 ms of kernel time)
 void drop_index(lsqr_ctx *c) {
+  c->n_sorted = 0;
+  c->n_cells = 0;
+  c->index_valid = false;
+}
+void free_index(lsqr_ctx *c) {
   if (c->d_sorted) (void)hipFree(c->d_sorted);
   if (c->d_boxes) (void)hipFree(c->d_boxes);
   c->d_sorted = nullptr;
   c->d_boxes = nullptr;
-  c->n_sorted = 0;
-  c->n_cells = 0;
-  c->index_valid = false;
+  c->sorted_cap = c->boxes_cap = 0;
+  drop_index(c);
 }
 
 // k_bounds over the current upload (point models): min / max per dimension, max |coordinate|, non-finite count
@@ -499,7 +510,6 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   c->cell_pts = cell_pts;
   if (getenv("LSQR_TEST_FAIL_INDEX"))  // test hook: behave as if the sorted copy could not be allocated
     return fail(c, LSQR_ERR_HIP, "index build failure requested by LSQR_TEST_FAIL_INDEX");
-  ProfScope ps(c, KID_INDEX);
   const size_t n = c->n;
 #define IDXCHK(call)                                                                          \
   do {                                                                                        \
@@ -510,7 +520,7 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
                   __FILE__, __LINE__);                                                        \
     }                                                                                         \
   } while (0)
-  int st = run_bounds<D>(c);
+  int st = run_bounds<D>(c);  // (usually already there: the fp32 filters asked for max |x| when the hypotheses came)
   if (st != LSQR_OK) return st;
   const BoundsRow &hb = c->h_bounds;
   if (hb.mn[0] == ~0ULL) {  // no finite record at all: nothing can agree
@@ -548,6 +558,12 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
     IDXCHK(hipMalloc(&c->d_idx_scratch, need));
     c->idx_scratch_cap = need;
   }
+  if ((st = ensure(c, &c->d_sorted, &c->sorted_cap, std::max<size_t>(n, 1) * D)) != LSQR_OK) return st;
+  const size_t n_sorted = n - (size_t)hb.nonfinite;  // the non-finite records carry the largest key: they sort to the tail
+  const uint32_t n_cells = (uint32_t)((n_sorted + cell_pts - 1) / cell_pts);
+  if ((st = ensure(c, &c->d_boxes, &c->boxes_cap, std::max<size_t>(n_cells, 1))) != LSQR_OK) return st;
+  // every buffer is in place (kept across uploads): from here on the build is device work only
+  ProfScope ps(c, KID_INDEX);
   uint32_t *k_in = (uint32_t *)c->d_idx_scratch, *v_in = k_in + words, *k_out = v_in + words,
            *v_out = k_out + words;
   void *tmp = (void *)(v_out + words);
@@ -555,10 +571,8 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   hipLaunchKernelGGL((k_keys<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n, g, k_in, v_in);
   IDXCHK(hipGetLastError());
   IDXCHK(sort_pairs_u32(tmp, &tmp_bytes, k_in, k_out, v_in, v_out, n, (unsigned)(bits * D + 1), c->stream));
-  IDXCHK(hipMalloc((void **)&c->d_sorted, std::max<size_t>(n, 1) * D * sizeof(double)));
-  c->n_sorted = n - (size_t)hb.nonfinite;  // the non-finite records carry the largest key: they sort to the tail
-  c->n_cells = (uint32_t)((c->n_sorted + cell_pts - 1) / cell_pts);
-  IDXCHK(hipMalloc((void **)&c->d_boxes, std::max<size_t>(c->n_cells, 1) * sizeof(CellBox)));
+  c->n_sorted = n_sorted;
+  c->n_cells = n_cells;
   if (c->n_cells) {
     hipLaunchKernelGGL((k_gather_boxes<D>), dim3((c->n_cells + 3) / 4), dim3(256), 0, c->stream, c->d_data,
                        c->stride, v_out, c->n_sorted, c->n_cells, cell_pts, c->d_sorted, c->d_boxes);
@@ -1076,7 +1090,29 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           // one launch per evaluation: trial point by value, block sums + final sum in the same kernel, the
           // result lands in pinned host memory and the host polls its sequence flag (no stream synchronisation,
           // no staging copies): per evaluation = the pass + one launch latency + a few hundred host flops
-          size_t cnt = c->n;
+          // the consensus set, tight and in order (every evaluation then streams n_in records, all lanes busy)
+          const double *lm_data = c->d_data;
+          size_t lm_stride = c->stride, cnt = c->n;
+          if (use_mask) {
+            int cb = grid_for(c->n, kBlock * 8, 1024);
+            size_t cchunk = (c->n + cb - 1) / cb;
+            cchunk = (cchunk + kBlock - 1) / kBlock * kBlock;
+            cb = (int)((c->n + cchunk - 1) / cchunk);
+            uint32_t *d_cnt = (uint32_t *)c->d_partials, *d_off = d_cnt + 1024;  // scratch (4.4 MB buffer)
+            ProfScope ps(c, KID_MASK);
+            hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(kBlock), 0, c->stream, c->d_mask, c->n, cchunk, d_cnt);
+            hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, d_cnt, cb, d_off);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(pin + 200, d_off + cb, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            cnt = *(const uint32_t *)(pin + 200);
+            if ((st = ensure(c, &c->d_lmrec, &c->lmrec_cap, std::max<size_t>(cnt, 1) * M::ND)) != LSQR_OK) return st;
+            hipLaunchKernelGGL((k_compact_write<M::ND>), dim3(cb), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
+                               c->d_mask, c->n, cchunk, d_off, c->d_lmrec);
+            HIPCHK(c, hipGetLastError());
+            lm_data = c->d_lmrec;
+            lm_stride = M::ND;
+          }
           int nb = grid_for(cnt, kBlock * 8, kMaxPartials);
           size_t chunk = (cnt + nb - 1) / nb;
           chunk = (chunk + kBlock - 1) / kBlock * kBlock;
@@ -1089,18 +1125,24 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             LmX xk;
             for (int j = 0; j < LM_NMAX; j++) xk.x[j] = j < n ? s.xtrial[j] : 0.0;
             const double seq = (c->lm_seq += 1.0);
+            // profiling: every 16th evaluation carries event pairs (four event records per evaluation would cost
+            // more host time than the evaluation's own launches); lsqr_profile_get's averages are unaffected
+            const bool timed = c->prof && (s.nfev & 15) == 0;
+            const bool prof_saved = c->prof;
+            c->prof = timed;
             {
               ProfScope ps(c, KID_MOMENTS);
-              if (use_mask)
-                hipLaunchKernelGGL((k_lm_pass<M, true>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
-                                   c->stride, (size_t)0, c->n, chunk, c->d_mask, xk, c->mc, c->d_partials,
-                                   (unsigned int *)(c->d_counter + 7), c->h_lmres, seq);
-              else
-                hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data,
-                                   c->stride, (size_t)0, c->n, chunk, c->d_mask, xk, c->mc, c->d_partials,
-                                   (unsigned int *)(c->d_counter + 7), c->h_lmres, seq);
+              hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
+                                 (size_t)0, cnt, chunk, (const uint8_t *)nullptr, xk, c->mc, c->d_partials);
               HIPCHK(c, hipGetLastError());
             }
+            {
+              ProfScope ps(c, KID_SOLVE);
+              hipLaunchKernelGGL(k_lm_publish, dim3((unsigned)M::NMOM_LM), dim3(64), 0, c->stream, c->d_partials, nb,
+                                 (int)M::NMOM_LM, (unsigned int *)(c->d_counter + 7), c->h_lmres, seq);
+              HIPCHK(c, hipGetLastError());
+            }
+            c->prof = prof_saved;
             unsigned long long spins = 0;
             while (res[M::NMOM_LM] != seq) {
               if ((++spins & 0xFFFF) == 0) {  // every 65 k polls: is the stream still alive?
@@ -1391,8 +1433,8 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  drop_index(c);
-  void *bufs[] = {c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  free_index(c);
+  void *bufs[] = {c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -1409,6 +1451,8 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (hipEvent_t e : c->slot_ev)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->step_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->mdev_ev)
     if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1839,9 +1883,15 @@ int lsqr_moments_dev(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int ph
   if (begin > end || end > c->n || !block_dev) return fail(c, LSQR_ERR_INVALID, "bad range");
   if (use_mask && !c->mask_valid) return fail(c, LSQR_ERR_STATE, "no mask on the device");
   if (!x) return fail(c, LSQR_ERR_INVALID, "moments need an origin / evaluation point");
-  double *pin = (double *)((char *)c->h_pin + 57344);  // x staged in pinned memory: the copy stays asynchronous
+  // x staged in pinned memory (the copy stays asynchronous): four slots in rotation, each guarded by an event, so
+  // that a call issued before an earlier call's copy has executed cannot overwrite that copy's source
+  const int slot = c->mdev_next++ & 3;
+  if (!c->mdev_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->mdev_ev[slot], hipEventDisableTiming));
+  else HIPCHK(c, hipEventSynchronize(c->mdev_ev[slot]));
+  double *pin = (double *)((char *)c->h_pin + 57344 + slot * 512);
   memcpy(pin, x, sizeof(double) * 32);
   HIPCHK(c, hipMemcpyAsync(c->d_vec, pin, sizeof(double) * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->mdev_ev[slot], c->stream));
   int nmom = 0;
   st = dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
@@ -2636,6 +2686,397 @@ int lsqr_step_finish(lsqr_ctx *c, const uint64_t *packed_dev, const double *bloc
   int st = lsqr_step_finish_enqueue(c, packed_dev, block_dev, 0);
   if (st != LSQR_OK) return st;
   return lsqr_step_finish_wait(c, 0, winner_out, params_out, info);
+}
+
+// ---- several devices from ONE process (lsqr_hip.h: lsqr_multi_*) ------------------------------------------------
+// The hypothesis stream is sharded over n contexts, one per listed device, exactly as bench.py's ranks shard it
+// (lsqr_step_scan / _winner / _finish per context); the two exchanges of a step -- 8 B winner, <= 17 KB moment
+// block -- are peer copies into rank 0's gather area (hipMemcpyPeerAsync: xGMI between GPUs of a node), a
+// fixed-order reduction kernel there, and a peer copy of the winner back.  Streams are chained with events; the
+// host synchronises once per step.  (Between PROCESSES the same exchanges are RCCL all-reduces: distributed.py.)
+}  // extern "C"
+
+namespace {
+constexpr int kMultiBlk = 2304;  // >= dense_ne(64) + 1 + count, in doubles
+
+__global__ void k_multi_max(const unsigned long long *__restrict__ g, int n, unsigned long long *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long b = 0;
+  for (int r = 0; r < n; r++) b = g[r] > b ? g[r] : b;
+  *out = b;
+}
+__global__ void k_multi_sum(const double *__restrict__ g, int n, int len, int pitch, double *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= len) return;
+  double t = 0.0;
+  for (int r = 0; r < n; r++) t += g[(size_t)r * pitch + k];  // rank order: deterministic
+  out[k] = t;
+}
+}  // namespace
+
+struct lsqr_multi {
+  int n = 0;
+  std::vector<lsqr_ctx *> ctx;
+  std::vector<unsigned long long *> packed;  // per rank: the step's packed winner (device)
+  std::vector<double *> block;               // per rank: moment block + count (device)
+  unsigned long long *g_packed = nullptr;    // rank 0: gather areas
+  double *g_block = nullptr;
+  std::vector<hipEvent_t> ev;                // per rank: "my contribution has been sent"
+  hipEvent_t ev_root = nullptr;              // rank 0: "the reduced value is on its way back"
+  char err[512] = {0};
+};
+
+namespace {
+int mfail(lsqr_multi *m, int st, const char *what, lsqr_ctx *c = nullptr) {
+  if (m) snprintf(m->err, sizeof m->err, "%s%s%s", what, c ? ": " : "", c ? c->err : "");
+  return st;
+}
+#define MHIP(m, call)                                                                                     \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      snprintf((m)->err, sizeof(m)->err, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+               __LINE__);                                                                                 \
+      return LSQR_ERR_HIP;                                                                                \
+    }                                                                                                     \
+  } while (0)
+
+// every rank's `src[r]` (bytes) -> rank 0's gather area at r * pitch; rank 0's stream waits for all of them
+int multi_gather(lsqr_multi *m, const std::vector<const void *> &src, void *gather, size_t bytes, size_t pitch) {
+  lsqr_ctx *c0 = m->ctx[0];
+  for (int r = 0; r < m->n; r++) {
+    lsqr_ctx *c = m->ctx[r];
+    MHIP(m, hipSetDevice(c->device));
+    MHIP(m, hipMemcpyPeerAsync((char *)gather + (size_t)r * pitch, c0->device, src[r], c->device, bytes, c->stream));
+    if (r) {
+      MHIP(m, hipEventRecord(m->ev[r], c->stream));
+      MHIP(m, hipSetDevice(c0->device));
+      MHIP(m, hipStreamWaitEvent(c0->stream, m->ev[r], 0));
+    }
+  }
+  MHIP(m, hipSetDevice(c0->device));
+  return LSQR_OK;
+}
+
+// rank 0's `src` (bytes) -> every other rank's dst[r]; their streams wait for it
+int multi_bcast(lsqr_multi *m, const void *src, const std::vector<void *> &dst, size_t bytes) {
+  lsqr_ctx *c0 = m->ctx[0];
+  MHIP(m, hipSetDevice(c0->device));
+  for (int r = 1; r < m->n; r++)
+    MHIP(m, hipMemcpyPeerAsync(dst[r], m->ctx[r]->device, src, c0->device, bytes, c0->stream));
+  MHIP(m, hipEventRecord(m->ev_root, c0->stream));
+  for (int r = 1; r < m->n; r++) {
+    MHIP(m, hipSetDevice(m->ctx[r]->device));
+    MHIP(m, hipStreamWaitEvent(m->ctx[r]->stream, m->ev_root, 0));
+  }
+  MHIP(m, hipSetDevice(c0->device));
+  return LSQR_OK;
+}
+
+void slice_of(size_t n, int r, int w, size_t *lo, size_t *hi) {
+  *lo = n * (size_t)r / (size_t)w;
+  *hi = n * (size_t)(r + 1) / (size_t)w;
+}
+
+// winner known on every rank (packed[r] holds it, in-batch index relative to batch_first): masks of the slices,
+// summed moment block, final fit on rank 0 (LM fits: one summed block per evaluation), consensus slices to host
+int multi_finish(lsqr_multi *m, uint64_t seed, uint64_t batch_first, double *params_out, uint8_t *consensus_out,
+                 lsqr_ransac_info *info) {
+  const int n = m->n;
+  lsqr_ctx *c0 = m->ctx[0];
+  const int len = lsqr_moments_len(&c0->cfg, 0);
+  if (len + 1 > kMultiBlk) return mfail(m, LSQR_ERR_INVALID, "moment block too large");
+  std::vector<size_t> lo(n), hi(n);
+  std::vector<const void *> src(n);
+  int st;
+  for (int r = 0; r < n; r++) {
+    slice_of(c0->n, r, n, &lo[r], &hi[r]);
+    if ((st = lsqr_step_winner(m->ctx[r], seed, batch_first, (const uint64_t *)m->packed[r], lo[r], hi[r],
+                               m->block[r])) != LSQR_OK)
+      return mfail(m, st, "lsqr_step_winner", m->ctx[r]);
+    src[r] = m->block[r];
+  }
+  if ((st = multi_gather(m, src, m->g_block, sizeof(double) * (len + 1), sizeof(double) * kMultiBlk)) != LSQR_OK)
+    return st;
+  hipLaunchKernelGGL(k_multi_sum, dim3((len + 1 + 255) / 256), dim3(256), 0, c0->stream, m->g_block, n, len + 1,
+                     kMultiBlk, m->block[0]);
+  MHIP(m, hipGetLastError());
+  double winner[64], fit[64];
+  lsqr_ransac_info local;
+  if (!info) info = &local;
+  st = lsqr_step_finish(c0, (const uint64_t *)m->packed[0], m->block[0], winner, fit, info);  // synchronises rank 0
+  if (st != LSQR_OK && st != LSQR_EMPTY) return mfail(m, st, "lsqr_step_finish", c0);
+  info->fraction = c0->n ? (double)info->fit.n_used / (double)c0->n : 0.0;
+  if (info->evaluated == 0) return LSQR_EMPTY;  // no valid hypothesis
+  if (consensus_out)
+    for (int r = 0; r < n; r++) {
+      lsqr_ctx *c = m->ctx[r];
+      MHIP(m, hipSetDevice(c->device));
+      if (hi[r] > lo[r])
+        MHIP(m, hipMemcpyAsync(consensus_out + lo[r], c->d_mask + lo[r], hi[r] - lo[r], hipMemcpyDeviceToHost,
+                               c->stream));
+    }
+  if (st == LSQR_OK && wants_lm(c0->cfg) && c0->cfg.model != LSQR_MODEL_PHANTOM) {
+    // Levenberg-Marquardt over the sharded consensus set: per evaluation every rank reduces its slice at the trial
+    // point, the blocks are summed on rank 0, MINPACK's control flow runs there (lsqr_lm_begin / lsqr_lm_step)
+    const int n1 = lsqr_moments_len(&c0->cfg, 1);
+    double xt[64] = {0}, x0[64] = {0}, blk[LM_MOM_MAX + 8];
+    for (int j = 0; j < info->n_params && j < 64; j++) x0[j] = fit[j];
+    if ((st = lsqr_lm_begin(c0, x0, xt)) != LSQR_OK) return mfail(m, st, "lsqr_lm_begin", c0);
+    for (;;) {
+      for (int r = 0; r < n; r++) {
+        if ((st = lsqr_moments_dev(m->ctx[r], 1, lo[r], hi[r], 1, xt, m->block[r])) != LSQR_OK)
+          return mfail(m, st, "lsqr_moments_dev", m->ctx[r]);
+        src[r] = m->block[r];
+      }
+      if ((st = multi_gather(m, src, m->g_block, sizeof(double) * n1, sizeof(double) * kMultiBlk)) != LSQR_OK)
+        return st;
+      hipLaunchKernelGGL(k_multi_sum, dim3((n1 + 255) / 256), dim3(256), 0, c0->stream, m->g_block, n, n1,
+                         kMultiBlk, m->block[0]);
+      MHIP(m, hipGetLastError());
+      MHIP(m, hipMemcpyAsync(c0->h_pin, m->block[0], sizeof(double) * n1, hipMemcpyDeviceToHost, c0->stream));
+      for (int r = 0; r < n; r++) {  // every rank's x staging must be consumed before the next trial point
+        MHIP(m, hipSetDevice(m->ctx[r]->device));
+        MHIP(m, hipStreamSynchronize(m->ctx[r]->stream));
+      }
+      memcpy(blk, c0->h_pin, sizeof(double) * n1);
+      int cont = 0;
+      lsqr_fit_info fi;
+      st = lsqr_lm_step(c0, blk, xt, &cont, fit, &fi);
+      if (st != LSQR_OK && st != LSQR_EMPTY) return mfail(m, st, "lsqr_lm_step", c0);
+      if (!cont) {
+        const uint64_t used = info->fit.n_used;
+        info->fit = fi;
+        info->fit.n_used = used;
+        info->n_params = fi.n_params;
+        break;
+      }
+    }
+  }
+  for (int r = 0; r < n; r++) {
+    MHIP(m, hipSetDevice(m->ctx[r]->device));
+    MHIP(m, hipStreamSynchronize(m->ctx[r]->stream));
+  }
+  MHIP(m, hipSetDevice(c0->device));
+  if (st != LSQR_OK) return st;
+  if (params_out)
+    for (int j = 0; j < info->n_params; j++) params_out[j] = fit[j];
+  return LSQR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lsqr_multi_create(const int *devices, int n, lsqr_multi **out) {
+  if (!out || !devices || n < 1 || n > 64) return LSQR_ERR_INVALID;
+  *out = nullptr;
+  lsqr_multi *m = new lsqr_multi();
+  m->n = n;
+  int st = LSQR_OK;
+  for (int r = 0; r < n && st == LSQR_OK; r++) {
+    lsqr_ctx *c = nullptr;
+    st = lsqr_ctx_create(devices[r], &c);
+    if (st != LSQR_OK) break;
+    m->ctx.push_back(c);
+    unsigned long long *p = nullptr;
+    double *b = nullptr;
+    hipEvent_t e = nullptr;
+    if (hipMalloc((void **)&p, 64) != hipSuccess || hipMalloc((void **)&b, sizeof(double) * kMultiBlk) != hipSuccess ||
+        hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+      st = LSQR_ERR_HIP;
+    m->packed.push_back(p);
+    m->block.push_back(b);
+    m->ev.push_back(e);
+    for (int q = 0; q < r && st == LSQR_OK; q++)  // peer access both ways where the devices differ
+      if (devices[q] != devices[r]) {
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, devices[r], devices[q]);
+        if (can) {
+          (void)hipSetDevice(devices[r]);
+          (void)hipDeviceEnablePeerAccess(devices[q], 0);
+          (void)hipSetDevice(devices[q]);
+          (void)hipDeviceEnablePeerAccess(devices[r], 0);
+          (void)hipGetLastError();  // "already enabled" is fine
+        }
+      }
+  }
+  if (st == LSQR_OK) {
+    (void)hipSetDevice(devices[0]);
+    if (hipMalloc((void **)&m->g_packed, sizeof(unsigned long long) * 64) != hipSuccess ||
+        hipMalloc((void **)&m->g_block, sizeof(double) * kMultiBlk * n) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_root, hipEventDisableTiming) != hipSuccess)
+      st = LSQR_ERR_HIP;
+  }
+  if (st != LSQR_OK) {
+    lsqr_multi_destroy(m);
+    return st;
+  }
+  *out = m;
+  return LSQR_OK;
+}
+
+void lsqr_multi_destroy(lsqr_multi *m) {
+  if (!m) return;
+  for (size_t r = 0; r < m->ctx.size(); r++) {
+    (void)hipSetDevice(m->ctx[r]->device);
+    (void)hipStreamSynchronize(m->ctx[r]->stream);
+    if (r < m->packed.size() && m->packed[r]) (void)hipFree(m->packed[r]);
+    if (r < m->block.size() && m->block[r]) (void)hipFree(m->block[r]);
+    if (r < m->ev.size() && m->ev[r]) (void)hipEventDestroy(m->ev[r]);
+  }
+  if (!m->ctx.empty()) (void)hipSetDevice(m->ctx[0]->device);
+  if (m->g_packed) (void)hipFree(m->g_packed);
+  if (m->g_block) (void)hipFree(m->g_block);
+  if (m->ev_root) (void)hipEventDestroy(m->ev_root);
+  for (lsqr_ctx *c : m->ctx) lsqr_ctx_destroy(c);
+  delete m;
+}
+
+int lsqr_multi_size(const lsqr_multi *m) { return m ? m->n : 0; }
+lsqr_ctx *lsqr_multi_ctx(lsqr_multi *m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
+const char *lsqr_multi_last_error(const lsqr_multi *m) { return m ? m->err : "null handle"; }
+
+int lsqr_multi_set_model(lsqr_multi *m, const lsqr_model_cfg *cfg) {
+  if (!m || !cfg) return LSQR_ERR_INVALID;
+  for (lsqr_ctx *c : m->ctx) {
+    int st = lsqr_set_model(c, cfg);
+    if (st != LSQR_OK) return mfail(m, st, "lsqr_set_model", c);
+  }
+  return LSQR_OK;
+}
+
+int lsqr_multi_upload(lsqr_multi *m, const void *host, size_t count, size_t stride_bytes) {
+  if (!m) return LSQR_ERR_INVALID;
+  lsqr_ctx *c0 = m->ctx[0];
+  int st = lsqr_upload(c0, host, count, stride_bytes);  // ONE host -> device transfer
+  if (st != LSQR_OK) return mfail(m, st, "lsqr_upload", c0);
+  for (int r = 1; r < m->n; r++) {  // replicas: device to device
+    lsqr_ctx *c = m->ctx[r];
+    if ((st = need_ready(c, false)) != LSQR_OK) return mfail(m, st, "context not ready", c);
+    if ((st = set_data_common(c, count, stride_bytes)) != LSQR_OK) return mfail(m, st, "bad records", c);
+    if ((st = ensure(c, &c->d_data_owned, &c->data_cap, std::max<size_t>(count * c->stride, 1))) != LSQR_OK)
+      return mfail(m, st, "replica allocation", c);
+    if (count) MHIP(m, hipMemcpyPeerAsync(c->d_data_owned, c->device, c0->d_data, c0->device, count * stride_bytes,
+                                           c->stream));
+    c->d_data = c->d_data_owned;
+  }
+  for (int r = 1; r < m->n; r++) {
+    MHIP(m, hipSetDevice(m->ctx[r]->device));
+    MHIP(m, hipStreamSynchronize(m->ctx[r]->stream));
+  }
+  MHIP(m, hipSetDevice(c0->device));
+  return LSQR_OK;
+}
+
+int lsqr_multi_batch_fit(lsqr_multi *m, uint64_t seed, uint64_t first, size_t H, double *params_out,
+                         uint8_t *consensus_out, lsqr_ransac_info *info) {
+  if (!m || H == 0 || H * (size_t)m->n > 0xFFFFFFF0ull) return LSQR_ERR_INVALID;
+  const int n = m->n;
+  lsqr_ctx *c0 = m->ctx[0];
+  int st;
+  std::vector<const void *> src(n);
+  std::vector<void *> dst(n);
+  for (int r = 0; r < n; r++) {
+    if ((st = lsqr_step_scan(m->ctx[r], seed, first + (uint64_t)r * H, H, (uint32_t)((size_t)r * H),
+                             (uint64_t *)m->packed[r])) != LSQR_OK)
+      return mfail(m, st, "lsqr_step_scan", m->ctx[r]);
+    src[r] = m->packed[r];
+    dst[r] = m->packed[r];
+  }
+  if ((st = multi_gather(m, src, m->g_packed, 8, 8)) != LSQR_OK) return st;
+  hipLaunchKernelGGL(k_multi_max, dim3(1), dim3(64), 0, c0->stream, m->g_packed, n, m->packed[0]);
+  MHIP(m, hipGetLastError());
+  if ((st = multi_bcast(m, m->packed[0], dst, 8)) != LSQR_OK) return st;
+  lsqr_ransac_info local;
+  if (!info) info = &local;
+  st = multi_finish(m, seed, first, params_out, consensus_out, info);
+  info->iterations = H * (uint64_t)n;
+  info->evaluated = info->evaluated ? H * (uint64_t)n : 0;
+  if (info->best_votes) info->best_index += first;  // stream index of the winner
+  return st;
+}
+
+// RANSAC<T,S>::compute() over several devices: every batch of the adaptive loop is sharded (rank r scans the r-th
+// contiguous part), the replay runs on the host over the batch in stream order -- same winner, iteration count and
+// consensus set as lsqr_ransac on one device.
+int lsqr_multi_ransac(lsqr_multi *m, double p, uint64_t seed, double *params_out, uint8_t *consensus_out,
+                      lsqr_ransac_info *info) {
+  lsqr_ransac_info local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof *info);
+  if (!m) return LSQR_ERR_INVALID;
+  const int n = m->n;
+  lsqr_ctx *c0 = m->ctx[0];
+  int st = need_ready(c0, false);
+  if (st != LSQR_OK) return mfail(m, st, "context not ready", c0);
+  const int k = c0->K;
+  if (c0->n < (size_t)k || !(p < 1.0) || !(p > 0.0)) return LSQR_ERR_INVALID;  // RANSAC.hxx:16-19
+  uint64_t rs[6];
+  lsqr_replay_init(c0->n, k, p, rs);
+  DedupSet dedup;
+  uint64_t base = 0;
+  size_t per = 256;  // hypotheses per device per batch
+  std::vector<uint32_t> votes, subs;
+  std::vector<uint8_t> valid;
+  while (!rs[RS_DONE]) {
+    uint64_t remaining = rs[RS_TRIES] - base;
+    size_t total = (size_t)std::min<uint64_t>(remaining, (uint64_t)per * n);
+    if (total == 0) break;
+    votes.resize(total);
+    valid.resize(total);
+    subs.resize(total * k);
+    std::vector<size_t> off(n + 1, 0);
+    for (int r = 0; r < n; r++) off[r + 1] = std::min(total, off[r] + per);
+    for (int r = 0; r < n; r++) {
+      const size_t h = off[r + 1] - off[r];
+      if (!h) continue;
+      lsqr_ctx *c = m->ctx[r];
+      c->hyp_expected = rs[RS_HAS] ? std::min<uint64_t>(remaining / n, 1u << 20) : 0;
+      if ((st = lsqr_hypotheses_sample(c, seed, base + off[r], h, nullptr)) != LSQR_OK ||
+          (st = lsqr_scan(c)) != LSQR_OK)
+        return mfail(m, st, "batch scan", c);
+    }
+    for (int r = 0; r < n; r++) {
+      const size_t h = off[r + 1] - off[r];
+      if (!h) continue;
+      lsqr_ctx *c = m->ctx[r];
+      MHIP(m, hipSetDevice(c->device));
+      MHIP(m, hipMemcpyAsync(subs.data() + off[r] * k, c->d_subsets, h * k * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             c->stream));
+      if ((st = lsqr_get_hypotheses(c, nullptr, valid.data() + off[r], votes.data() + off[r])) != LSQR_OK)
+        return mfail(m, st, "lsqr_get_hypotheses", c);
+    }
+    size_t used = lsqr_replay(c0->n, k, p, subs.data(), valid.data(), votes.data(), total, base, &dedup, rs);
+    info->evaluated += total;
+    base += used;
+    if (used < total) break;
+    per = std::min<size_t>(per * 4, 4096);
+    if (!rs[RS_HAS] && base >= (1ull << 22)) break;
+    if (c0->opt_max_iter > 0 && base >= (uint64_t)c0->opt_max_iter) break;
+  }
+  info->iterations = rs[RS_I];
+  info->best_index = rs[RS_BEST_IDX];
+  info->best_votes = (uint32_t)rs[RS_BEST];
+  info->fraction = (double)rs[RS_BEST] / (double)c0->n;
+  if (!rs[RS_HAS] || rs[RS_BEST] == 0) return LSQR_EMPTY;  // RANSAC.hxx:129: nothing written
+  // the winner, as a packed value relative to its own stream index, on every rank
+  const unsigned long long pk = ((unsigned long long)rs[RS_BEST] << 32) | 0xFFFFFFFFull;
+  for (int r = 0; r < n; r++) {
+    lsqr_ctx *c = m->ctx[r];
+    MHIP(m, hipSetDevice(c->device));
+    MHIP(m, hipMemcpyAsync(m->packed[r], &pk, 8, hipMemcpyHostToDevice, c->stream));
+    MHIP(m, hipStreamSynchronize(c->stream));  // pk lives on this stack frame
+  }
+  const uint64_t iters = info->iterations, eval = info->evaluated, bidx = info->best_index;
+  const uint32_t bv = info->best_votes;
+  st = multi_finish(m, seed, rs[RS_BEST_IDX], params_out, consensus_out, info);
+  info->iterations = iters;
+  info->evaluated = eval;
+  info->best_index = bidx;
+  info->best_votes = bv;
+  if ((st == LSQR_OK || st == LSQR_EMPTY) && info->fit.n_used != bv)
+    return mfail(m, LSQR_ERR_HIP, "consensus count of the slices differs from the winner's votes");
+  return st;
 }
 
 int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {

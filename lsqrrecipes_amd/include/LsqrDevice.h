@@ -41,13 +41,45 @@ class Device {
                              " (" + (h ? lsqr_last_error(h) : "") + ")");
   }
   void model(const lsqr_model_cfg &cfg) { check(lsqr_set_model(ctx(), &cfg)); }
+  // LSQR_DEVICES="0,1,2,3": RANSAC<T,S>::compute() shards its hypothesis batches over these devices
+  // (lsqr_multi_*); unset or a single device: the one context above.  NULL when not requested.
+  lsqr_multi *multi() {
+    if (!multiTried) {
+      multiTried = true;
+      if (const char *e = std::getenv("LSQR_DEVICES")) {
+        std::vector<int> devs;
+        for (const char *p = e; *p;) {
+          char *end = 0;
+          long v = std::strtol(p, &end, 10);
+          if (end == p) break;
+          devs.push_back((int)v);
+          p = (*end == ',') ? end + 1 : end;
+        }
+        if (devs.size() > 1) {
+          int st = lsqr_multi_create(&devs[0], (int)devs.size(), &hm);
+          if (st != LSQR_OK)
+            throw std::runtime_error(std::string("lsqrRecipes: LSQR_DEVICES=") + e + ": " + lsqr_status_string(st));
+        }
+      }
+    }
+    return hm;
+  }
+  bool checkMulti(int st) {
+    if (st == LSQR_OK) return true;
+    if (st == LSQR_EMPTY) return false;
+    throw std::runtime_error(std::string("lsqrRecipes multi-device error: ") + lsqr_status_string(st) + " (" +
+                             (hm ? lsqr_multi_last_error(hm) : "") + ")");
+  }
   ~Device() {
+    if (hm) lsqr_multi_destroy(hm);
     if (h) lsqr_ctx_destroy(h);
   }
 
  private:
-  Device() : h(0) {}
+  Device() : h(0), hm(0), multiTried(false) {}
   lsqr_ctx *h;
+  lsqr_multi *hm;
+  bool multiTried;
 };
 
 // contiguous copy of the records behind a vector of pointers (the reference passes

@@ -45,14 +45,24 @@ class RANSAC {
     if (!paramEstimator->deviceModel(cfg) || forceHostLoop())
       return pluginCompute(parameters, paramEstimator, data, desiredProbabilityForNoOutliers, consensusSet);
     detail::Device &d = detail::Device::instance();
-    d.model(cfg);
-    d.check(lsqr_upload(d.ctx(), &data[0], data.size(), sizeof(T)));
     std::vector<double> p(64);
     std::vector<uint8_t> cons(consensusSet ? data.size() : 0);
     lsqr_ransac_info info;
+    bool ok;
+    if (lsqr_multi *m = d.multi()) {  // LSQR_DEVICES lists several devices: batches sharded over them
+      d.checkMulti(lsqr_multi_set_model(m, &cfg));
+      d.checkMulti(lsqr_multi_upload(m, &data[0], data.size(), sizeof(T)));
+      parameters.clear();
+      ok = d.checkMulti(lsqr_multi_ransac(m, desiredProbabilityForNoOutliers, seed(), &p[0],
+                                          consensusSet ? &cons[0] : NULL, &info));
+      lastInfo() = info;
+      return finish(ok, info, p, cons, parameters, consensusSet);
+    }
+    d.model(cfg);
+    d.check(lsqr_upload(d.ctx(), &data[0], data.size(), sizeof(T)));
     parameters.clear();  // RANSAC.hxx:43
-    bool ok = d.check(lsqr_ransac(d.ctx(), desiredProbabilityForNoOutliers, seed(), NULL, 0, &p[0],
-                                  consensusSet ? &cons[0] : NULL, &info));
+    ok = d.check(lsqr_ransac(d.ctx(), desiredProbabilityForNoOutliers, seed(), NULL, 0, &p[0],
+                             consensusSet ? &cons[0] : NULL, &info));
     lastInfo() = info;
     return finish(ok, info, p, cons, parameters, consensusSet);
   }

@@ -221,7 +221,7 @@ def test_error_conventions(ctx):
     assert len(got) == 0
     # unsupported model / stride errors are reported, not ignored
     with pytest.raises(L.LsqrError):
-        ctx.set_model(L.PLANE, 7, 0.5)
+        ctx.set_model(L.PLANE, 9, 0.5)          # device models exist for dimensions 2..8
     with pytest.raises(L.LsqrError):
         ctx.set_model(L.SPHERE, 3, 0.5, ls_type=5)
 
