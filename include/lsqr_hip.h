@@ -25,7 +25,7 @@
  *                                                                common/Frame.h:30-31,41
  *   CalibratedPointer DataType 18 slots (+ Point3D p)            .../SinglePointTarget...h:335-339
  *   pair<Point3D,Point3D>      6 doubles (first, second)         .../AbsoluteOrientation...h:14-15
- *                              (ls_type 1 = weightedLeastSquaresEstimate, .h:86: 7 doubles, slot 6 = weight)
+ *                              (ls_type 2 = weightedLeastSquaresEstimate, .h:86: 7 doubles, slot 6 = weight)
  *   Frame                      13 slots (104 B)                  common/Frame.h:30-31,41
  *   Ray3D                      6 doubles (Point3D p, Vector3D n) common/Ray3D.h:23-24
  * A caller's std::vector<T> is passed as (pointer, count, stride in bytes) without repacking.
@@ -78,7 +78,7 @@ typedef struct {
   int32_t model;   /* lsqr_model */
   int32_t dim;     /* point dimension (plane/sphere/line: 2 or 3), n for DENSE (1..64) */
   double delta;    /* constructor argument, NOT squared (PlaneParametersEstimator.hxx:13-17) */
-  int32_t ls_type; /* sphere / US; ABSOR: 1 = records carry a weight in slot 6 (weighted fit) */
+  int32_t ls_type; /* sphere / US; ABSOR: 2 = records carry a weight in slot 6 (weighted fit) */
   int32_t reserved;
   double aux;      /* RAY: minimalAngularDeviation in radians (RayIntersection...Estimator.h:34-35);
                       unused by the other models */

@@ -1510,7 +1510,7 @@ int lsqr_record_doubles(const lsqr_model_cfg *cfg) {
     case LSQR_MODEL_DENSE: return cfg->dim + 1;
     case LSQR_MODEL_US_SINGLE: return 15;
     case LSQR_MODEL_US_POINTER: return 18;
-    case LSQR_MODEL_ABSOR: return cfg->ls_type == 1 ? 7 : 6;  // weighted fit: [first, second, weight]
+    case LSQR_MODEL_ABSOR: return cfg->ls_type == 2 ? 7 : 6;  // weighted fit: [first, second, weight]
     case LSQR_MODEL_PIVOT: return 13;
     case LSQR_MODEL_RAY: return 6;
     case LSQR_MODEL_LINE2D: return 2;

@@ -60,13 +60,13 @@ LSQR_HD void frame_quaternion(const double *R, double *q) {
 // scan parameters: the 7 + the 9 rotation entries agree() would rebuild per datum
 // (Frame ctor, Frame.cxx:174-198, no normalisation).
 struct AbsOrModel {
-  // REC = 7: slot 6 is the pair's weight -- read from the record when ls_type == 1 (weighted fit,
+  // REC = 7: slot 6 is the pair's weight -- read from the record when ls_type == 2 (weighted fit,
   // AbsoluteOrientation...cxx:208-291; records of 7 doubles), 1.0 otherwise (records of 6 doubles)
   enum { ND = 6, K = 3, P = 7, SP = 16, REC = 7, PPL = 4, IS_DENSE = 0, IS_US = 0, ORIGIN_FIRST = 1 };
   enum { NMOM = 1 + 3 + 3 + 9 };
   static LSQR_HD void load(const double *p, const ModelConsts &c, double *rec) {
     for (int i = 0; i < 6; i++) rec[i] = p[i];
-    rec[6] = c.ls_type == 1 ? p[6] : 1.0;
+    rec[6] = c.ls_type == 2 ? p[6] : 1.0;
   }
   // vnl_vector::normalize(): multiply by 1/sqrt(sum of squares) unless the sum is zero
   static LSQR_HD void normalize3(double *v) {
@@ -164,7 +164,7 @@ struct AbsOrModel {
   // (weighted: n = sum of the weights; the caller has checked the pair count, :213-216)
   static LSQR_HD bool solve(const double *m, const double *org, const ModelConsts &c, double *par) {
     const double n = m[0];
-    if (c.ls_type == 1 ? !(n > 0.0) : n < 3.0) return false;  // :129
+    if (c.ls_type == 2 ? !(n > 0.0) : n < 3.0) return false;  // :129
     double ml[3], mr[3], M[9], Nm[16], w[4], V[16], R[9];
     for (int i = 0; i < 3; i++) {
       ml[i] = m[1 + i] / n;

@@ -63,7 +63,7 @@ class AbsoluteOrientationParametersEstimator
       rec[7 * i + 6] = weights[i];
     }
     lsqr_model_cfg c = cfg();
-    c.ls_type = 1;
+    c.ls_type = 2;  // records [first, second, weight]
     detail::lsFitRaw(c, &rec[0], data.size(), 7 * sizeof(double), parameters);
   }
   virtual bool agree(std::vector<double> &parameters, DataT &data) {

@@ -125,7 +125,7 @@ def test_absolute_orientation_weighted_fit(ctx):
     w = g.uniform(0.0, 3.0, len(pairs))
     w[~lab] = 0.0                                   # outliers weighted out
     rec = np.hstack([pairs, w[:, None]])
-    ctx.set_model(L.ABSOR, 3, 0.5, 1).upload(rec)   # ls_type 1: records carry a weight
+    ctx.set_model(L.ABSOR, 3, 0.5, 2).upload(rec)   # ls_type 2: records carry a weight
     assert ctx.ND == 7
     got, _ = ctx.ls_fit()
     want = O.absor_weighted_ls(pairs, w)
@@ -140,7 +140,7 @@ def test_absolute_orientation_weighted_fit(ctx):
     got0, _ = ctx.ls_fit()
     assert np.array_equal(got1, got0)
     # the minimal solve and agree() ignore the weight slot
-    ctx.set_model(L.ABSOR, 3, 0.5, 1).upload(rec)
+    ctx.set_model(L.ABSOR, 3, 0.5, 2).upload(rec)
     subs = O.ctr_subsets(2, 0, 32, len(rec), 3)
     ctx.hypotheses_from_subsets(subs)
     ctx.scan()
