@@ -339,6 +339,11 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = the
  *                model's default), "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default), "scan_block":
  *                workgroup size (256 / 1024), "scan_hsplit": hypothesis segments per tile (A/B knobs);
+ * "scan_bound":  1 (default) = the batch entry points (lsqr_batch_fit*, lsqr_step_scan, lsqr_ransac) over an indexed
+ *                upload count only hypotheses that can still become the running maximum (an upper bound on every
+ *                hypothesis' votes from the cell boxes, a few early candidates counted first); the others
+ *                report 0 votes -- winner, consensus set and iteration count are unchanged (RANSAC.hxx:94 abandons
+ *                exactly such hypotheses).  0 = every hypothesis is counted.  lsqr_scan always counts all;
  * "dense_fast_solve": 1 (default) = the n x n minimal solves of the dense system use elimination with
  *                partial pivoting and only fall back to the SVD pseudo-inverse near the rank decision,
  *                0 = always the SVD pseudo-inverse;

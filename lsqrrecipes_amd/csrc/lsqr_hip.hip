@@ -72,6 +72,16 @@ struct lsqr_ctx {
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   uint32_t *d_ub = nullptr;  // per-hypothesis vote bound of the two-level scan's first level (k_cells_bounds)
+  // bounded scan (cells.h: k_pick_*): the selected hypotheses as a compact batch
+  uint32_t *d_sel = nullptr;        // [kPilots pilots | H_cap rest]
+  BoundSel *d_bsel = nullptr;
+  double *d_hparams2 = nullptr;
+  float *d_hparams2_f32 = nullptr;
+  uint32_t *d_votes2 = nullptr;     // [kPilots | H_cap]
+  int opt_bound = 1;                // 1: batch entry points skip hypotheses that cannot win (exact winner), 0: count all
+  uint32_t best_before = 0;         // exact votes of the best hypothesis of earlier batches (lsqr_ransac)
+  bool allow_bound = false;         // set by the batch entry points around run_scan (lsqr_scan always counts all)
+  uint64_t last_bound[4] = {0, 0, 0, 0};  // diagnostics of the last bounded scan: {used, pilots, rest, H}
   bool scanned = false;
   bool external_stream = false;
   hipEvent_t slot_ev[2] = {nullptr, nullptr};  // lsqr_batch_fit_enqueue / _wait
@@ -290,6 +300,9 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   if (c->d_votes) (void)hipFree(c->d_votes);
   if (c->d_ub) (void)hipFree(c->d_ub);
   c->d_ub = nullptr;
+  for (void *b : {(void *)c->d_sel, (void *)c->d_bsel, (void *)c->d_hparams2, (void *)c->d_hparams2_f32, (void *)c->d_votes2})
+    if (b) (void)hipFree(b);
+  c->d_sel = nullptr; c->d_bsel = nullptr; c->d_hparams2 = nullptr; c->d_hparams2_f32 = nullptr; c->d_votes2 = nullptr;
   c->d_subsets = nullptr; c->d_hparams = nullptr; c->d_valid = nullptr; c->d_votes = nullptr;
   c->H_cap = 0;
   HIPCHK(c, hipMalloc((void **)&c->d_subsets, cap * 64 * sizeof(uint32_t)));
@@ -298,6 +311,11 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   HIPCHK(c, hipMalloc((void **)&c->d_valid, cap));
   HIPCHK(c, hipMalloc((void **)&c->d_votes, cap * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc((void **)&c->d_ub, cap * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc((void **)&c->d_sel, (cap + kPilots) * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc((void **)&c->d_bsel, sizeof(BoundSel)));
+  HIPCHK(c, hipMalloc((void **)&c->d_hparams2, (cap + kPilots) * 64 * sizeof(double)));
+  HIPCHK(c, hipMalloc((void **)&c->d_hparams2_f32, (cap + kPilots) * 32 * sizeof(float)));
+  HIPCHK(c, hipMalloc((void **)&c->d_votes2, (cap + kPilots) * sizeof(uint32_t)));
   c->H_cap = cap;
   return LSQR_OK;
 }
@@ -583,18 +601,27 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   return LSQR_OK;
 }
 
+// a batch of hypotheses handed to the two-level scan: the context's current batch, or a compacted selection of it
+struct ScanBatch {
+  const double *sp;       // fp64 scan parameters, M::SP per hypothesis
+  const float *spf;       // fp32 block, M::SPF per hypothesis
+  size_t H;               // hypotheses (capacity when h_dev is set)
+  uint32_t *votes;        // zeroed by the caller when h_dev is set
+  const uint32_t *h_dev;  // device-side count (bounded scan) or null
+};
+
 template <class CM, int PP, int CPT, int BS, bool LDSB = false>
-int launch_scan_cells(lsqr_ctx *c) {
+int launch_scan_cells(lsqr_ctx *c, const ScanBatch &b) {
   typedef typename CM::M M;
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
-  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+  HIPCHK(c, hipMemsetAsync(b.votes, 0, b.H * sizeof(uint32_t), c->stream));
   if (c->n_cells == 0) return LSQR_OK;
   const size_t wtiles = ((size_t)c->n_cells + CPT - 1) / CPT;
   constexpr int wpb = BS / 64;  // waves per workgroup
   if (!c->d_queues) HIPCHK(c, hipMalloc((void **)&c->d_queues, kQueues * kQueuePitch * sizeof(uint32_t)));
   uint32_t *d_next = c->d_queues;
-  for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
-    uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
+  for (size_t h0 = 0; h0 < b.H; h0 += kScanChunk) {
+    uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, b.H - h0);
     size_t lds = (size_t)((hc + 3) & ~3u) * sizeof(uint32_t) + (LDSB ? (size_t)wpb * 2048 : 0);
     int per_cu = (int)std::min<size_t>(32 / wpb, (160 * 1024) / std::max<size_t>(lds, 1));
     {  // persistent waves pulling tiles from the queues: launch exactly what is resident at once
@@ -619,22 +646,25 @@ int launch_scan_cells(lsqr_ctx *c) {
     HIPCHK(c, hipMemsetAsync(d_next, 0, kQueues * kQueuePitch * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL((k_scan_cells<CM, PP, CPT, BS, LDSB>), dim3((unsigned)blocks), dim3(BS), lds,
                        c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
-                       c->d_hparams + h0 * M::SP,
-                       CM::ROW_F32 ? c->d_hparams_f32 + h0 * M::SPF
-                                   : (const float *)(c->d_hparams + h0 * M::SP),
-                       c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, cc, c->d_votes + h0, d_next, grab,
-                       hsplit);
+                       b.sp + h0 * M::SP,
+                       CM::ROW_F32 ? b.spf + h0 * M::SPF : (const float *)(b.sp + h0 * M::SP),
+                       b.spf + h0 * M::SPF, hc, c->mc, cc, b.votes + h0, d_next, grab, hsplit, b.h_dev);
     HIPCHK(c, hipGetLastError());
   }
   return LSQR_OK;
 }
 template <class CM, int PP, int CPT>
-int run_scan_cells(lsqr_ctx *c) {
+int run_scan_cells(lsqr_ctx *c, const ScanBatch &b) {
   // hypothesis broadcast to the survivors: v_readlane, or (scan_block 257 / the model's choice)
   // uniform-address LDS reads.  (1024-thread workgroups measured 3-5 % slower and are no longer built.)
   if (c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST))
-    return launch_scan_cells<CM, PP, CPT, 256, true>(c);
-  return launch_scan_cells<CM, PP, CPT, 256>(c);
+    return launch_scan_cells<CM, PP, CPT, 256, true>(c, b);
+  return launch_scan_cells<CM, PP, CPT, 256>(c, b);
+}
+template <class CM, int PP, int CPT>
+int run_scan_cells(lsqr_ctx *c) {
+  const ScanBatch b = {c->d_hparams, c->d_hparams_f32, c->H, c->d_votes, nullptr};
+  return run_scan_cells<CM, PP, CPT>(c, b);
 }
 
 // level 1 of the two-level scan alone over the current batch: d_ub[h] = vote bound, d_counter[4] = surviving pairs
@@ -652,6 +682,42 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub) {
                      c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
                      (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4);
   HIPCHK(c, hipGetLastError());
+  return LSQR_OK;
+}
+
+// The bounded scan of the current batch over the index (cells.h, "bounded scan"): bounds, pilots counted exactly,
+// then only the hypotheses that can still become the running maximum.  Everything is chained on the stream.
+template <class CM, int PP>
+int run_scan_bounded(lsqr_ctx *c) {
+  typedef typename CM::M M;
+  int st = run_cells_bounds<CM, PP>(c, c->d_ub);
+  if (st != LSQR_OK) return st;
+  const uint32_t H = (uint32_t)c->H;
+  uint32_t *sel_a = c->d_sel, *sel_b = c->d_sel + kPilots;
+  uint32_t *votes_a = c->d_votes2, *votes_b = c->d_votes2 + kPilots;
+  double *sp_a = c->d_hparams2, *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
+  float *spf_a = c->d_hparams2_f32, *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;
+  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel);
+  hipLaunchKernelGGL(k_gather_rows, dim3(kPilots / 4), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
+                     (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
+  HIPCHK(c, hipGetLastError());
+  const ScanBatch pa = {sp_a, spf_a, (size_t)kPilots, votes_a, &c->d_bsel->n_pilot};
+  if ((st = run_scan_cells<CM, PP, 1>(c, pa)) != LSQR_OK) return st;
+  hipLaunchKernelGGL(k_pick_rest, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, votes_a,
+                     c->best_before, sel_b, c->d_bsel);
+  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, H,
+                     c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
+  HIPCHK(c, hipGetLastError());
+  const ScanBatch pb = {sp_b, spf_b, (size_t)H, votes_b, &c->d_bsel->n_rest};
+  if ((st = run_scan_cells<CM, PP, 1>(c, pb)) != LSQR_OK) return st;
+  hipLaunchKernelGGL(k_scatter_votes, dim3(1), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot, votes_a,
+                     c->d_votes);
+  hipLaunchKernelGGL(k_scatter_votes, dim3((H + 255) / 256), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest,
+                     votes_b, c->d_votes);
+  HIPCHK(c, hipGetLastError());
+  c->last_bound[0] = 1;
+  c->last_bound[3] = H;
   return LSQR_OK;
 }
 
@@ -795,6 +861,13 @@ int run_scan(lsqr_ctx *c) {
           // one cell per wave tile; several cells per tile and 128-record cells were measured dead ends
           //  and are no longer instantiated
           if (usable) {
+            c->last_bound[0] = 0;
+            // batch entry points: hypotheses that cannot become the running maximum are not counted (the extra
+            // launches only pay for batches of >= 1024; the selection kernels handle <= 8192)
+            if (c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
+              if (cell_pts == 512) return run_scan_bounded<CM, 4>(c);
+              return run_scan_bounded<CM, 2>(c);
+            }
             if (cell_pts == 512) return run_scan_cells<CM, 4, 1>(c);
             return run_scan_cells<CM, 2, 1>(c);
           }
@@ -823,6 +896,17 @@ int run_scan(lsqr_ctx *c) {
       return run_scan_ppl<M, M::PPL>(c);
     }
   });
+}
+
+// run_scan for the entry points that only need the first-max winner (and, for lsqr_ransac's replay, exact votes
+// of the hypotheses that become the running maximum): the bounded scan may leave the rest uncounted
+int run_scan_batch(lsqr_ctx *c, uint32_t best_before) {
+  c->allow_bound = true;
+  c->best_before = best_before;
+  int st = run_scan(c);
+  c->allow_bound = false;
+  c->best_before = 0;
+  return st;
 }
 
 // ---- moments / solves ---------------------------------------------------------------------------
@@ -1434,7 +1518,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -2282,7 +2366,8 @@ int lsqr_ransac(lsqr_ctx *c, double p, uint64_t seed, const uint32_t *subsets, s
     // what the adaptive bound still asks for (saturated: a poor start leaves it at C(N,k)); the index build
     // heuristic weighs it against the cost of the build
     c->hyp_expected = has_any_best(rs) ? std::min<uint64_t>(rs[RS_TRIES] - base, 1u << 20) : 0;
-    if ((st = lsqr_scan(c)) != LSQR_OK) return st;
+    if ((st = run_scan_batch(c, has_any_best(rs) ? (uint32_t)rs[RS_BEST] : 0u)) != LSQR_OK) return st;
+    c->scanned = true;
     if (!subsets)
       HIPCHK(c, hipMemcpyAsync(p_sub, c->d_subsets, H * k * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                c->stream));
@@ -2376,7 +2461,7 @@ int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double 
                    uint8_t *consensus_out, lsqr_ransac_info *info) {
   int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
   if (st != LSQR_OK) return st;
-  if ((st = run_scan(c)) != LSQR_OK) return st;
+  if ((st = run_scan_batch(c, 0)) != LSQR_OK) return st;
   c->scanned = true;
   hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
                      (uint32_t)c->H, c->d_counter + 1);
@@ -2476,7 +2561,7 @@ int lsqr_batch_fit_enqueue(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
     return fail(c, LSQR_ERR_INVALID, "this model's fit needs the host between device passes");
   int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
   if (st != LSQR_OK) return st;
-  if ((st = run_scan(c)) != LSQR_OK) return st;
+  if ((st = run_scan_batch(c, 0)) != LSQR_OK) return st;
   c->scanned = true;
   hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
                      (uint32_t)c->H, c->d_counter + 1, 0u);
@@ -2551,7 +2636,7 @@ int lsqr_step_scan(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, uint32_
   if (!packed_dev) return c ? fail(c, LSQR_ERR_INVALID, "null exchange buffer") : LSQR_ERR_INVALID;
   int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
   if (st != LSQR_OK) return st;
-  if ((st = run_scan(c)) != LSQR_OK) return st;
+  if ((st = run_scan_batch(c, 0)) != LSQR_OK) return st;
   c->scanned = true;
   hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
                      (uint32_t)c->H, (unsigned long long *)packed_dev, index_base);
@@ -3101,6 +3186,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "syrk_diag")) {  // 1: loads only, 2: MFMAs only (timing diagnostics, wrong sums)
     c->opt_syrk_diag = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_bound")) {  // 1 (default): batch entry points skip hypotheses that cannot win; 0: count all
+    c->opt_bound = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "lm_fused")) {  // 1 (default): one launch per LM evaluation, result polled in pinned memory

@@ -62,6 +62,7 @@ def _point_model_fullsize(ctx, model, omodel, gen, ls_type, expect_cell):
     assert info.best_votes == vv.max() and bi == int(np.argmax(vv))      # first max (RANSAC.hxx:100)
     checked = _pick(votes, valid, bi, 8, 40, 11)
     assert len(checked) >= 32
+    skipped = 0
     for h in checked:
         want = O.estimate(oc, data[subs[h]])
         assert bool(valid[h]) == (len(want) > 0), h
@@ -69,7 +70,13 @@ def _point_model_fullsize(ctx, model, omodel, gen, ls_type, expect_cell):
             assert votes[h] == 0
             continue
         assert np.array_equal(par[h], want), "minimal-subset model differs at h=%d" % h
-        assert votes[h] == O.scan(oc, want, data)[0], "vote count differs at h=%d" % h
+        exact = O.scan(oc, want, data)[0]
+        if votes[h] != exact:
+            # the bounded scan (scan_bound, default for batches): a hypothesis that cannot become the running
+            # maximum is not counted and reports 0 -- RANSAC.hxx:94 abandons exactly these
+            assert votes[h] == 0 and h > 0 and exact <= votes[:h].max(), "vote count differs at h=%d" % h
+            skipped += 1
+    assert skipped < len(checked) - 10            # the winner, the best-voted ones etc. were counted exactly
     wcnt, wmask = O.scan(oc, par[bi], data)
     assert wcnt == info.best_votes == info.fit.n_used
     assert np.array_equal(r["consensus"], wmask), "winner's consensus mask differs from the oracle"

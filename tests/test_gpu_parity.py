@@ -1785,3 +1785,65 @@ def test_fused_mask_and_moments_equal_two_kernels(ctx, model, dim, ls):
            (two["info"].best_votes, two["info"].best_index, two["info"].fit.n_used)
     assert np.array_equal(one["params"], two["params"])
     assert one["consensus"].sum() == one["info"].fit.n_used
+
+
+# ---- bounded scan (cells.h: hypotheses that cannot win are not counted) ------------------------------------------
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3), (L.PLANE, 2)])
+@pytest.mark.parametrize("outliers", [0.5, 0.9])
+def test_bounded_scan_keeps_winner_and_replay(ctx, model, dim, outliers):
+    """scan_bound 1 (default of the batch entry points) against scan_bound 0: every counted hypothesis has its
+    exact votes, every skipped one reports 0 and could not have become the running maximum, so the first-max
+    winner, its consensus set, and the replay of RANSAC.hxx's adaptive loop over the batch are identical."""
+    n, H = 300_000, 2048
+    data = _data(model, dim, n, 4242, outliers=outliers)
+    ls = L.LS_ALGEBRAIC if model == L.SPHERE else 0
+    ctx.set_model(model, dim, 0.5, ls).upload(data)
+    ctx.set_option("scan_index", 2)
+    res = {}
+    for bound in (0, 1):
+        ctx.set_option("scan_bound", bound)
+        r = ctx.batch_fit(77, 0, H, want_consensus=True)
+        _, valid, votes = ctx.hypotheses(params=False)
+        subs = O.ctr_subsets(77, 0, H, n, ctx.K)
+        res[bound] = (r, votes.copy(), valid.copy(), context_replay(n, ctx.K, 0.999, subs, valid, votes))
+    ctx.set_option("scan_bound", 1)
+    ctx.set_option("scan_index", 1)
+    (r0, v0, ok0, rp0), (r1, v1, ok1, rp1) = res[0], res[1]
+    assert np.array_equal(ok0, ok1)
+    assert (r0["info"].best_index, r0["info"].best_votes) == (r1["info"].best_index, r1["info"].best_votes)
+    assert np.array_equal(r0["consensus"], r1["consensus"]) and np.array_equal(r0["params"], r1["params"])
+    runmax = np.maximum.accumulate(np.where(ok0 > 0, v0, 0))
+    same = v1 == v0
+    skipped = ~same
+    assert np.all(v1[skipped] == 0)
+    assert np.all(v0[skipped][1:] <= runmax[np.flatnonzero(skipped)[1:] - 1]) if skipped.sum() > 1 else True
+    assert not skipped[0] or v0[0] == 0
+    assert rp0 == rp1                                   # same adaptive-loop state over the batch
+    if outliers == 0.5:
+        assert skipped.sum() > 0.5 * H                 # most random hypotheses are never counted
+
+
+def context_replay(n, k, p, subs, valid, votes):
+    from lsqrrecipes_amd.context import replay
+    r = replay(n, k, p, subs, valid, votes)
+    return (r["used"], r["i"], r["num_tries"], r["best_votes"], r["best_index"], r["has_best"], r["done"])
+
+
+def test_bounded_scan_inside_adaptive_ransac(ctx):
+    """lsqr_ransac with batches large enough for the bounded scan (80 % outliers: thousands of iterations), the
+    best votes of earlier batches carried as the lower bound: same iterations, winner and consensus as counting all"""
+    n = 250_000
+    data, truth, lab = synth.plane(n, 0.8, seed=31)
+    ctx.set_model(L.PLANE, 3, 0.5).upload(data)
+    ctx.set_option("scan_index", 2)
+    out = []
+    for bound in (0, 1):
+        ctx.set_option("scan_bound", bound)
+        r = ctx.ransac(0.999, seed=5)
+        out.append((r["info"].iterations, r["info"].best_index, r["info"].best_votes, r["consensus"].copy(), r["params"]))
+    ctx.set_option("scan_bound", 1)
+    ctx.set_option("scan_index", 1)
+    assert out[0][:3] == out[1][:3] and out[0][0] > 1500
+    assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
+    w = O.ransac(O.cfg(O.PLANE, 3, 0.5), data, 0.999, sampler="ctr", seed=5)
+    assert out[1][0] == w["iters"] and np.array_equal(out[1][3], w["consensus"])
