@@ -356,11 +356,13 @@ LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
 LSQR_API int lsqr_index_info(const lsqr_ctx *ctx, uint64_t out[4]);
 
 /* Work of the two-level scan for the CURRENT batch of hypotheses over the indexed upload: runs level 1 (the
- * cell-box test) alone.  out = {surviving (hypothesis, cell) pairs -- what level 2 evaluates --, (64-hypothesis
- * group, cell) level-1 evaluations, cells, observations per cell}; bound_out (nullable, H entries) receives per
- * hypothesis the summed population of its surviving cells: an upper bound on its votes.  LSQR_ERR_STATE when
- * the upload has no index.  Used by bench.py to price the scan against the instruction-issue roof. */
-LSQR_API int lsqr_scan_workload(lsqr_ctx *ctx, uint32_t *bound_out, uint64_t out[4]);
+ * cell-box test) alone.  out[0..7] = {surviving (hypothesis, cell) pairs of ALL hypotheses, (64-hypothesis group,
+ * cell) level-1 evaluations of one pass over all hypotheses, cells, observations per cell, 1 if the batch was last
+ * scanned by the bounded scan ("scan_bound"), its pilots, its second-pass hypotheses, surviving pairs of the
+ * hypotheses it actually counted (= out[0] when not bounded)}; bound_out (nullable, H entries) receives per
+ * hypothesis the summed population of its surviving cells: an upper bound on its votes.  LSQR_ERR_STATE when the
+ * upload has no index.  Used by bench.py to price the scan against the instruction-issue roof. */
+LSQR_API int lsqr_scan_workload(lsqr_ctx *ctx, uint32_t *bound_out, uint64_t out[8]);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,

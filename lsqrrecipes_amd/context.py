@@ -319,10 +319,11 @@ class Context:
         dict(pairs, level1_evaluations, cells, cell_points[, bounds])"""
         H = self._lib.lsqr_num_hypotheses(self._h)
         ub = np.zeros(H, dtype=np.uint32) if want_bounds else None
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         self._chk(self._lib.lsqr_scan_workload(self._h, L.ptr(ub), out))
         r = {"pairs": int(out[0]), "level1_evaluations": int(out[1]), "cells": int(out[2]),
-             "cell_points": int(out[3])}
+             "cell_points": int(out[3]), "bounded": bool(out[4]), "pilots": int(out[5]),
+             "second_pass": int(out[6]), "pairs_counted": int(out[7])}
         if want_bounds:
             r["bounds"] = ub
         return r

@@ -938,6 +938,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint32_t *__restrict_
   for (int k = lane; k < spd; k += 64) sp_out[(size_t)j * spd + k] = live ? sp[(size_t)h * spd + k] : __builtin_nan("");
   for (int k = lane; k < spfd; k += 64) spf_out[(size_t)j * spfd + k] = live ? spf[(size_t)h * spfd + k] : __builtin_nanf("");
 }
+// diagnostics: sum of per-hypothesis values over a selection
+__global__ __launch_bounds__(256) void k_sum_selected(const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel,
+                                                      const uint32_t *__restrict__ v, unsigned long long *__restrict__ out) {
+  unsigned long long t = 0;
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < *n_sel; j += gridDim.x * 256) t += v[sel[j]];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if ((threadIdx.x & 63) == 0 && t) atomicAdd(out, t);
+}
 __global__ __launch_bounds__(256) void k_scatter_votes(const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel,
                                                        const uint32_t *__restrict__ v, uint32_t *__restrict__ votes) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -954,7 +962,8 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
                                                       const float *__restrict__ spf, uint32_t H,
                                                       CellConsts cc, uint32_t cells_per_block,
                                                       uint32_t *__restrict__ ub,
-                                                      unsigned long long *__restrict__ total) {
+                                                      unsigned long long *__restrict__ total,
+                                                      uint32_t *__restrict__ ncells_out) {
   typedef typename CM::M M;
   constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4, CP = 128 * PP;
   const int lane = threadIdx.x & 63;
@@ -995,6 +1004,7 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
     nc += s ? 1u : 0u;
   }
   if (h < H && u) atomicAdd(&ub[h], u);
+  if (ncells_out && h < H && nc) atomicAdd(&ncells_out[h], nc);  // surviving cells of the hypothesis (diagnostics)
   for (int o = 32; o > 0; o >>= 1) nc += __shfl_down(nc, o);
   if (lane == 0 && nc) atomicAdd(total, (unsigned long long)nc);
 }

@@ -669,9 +669,10 @@ int run_scan_cells(lsqr_ctx *c) {
 
 // level 1 of the two-level scan alone over the current batch: d_ub[h] = vote bound, d_counter[4] = surviving pairs
 template <class CM, int PP>
-int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub) {
+int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
   HIPCHK(c, hipMemsetAsync(d_ub, 0, c->H * sizeof(uint32_t), c->stream));
+  if (d_nc) HIPCHK(c, hipMemsetAsync(d_nc, 0, c->H * sizeof(uint32_t), c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_counter + 4, 0, sizeof(unsigned long long), c->stream));
   if (c->n_cells == 0) return LSQR_OK;
   const unsigned gy = (unsigned)((c->H + 255) / 256);
@@ -680,7 +681,7 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub) {
   gx = (c->n_cells + per - 1) / per;
   hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
                      c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
-                     (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4);
+                     (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4, d_nc);
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
 }
@@ -690,6 +691,14 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub) {
 template <class CM, int PP>
 int run_scan_bounded(lsqr_ctx *c) {
   typedef typename CM::M M;
+  // profiling: ONE scope over the whole scan phase (bounds, selections, both counting launches)
+  ProfScope whole(c, KID_SCAN);
+  struct Mute {
+    lsqr_ctx *c;
+    bool was;
+    ~Mute() { c->prof = was; }
+  } mute{c, c->prof};
+  c->prof = false;
   int st = run_cells_bounds<CM, PP>(c, c->d_ub);
   if (st != LSQR_OK) return st;
   const uint32_t H = (uint32_t)c->H;
@@ -3246,32 +3255,53 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);
 }
 
-int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[4]) {
+int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[8]) {
   int st = need_ready(c, true);
   if (st != LSQR_OK) return st;
   if (!out) return fail(c, LSQR_ERR_INVALID, "null argument");
   if (c->H == 0) return fail(c, LSQR_ERR_STATE, "no hypotheses");
   if (!c->index_valid) return fail(c, LSQR_ERR_STATE, "this upload has no spatial index (scan_index)");
+  uint32_t *d_nc = c->d_votes2 + kPilots;  // scratch: per-hypothesis surviving cells (the batch has been read)
+  const bool bounded = c->last_bound[0] != 0 && c->last_bound[3] == c->H;
+  uint32_t h_sel[2] = {0, 0};
+  if (bounded) {  // the selection of the bounded scan that just ran is still on the device
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(h_sel, c->h_pin, sizeof h_sel);
+  }
   st = dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     if constexpr (requires { typename CellOf<M>::type; }) {
       typedef typename CellOf<M>::type CM;
-      if (c->cell_pts == 512) return run_cells_bounds<CM, 4>(c, c->d_ub);
-      return run_cells_bounds<CM, 2>(c, c->d_ub);
+      if (c->cell_pts == 512) return run_cells_bounds<CM, 4>(c, c->d_ub, d_nc);
+      return run_cells_bounds<CM, 2>(c, c->d_ub, d_nc);
     } else {
       return fail(c, LSQR_ERR_INVALID, "model has no two-level scan");
     }
   });
   if (st != LSQR_OK) return st;
-  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                           c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
+  if (bounded) {
+    hipLaunchKernelGGL(k_sum_selected, dim3(1), dim3(256), 0, c->stream, c->d_sel, &c->d_bsel->n_pilot, d_nc,
+                       c->d_counter + 2);
+    hipLaunchKernelGGL(k_sum_selected, dim3(8), dim3(256), 0, c->stream, c->d_sel + kPilots, &c->d_bsel->n_rest, d_nc,
+                       c->d_counter + 2);
+    HIPCHK(c, hipGetLastError());
+  }
+  unsigned long long *pin = (unsigned long long *)c->h_pin;
+  HIPCHK(c, hipMemcpyAsync(pin, c->d_counter + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + 1, c->d_counter + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   if (bound_out)
     HIPCHK(c, hipMemcpyAsync(bound_out, c->d_ub, c->H * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  out[0] = *(unsigned long long *)c->h_pin;
+  out[0] = pin[0];
   out[1] = (uint64_t)c->n_cells * ((c->H + 63) / 64);
   out[2] = c->n_cells;
   out[3] = c->cell_pts;
+  out[4] = bounded ? 1 : 0;
+  out[5] = h_sel[0];
+  out[6] = h_sel[1];
+  out[7] = bounded ? pin[1] : pin[0];
   return LSQR_OK;
 }
 
