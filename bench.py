@@ -91,6 +91,7 @@ OPS_PER_PAIR = {"plane": 9, "sphere": 10, "line": 20, "dense": 130, "us": 69, "p
 # 1024 * 2.4e9 / 4 = 614.4 G wave-instructions/s; fp64 MFMA dense peak 78.6 TFLOP/s.
 VALU_ISSUE_PEAK_GWIPS = 1024 * 2.4 / 4.0
 FP64_MFMA_PEAK_TFLOPS = 78.6
+FP32_MFMA_PEAK_TFLOPS = 157.3
 # USEFUL vector instructions of the scan kernels, counted from the source (csrc/cells.h, models.h, us.h; table in
 # DESIGN.md section 6): l1 = arithmetic of CM::level1 per (64-hypothesis group, cell); pk = packed-fp32
 # instructions of the filter measure per packed pair of observations per lane (128 observations per wave).
@@ -332,11 +333,14 @@ def scan_roofline(a, ctx, idx, H, scan_ms, n_scan, rec):
     if w == "dense":
         flops = 2.0 * a.points * 64 * H              # the residual block rows x hypotheses as a GEMM
         ach = flops / t / 1e12 if t > 0 else 0.0
-        base.update({"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": "k_scan_dense_mfma2<64> (fp64 MFMA filter, v_mfma_f64_16x16x4) + k_dense_recheck",
-                     "note": "flops = 2*m*n*H of the filter GEMM per launch; the exact re-check worklist holds "
-                             "~1e-13 of the pairs"})
+        base.update({"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "frac_of_fp64_mfma_peak": ach / FP64_MFMA_PEAK_TFLOPS,
+                     "kernel": "k_scan_dense_mfma32<64> (fp32 MFMA filter, v_mfma_f32_16x16x4_f32, A fragments in "
+                               "registers, two accumulator sets) + k_dense_recheck_seg (exact fp64 decision of the "
+                               "~1e-4 of the pairs inside the filter's band); launch_ms covers both and the thresholds",
+                     "note": "flops = 2*m*n*H of the filter GEMM per launch; peak = the fp32 dense matrix rate the "
+                             "filter runs at (the fp64 MFMA filter of round 1 reached 0.65 of the fp64 rate = 51 TFLOP/s)"})
         return base
     u = SCAN_USEFUL[w]
     cells = w in ("plane", "sphere", "line") and idx["built"] and not a.no_filter

@@ -317,6 +317,7 @@ struct PlaneCell {
   typedef PlaneModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 0, ROW2_OFF = 0 };  // row = fp64 scan parameters
   enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0, MIN_WAVES = 6 };  // measured best (tools/ab_cells.py)
+  enum { USE_BOUND = 1 };  // bounded scan pays: a random plane still cuts ~13 % of the cells
   struct Hyp {
     double n[3], c;
     float nf[3], e0;
@@ -410,6 +411,7 @@ struct SphereCell {
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
   enum { MIN_WAVES = 4 };  // 72 VGPRs = 7 waves per SIMD as compiled
   enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // measured (tools/ab_cells.py): 1.9 ms; 512 / v_readlane 2.1 ms
+  enum { USE_BOUND = 1 };
   struct Hyp {
     double c[3], mid;
     float half;
@@ -496,6 +498,9 @@ struct LineCell {
   typedef LineModel<D> M;
   enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
   enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1, MIN_WAVES = 4 };  // measured (tools/ab_cells.py): 2.17 ms against 2.34 ms with 512 / v_readlane
+  // a line that misses the inliers touches < 1 % of the cells: the consensus candidates are 99 % of the work
+  // anyway, the bounded scan's extra launches only cost (2.39 against 2.2 ms)
+  enum { USE_BOUND = 0 };
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;

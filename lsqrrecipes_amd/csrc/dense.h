@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_scan_dense_t(const double *__restrict__
 // 16 x 4 fragment reads of a wave hit 32 distinct 8-byte slots); wave w owns rows 16w..16w+15 and
 // four 16 x 16 accumulator tiles; each lane counts the inliers of its own hypothesis columns.
 constexpr int kDmPitch = 66;
-constexpr unsigned kAmbCap = 1u << 20;
+constexpr unsigned kAmbCap = 1u << 22;  // worklist entries (the fp32 filter sends ~1e-4 of the pairs there)
 constexpr int kDmHypChunk = 2048;  // hypotheses per launch (LDS vote counters: 8 KiB)
 
 // per hypothesis thresholds {delta - E_h, delta + E_h} of the MFMA filter ({-1,-1}: never agrees)
@@ -444,6 +444,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (uint32_t h = tid; h < H; h += 256) {
     uint32_t c = s_cnt[h];
     if (c) atomicAdd(&votes[h], c);
+  }
+}
+
+// Third arrangement (default at n > 32): the same tiling as k_scan_dense_mfma2 in SINGLE precision
+// (v_mfma_f32_16x16x4_f32: twice the fp64 matrix rate, half the LDS bytes).  The filter's band widens from ~1e-13
+// to ~1e-4 of the pairs, which is still a worklist (k_dense_recheck decides them with the exact fp64 formula), so
+// the votes stay bit-identical.  Error of the fp32 evaluation r32 = fl(fl(sum fl(a_i) fl(x_i)) - fl(b)) against
+// the exact residual, u = 2^-24: inputs 2u |a_i x_i| each, n fused accumulations gamma_n sum|a_i x_i|, the
+// subtraction and fl(b): 2u (|S| + |b|)  =>  |r32 - res| <= (n + 4) u (1 + 1e-3) (Amax ||x||_1 + Bmax), Amax / Bmax
+// the largest |coefficient| / |right-hand side| of the upload (taken separately: a random minimal solve has
+// ||x||_1 in the thousands, and pricing it with the right-hand sides' magnitude put 1.5 % of the pairs in the band);
+// the reference's fp64 running sum is within 1e-14 of that scale of res.  k_dense_thresholds32 takes
+// E_h = 1.5 (n + 4) u (Amax ||x||_1 + Bmax) + 1e-30 (denormal products may be flushed) and rounds the two
+// thresholds outwards to fp32.
+__global__ void k_dense_thresholds32(const double *__restrict__ sp, uint32_t H, int n, int nr, double delta,
+                                     double amax, double bmax, float *__restrict__ thr,
+                                     float *__restrict__ sp32) {
+  uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  double l1 = 0.0;
+  for (int k = 0; k < nr; k++) {
+    const double v = k < n ? sp[(size_t)h * nr + k] : 0.0;
+    l1 += fabs(v);
+    // FRAGMENT order: unknown k = 4 q + k4 is stored at k4 * 16 + q, so that the 16 values a lane of the scan
+    // needs (its k4, q = 0..15) are 64 contiguous bytes = four 16-byte loads instead of sixteen 4-byte ones
+    sp32[(size_t)h * nr + (k & 3) * (nr / 4) + (k >> 2)] = (float)v;
+  }
+  const double u = 5.9604644775390625e-08;
+  const double E = 1.5 * (double)(n + 4) * u * (amax * l1 + bmax) + 1e-30;
+  // fp32 must be able to hold the products: magnitudes beyond 1e15 (or a NaN model) never agree through the filter
+  const bool live = l1 == l1 && l1 < 1e15 && amax < 1e15 && bmax < 1e15;
+  float ti = (float)(delta - E), to = (float)(delta + E);
+  if ((double)ti > delta - E) ti = nextafterf(ti, -INFINITY);
+  if ((double)to < delta + E) to = nextafterf(to, INFINITY);
+  thr[2 * (size_t)h] = live ? ti : -1.0f;
+  thr[2 * (size_t)h + 1] = live ? to : (l1 == l1 ? INFINITY : -1.0f);  // not live but finite: everything re-checked
+}
+
+constexpr int kDmPitch32 = 68;  // floats: the 16 x 4 fragment reads of a wave hit 64 distinct banks
+template <int NR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_scan_dense_mfma32(
+    const double *__restrict__ data, size_t stride, size_t m, size_t rows_per_block,
+    const float *__restrict__ sp32, const float *__restrict__ thr, uint32_t H, int n,
+    uint32_t *__restrict__ votes, unsigned long long *__restrict__ amb_list,
+    unsigned int *__restrict__ amb_counts, uint32_t seg_cap, uint32_t hyp_base) {
+  // the worklist is one segment per workgroup with its counter in LDS: a single global counter would take ~14 ns
+  // per (same-address) append, seconds' worth at the ~1e5..1e6 ambiguous pairs of the fp32 band
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  static_assert(NR == 64, "fragment bookkeeping below assumes 64 padded unknowns");
+  extern __shared__ float smf[];
+  float *At = smf;                    // 64 rows x pitch
+  float *bv = At + 64 * kDmPitch32;   // 64 right-hand sides
+  uint32_t *s_cnt = (uint32_t *)(bv + 64);
+  uint32_t *s_amb = s_cnt + H;        // entries of this workgroup's worklist segment so far
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, k4 = lane >> 4;
+  const uint32_t nhb = (H + 63) / 64;
+  for (uint32_t h = tid; h < H; h += 256) s_cnt[h] = 0;
+  if (tid == 0) *s_amb = amb_counts[blockIdx.x];
+  size_t lo = (size_t)blockIdx.x * rows_per_block;
+  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
+  float nb[16], nti = -1.0f, nto = -1.0f;
+  auto fetch_hyp = [&](uint32_t hb) {
+    const uint32_t h = hb * 64 + wave * 16 + c16;
+    const uint32_t hc = h < H ? h : 0;  // loads are unconditional (no divergent branches in the loop) ...
+    const f4 *row = (const f4 *)(sp32 + (size_t)hc * NR + k4 * 16);  // fragment order (k_dense_thresholds32)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f4 v = row[j];
+      nb[4 * j] = v.x, nb[4 * j + 1] = v.y, nb[4 * j + 2] = v.z, nb[4 * j + 3] = v.w;  // (columns >= n are 0)
+    }
+    nti = h < H ? thr[2 * (size_t)hc] : -1.0f;            // ... a lane past the batch gets thresholds that never pass
+    nto = h < H ? thr[2 * (size_t)hc + 1] : -1.0f;
+  };
+  if (lo < hi) fetch_hyp(0);
+  for (size_t base = lo; base < hi; base += 64) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      int r = idx >> 6, kk = idx & 63;
+      size_t row = base + r;
+      At[r * kDmPitch32 + kk] = (row < hi && kk < n) ? (float)data[row * stride + kk] : 0.0f;
+    }
+    if (tid < 64) {
+      size_t row = base + tid;
+      bv[tid] = row < hi ? (float)data[row * stride + n] : __builtin_nanf("");  // NaN: row never counts
+    }
+    __syncthreads();
+    // The wave's A fragments of the whole tile (64 floats per lane) and its 16 right-hand sides are read from LDS
+    // ONCE and stay in registers for all hypothesis blocks.  The hypothesis loop is software-pipelined over two
+    // accumulator sets: while the matrix pipe works through the 64 instructions of block hb + 1, the same wave
+    // issues the (branch-free) counting of block hb in their shadow -- with two waves per SIMD nothing else hides it.
+    float a[4][16], bvr[16];
+    {
+      const float *ap = At + c16 * kDmPitch32 + k4;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) a[t][q] = ap[t * 16 * kDmPitch32 + 4 * q];
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bvr[4 * t + rg] = bv[t * 16 + 4 * k4 + rg];
+    }
+    auto mfma_block = [&](f4(&acc)[4], const float(&b)[16]) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][q], b[q], acc[t], 0, 0, 0);
+      }
+    };
+    // D layout of the fp32 instruction: column (hypothesis) = lane & 15, row = 4 * (lane >> 4) + reg (+ 16 * row
+    // group) -- four CONSECUTIVE rows per lane, unlike the fp64 instruction's (lane >> 4) + 4 * reg
+    auto count_block = [&](const f4(&acc)[4], float ti, float to, uint32_t hb) {
+      uint32_t c = 0, may = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const float res = __builtin_fabsf(acc[t][rg] - bvr[4 * t + rg]);
+          c += res < ti ? 1u : 0u;
+          may += res < to ? 1u : 0u;
+        }
+      if (may != c) {  // rare: some pair sits in the band -> worklist, decided exactly by k_dense_recheck_seg
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const float res = __builtin_fabsf(acc[t][rg] - bvr[4 * t + rg]);
+            if (res >= ti && res < to) {
+              const unsigned slot = atomicAdd(s_amb, 1u);
+              if (slot < seg_cap)
+                amb_list[(size_t)blockIdx.x * seg_cap + slot] =
+                    ((unsigned long long)(base + t * 16 + 4 * k4 + rg) << 32) |
+                    (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
+            }
+          }
+      }
+      c += __shfl_xor(c, 16);  // lanes l, l^16, l^32, l^48 hold the same hypothesis column
+      c += __shfl_xor(c, 32);
+      if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + wave * 16 + c16], c);
+    };
+    const uint32_t nhb2 = (nhb + 1) & ~1u;  // blocks past the batch carry thresholds that never pass
+    f4 accA[4], accB[4];
+    float bA[16], bB[16], tiA, toA, tiB, toB;
+#pragma unroll
+    for (int q = 0; q < 16; q++) bA[q] = nb[q];
+    tiA = nti, toA = nto;
+    fetch_hyp(1);
+    mfma_block(accA, bA);
+    for (uint32_t hb = 0; hb < nhb2; hb += 2) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) bB[q] = nb[q];
+      tiB = nti, toB = nto;
+      fetch_hyp(hb + 2 < nhb2 ? hb + 2 : 0);
+      mfma_block(accB, bB);
+      count_block(accA, tiA, toA, hb);
+      if (hb + 2 < nhb2) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) bA[q] = nb[q];
+        tiA = nti, toA = nto;
+        fetch_hyp(hb + 3 < nhb2 ? hb + 3 : 0);
+        mfma_block(accA, bA);
+      }
+      count_block(accB, tiB, toB, hb + 1);
+    }
+  }
+  __syncthreads();
+  for (uint32_t h = tid; h < H; h += 256) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
+  }
+  if (tid == 0) amb_counts[blockIdx.x] = *s_amb;
+}
+
+// exact decision of the segmented worklist (one block per segment); out_max[0] = largest segment fill (overflow check)
+template <int NR>
+__global__ __launch_bounds__(256) void k_dense_recheck_seg(const double *__restrict__ data, size_t stride,
+                                                           const double *__restrict__ sp, ModelConsts mc,
+                                                           const unsigned long long *__restrict__ amb_list,
+                                                           const unsigned int *__restrict__ amb_counts,
+                                                           uint32_t seg_cap, uint32_t *__restrict__ votes,
+                                                           unsigned int *__restrict__ out_max) {
+  typedef DenseModel<NR> M;
+  const unsigned filled = amb_counts[blockIdx.x];
+  if (threadIdx.x == 0 && filled) atomicMax(out_max, filled);
+  const unsigned total = filled < seg_cap ? filled : seg_cap;
+  for (unsigned e = threadIdx.x; e < total; e += 256) {
+    unsigned long long v = amb_list[(size_t)blockIdx.x * seg_cap + e];
+    size_t row = (size_t)(v >> 32);
+    uint32_t h = (uint32_t)(v & 0xffffffffu);
+    double x[M::REC];
+    M::load(data + row * stride, mc, x);
+    if (M::agree(sp + (size_t)h * NR, x, mc)) atomicAdd(&votes[h], 1u);
   }
 }
 

@@ -67,6 +67,8 @@ struct lsqr_ctx {
   size_t idx_scratch_cap = 0;
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
   uint64_t hyp_expected = 0;      // hypotheses the caller still expects to scan on this upload (lsqr_ransac: numTries)
+  unsigned dense_amb_max = 0;  // fullest worklist segment of the last fp32 dense scan (diagnostics)
+  int opt_dense_f32 = 1;  // dense scan filter on the fp32 matrix cores (worklist of ~1e-4 of the pairs); 0: fp64 MFMA
   int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
@@ -364,7 +366,8 @@ int ensure_absmax(lsqr_ctx *c) {
   {
     ProfScope ps(c, KID_ABSMAX);
     hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, c->stream, c->d_data, c->stride, c->n,
-                       c->ND, us ? 12 : -1, us ? 9 : c->ND, c->d_counter + 5);
+                       c->ND, us ? 12 : -1, us ? 9 : (c->cfg.model == LSQR_MODEL_DENSE ? c->ND - 1 : c->ND),
+                       c->d_counter + 5);  // dense: the coefficient columns separately from the right-hand side
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 5, 2 * sizeof(unsigned long long),
@@ -748,6 +751,51 @@ int run_scan(lsqr_ctx *c) {
           size_t nblk = std::min<size_t>(tiles, c->opt_dense_v1 ? 512 : 768);  // 2 / 3 workgroups per CU
           size_t rpb = (tiles + nblk - 1) / nblk * 64;
           nblk = (c->n + rpb - 1) / rpb;
+          if constexpr (M::NR == 64) {
+            // default at n > 32: the filter in fp32 on the matrix cores (twice the fp64 MFMA rate); its band holds
+            // ~1e-4 of the pairs, decided exactly from a per-workgroup worklist.  A segment overflow (not seen)
+            // falls through to the fp64 filter below.
+            if (c->opt_dense_f32 && !c->opt_dense_v1 && c->H <= 8192 && c->mc.absmax < 1e15) {
+              const uint32_t seg_cap = kAmbCap / 1024;  // <= 512 segments
+              {  // two waves per SIMD (the A fragments live in registers): exactly two workgroups per CU
+                size_t nb2 = std::min<size_t>(tiles, 512);
+                rpb = (tiles + nb2 - 1) / nb2 * 64;
+                nblk = (c->n + rpb - 1) / rpb;
+              }
+              float *d_thr32 = (float *)c->d_partials;                        // 2 floats per hypothesis
+              float *d_sp32 = (float *)c->d_partials + 2 * 8192;              // 64 floats per hypothesis (2 MB)
+              unsigned int *d_segcnt = (unsigned int *)((float *)c->d_partials + 2 * 8192 + 64 * 8192);  // 1024 words
+              HIPCHK(c, hipMemsetAsync(d_segcnt, 0, 1024 * sizeof(unsigned int), c->stream));
+              {
+                ProfScope ps(c, KID_SCAN);
+                hipLaunchKernelGGL(k_dense_thresholds32, dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot,
+                                   c->mc.absmax, d_thr32, d_sp32);
+                HIPCHK(c, hipGetLastError());
+                for (size_t h0 = 0; h0 < c->H; h0 += kDmHypChunk) {
+                  uint32_t hc = (uint32_t)std::min<size_t>(kDmHypChunk, c->H - h0);
+                  size_t lds = sizeof(float) * (64 * kDmPitch32 + 64) + sizeof(uint32_t) * (hc + 1);
+                  hipLaunchKernelGGL((k_scan_dense_mfma32<64>), dim3((unsigned)nblk), dim3(256), lds, c->stream,
+                                     c->d_data, c->stride, c->n, rpb, d_sp32 + h0 * 64, d_thr32 + 2 * h0, hc,
+                                     (int)c->cfg.dim, c->d_votes + h0, c->d_amb, d_segcnt, seg_cap, (uint32_t)h0);
+                  HIPCHK(c, hipGetLastError());
+                }
+                hipLaunchKernelGGL((k_dense_recheck_seg<64>), dim3((unsigned)nblk), dim3(256), 0, c->stream, c->d_data,
+                                   c->stride, c->d_hparams, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes,
+                                   (unsigned int *)(c->d_counter + 3));
+                HIPCHK(c, hipGetLastError());
+              }
+              HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                       c->stream));
+              HIPCHK(c, hipStreamSynchronize(c->stream));
+              c->dense_amb_max = *(unsigned int *)c->h_pin;
+              if (c->dense_amb_max <= seg_cap) return LSQR_OK;
+              (void)fail(c, LSQR_OK, "dense fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used",
+                         c->dense_amb_max, seg_cap);
+              HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));   // overflow: fp64 filter
+              HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+            }
+          }
           {
             ProfScope ps(c, KID_SCAN);
             hipLaunchKernelGGL(k_dense_thresholds, dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0,
@@ -873,7 +921,7 @@ int run_scan(lsqr_ctx *c) {
             c->last_bound[0] = 0;
             // batch entry points: hypotheses that cannot become the running maximum are not counted (the extra
             // launches only pay for batches of >= 1024; the selection kernels handle <= 8192)
-            if (c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
+            if (CM::USE_BOUND && c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
               if (cell_pts == 512) return run_scan_bounded<CM, 4>(c);
               return run_scan_bounded<CM, 2>(c);
             }
@@ -3238,6 +3286,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
     if (value != 0 && value != 256 && value != 512)
       return fail(c, LSQR_ERR_INVALID, "scan_cell must be 0, 256 or 512");
     c->opt_cell = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_f32")) {  // 1 (default): dense scan filter on the fp32 matrix cores; 0: fp64 MFMA filter
+    c->opt_dense_f32 = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_scan_v1")) {  // 1: first MFMA scan arrangement (hypothesis block through LDS)

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402
 
 KERNEL = {"plane": "k_scan_cells", "sphere": "k_scan_cells", "line": "k_scan_cells", "us": "k_scan_us_f32",
-          "dense": "k_scan_dense_mfma2"}
+          "dense": "k_scan_dense_mfma"}
 SETS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM",
         "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY",
