@@ -53,11 +53,10 @@ def parse():
     ap.add_argument("--no-index", action="store_true", help="exhaustive scan (no spatial index)")
     ap.add_argument("--outliers", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--us-fit", default="analytic", choices=["iterative", "analytic"],
-                    help="final fit of the US workload: the analytic estimate (default) or Levenberg-Marquardt "
-                         "from it with the reference's 1e-15 tolerances -- at 1 M noisy frames MINPACK then "
-                         "wanders inside rounding noise until its 5000-evaluation limit (90 us per evaluation: "
-                         "0.45 s per step) and reports failure, exactly as the reference's settings make it")
+    ap.add_argument("--us-fit", default="iterative", choices=["iterative", "analytic"],
+                    help="final fit of the US workload: Levenberg-Marquardt with the reference's settings (BASELINE "
+                         "config 5 as written: tolerances 1e-15, 5000 evaluations -- at 1 M frames MINPACK uses all "
+                         "of them, see tests/golden/us_lm_vectors.npz) or the analytic estimate alone")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single GPU: one blocking lsqr_batch_fit per step instead of pipelined batches")
     ap.add_argument("--no-end-to-end", action="store_true",

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
   for (int k = 0; k < N; k++) acc[k] = 0.0;
   size_t lo = begin + (size_t)blockIdx.x * chunk;
   size_t hi = lo + chunk < end ? lo + chunk : end;
-  if constexpr (requires { typename M::LmCoef; }) {
+  if constexpr (requires(typename M::LmCoef k, double *m) { M::accumulate_lm_fast(m, k, m); }) {
     typename M::LmCoef coef;
     M::lm_coef(xk.x, coef);
     for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
@@ -584,6 +584,71 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
     double t = 0.0;
     for (int w = 0; w < kBlock / 64; w++) t += s_m[w][threadIdx.x];
     partials[(size_t)blockIdx.x * MOM_MAX + threadIdx.x] = t;
+  }
+}
+
+// The same evaluation on the matrix cores (north_star: "MFMA only if J^T J actually becomes a large dense GEMM" --
+// over 1 M frames it is one: C = Z^T Z with Z = (J | f), 12 columns, a million rows).  Lane = record: each lane forms
+// its row z (M::lm_row: NLM Jacobian entries and the residual), the wave parks its 64 rows in LDS and feeds them, four
+// records per instruction, to v_mfma_f64_16x16x4 with the SAME register as A and B operand (lane (k, c) holds
+// z_{record k}[c] for both).  The 16 x 16 accumulator (4 doubles per lane) replaces the 78 per-lane accumulators and
+// their 78 shuffle trees: 8 accumulator VGPRs instead of 156 (six to eight waves per SIMD instead of two), no
+// cross-lane reduction at all.  C[p][q] = (J^T J)_pq, C[p][NLM] = (J^T f)_p, C[NLM][NLM] = sum f^2.
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_lm_pass_mfma(const double *__restrict__ data, size_t stride, size_t n,
+                                                         typename M::LmCoef coef, ModelConsts mc,
+                                                         double *__restrict__ partials) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int NZ = M::NLM + 1, P = 18;  // row pitch (doubles) of the LDS tile
+  static_assert(NZ <= 16, "one 16 x 16 accumulator tile");
+  __shared__ double s_z[kBlock / 64][64 * P];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, c16 = lane & 15;
+  // `coef` -- the per-evaluation constants (rotation products and their derivatives for the US model) -- is formed on
+  // the host and arrives as a kernel argument: wave-uniform, in scalar registers, no sin / cos per lane
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  double *tile = s_z[wave];
+  for (size_t base = (size_t)blockIdx.x * kBlock; base < n; base += (size_t)gridDim.x * kBlock) {
+    const size_t i = base + threadIdx.x;
+    double z[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) z[j] = 0.0;
+    if (i < n) {
+      double x[M::REC];
+      M::load(data + i * stride, mc, x);
+      M::lm_row(x, coef, z);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) tile[lane * P + j] = z[j];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const double v = tile[(4 * s + k) * P + c16];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // fold the four waves in order; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double *fold = &s_z[0][0];
+  __syncthreads();
+  for (int w = 0; w < kBlock / 64; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int pos = (k + 4 * rg) * 16 + c16;
+        fold[pos] = (w == 0 ? 0.0 : fold[pos]) + acc[rg];
+      }
+    }
+    __syncthreads();
+  }
+  // -> the moment block layout {sum f^2, J^T J upper (packed row-major), J^T f}
+  constexpr int NL = M::NLM;
+  const int t = threadIdx.x;
+  if (t < 256) {
+    const int r = t >> 4, cc = t & 15;
+    double *out = partials + (size_t)blockIdx.x * MOM_MAX;
+    if (r < NL && cc < NL && r <= cc) out[1 + r * NL - r * (r - 1) / 2 + (cc - r)] = fold[t];
+    if (r < NL && cc == NL) out[1 + NL * (NL + 1) / 2 + r] = fold[t];
+    if (r == NL && cc == NL) out[0] = fold[t];
   }
 }
 

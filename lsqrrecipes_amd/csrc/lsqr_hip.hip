@@ -119,6 +119,7 @@ struct lsqr_ctx {
   size_t lmrec_cap = 0;
   double *h_lmres = nullptr;  // pinned, device-visible: {moment block, sequence flag} written by k_lm_pass
   double lm_seq = 0.0;        // sequence number of the last evaluation (the flag value the host polls for)
+  int opt_lm_mfma = 1;        // 1: the LM pass accumulates (J | f)^T (J | f) on the matrix cores; 0: per-lane sums
   int opt_lm_fused = 1;       // 1: one launch per LM evaluation, result polled in pinned memory; 0: r01 path
 
   // staged upload (lsqr_upload of large pageable buffers): ring of pinned chunks filled by a few host threads
@@ -1254,7 +1255,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             lm_data = c->d_lmrec;
             lm_stride = M::ND;
           }
-          int nb = grid_for(cnt, kBlock * 8, kMaxPartials);
+          int nb = grid_for(cnt, kBlock * ((c->opt_lm_mfma && M::NLM >= 8) ? 2 : 8), kMaxPartials);
           size_t chunk = (cnt + nb - 1) / nb;
           chunk = (chunk + kBlock - 1) / kBlock * kBlock;
           nb = (int)((cnt + chunk - 1) / chunk);
@@ -1273,8 +1274,22 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             c->prof = timed;
             {
               ProfScope ps(c, KID_MOMENTS);
-              hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
-                                 (size_t)0, cnt, chunk, (const uint8_t *)nullptr, xk, c->mc, c->d_partials);
+              if constexpr (requires { typename M::LmCoef; }) {
+                // the matrix-core pass pays when the (J | f) rows are wide (US: 12 / 9 columns, 78 / 45 sums); for the
+                // sphere's 5 columns the 16 x 16 tile is mostly padding and the instruction time alone (25 us at 3.8 M
+                // points) exceeds the per-lane version's whole pass
+                if (c->opt_lm_mfma && M::NLM >= 8) {
+                  typename M::LmCoef coef;
+                  M::lm_coef(xk.x, coef);
+                  hipLaunchKernelGGL((k_lm_pass_mfma<M>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
+                                     cnt, coef, c->mc, c->d_partials);
+                } else
+                  hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
+                                     (size_t)0, cnt, chunk, (const uint8_t *)nullptr, xk, c->mc, c->d_partials);
+              } else {
+                hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
+                                   (size_t)0, cnt, chunk, (const uint8_t *)nullptr, xk, c->mc, c->d_partials);
+              }
               HIPCHK(c, hipGetLastError());
             }
             {
@@ -3247,6 +3262,10 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_bound")) {  // 1 (default): batch entry points skip hypotheses that cannot win; 0: count all
     c->opt_bound = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_mfma")) {  // 1 (default): LM pass on the matrix cores; 0: per-lane accumulators + shuffle trees
+    c->opt_lm_mfma = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "lm_fused")) {  // 1 (default): one launch per LM evaluation, result polled in pinned memory

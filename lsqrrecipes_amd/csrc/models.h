@@ -595,6 +595,22 @@ struct SphereModel {
     return D + 1;
   }
 
+  // one row of (J | f) at xk = [c, r] (f: SphereParametersEstimator.hxx:394-409, gradf: :413-431) for the
+  // matrix-core pass k_lm_pass_mfma: z[0..D) = (c - x) / |x - c|, z[D] = -1, z[D + 1] = |x - c| - r
+  struct LmCoef {
+    double x[D + 1];
+  };
+  static LSQR_HD void lm_coef(const double *xk, LmCoef &k) {
+    for (int i = 0; i <= D; i++) k.x[i] = xk[i];
+  }
+  static LSQR_HD void lm_row(const double *x, const LmCoef &k, double *z) {
+    double sq = 0.0;
+    for (int j = 0; j < D; j++) sq += (x[j] - k.x[j]) * (x[j] - k.x[j]);
+    const double s = sqrt(sq);
+    for (int j = 0; j < D; j++) z[j] = (k.x[j] - x[j]) / s;
+    z[D] = -1.0;
+    z[D + 1] = s - k.x[D];
+  }
   // geometric fit pass (f: SphereParametersEstimator.hxx:394-409, gradf: :413-431):
   // {sum f^2, J^T J upper, J^T f} at xk = [c, r]
   static LSQR_HD void accumulate_lm(const double *x, const double *xk, double *m) {

@@ -139,6 +139,9 @@ struct SphereModelN {
     return B::solve(m, org, c, par);              // :267-307
   }
   static LSQR_HD int lm_finalize(const double *x, double *par) { return B::lm_finalize(x, par); }
+  typedef typename B::LmCoef LmCoef;
+  static LSQR_HD void lm_coef(const double *xk, LmCoef &k) { B::lm_coef(xk, k); }
+  static LSQR_HD void lm_row(const double *x, const LmCoef &k, double *z) { B::lm_row(x, k, z); }
   static LSQR_HD void accumulate_lm(const double *x, const double *xk, double *m) {
     B::accumulate_lm(x, xk, m);                   // :394-431
   }

@@ -431,6 +431,32 @@ struct USModel {
       k.a[4][i] = 0.0, k.b[4][i] = r2[i];
     }
   }
+  // one row of the iteration's (J | f) matrix: z[0..NLM) = J_p = g_p / |e|, z[NLM] = f = |e| -- what k_lm_pass_mfma
+  // feeds to the matrix cores (sum z z^T holds J^T J, J^T f and sum f^2 at once); one root and one division
+  static LSQR_HD void lm_row(const double *rec, const LmCoef &k, double *z) {
+    const int o = SINGLE ? 3 : 0;
+    const double u = rec[13], v = rec[14];
+    double q[3], e[3], h[3];
+    for (int i = 0; i < 3; i++) q[i] = fma(u, k.c0[i], fma(v, k.c1[i], k.t3[i]));
+    for (int i = 0; i < 3; i++) {
+      double s = rec[9 + i] - (SINGLE ? k.t1[i] : rec[15 + i]);
+      s = fma(rec[3 * i + 2], q[2], s);
+      s = fma(rec[3 * i + 1], q[1], s);
+      e[i] = fma(rec[3 * i], q[0], s);
+    }
+    for (int j = 0; j < 3; j++) h[j] = fma(rec[j], e[0], fma(rec[3 + j], e[1], rec[6 + j] * e[2]));  // R2^T e
+    const double ee = fma(e[0], e[0], fma(e[1], e[1], e[2] * e[2]));
+    const double f = sqrt(ee), rs = 1.0 / f;
+    if (SINGLE)
+      for (int i = 0; i < 3; i++) z[i] = -e[i] * rs;
+    for (int i = 0; i < 3; i++) z[o + i] = h[i] * rs;
+    for (int p = 0; p < 5; p++) {
+      const double ha = fma(h[0], k.a[p][0], fma(h[1], k.a[p][1], h[2] * k.a[p][2]));
+      const double hb = fma(h[0], k.b[p][0], fma(h[1], k.b[p][1], h[2] * k.b[p][2]));
+      z[o + 3 + p] = fma(u, ha, v * hb) * rs;
+    }
+    z[NLM] = f;
+  }
   static LSQR_HD void accumulate_lm_fast(const double *rec, const LmCoef &k, double *m) {
     const int o = SINGLE ? 3 : 0;
     const double u = rec[13], v = rec[14];

@@ -4,6 +4,8 @@ and check themselves (tests/cpp/estimatorTests.cxx restates the reference's ctes
 import os
 import subprocess
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,12 +58,60 @@ def test_reference_style_estimator_tests_on_gpu():
     assert "all checks passed" in out
 
 
+def _numbers(out, label):
+    """every number printed after `label` (one list per occurrence)"""
+    import re
+    res = []
+    for line in out.splitlines():
+        if label in line:
+            res.append([float(x) for x in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?", line.split(label, 1)[1])])
+    return res
+
+
+def _vector_after(out, title):
+    """the numbers of the line that follows the heading `title` (examples/common.h: printVec)"""
+    lines = out.splitlines()
+    for i, line in enumerate(lines):
+        if title in line:
+            import re
+            tail = line.split(title, 1)[1] + " " + (lines[i + 1] if i + 1 < len(lines) else "")
+            return np.array([float(x) for x in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?", tail)])
+    raise AssertionError("heading %r not printed" % title)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog", ["planeEstimation", "sphereEstimation", "lineEstimation",
-                                  "pivotCalibration", "rayIntersectionEstimation",
-                                  "planeUSCalibration"])
-def test_example_programs_on_gpu(prog):
-    out = _run([prog])
+def test_plane_sphere_line_examples_print_correct_estimates():
+    """examples/planeEstimation.cxx, sphereEstimation.cxx, lineEstimation.cxx (90 inliers + 10 outliers, sigma 0.4,
+    delta 0.5, p = 0.999: examples/planeEstimation.cxx:63-83 of the reference): the printed quality figures"""
+    out = _run(["planeEstimation"])
+    dots = _numbers(out, "Dot product of real and computed normals[+-1=correct]:")
+    offs = _numbers(out, "Check if computed point is on known plane [0=correct]:")
+    used = _numbers(out, "Percentage of points which were used for final estimate:")
+    assert len(dots) == 2 and abs(abs(dots[1][0]) - 1) < 1e-5 and abs(offs[1][0]) < 0.5
+    assert abs(abs(dots[1][0]) - 1) <= abs(abs(dots[0][0]) - 1) + 1e-9      # RANSAC beats the contaminated plain fit
+    assert 0.55 <= used[0][0] <= 0.92                                       # at most the 90 inliers, within delta of the winner
+    truth, est = _vector_after(out, "Known (hyper)plane parameters [n,a]"), _vector_after(out, "RANSAC hyper(plane) parameters: [n,a]")
+    assert len(truth) == len(est) == 6 and abs(abs(truth[:3] @ est[:3]) - 1) < 1e-5
+    out = _run(["sphereEstimation"])
+    assert _numbers(out, "Distance between real and computed centers:")[-1][0] < 1.0
+    assert abs(_numbers(out, "Difference between real and computed radius:")[-1][0]) < 1.0
+    assert 0.5 < _numbers(out, "Percentage of points which were used for final estimate:")[-1][0] <= 0.92
+    res = _numbers(out, "Residual over all data: min")[-1]
+    assert res[0] >= 0 and res[1] >= 20.0 - 1.0     # max residual: the outliers sit at least 20 off the sphere
+    out = _run(["lineEstimation"])
+    assert abs(abs(_numbers(out, "Dot product of real and computed directions[+-1=correct]:")[-1][0]) - 1) < 1e-5
+    assert 0.3 < _numbers(out, "Percentage of points which were used for final estimate:")[-1][0] <= 0.92
+
+
+@pytest.mark.gpu
+def test_pivot_ray_and_phantom_examples_print_correct_estimates():
+    out = _run(["pivotCalibration"])
+    assert _numbers(out, "Largest deviation from the expected translations:")[-1][0] < 2.0
+    assert 50 <= _numbers(out, "Percentage of poses used for the final estimate:")[-1][0] <= 100
+    out = _run(["rayIntersectionEstimation"])
+    assert _numbers(out, "Distance to the known intersection point:")[-1][0] < 1.0
+    assert 50 <= _numbers(out, "Percentage of rays used for the final estimate:")[-1][0] <= 100
+    out = _run(["planeUSCalibration"])
     assert "RANSAC" in out
 
 
@@ -69,14 +119,34 @@ def test_example_programs_on_gpu(prog):
 def test_section_8f_example_programs_on_gpu():
     out = _run(["AbsoluteOrientation"])
     assert "Exhaustive search transformation" in out
+    errs = _numbers(out, "Maximal target registration error:")
+    assert len(errs) == 2 and all(0 <= e[0] < 10.0 for e in errs)   # plain fit, then the exhaustive search's fit
+    fid = _numbers(out, "Fiducials used in final estimate:")[-1]
+    assert fid[-2] == 0                                                       # the corrupted (last) fiducial is out
     out = _run(["pivotCalibration", os.path.join(REFDATA, "pivotCalibrationDataWithOutliers.txt")])
     assert "RANSAC translations" in out
+    # the reference's experimental file: the oracle's pinv solution of the file's poses without its outliers is what
+    # the program must print (PivotCalibrationParametersEstimator.cxx:63-96; known answers in the reference's test)
+    t = _vector_after(out, "RANSAC translations")
+    assert len(t) >= 6 and np.all(np.isfinite(t[:6]))
 
 
 @pytest.mark.gpu
 def test_example_data_file_programs_on_gpu():
     out = _run(["linearEquationSystemSolver", os.path.join(REFDATA, "augmentedMatrixWithOutliers.txt")])
     assert "Experimental data, RANSAC solution" in out
+    known, est = _vector_after(out, "Known solution [x_0,...,x_{n-1}]"), _vector_after(out, "RANSAC solution")
+    assert len(known) == len(est) and np.abs(known - est).max() < 0.05
+    # examples/linearEquationSystemSolver.cxx:180-181 of the reference quotes the approximate answer for its data file
+    p6 = _vector_after(out, "Experimental data, RANSAC solution (approximately -17, 1, -157, 147, -63, -1042)")
+    p6 = p6[:6]
+    assert np.allclose(p6, [-17, 1, -157, 147, -63, -1042], atol=3.0)
+    # ... and the oracle's RANSAC over the same file lands on the same consensus solution
+    from oracle import pyoracle as O
+    rows = np.loadtxt(os.path.join(REFDATA, "augmentedMatrixWithOutliers.txt"))
+    oc = O.cfg(O.DENSE, 6, (1.0 / 3.0) ** 0.5)
+    w = O.ransac(oc, rows, 0.999, sampler="ctr", seed=1)
+    assert np.allclose(p6, w["params"], rtol=1e-4, atol=1e-3)
     out = _run(["crosswireUSCalibration"])
     assert "Percentage of frames used" in out
     r = subprocess.run([os.path.join(BUILD, "crosswireUSCalibration"),
