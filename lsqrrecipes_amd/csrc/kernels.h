@@ -612,20 +612,46 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass_mfma(const double *__restric
     double z[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) z[j] = 0.0;
-    if (i < n) {
+    if constexpr (M::REC > 8 && M::REC <= P) {
+      // wide records (US: 120 B / 144 B): the wave's 64 records are one contiguous run when the input is the
+      // compacted consensus set (stride == REC).  Read it as a coalesced stream (lane l takes doubles l, l + 64, ...)
+      // into the wave's LDS rows and pick the own record up from there -- a lane-per-record read touches 64
+      // different cache lines per load instruction.
+      const size_t w0 = base + (size_t)wave * 64;  // first record of this wave
+      if (stride == (size_t)M::REC && w0 + 64 <= n) {
+        const double *src = data + w0 * M::REC;
+#pragma unroll
+        for (int j = 0; j < M::REC; j++) {
+          const int e = lane + 64 * j;             // element of the run
+          tile[(e / M::REC) * P + (e % M::REC)] = src[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        double x[M::REC];
+#pragma unroll
+        for (int j = 0; j < M::REC; j++) x[j] = (j == 12 && M::IS_US) ? 0.0 : tile[lane * P + j];
+        __builtin_amdgcn_wave_barrier();
+        M::lm_row(x, coef, z);
+      } else if (i < n) {
+        double x[M::REC];
+        M::load(data + i * stride, mc, x);
+        M::lm_row(x, coef, z);
+      }
+    } else if (i < n) {
       double x[M::REC];
       M::load(data + i * stride, mc, x);
       M::lm_row(x, coef, z);
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) tile[lane * P + j] = z[j];
-    __syncthreads();
+    // the tile is private to the wave and the LDS serves a wave's requests in order: a wave barrier (no instruction,
+    // it only stops the compiler from reordering) is all the write -> transposed read hand-over needs
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int s = 0; s < 16; s++) {
       const double v = tile[(4 * s + k) * P + c16];
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
   // fold the four waves in order; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   double *fold = &s_z[0][0];

@@ -1241,7 +1241,6 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             cchunk = (cchunk + kBlock - 1) / kBlock * kBlock;
             cb = (int)((c->n + cchunk - 1) / cchunk);
             uint32_t *d_cnt = (uint32_t *)c->d_partials, *d_off = d_cnt + 1024;  // scratch (4.4 MB buffer)
-            ProfScope ps(c, KID_MASK);
             hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(kBlock), 0, c->stream, c->d_mask, c->n, cchunk, d_cnt);
             hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, d_cnt, cb, d_off);
             HIPCHK(c, hipGetLastError());
