@@ -762,7 +762,10 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
             s[p] = CM::value(xs[q][p], fp);
             m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(s[p].x), __builtin_fabsf(s[p].y)));
           }
-          if (__ballot(m < btout) == 0) continue;
+          // a hypothesis whose filter is off (t_out = +inf: literal-formula sphere, |n_i| > 1, out-of-range magnitudes)
+          // takes the exact predicate for the whole cell whatever the fp32 measure says -- it may be inf or NaN there
+          const bool exact_all = !(btout < __builtin_inff());
+          if (!exact_all && __ballot(m < btout) == 0) continue;
           const float btin = LDSB ? btin_l
                                   : __builtin_bit_cast(float, __builtin_amdgcn_readlane(
                                                                   __builtin_bit_cast(int, bc[NB - 2]), b));
@@ -782,7 +785,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
             dmin = dx < dmin ? dx : dmin;
             dmin = dy < dmin ? dy : dmin;
           }
-          const unsigned long long amb = __ballot(dmin <= __builtin_bit_cast(uint32_t, btout - btin));
+          const unsigned long long amb =
+              exact_all ? ~0ULL : __ballot(dmin <= __builtin_bit_cast(uint32_t, btout - btin));
           if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
             const double *hp = sp + (size_t)(h0 + b) * SPD;  // wave-uniform -> scalar loads
 #pragma unroll

@@ -114,11 +114,19 @@ class ShardedRansac:
             par, _ = e.hypothesis(0)
         return int(wvotes), gidx, par
 
+    def _check_packable(self):
+        """the winner travels as (votes << 32) | ~index in a SIGNED int64 all-reduce(MAX): votes must stay below 2^31
+        (the C ABI itself compares the word unsigned and accepts up to 0xFFFFFFF0 observations)"""
+        if getattr(self.e, "n", 0) >= 2 ** 31:
+            raise ValueError("ShardedRansac: %d observations -- the int64 MAX all-reduce of the packed winner needs "
+                             "fewer than 2^31" % self.e.n)
+
     def step(self, seed, batch_index, H):
         """One whole multi-GPU step: batch() + fit() with the fewest host synchronisations the
         engine offers.  Returns (votes, global_index, params_of_winner, fit, inliers, info) or None
         when no hypothesis of the batch was valid."""
         e, c = self.e, self.c
+        self._check_packable()
         if not hasattr(e, "winner_moments"):
             votes, gidx, par = self.batch(seed, batch_index, H)
             if gidx is None:
@@ -152,6 +160,7 @@ class ShardedRansac:
         process that uses both (two runtimes initialised in the other order do not see the devices)."""
         import torch
         e, c = self.e, self.c
+        self._check_packable()
         if self._xbuf is None:
             dev = torch.device("cuda", torch.cuda.current_device())
             nmom = e.moments_len(0)

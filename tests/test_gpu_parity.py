@@ -1851,3 +1851,26 @@ def test_bounded_scan_inside_adaptive_ransac(ctx):
     assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
     w = O.ransac(O.cfg(O.PLANE, 3, 0.5), data, 0.999, sampler="ctr", seed=5)
     assert out[1][0] == w["iters"] and np.array_equal(out[1][3], w["consensus"])
+
+
+def test_cell_scan_with_the_filter_switched_off_per_hypothesis(ctx):
+    """small spheres far from the origin: the fp32 band of most hypotheses exceeds a quarter of the squared radius,
+    prepare_f32 switches their filter off (t_in = -inf, t_out = +inf) and the two-level scan has to send every
+    observation of every cell down the exact path -- whatever the fp32 measure evaluates to.  Same for a plane model
+    whose normal is not a unit vector (|n_i| > 1: E = inf)."""
+    g = np.random.default_rng(12)
+    n = 70_000
+    c0 = np.array([3.0e6, -2.0e6, 1.0e6])
+    u = g.normal(size=(n, 3))
+    pts = c0 + 2.0 * u / np.linalg.norm(u, axis=1)[:, None] + g.normal(scale=0.01, size=(n, 3))
+    pts[::3] = c0 + g.uniform(-6, 6, size=(len(pts[::3]), 3))
+    oc = O.cfg(O.SPHERE, 3, 0.05)
+    ctx.set_model(L.SPHERE, 3, 0.05).upload(pts)
+    ctx.hypotheses_sample(4, 0, 300)
+    plain = _scan_votes(ctx, 0)
+    assert np.array_equal(_scan_votes(ctx, 2), plain)
+    par, valid, _ = ctx.hypotheses(votes=False)
+    for h in range(0, 300, 37):
+        if valid[h]:
+            assert plain[h] == O.scan(oc, par[h], pts)[0]
+    assert plain.max() > 0.3 * n

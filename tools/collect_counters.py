@@ -23,6 +23,7 @@ from bench import kernel_source_hash  # noqa: E402
 
 KERNEL = {"plane": "k_scan_cells", "sphere": "k_scan_cells", "line": "k_scan_cells", "us": "k_scan_us_f32",
           "dense": "k_scan_dense_mfma"}
+LAUNCHES = 0
 SETS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM",
         "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY",
@@ -46,7 +47,9 @@ def run_pass(w, counters, d):
         if KERNEL[w] in row["Kernel_Name"]:
             acc[row["Counter_Name"]] += float(row["Counter_Value"])
             launches[row["Counter_Name"]] += 1
-    return {k: v / max(launches[k], 1) for k, v in acc.items()}
+    global LAUNCHES
+    LAUNCHES = max(launches.values()) if launches else 0
+    return dict(acc)   # SUM over the scan launches of the one bench step (bounded scan: pilots + second pass)
 
 
 def main():
@@ -70,14 +73,19 @@ def main():
                    timeout=300)
     avg_ns = None
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+        tot = 0.0
         for row in csv.DictReader(open(f)):
             if KERNEL[w] in row["Name"]:
-                avg_ns = float(row["AverageNs"])
+                tot += float(row["TotalDurationNs"])
+        if tot:
+            avg_ns = tot / 3.0        # per bench step (3 steps in this pass)
     out = {"workload": w, "kernel": KERNEL[w], "kernel_source_hash": kernel_source_hash(),
            "collected_at": time.strftime("%Y-%m-%d %H:%M:%S"),
            "source": "tools/collect_counters.py %s: rocprofv3 --pmc passes (one counter set each, --kernel-trace only) of "
-                     "tools/scan_once.py %s -- the bench's shapes and sampler stream, one launch" % (w, w),
-           "counters_per_launch_sum_over_chip": c, "kernel_avg_ms": avg_ns / 1e6 if avg_ns else None}
+                     "tools/scan_once.py %s -- the bench's shapes and sampler stream, one step" % (w, w),
+           "counters_per_launch_sum_over_chip": c, "scan_launches_per_step": LAUNCHES,
+           "kernel_avg_ms": avg_ns / 1e6 if avg_ns else None,
+           "note": "counters and kernel time are SUMS over the scan launches of ONE bench step (lsqr_batch_fit)"}
     if "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
         cyc = c["SQ_BUSY_CYCLES"] / 32.0            # per shader engine -> cycles of the launch
         out["cycles_per_simd"] = cyc

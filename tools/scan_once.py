@@ -1,4 +1,4 @@
-# one scan launch of a BASELINE workload on the bench's shapes and seed (for rocprofv3 --pmc passes):
+# one bench step (lsqr_batch_fit) of a BASELINE workload on the bench's shapes and seed (for rocprofv3 --pmc passes):
 #   python3 tools/scan_once.py plane|sphere|line|us|dense [launches]
 import sys
 sys.path.insert(0, '.')
@@ -14,9 +14,9 @@ model = {'plane': L.PLANE, 'sphere': L.SPHERE, 'line': L.LINE, 'us': L.US_SINGLE
 delta = {'dense': 0.1, 'us': 3.0}.get(wl, 0.5)
 ctx = Context(0)
 ctx.set_model(model, 64 if wl == 'dense' else 3, delta, L.LS_ANALYTIC).upload(data)
-ctx.hypotheses_sample(0xC0FFEE, 0, H)
 if wl in ('plane', 'sphere', 'line'):
     ctx.set_option('scan_index', 2)
 for _ in range(reps):
-    ctx.scan()
+    # one bench step: sample, solve, scan (bounded for plane / sphere), winner, mask, closed-form fit
+    ctx.batch_fit(0xC0FFEE, 0, H)
     ctx.synchronize()
