@@ -32,6 +32,7 @@
 namespace lsqr {
 
 constexpr int kCellPtsMin = 128;
+constexpr uint32_t kGroupPad = 4, kCellPad = 16;  // k_scan_pairs: cost padding per group / per cell, in pairs (see there)
 constexpr uint32_t kQueues = 32;   // work queues of k_scan_cells (one atomic counter each)
 constexpr uint32_t kQueuePitch = 1088;  // uint32 words between counters: separate cache lines / channels  // cell sizes are multiples of one packed fp32 pair per lane
 
@@ -574,6 +575,132 @@ inline CellConsts cell_consts(const LineCell<D> *, const ModelConsts &mc) {
   return cc;
 }
 
+// ---- level 2 of one (cell, group of 64 hypotheses): the surviving hypotheses of the group (bits of `surv`) against
+// the cell's observations held in registers.  bc[] are the lane's (= hypothesis') per-cell constants from level 1;
+// votes are added to lane b of accv for hypothesis b of the group.
+template <class CM, int PP, bool LDSB>
+__device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const float (&bc)[CM::NB], float *s_bc,
+                                                unsigned long long surv, const int lane,
+                                                const double *__restrict__ sorted, const size_t ns, const size_t cell,
+                                                const double *__restrict__ spg, const ModelConsts &mc,
+                                                uint32_t &accv) {
+  typedef typename CM::M M;
+  constexpr int D = M::ND, NB = CM::NB, NV = CM::NV, SPD = M::SP, CP = 128 * PP;
+  (void)D, (void)NV, (void)CP;
+  if (LDSB && surv) {  // the lane's values -> LDS; survivors are fetched with uniform-address reads
+    float4 w0, w1;
+    w0.x = bc[0], w0.y = NB > 1 ? bc[1 < NB ? 1 : 0] : 0.0f, w0.z = NB > 2 ? bc[2 < NB ? 2 : 0] : 0.0f,
+    w0.w = NB > 3 ? bc[3 < NB ? 3 : 0] : 0.0f;
+    w1.x = NB > 4 ? bc[4 < NB ? 4 : 0] : 0.0f, w1.y = NB > 5 ? bc[5 < NB ? 5 : 0] : 0.0f,
+    w1.z = NB > 6 ? bc[6 < NB ? 6 : 0] : 0.0f, w1.w = NB > 7 ? bc[7 < NB ? 7 : 0] : 0.0f;
+    ((float4 *)s_bc)[2 * lane] = w0;
+    ((float4 *)s_bc)[2 * lane + 1] = w1;
+  }
+  while (surv) {
+    const int b = __builtin_ctzll(surv);
+    asm("s_bitset0_b64 %0, %1" : "+s"(surv) : "s"(b));  // surv &= ~(1 << b)
+    v2f fp[NV];
+    float btout, btin_l = 0.0f;
+    if (LDSB) {
+      static_assert(NB <= 8, "broadcast area holds 8 floats per lane");
+      const float4 r0 = ((const float4 *)s_bc)[2 * b], r1 = ((const float4 *)s_bc)[2 * b + 1];
+      const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+      for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
+      btout = rb[NB - 1];
+      btin_l = rb[NB - 2];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        float v = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[k]), b));
+        fp[k].x = v;
+        fp[k].y = v;
+      }
+      btout = __builtin_bit_cast(
+          float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b));
+    }
+    // candidate test on the smallest |value| of the lane: NaN rows are ignored by min
+    v2f s[PP];
+    float m = __builtin_inff();
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+      s[p] = CM::value(xs[p], fp);
+      m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(s[p].x), __builtin_fabsf(s[p].y)));
+    }
+    // a hypothesis whose filter is off (t_out = +inf: literal-formula sphere, |n_i| > 1, out-of-range magnitudes)
+    // takes the exact predicate for the whole cell whatever the fp32 measure says -- it may be inf or NaN there
+    const bool exact_all = !(btout < __builtin_inff());
+    if (__ballot(exact_all || m < btout) == 0) continue;  // (ballots keep the control flow wave-uniform)
+    const float btin = LDSB ? btin_l
+                            : __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                            __builtin_bit_cast(int, bc[NB - 2]), b));
+    // Does any observation sit in the band tin <= |v| < tout?  One ballot instead of one per value: the
+    // smallest NON-NEGATIVE difference |v| - tin of the lane, found as the unsigned minimum of the bit patterns
+    // (a negative difference -- a certain inlier -- has its sign bit set and looks huge; a NaN row looks
+    // larger than any finite number), against fl(tout - tin).  Conservative: rounding is monotone, so
+    // tin <= |v| < tout implies fl(|v| - tin) <= fl(tout - tin); flagging |v| == tout too only costs a re-check.
+    unsigned long long in[2 * PP];
+    uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+      const float ax = __builtin_fabsf(s[p].x), ay = __builtin_fabsf(s[p].y);
+      in[2 * p] = __ballot(ax < btin);
+      in[2 * p + 1] = __ballot(ay < btin);
+      const uint32_t dx = __builtin_bit_cast(uint32_t, ax - btin), dy = __builtin_bit_cast(uint32_t, ay - btin);
+      dmin = dx < dmin ? dx : dmin;
+      dmin = dy < dmin ? dy : dmin;
+    }
+    const unsigned long long amb =
+        __ballot(exact_all || dmin <= __builtin_bit_cast(uint32_t, btout - btin));
+    if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
+      const double *hp = spg + (size_t)b * SPD;  // wave-uniform -> scalar loads
+#pragma unroll
+      for (int p = 0; p < PP; p++) {
+        const size_t i0 = cell * CP + p * 128 + lane, i1 = i0 + 64;
+        double r0[D], r1[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+          r0[d] = i0 < ns ? sorted[i0 * D + d] : __builtin_nan("");
+          r1[d] = i1 < ns ? sorted[i1 * D + d] : __builtin_nan("");
+        }
+        in[2 * p] = __ballot(M::agree(hp, r0, mc));
+        in[2 * p + 1] = __ballot(M::agree(hp, r1, mc));
+      }
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int p = 0; p < 2 * PP; p++) cnt += (uint32_t)__builtin_popcountll(in[p]);
+    cnt += (uint32_t)__builtin_amdgcn_readlane((int)accv, b);
+    // v_writelane takes one SGPR on the constant bus: the lane select goes through m0
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                 : "+v"(accv)
+                 : "s"(cnt), "s"(b)
+                 : "m0");
+  }
+}
+
+// the observations of cell `cell` as packed fp32 pairs, relative to the cell centre where the model asks for it
+template <class CM, int PP>
+__device__ __forceinline__ void cells_load(const double *__restrict__ sorted, const size_t ns, const size_t cell,
+                                           const int lane, const double (&ctr)[3], v2f (&xs)[PP][3]) {
+  constexpr int D = CM::M::ND, CP = 128 * PP;
+#pragma unroll
+  for (int p = 0; p < PP; p++) {
+    const size_t i0 = cell * CP + p * 128 + lane, i1 = i0 + 64;
+    // rows past the end are NaN (never candidates); the loads themselves are unconditional
+    const double *p0 = sorted + (i0 < ns ? i0 : 0) * D, *p1 = sorted + (i1 < ns ? i1 : 0) * D;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const double off = CM::RELATIVE ? ctr[d] : 0.0;
+      const float a0 = d < D ? (float)(p0[d < D ? d : 0] - off) : 0.0f;
+      const float a1 = d < D ? (float)(p1[d < D ? d : 0] - off) : 0.0f;
+      xs[p][d].x = (d < D && !(i0 < ns)) ? __builtin_nanf("") : a0;
+      xs[p][d].y = (d < D && !(i1 < ns)) ? __builtin_nanf("") : a1;
+    }
+  }
+}
+
 // ---- the scan ----------------------------------------------------------------------------------------
 // A cell is 128*PP consecutive records of the sorted copy (PP packed pairs per lane); a wave tile is
 // CPT cells whose observations stay in registers for the whole hypothesis loop.  Tiles are handed
@@ -594,8 +721,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
                                                     uint32_t *__restrict__ next_tile, uint32_t grab,
                                                     uint32_t hsplit, const uint32_t *__restrict__ h_dev) {
   typedef typename CM::M M;
-  constexpr int D = M::ND;
-  constexpr int NB = CM::NB, NV = CM::NV;
+  constexpr int NB = CM::NB;
   // the number of hypotheses may be decided on the device (bounded scan: the batch is a compacted selection);
   // `H` then is the capacity the launch was sized for
   if (h_dev) {
@@ -605,7 +731,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
   constexpr int SPD = M::SP;
   constexpr int ROW = CM::ROW, NR4 = ROW / 4;  // per-hypothesis row of the level-1 pass, 16-byte loads
   constexpr int NR2 = CM::ROW2 / 4;            // optional second piece, taken from the fp32 block
-  constexpr int CP = 128 * PP;                 // observations per cell
   static_assert(ROW % 4 == 0, "hypothesis rows are fetched as 16-byte loads");
   extern __shared__ uint32_t s_cnt[];
   for (uint32_t h = threadIdx.x; h < H; h += BS) s_cnt[h] = 0;
@@ -661,20 +786,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
       }
 #pragma unroll
       for (int d = 0; d < 3; d++) ctr[q][d] = (double)bx[q].c[d];
-#pragma unroll
-      for (int p = 0; p < PP; p++) {
-        const size_t i0 = (size_t)cell * CP + p * 128 + lane, i1 = i0 + 64;
-        // rows past the end are NaN (never candidates); the loads themselves are unconditional
-        const double *p0 = sorted + (i0 < ns ? i0 : 0) * D, *p1 = sorted + (i1 < ns ? i1 : 0) * D;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          const double off = CM::RELATIVE ? ctr[q][d] : 0.0;
-          const float a0 = d < D ? (float)(p0[d < D ? d : 0] - off) : 0.0f;
-          const float a1 = d < D ? (float)(p1[d < D ? d : 0] - off) : 0.0f;
-          xs[q][p][d].x = (d < D && !(i0 < ns)) ? __builtin_nanf("") : a0;
-          xs[q][p][d].y = (d < D && !(i1 < ns)) ? __builtin_nanf("") : a1;
-        }
-      }
+      cells_load<CM, PP>(sorted, ns, (size_t)cell, lane, ctr[q], xs[q]);
     }
     float4 nxt[NR4];
     {
@@ -721,97 +833,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
       for (int q = 0; q < CPT; q++) {
         float bc[NB];
         unsigned long long surv = __ballot(CM::level1(hy, bx[q], ctr[q], cc, bc));
-        if (LDSB && surv) {  // the lane's values -> LDS; survivors are fetched with uniform-address reads
-          float4 w0, w1;
-          w0.x = bc[0], w0.y = NB > 1 ? bc[1 < NB ? 1 : 0] : 0.0f, w0.z = NB > 2 ? bc[2 < NB ? 2 : 0] : 0.0f,
-          w0.w = NB > 3 ? bc[3 < NB ? 3 : 0] : 0.0f;
-          w1.x = NB > 4 ? bc[4 < NB ? 4 : 0] : 0.0f, w1.y = NB > 5 ? bc[5 < NB ? 5 : 0] : 0.0f,
-          w1.z = NB > 6 ? bc[6 < NB ? 6 : 0] : 0.0f, w1.w = NB > 7 ? bc[7 < NB ? 7 : 0] : 0.0f;
-          ((float4 *)s_bc)[2 * lane] = w0;
-          ((float4 *)s_bc)[2 * lane + 1] = w1;
-        }
-        while (surv) {
-          const int b = __builtin_ctzll(surv);
-          asm("s_bitset0_b64 %0, %1" : "+s"(surv) : "s"(b));  // surv &= ~(1 << b)
-          v2f fp[NV];
-          float btout, btin_l = 0.0f;
-          if (LDSB) {
-            static_assert(NB <= 8, "broadcast area holds 8 floats per lane");
-            const float4 r0 = ((const float4 *)s_bc)[2 * b], r1 = ((const float4 *)s_bc)[2 * b + 1];
-            const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-            for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
-            btout = rb[NB - 1];
-            btin_l = rb[NB - 2];
-          } else {
-#pragma unroll
-            for (int k = 0; k < NV; k++) {
-              float v = __builtin_bit_cast(
-                  float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[k]), b));
-              fp[k].x = v;
-              fp[k].y = v;
-            }
-            btout = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b));
-          }
-          // candidate test on the smallest |value| of the lane: NaN rows are ignored by min
-          v2f s[PP];
-          float m = __builtin_inff();
-#pragma unroll
-          for (int p = 0; p < PP; p++) {
-            s[p] = CM::value(xs[q][p], fp);
-            m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(s[p].x), __builtin_fabsf(s[p].y)));
-          }
-          // a hypothesis whose filter is off (t_out = +inf: literal-formula sphere, |n_i| > 1, out-of-range magnitudes)
-          // takes the exact predicate for the whole cell whatever the fp32 measure says -- it may be inf or NaN there
-          const bool exact_all = !(btout < __builtin_inff());
-          if (!exact_all && __ballot(m < btout) == 0) continue;
-          const float btin = LDSB ? btin_l
-                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                                                  __builtin_bit_cast(int, bc[NB - 2]), b));
-          // Does any observation sit in the band tin <= |v| < tout?  One ballot instead of one per value: the
-          // smallest NON-NEGATIVE difference |v| - tin of the lane, found as the unsigned minimum of the bit patterns
-          // (a negative difference -- a certain inlier -- has its sign bit set and looks huge; a NaN row looks
-          // larger than any finite number), against fl(tout - tin).  Conservative: rounding is monotone, so
-          // tin <= |v| < tout implies fl(|v| - tin) <= fl(tout - tin); flagging |v| == tout too only costs a re-check.
-          unsigned long long in[2 * PP];
-          uint32_t dmin = 0xFFFFFFFFu;
-#pragma unroll
-          for (int p = 0; p < PP; p++) {
-            const float ax = __builtin_fabsf(s[p].x), ay = __builtin_fabsf(s[p].y);
-            in[2 * p] = __ballot(ax < btin);
-            in[2 * p + 1] = __ballot(ay < btin);
-            const uint32_t dx = __builtin_bit_cast(uint32_t, ax - btin), dy = __builtin_bit_cast(uint32_t, ay - btin);
-            dmin = dx < dmin ? dx : dmin;
-            dmin = dy < dmin ? dy : dmin;
-          }
-          const unsigned long long amb =
-              exact_all ? ~0ULL : __ballot(dmin <= __builtin_bit_cast(uint32_t, btout - btin));
-          if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
-            const double *hp = sp + (size_t)(h0 + b) * SPD;  // wave-uniform -> scalar loads
-#pragma unroll
-            for (int p = 0; p < PP; p++) {
-              const size_t i0 = (size_t)(wt * CPT + q) * CP + p * 128 + lane, i1 = i0 + 64;
-              double r0[D], r1[D];
-#pragma unroll
-              for (int d = 0; d < D; d++) {
-                r0[d] = i0 < ns ? sorted[i0 * D + d] : __builtin_nan("");
-                r1[d] = i1 < ns ? sorted[i1 * D + d] : __builtin_nan("");
-              }
-              in[2 * p] = __ballot(M::agree(hp, r0, mc));
-              in[2 * p + 1] = __ballot(M::agree(hp, r1, mc));
-            }
-          }
-          uint32_t cnt = 0;
-#pragma unroll
-          for (int p = 0; p < 2 * PP; p++) cnt += (uint32_t)__builtin_popcountll(in[p]);
-          cnt += (uint32_t)__builtin_amdgcn_readlane((int)accv, b);
-          // v_writelane takes one SGPR on the constant bus: the lane select goes through m0
-          asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
-                       : "+v"(accv)
-                       : "s"(cnt), "s"(b)
-                       : "m0");
-        }
+        cells_survivors<CM, PP, LDSB>(xs[q], bc, s_bc, surv, lane, sorted, ns, (size_t)(wt * CPT + q),
+                                      sp + (size_t)h0 * SPD, mc, accv);
       }
       if (accv) atomicAdd(&s_cnt[h], accv);  // h < H whenever accv != 0 (lanes past H never survive)
     }
@@ -972,11 +995,18 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
                                                       CellConsts cc, uint32_t cells_per_block,
                                                       uint32_t *__restrict__ ub,
                                                       unsigned long long *__restrict__ total,
-                                                      uint32_t *__restrict__ ncells_out) {
+                                                      uint32_t *__restrict__ ncells_out,
+                                                      uint8_t *__restrict__ cnt, uint32_t gstride,
+                                                      const uint32_t *__restrict__ h_dev) {
   typedef typename CM::M M;
   constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4, CP = 128 * PP;
   const int lane = threadIdx.x & 63;
-  const uint32_t h = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64 + lane;
+  if (h_dev) {
+    const uint32_t hd = *h_dev;
+    H = hd < H ? hd : H;
+  }
+  const uint32_t grp = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t h = grp * 64 + lane;
   if (h - lane >= H) return;  // wave-uniform
   float row[ROW], row2[NR2 ? 4 * NR2 : 4];
   {
@@ -1011,11 +1041,277 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
     const uint32_t pop = first + CP <= ns ? (uint32_t)CP : (uint32_t)(ns - first);
     u += s ? pop : 0u;
     nc += s ? 1u : 0u;
+    if (cnt) {  // survivors of this group in this cell: the cost table of k_scan_pairs (pre-zeroed by the host)
+      const uint32_t pc = (uint32_t)__builtin_popcountll(__ballot(s));
+      if (lane == 0 && pc) cnt[(size_t)c * gstride + grp] = (uint8_t)(pc + kGroupPad);  // <= 64 + pad
+    }
   }
-  if (h < H && u) atomicAdd(&ub[h], u);
+  if (ub && h < H && u) atomicAdd(&ub[h], u);
   if (ncells_out && h < H && nc) atomicAdd(&ncells_out[h], nc);  // surviving cells of the hypothesis (diagnostics)
-  for (int o = 32; o > 0; o >>= 1) nc += __shfl_down(nc, o);
-  if (lane == 0 && nc) atomicAdd(total, (unsigned long long)nc);
+  if (total) {
+    for (int o = 32; o > 0; o >>= 1) nc += __shfl_down(nc, o);
+    if (lane == 0 && nc) atomicAdd(total, (unsigned long long)nc);
+  }
+}
+
+// ---- statically balanced level 2 ------------------------------------------------------------------------------
+// Handing (tile, hypothesis range) units to waves dynamically does not work for the light launches of the bounded
+// scan: a returning atomic on a counter shared across the eight XCDs costs ~120 ns of serialised memory-side time
+// (19 532 grabs on 32 counters add 75 us to a 140 us launch; finer units cost proportionally more), while whole tiles
+// are too coarse -- with ~500 near-model hypotheses a near-model tile is 280 us of one wave's time in a 660 us launch
+// and half of the waves' lifetime is spent waiting for the slowest (measured with s_memrealtime).  So the work is
+// COUNTED first and then cut into equal pieces:
+//   k_cells_bounds(cnt)  level 1 alone: cnt[cell][group] = surviving hypotheses of the group in the cell
+//   k_tile_costs         cost[cell] = sum over groups, csum[chunk] = sum over the 128 cells of a chunk
+//   k_scan_pairs         wave w of W takes the (hypothesis, cell) pairs [w C / W, (w + 1) C / W) of the
+//                        cell-major, group-major, lane-major enumeration: it finds its first cell from csum / cost
+//                        (two wave-wide prefix sums), walks cells and groups from there, repeats level 1 for the
+//                        groups it touches (bit-identical to the counting pass) and runs cells_survivors on its part
+//                        of the survivor mask.  No atomics except the vote flush, no waiting, every wave the same
+//                        number of pairs (a pair costs 27 - 55 vector instructions, a mix the 800+ pairs of a wave
+//                        average out).
+constexpr uint32_t kChunkCells = 128;
+// A pair is the unit of cost; what a wave pays per group it evaluates (rows, level 1: ~2 pairs' worth of instructions
+// and a dependent load) and per cell it opens (box, 12 KB of observations) is charged as padding in front of the
+// group's / cell's pairs, so that a stretch of far cells with one or two survivors per group is not handed to one
+// wave as if it were free (measured before the padding: one wave walking 574 groups for 662 pairs, 1.5 ms against a
+// mean of 0.44 ms).
+
+__global__ __launch_bounds__(128) void k_tile_costs(const uint8_t *__restrict__ cnt, uint32_t gstride, uint32_t H,
+                                                    const uint32_t *__restrict__ h_dev, uint32_t ncells,
+                                                    uint32_t *__restrict__ cost, uint32_t *__restrict__ csum) {
+  if (h_dev) {
+    const uint32_t hd = *h_dev;
+    H = hd < H ? hd : H;
+  }
+  const uint32_t G = (H + 63) / 64;
+  const uint32_t c = blockIdx.x * kChunkCells + threadIdx.x;
+  uint32_t t = 0;
+  if (c < ncells) {
+    const uint8_t *p = cnt + (size_t)c * gstride;
+    if ((gstride & 15u) == 0) {
+      for (uint32_t g = 0; g < G; g += 16) {
+        const uint4 v = *(const uint4 *)(p + g);  // groups past G hold zeros
+        t += __builtin_amdgcn_sad_u8(v.x, 0u, 0u) + __builtin_amdgcn_sad_u8(v.y, 0u, 0u) +
+             __builtin_amdgcn_sad_u8(v.z, 0u, 0u) + __builtin_amdgcn_sad_u8(v.w, 0u, 0u);
+      }
+    } else {
+      for (uint32_t g = 0; g < G; g++) t += p[g];
+    }
+    t = t ? t + kCellPad : 0u;
+    cost[c] = t;
+  }
+  __shared__ uint32_t s_w[2];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) csum[blockIdx.x] = s_w[0] + s_w[1];
+}
+
+// inclusive prefix sum across the wave (lane i: sum of lanes 0..i)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t a = __shfl_up(v, o);
+    v += lane >= o ? a : 0u;
+  }
+  return v;
+}
+
+template <class CM, int PP, int BS, bool LDSB>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CM::MIN_WAVES, 8))) void k_scan_pairs(
+    const double *__restrict__ sorted, size_t ns, const CellBox *__restrict__ boxes, uint32_t ncells,
+    const double *__restrict__ sp, const float *__restrict__ rows, const float *__restrict__ spf, uint32_t H,
+    ModelConsts mc, CellConsts cc, uint32_t *__restrict__ vpart, uint32_t vstride,
+    const uint32_t *__restrict__ h_dev, const uint8_t *__restrict__ cnt, uint32_t gstride, const uint32_t *__restrict__ cost,
+    const uint32_t *__restrict__ csum, uint32_t nchunks) {
+  typedef typename CM::M M;
+  constexpr int NB = CM::NB;
+  constexpr int SPD = M::SP;
+  constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4;
+  if (h_dev) {
+    const uint32_t hd = *h_dev;
+    H = hd < H ? hd : H;
+  }
+  extern __shared__ uint32_t s_cnt[];
+  for (uint32_t h = threadIdx.x; h < H; h += BS) s_cnt[h] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  float *s_bc = (float *)(s_cnt + ((H + 3) & ~3u)) + (size_t)(threadIdx.x >> 6) * 512;
+  const uint32_t W = gridDim.x * (BS / 64);
+  const uint32_t wid = blockIdx.x * (BS / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+  // ---- my share of the pairs: [t0, t0 + budget) of C
+  unsigned long long C = 0;
+  for (uint32_t k0 = 0; k0 < nchunks; k0 += 64) {
+    uint32_t v = k0 + lane < nchunks ? csum[k0 + lane] : 0u;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    C += (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  }
+  const unsigned long long t0 = C * wid / W, t1 = C * (wid + 1) / W;
+  uint32_t budget = (uint32_t)(t1 - t0);
+  uint32_t cell = ncells, skip = 0;
+  if (budget) {  // wave-uniform
+    // the chunk that holds pair t0 ...
+    unsigned long long base = 0;
+    uint32_t chunk = 0;
+    for (uint32_t k0 = 0; k0 < nchunks; k0 += 64) {
+      const uint32_t v = k0 + lane < nchunks ? csum[k0 + lane] : 0u;
+      const uint32_t inc = wave_incl_scan(v, lane);
+      const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      if (base + tot > t0) {
+        const unsigned long long hit = __ballot(base + inc > t0);
+        const int l = __builtin_ctzll(hit);
+        chunk = k0 + l;
+        base += (uint32_t)__builtin_amdgcn_readlane((int)(inc - v), l);
+        break;
+      }
+      base += tot;
+    }
+    // ... and the cell inside it (kChunkCells = 2 per lane)
+    const uint32_t cb = chunk * kChunkCells + 2 * lane;
+    const uint32_t v0 = cb < ncells ? cost[cb] : 0u, v1 = cb + 1 < ncells ? cost[cb + 1] : 0u;
+    const uint32_t inc = wave_incl_scan(v0 + v1, lane);
+    const uint32_t r = (uint32_t)(t0 - base);  // pairs of the chunk before mine
+    const unsigned long long hit = __ballot(inc > r);
+    const int l = hit ? __builtin_ctzll(hit) : 63;
+    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(inc - v0 - v1), l);
+    const uint32_t c0v = (uint32_t)__builtin_amdgcn_readlane((int)v0, l);
+    const bool second = r - before >= c0v;
+    cell = chunk * kChunkCells + 2 * l + (second ? 1u : 0u);
+    skip = r - before - (second ? c0v : 0u);
+  }
+
+  const uint32_t G = (H + 63) / 64;
+  // cost units [skip, skip + budget) of the enumeration that starts at `cell`: a padded item of P units in front of
+  // the position consumes what of it lies in my range
+  auto pad = [&](uint32_t P) {
+    if (skip >= P) {
+      skip -= P;
+    } else {
+      const uint32_t take = P - skip < budget ? P - skip : budget;
+      budget -= take;
+      skip = 0;
+    }
+  };
+  auto load_rows = [&](uint32_t g, float4(&r)[NR4], float4(&r2)[NR2 ? NR2 : 1]) {
+    const uint32_t h = g * 64 + lane;
+    const float4 *r4 = (const float4 *)(rows + (size_t)(h < H ? h : 0) * ROW);
+#pragma unroll
+    for (int k = 0; k < NR4; k++) r[k] = r4[k];
+    if constexpr (NR2 > 0) {
+      const float4 *q4 = (const float4 *)(spf + (size_t)(h < H ? h : 0) * M::SPF + CM::ROW2_OFF);
+#pragma unroll
+      for (int k = 0; k < NR2; k++) r2[k] = q4[k];
+    }
+  };
+  while (budget && cell < ncells) {
+    // jump over cells nothing survives in
+    {
+      const uint32_t v = cell + lane < ncells ? cost[cell + lane] : 0u;
+      const unsigned long long nz = __ballot(v != 0);
+      if (!nz) {
+        cell += 64;
+        continue;
+      }
+      cell += (uint32_t)__builtin_ctzll(nz);
+    }
+    pad(kCellPad);
+    // padded survivor counts of the cell's groups: lane g <-> group g
+    const uint32_t gc = (uint32_t)lane < G ? (uint32_t)cnt[(size_t)cell * gstride + lane] : 0u;
+    unsigned long long gm = __ballot(gc != 0);
+    // groups that lie before my range altogether
+    while (gm && budget) {
+      const int g = __builtin_ctzll(gm);
+      const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)gc, g);
+      if (skip < cg) break;
+      skip -= cg;
+      gm &= gm - 1;
+    }
+    if (!gm || !budget) {
+      cell++;
+      continue;
+    }
+    const CellBox bx = boxes[cell];  // wave-uniform address -> scalar load
+    double ctr[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) ctr[d] = (double)bx.c[d];
+    v2f xs[PP][3];
+    cells_load<CM, PP>(sorted, ns, (size_t)cell, lane, ctr, xs);
+    float4 nxt[NR4], nxt2[NR2 ? NR2 : 1];
+    load_rows((uint32_t)__builtin_ctzll(gm), nxt, nxt2);
+    while (gm && budget) {
+      const int g = __builtin_ctzll(gm);
+      gm &= gm - 1;
+      const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)gc, g);
+      float row[ROW], row2[NR2 ? 4 * NR2 : 4];
+#pragma unroll
+      for (int k = 0; k < NR4; k++)
+        row[4 * k] = nxt[k].x, row[4 * k + 1] = nxt[k].y, row[4 * k + 2] = nxt[k].z, row[4 * k + 3] = nxt[k].w;
+      if constexpr (NR2 > 0) {
+#pragma unroll
+        for (int k = 0; k < NR2; k++)
+          row2[4 * k] = nxt2[k].x, row2[4 * k + 1] = nxt2[k].y, row2[4 * k + 2] = nxt2[k].z,
+                   row2[4 * k + 3] = nxt2[k].w;
+      }
+      if (gm) load_rows((uint32_t)__builtin_ctzll(gm), nxt, nxt2);  // the next group's rows while this one is counted
+      // my part [lo, hi) of the group's cost units; pair j sits at unit kGroupPad + j
+      const uint32_t lo = skip, hi = cg < skip + budget ? cg : skip + budget;  // skip < cg here
+      budget -= hi - lo;
+      skip = 0;
+      const uint32_t jlo = (lo > kGroupPad ? lo : kGroupPad) - kGroupPad, jhi = (hi > kGroupPad ? hi : kGroupPad) - kGroupPad;
+      if (jhi <= jlo) continue;
+      const uint32_t h0 = (uint32_t)g * 64, h = h0 + lane;
+      typename CM::Hyp hy;
+      CM::load(row, row2, h < H, cc, hy);
+      float bc[NB];
+      unsigned long long surv = __ballot(CM::level1(hy, bx, ctr, cc, bc));  // == the counting pass: cg - kGroupPad bits
+      for (uint32_t k = 0; k < jlo; k++) surv &= surv - 1;                  // the first jlo are not mine
+      if (jhi < cg - kGroupPad) {  // the tail belongs to the next wave: keep the lowest jhi - jlo bits
+        unsigned long long keep = 0, m = surv;
+        for (uint32_t k = jlo; k < jhi; k++) {
+          keep |= m & (0ull - m);
+          m &= m - 1;
+        }
+        surv = keep;
+      }
+      uint32_t accv = 0;
+      cells_survivors<CM, PP, LDSB>(xs, bc, s_bc, surv, lane, sorted, ns, (size_t)cell, sp + (size_t)h0 * SPD, mc,
+                                    accv);
+      if (accv) atomicAdd(&s_cnt[h], accv);
+    }
+    cell++;
+  }
+  __syncthreads();
+  // Every workgroup gets here at the same moment (that is the point of the static split), so H atomics per
+  // workgroup would arrive as one burst on the few cache lines of votes[] (measured: 770 k atomics on 16 lines take
+  // ~0.9 ms to drain, three times the counting itself).  The partial counts go out as plain coalesced stores and
+  // k_votes_reduce adds them up.
+  for (uint32_t i = threadIdx.x; i < H; i += BS) vpart[(size_t)blockIdx.x * vstride + i] = s_cnt[i];
+}
+
+// votes[h] += sum over the workgroups of k_scan_pairs of their partial counts; blockIdx.x = 64 hypotheses,
+// blockIdx.y = a slice of the workgroups
+__global__ __launch_bounds__(256) void k_votes_reduce(const uint32_t *__restrict__ vpart, uint32_t vstride,
+                                                      uint32_t nparts, uint32_t H,
+                                                      const uint32_t *__restrict__ h_dev,
+                                                      uint32_t *__restrict__ votes) {
+  if (h_dev) {
+    const uint32_t hd = *h_dev;
+    H = hd < H ? hd : H;
+  }
+  const uint32_t h = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= H) return;
+  uint32_t t = 0;
+  if (h < H)
+    for (uint32_t r = blockIdx.y * 4 + ty; r < nparts; r += 4 * gridDim.y) t += vpart[(size_t)r * vstride + h];
+  __shared__ uint32_t s_t[256];
+  s_t[threadIdx.x] = t;
+  __syncthreads();
+  if (ty == 0 && h < H) {
+    t += s_t[64 + threadIdx.x] + s_t[128 + threadIdx.x] + s_t[192 + threadIdx.x];
+    if (t) atomicAdd(&votes[h], t);
+  }
 }
 
 }  // namespace lsqr

@@ -70,10 +70,14 @@ struct lsqr_ctx {
   unsigned dense_amb_max = 0;  // fullest worklist segment of the last fp32 dense scan (diagnostics)
   int opt_dense_f32 = 1;  // dense scan filter on the fp32 matrix cores (worklist of ~1e-4 of the pairs); 0: fp64 MFMA
   int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
-  int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
+  int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   uint32_t *d_ub = nullptr;  // per-hypothesis vote bound of the two-level scan's first level (k_cells_bounds)
+  uint8_t *d_paircnt = nullptr;   // k_scan_pairs: survivors per (cell, group of 64 hypotheses)
+  uint32_t *d_paircost = nullptr; // [n_cells cell costs | chunk sums]
+  uint32_t *d_vpart = nullptr;    // per-workgroup partial votes of k_scan_pairs
+  size_t paircnt_cap = 0, paircost_cap = 0, vpart_cap = 0;
   // bounded scan (cells.h: k_pick_*): the selected hypotheses as a compact batch
   uint32_t *d_sel = nullptr;        // [kPilots pilots | H_cap rest]
   BoundSel *d_bsel = nullptr;
@@ -685,9 +689,65 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   gx = (c->n_cells + per - 1) / per;
   hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
                      c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
-                     (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4, d_nc);
+                     (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4, d_nc, (uint8_t *)nullptr, 0u,
+                     (const uint32_t *)nullptr);
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
+}
+
+// Level 2 of a (compacted) batch in statically balanced pieces (cells.h, "statically balanced level 2"): count the
+// survivors per (cell, group), sum them per cell and per chunk, then k_scan_pairs.  Chained on the stream.
+template <class CM, int PP>
+int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
+  const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
+  HIPCHK(c, hipMemsetAsync(b.votes, 0, b.H * sizeof(uint32_t), c->stream));
+  if (c->n_cells == 0 || b.H == 0) return LSQR_OK;
+  const uint32_t Hc = (uint32_t)b.H, groups = (Hc + 63) / 64;
+  const uint32_t gstride = groups <= 1 ? 1u : (groups + 15) / 16 * 16;  // 16-byte rows for k_tile_costs
+  const uint32_t nchunks = (c->n_cells + kChunkCells - 1) / kChunkCells;
+  int st;
+  if ((st = ensure(c, &c->d_paircnt, &c->paircnt_cap, (size_t)c->n_cells * gstride)) != LSQR_OK) return st;
+  if ((st = ensure(c, &c->d_paircost, &c->paircost_cap, (size_t)c->n_cells + nchunks)) != LSQR_OK) return st;
+  uint32_t *d_cost = c->d_paircost, *d_csum = c->d_paircost + c->n_cells;
+  const float *rows = CM::ROW_F32 ? b.spf : (const float *)b.sp;
+  HIPCHK(c, hipMemsetAsync(c->d_paircnt, 0, (size_t)c->n_cells * gstride, c->stream));
+  {  // counting pass: waves past the device-side H leave at once, so the grid is cut finely in x
+    const unsigned gy = (Hc + 255) / 256;
+    const uint32_t per = std::max<uint32_t>(8, (c->n_cells + 1023) / 1024);
+    const unsigned gx = (c->n_cells + per - 1) / per;
+    hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
+                       c->n_sorted, rows, b.spf, Hc, cc, per, (uint32_t *)nullptr, (unsigned long long *)nullptr,
+                       (uint32_t *)nullptr, c->d_paircnt, gstride, b.h_dev);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
+                     c->n_cells, d_cost, d_csum);
+  HIPCHK(c, hipGetLastError());
+  const bool ldsb = c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST);
+  constexpr int BS = 256, wpb = BS / 64;
+  const size_t lds = (size_t)((Hc + 3) & ~3u) * sizeof(uint32_t) + (ldsb ? (size_t)wpb * 2048 : 0);
+  auto launch = [&](auto kern) -> int {
+    int per_cu = (int)std::min<size_t>(32 / wpb, (160 * 1024) / std::max<size_t>(lds, 1)), occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, BS, lds) == hipSuccess && occ >= 1)
+      per_cu = std::min(per_cu, occ);
+    else
+      (void)hipGetLastError();
+    if (per_cu < 1) per_cu = 1;
+    if (c->opt_pairs_waves > 0) per_cu = std::min(per_cu, c->opt_pairs_waves);
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)c->n_cells + wpb - 1) / wpb, (size_t)256 * per_cu);
+    int st2 = ensure(c, &c->d_vpart, &c->vpart_cap, (size_t)blocks * Hc);
+    if (st2 != LSQR_OK) return st2;
+    ProfScope ps(c, KID_SCAN);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BS), lds, c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
+                       b.sp, rows, b.spf, Hc, c->mc, cc, c->d_vpart, Hc, b.h_dev, (const uint8_t *)c->d_paircnt, gstride,
+                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_votes_reduce, dim3((Hc + 63) / 64, 8), dim3(256), 0, c->stream,
+                       (const uint32_t *)c->d_vpart, Hc, (uint32_t)blocks, Hc, b.h_dev, b.votes);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  };
+  return ldsb ? launch(k_scan_pairs<CM, PP, BS, true>) : launch(k_scan_pairs<CM, PP, BS, false>);
 }
 
 // The bounded scan of the current batch over the index (cells.h, "bounded scan"): bounds, pilots counted exactly,
@@ -716,14 +776,16 @@ int run_scan_bounded(lsqr_ctx *c) {
                      (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
   HIPCHK(c, hipGetLastError());
   const ScanBatch pa = {sp_a, spf_a, (size_t)kPilots, votes_a, &c->d_bsel->n_pilot};
-  if ((st = run_scan_cells<CM, PP, 1>(c, pa)) != LSQR_OK) return st;
+  if ((st = run_scan_pairs<CM, PP>(c, pa)) != LSQR_OK) return st;
+
   hipLaunchKernelGGL(k_pick_rest, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, votes_a,
                      c->best_before, sel_b, c->d_bsel);
   hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, H,
                      c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
   HIPCHK(c, hipGetLastError());
   const ScanBatch pb = {sp_b, spf_b, (size_t)H, votes_b, &c->d_bsel->n_rest};
-  if ((st = run_scan_cells<CM, PP, 1>(c, pb)) != LSQR_OK) return st;
+  if ((st = run_scan_pairs<CM, PP>(c, pb)) != LSQR_OK) return st;
+
   hipLaunchKernelGGL(k_scatter_votes, dim3(1), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot, votes_a,
                      c->d_votes);
   hipLaunchKernelGGL(k_scatter_votes, dim3((H + 255) / 256), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest,
@@ -925,6 +987,11 @@ int run_scan(lsqr_ctx *c) {
             if (CM::USE_BOUND && c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
               if (cell_pts == 512) return run_scan_bounded<CM, 4>(c);
               return run_scan_bounded<CM, 2>(c);
+            }
+            if (c->opt_pairs == 1) {  // A/B: the statically balanced kernel for a plain scan too
+              const ScanBatch b = {c->d_hparams, c->d_hparams_f32, c->H, c->d_votes, nullptr};
+              if (cell_pts == 512) return run_scan_pairs<CM, 4>(c, b);
+              return run_scan_pairs<CM, 2>(c, b);
             }
             if (cell_pts == 512) return run_scan_cells<CM, 4, 1>(c);
             return run_scan_cells<CM, 2, 1>(c);
@@ -1589,7 +1656,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -3283,6 +3350,14 @@ int lsqr_set_option(lsqr_ctx *c, const char *name, int value) {
   if (!strcmp(name, "scan_cpt")) {  // cells per wave tile of the two-level scan
     if (value != 0 && value != 1) return fail(c, LSQR_ERR_INVALID, "scan_cpt must be 0 or 1");
     c->opt_cpt = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_pairs")) {  // 0: default, 1: k_scan_pairs for plain scans too (A/B)
+    c->opt_pairs = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_pairs_waves")) {  // workgroups per CU of k_scan_pairs (0 = what fits)
+    c->opt_pairs_waves = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_hsplit")) {  // hypothesis segments per tile of the two-level scan (0 = auto)
