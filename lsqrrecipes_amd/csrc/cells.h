@@ -499,9 +499,10 @@ struct LineCell {
   typedef LineModel<D> M;
   enum { NB = 8, NV = 6, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 4, ROW2_OFF = 12 };
   enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1, MIN_WAVES = 4 };  // measured (tools/ab_cells.py): 2.17 ms against 2.34 ms with 512 / v_readlane
-  // a line that misses the inliers touches < 1 % of the cells: the consensus candidates are 99 % of the work
-  // anyway, the bounded scan's extra launches only cost (2.39 against 2.2 ms)
-  enum { USE_BOUND = 0 };
+  // a line that misses the inliers touches < 1 % of the cells: the consensus candidates (a quarter of the batch at
+  // 50 % outliers) are 99 % of the work with or without the bound; with the statically balanced second level the
+  // bounded path is the faster one all the same (2.17 against 2.34 ms per 4096 hypotheses)
+  enum { USE_BOUND = 1 };
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;
@@ -607,8 +608,9 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
       const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
       for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
-      btout = rb[NB - 1];
-      btin_l = rb[NB - 2];
+      // (the same value in every lane; said explicitly so that the control flow below stays scalar)
+      btout = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rb[NB - 1])));
+      btin_l = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rb[NB - 2])));
     } else {
 #pragma unroll
       for (int k = 0; k < NV; k++) {
@@ -640,6 +642,9 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
     // (a negative difference -- a certain inlier -- has its sign bit set and looks huge; a NaN row looks
     // larger than any finite number), against fl(tout - tin).  Conservative: rounding is monotone, so
     // tin <= |v| < tout implies fl(|v| - tin) <= fl(tout - tin); flagging |v| == tout too only costs a re-check.
+    // (Two compares per value with the mask logic and the counts on the scalar unit -- 36 vector and 40 scalar
+    // instructions per pair instead of 59 and 25 -- measured SLOWER: 551 against 528 us in the second pass of the
+    // bounded plane scan, 1.67 against 1.39 ms for a plain 4096-hypothesis scan.)
     unsigned long long in[2 * PP];
     uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
@@ -671,7 +676,7 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
     uint32_t cnt = 0;
 #pragma unroll
     for (int p = 0; p < 2 * PP; p++) cnt += (uint32_t)__builtin_popcountll(in[p]);
-    cnt += (uint32_t)__builtin_amdgcn_readlane((int)accv, b);
+    // (lane b of accv is written once per cell and group: every hypothesis of the group is visited once)
     // v_writelane takes one SGPR on the constant bus: the lane select goes through m0
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
                  : "+v"(accv)
@@ -828,6 +833,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? C
       }
       typename CM::Hyp hy;
       CM::load(row, row2, h < H, cc, hy);
+      static_assert(CPT == 1, "cells_survivors writes lane b of accv once per cell: one cell per wave tile");
       uint32_t accv = 0;  // lane b: votes of hypothesis h0 + b collected from this tile
 #pragma unroll
       for (int q = 0; q < CPT; q++) {
@@ -869,9 +875,11 @@ struct BoundSel {            // device-side state of one bounded scan
 // at least half the largest bound
 __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict__ ub,
                                                       const uint8_t *__restrict__ valid, uint32_t H,
-                                                      uint32_t *__restrict__ sel, BoundSel *__restrict__ st) {
+                                                      uint32_t *__restrict__ sel, BoundSel *__restrict__ st,
+                                                      uint32_t *__restrict__ votes) {
   __shared__ uint32_t s_red[16], s_scan[1024];
   const int t = threadIdx.x;
+  for (uint32_t h = t; h < H; h += 1024) votes[h] = 0;  // a hypothesis that is not counted reports 0 votes
   uint32_t mx = 0;
   for (uint32_t h = t; h < H; h += 1024) mx = valid[h] && ub[h] > mx ? ub[h] : mx;
   for (int o = 32; o > 0; o >>= 1) {
@@ -978,10 +986,21 @@ __global__ __launch_bounds__(256) void k_sum_selected(const uint32_t *__restrict
   for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
   if ((threadIdx.x & 63) == 0 && t) atomicAdd(out, t);
 }
-__global__ __launch_bounds__(256) void k_scatter_votes(const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel,
-                                                       const uint32_t *__restrict__ v, uint32_t *__restrict__ votes) {
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j < *n_sel) votes[sel[j]] = v[j];
+// exact votes of the two counted selections back to their places in the batch (block 0: the pilots)
+__global__ __launch_bounds__(256) void k_scatter_votes(const uint32_t *__restrict__ sel_a,
+                                                       const uint32_t *__restrict__ n_a,
+                                                       const uint32_t *__restrict__ v_a,
+                                                       const uint32_t *__restrict__ sel_b,
+                                                       const uint32_t *__restrict__ n_b,
+                                                       const uint32_t *__restrict__ v_b,
+                                                       uint32_t *__restrict__ votes) {
+  if (blockIdx.x == 0) {
+    static_assert(kPilots <= 256, "one block scatters the pilots");
+    if (threadIdx.x < *n_a) votes[sel_a[threadIdx.x]] = v_a[threadIdx.x];
+    return;
+  }
+  const uint32_t j = (blockIdx.x - 1) * 256 + threadIdx.x;
+  if (j < *n_b) votes[sel_b[j]] = v_b[j];
 }
 
 // Level 1 alone (measurement, and the vote bound of the two-pass scan): per hypothesis the summed population
@@ -1007,7 +1026,8 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
   }
   const uint32_t grp = blockIdx.y * 4 + (threadIdx.x >> 6);
   const uint32_t h = grp * 64 + lane;
-  if (h - lane >= H) return;  // wave-uniform
+  if (blockIdx.y * 256 >= H) return;   // workgroup-uniform: the barriers below are for whole workgroups
+  const bool active = h - lane < H;    // wave-uniform
   float row[ROW], row2[NR2 ? 4 * NR2 : 4];
   {
     const float4 *r4 = (const float4 *)(rows + (size_t)(h < H ? h : 0) * ROW);
@@ -1030,20 +1050,53 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
   const uint32_t c0 = blockIdx.x * cells_per_block;
   const uint32_t c1 = c0 + cells_per_block < ncells ? c0 + cells_per_block : ncells;
   uint32_t u = 0, nc = 0;
-  for (uint32_t c = c0; c < c1; c++) {
-    const CellBox bx = boxes[c];  // wave-uniform address -> scalar load
-    double ctr[3];
+  // The boxes go through LDS, 128 at a time: a scalar load per cell leaves every iteration waiting for its own
+  // s_load (SMEM returns out of order, so the wait is always lgkmcnt(0) and nothing can be fetched ahead) --
+  // measured 141 us for 1.25 M plane evaluations of ~20 instructions; LDS reads of one address are broadcasts that
+  // return in order and pipeline across the unrolled loop.
+  constexpr uint32_t BCH = 128;
+  __shared__ CellBox s_box[BCH];
+  __shared__ double s_ctr[BCH][3];
+  for (uint32_t cb = c0; cb < c1; cb += BCH) {
+    const uint32_t n = c1 - cb < BCH ? c1 - cb : BCH;
+    __syncthreads();  // the previous chunk has been consumed
+    if (threadIdx.x < 2 * n) ((float4 *)s_box)[threadIdx.x] = ((const float4 *)(boxes + cb))[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < n) {
 #pragma unroll
-    for (int d = 0; d < 3; d++) ctr[d] = (double)bx.c[d];
-    float bc[CM::NB];
-    const bool s = CM::level1(hy, bx, ctr, cc, bc);
-    const size_t first = (size_t)c * CP;
-    const uint32_t pop = first + CP <= ns ? (uint32_t)CP : (uint32_t)(ns - first);
-    u += s ? pop : 0u;
-    nc += s ? 1u : 0u;
-    if (cnt) {  // survivors of this group in this cell: the cost table of k_scan_pairs (pre-zeroed by the host)
-      const uint32_t pc = (uint32_t)__builtin_popcountll(__ballot(s));
-      if (lane == 0 && pc) cnt[(size_t)c * gstride + grp] = (uint8_t)(pc + kGroupPad);  // <= 64 + pad
+      for (int d = 0; d < 3; d++) s_ctr[threadIdx.x][d] = (double)s_box[threadIdx.x].c[d];
+    }
+    __syncthreads();
+    if (!active) continue;
+    auto one = [&](const uint32_t i, const CellBox &bx, const double (&ctr)[3]) {
+      const uint32_t c = cb + i;
+      float bc[CM::NB];
+      const bool s = CM::level1(hy, bx, ctr, cc, bc);
+      const size_t first = (size_t)c * CP;
+      const uint32_t pop = first + CP <= ns ? (uint32_t)CP : (uint32_t)(ns - first);
+      u += s ? pop : 0u;
+      nc += s ? 1u : 0u;
+      if (cnt) {  // survivors of this group in this cell: the cost table of k_scan_pairs
+        const uint32_t pc = (uint32_t)__builtin_popcountll(__ballot(s));
+        if (lane == 0) cnt[(size_t)c * gstride + grp] = (uint8_t)(pc ? pc + kGroupPad : 0u);  // <= 64 + pad
+      }
+    };
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) {  // four boxes in flight
+      const CellBox b0 = s_box[i], b1 = s_box[i + 1], b2 = s_box[i + 2], b3 = s_box[i + 3];
+      const double t0[3] = {s_ctr[i][0], s_ctr[i][1], s_ctr[i][2]};
+      const double t1[3] = {s_ctr[i + 1][0], s_ctr[i + 1][1], s_ctr[i + 1][2]};
+      const double t2[3] = {s_ctr[i + 2][0], s_ctr[i + 2][1], s_ctr[i + 2][2]};
+      const double t3[3] = {s_ctr[i + 3][0], s_ctr[i + 3][1], s_ctr[i + 3][2]};
+      one(i, b0, t0);
+      one(i + 1, b1, t1);
+      one(i + 2, b2, t2);
+      one(i + 3, b3, t3);
+    }
+    for (; i < n; i++) {
+      const CellBox b0 = s_box[i];
+      const double t0[3] = {s_ctr[i][0], s_ctr[i][1], s_ctr[i][2]};
+      one(i, b0, t0);
     }
   }
   if (ub && h < H && u) atomicAdd(&ub[h], u);
@@ -1079,7 +1132,9 @@ constexpr uint32_t kChunkCells = 128;
 
 __global__ __launch_bounds__(128) void k_tile_costs(const uint8_t *__restrict__ cnt, uint32_t gstride, uint32_t H,
                                                     const uint32_t *__restrict__ h_dev, uint32_t ncells,
-                                                    uint32_t *__restrict__ cost, uint32_t *__restrict__ csum) {
+                                                    uint32_t *__restrict__ cost, uint32_t *__restrict__ csum,
+                                                    uint32_t *__restrict__ votes) {
+  for (uint32_t i = blockIdx.x * kChunkCells + threadIdx.x; i < H; i += gridDim.x * kChunkCells) votes[i] = 0;
   if (h_dev) {
     const uint32_t hd = *h_dev;
     H = hd < H ? hd : H;
@@ -1089,15 +1144,15 @@ __global__ __launch_bounds__(128) void k_tile_costs(const uint8_t *__restrict__ 
   uint32_t t = 0;
   if (c < ncells) {
     const uint8_t *p = cnt + (size_t)c * gstride;
-    if ((gstride & 15u) == 0) {
-      for (uint32_t g = 0; g < G; g += 16) {
-        const uint4 v = *(const uint4 *)(p + g);  // groups past G hold zeros
+    // (only the groups below G have been written by the counting pass)
+    uint32_t g = 0;
+    if ((gstride & 15u) == 0)
+      for (; g + 16 <= G; g += 16) {
+        const uint4 v = *(const uint4 *)(p + g);
         t += __builtin_amdgcn_sad_u8(v.x, 0u, 0u) + __builtin_amdgcn_sad_u8(v.y, 0u, 0u) +
              __builtin_amdgcn_sad_u8(v.z, 0u, 0u) + __builtin_amdgcn_sad_u8(v.w, 0u, 0u);
       }
-    } else {
-      for (uint32_t g = 0; g < G; g++) t += p[g];
-    }
+    for (; g < G; g++) t += p[g];
     t = t ? t + kCellPad : 0u;
     cost[c] = t;
   }

@@ -681,7 +681,7 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
   HIPCHK(c, hipMemsetAsync(d_ub, 0, c->H * sizeof(uint32_t), c->stream));
   if (d_nc) HIPCHK(c, hipMemsetAsync(d_nc, 0, c->H * sizeof(uint32_t), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_counter + 4, 0, sizeof(unsigned long long), c->stream));
+  if (d_nc) HIPCHK(c, hipMemsetAsync(c->d_counter + 4, 0, sizeof(unsigned long long), c->stream));
   if (c->n_cells == 0) return LSQR_OK;
   const unsigned gy = (unsigned)((c->H + 255) / 256);
   unsigned gx = std::max(1u, std::min<unsigned>(c->n_cells, 2048u / gy));
@@ -689,8 +689,9 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   gx = (c->n_cells + per - 1) / per;
   hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
                      c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
-                     (uint32_t)c->H, cc, per, d_ub, c->d_counter + 4, d_nc, (uint8_t *)nullptr, 0u,
-                     (const uint32_t *)nullptr);
+                     (uint32_t)c->H, cc, per, d_ub, d_nc ? c->d_counter + 4 : (unsigned long long *)nullptr, d_nc,
+                     (uint8_t *)nullptr, 0u, (const uint32_t *)nullptr);  // (pair total: diagnostics only -- 8192
+                                                                           // atomics on one address are ~100 us)
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
 }
@@ -700,8 +701,10 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
 template <class CM, int PP>
 int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
-  HIPCHK(c, hipMemsetAsync(b.votes, 0, b.H * sizeof(uint32_t), c->stream));
-  if (c->n_cells == 0 || b.H == 0) return LSQR_OK;
+  if (c->n_cells == 0 || b.H == 0) {
+    HIPCHK(c, hipMemsetAsync(b.votes, 0, b.H * sizeof(uint32_t), c->stream));
+    return LSQR_OK;
+  }
   const uint32_t Hc = (uint32_t)b.H, groups = (Hc + 63) / 64;
   const uint32_t gstride = groups <= 1 ? 1u : (groups + 15) / 16 * 16;  // 16-byte rows for k_tile_costs
   const uint32_t nchunks = (c->n_cells + kChunkCells - 1) / kChunkCells;
@@ -710,7 +713,6 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
   if ((st = ensure(c, &c->d_paircost, &c->paircost_cap, (size_t)c->n_cells + nchunks)) != LSQR_OK) return st;
   uint32_t *d_cost = c->d_paircost, *d_csum = c->d_paircost + c->n_cells;
   const float *rows = CM::ROW_F32 ? b.spf : (const float *)b.sp;
-  HIPCHK(c, hipMemsetAsync(c->d_paircnt, 0, (size_t)c->n_cells * gstride, c->stream));
   {  // counting pass: waves past the device-side H leave at once, so the grid is cut finely in x
     const unsigned gy = (Hc + 255) / 256;
     const uint32_t per = std::max<uint32_t>(8, (c->n_cells + 1023) / 1024);
@@ -721,7 +723,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
-                     c->n_cells, d_cost, d_csum);
+                     c->n_cells, d_cost, d_csum, b.votes);  // (also zeroes the batch's votes for k_votes_reduce)
   HIPCHK(c, hipGetLastError());
   const bool ldsb = c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST);
   constexpr int BS = 256, wpb = BS / 64;
@@ -770,8 +772,8 @@ int run_scan_bounded(lsqr_ctx *c) {
   uint32_t *votes_a = c->d_votes2, *votes_b = c->d_votes2 + kPilots;
   double *sp_a = c->d_hparams2, *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
   float *spf_a = c->d_hparams2_f32, *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;
-  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel);
+  hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel,
+                     c->d_votes);  // (also zeroes the batch's votes: skipped hypotheses report 0)
   hipLaunchKernelGGL(k_gather_rows, dim3(kPilots / 4), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
                      (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
   HIPCHK(c, hipGetLastError());
@@ -786,10 +788,8 @@ int run_scan_bounded(lsqr_ctx *c) {
   const ScanBatch pb = {sp_b, spf_b, (size_t)H, votes_b, &c->d_bsel->n_rest};
   if ((st = run_scan_pairs<CM, PP>(c, pb)) != LSQR_OK) return st;
 
-  hipLaunchKernelGGL(k_scatter_votes, dim3(1), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot, votes_a,
-                     c->d_votes);
-  hipLaunchKernelGGL(k_scatter_votes, dim3((H + 255) / 256), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest,
-                     votes_b, c->d_votes);
+  hipLaunchKernelGGL(k_scatter_votes, dim3((H + 255) / 256 + 1), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
+                     votes_a, sel_b, &c->d_bsel->n_rest, votes_b, c->d_votes);
   HIPCHK(c, hipGetLastError());
   c->last_bound[0] = 1;
   c->last_bound[3] = H;
@@ -1544,6 +1544,7 @@ __global__ void k_take_best(const unsigned long long *__restrict__ packed,
                             const double *__restrict__ hparams, int hs, double *__restrict__ par) {
   const unsigned long long pk = *packed;
   const int t = threadIdx.x;
+  for (int k = hs + t; k < 128; k += blockDim.x) par[k] = 0.0;  // (the block holds 128 doubles)
   if (t >= hs) return;
   if (pk == 0) {
     par[t] = __builtin_nan("");  // no valid hypothesis: nothing agrees
@@ -2604,7 +2605,6 @@ int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double 
   hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
                      (uint32_t)c->H, c->d_counter + 1);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   hipLaunchKernelGGL(k_take_best, dim3(1), dim3(64), 0, c->stream, c->d_counter + 1, c->d_hparams,
                      c->HS, c->d_par);
   HIPCHK(c, hipGetLastError());
@@ -2704,7 +2704,6 @@ int lsqr_batch_fit_enqueue(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
   hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
                      (uint32_t)c->H, c->d_counter + 1, 0u);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   hipLaunchKernelGGL(k_take_best, dim3(1), dim3(64), 0, c->stream, c->d_counter + 1, c->d_hparams,
                      c->HS, c->d_par);
   HIPCHK(c, hipGetLastError());

@@ -1823,7 +1823,7 @@ def test_bounded_scan_keeps_winner_and_replay(ctx, model, dim, outliers):
     assert np.all(v0[skipped][1:] <= runmax[np.flatnonzero(skipped)[1:] - 1]) if skipped.sum() > 1 else True
     assert not skipped[0] or v0[0] == 0
     assert rp0 == rp1                                   # same adaptive-loop state over the batch
-    if outliers == 0.5 and model != L.LINE:            # (lines keep full counting: LineCell::USE_BOUND = 0)
+    if outliers == 0.5:
         assert skipped.sum() > 0.5 * H                 # most random hypotheses are never counted
 
 
