@@ -352,10 +352,11 @@ def scan_roofline(a, ctx, idx, H, scan_ms, n_scan, rec):
         if wl["bounded"]:                            # bounds pass + the pilots' group + the second pass' groups
             l1 += wl["cells"] * (1 + -(-wl["second_pass"] // 64))
         useful = l1 * u["l1"] + wl["pairs_counted"] * v2
-        kname = ("k_scan_cells<%s> (two-level: cell-box culling over a Morton-sorted copy, packed fp32 filter + "
-                 "exact fp64 re-check in surviving cells)%s" % (
-                     w, "; bounded scan: k_cells_bounds -> pilots -> only hypotheses that can still win"
-                     if wl["bounded"] else ""))
+        kname = ("two-level scan of <%s> over a Morton-sorted copy: cell-box culling, packed fp32 filter + exact fp64 "
+                 "re-check in surviving cells; %s" % (
+                     w, "bounded: k_cells_bounds (vote bounds) -> pilots -> only hypotheses that can still win, each "
+                     "counted by k_scan_pairs (level 1 counted first, then an equal share of the surviving "
+                     "(hypothesis, cell) pairs per wave)" if wl["bounded"] else "k_scan_cells"))
         model = {"level1_evaluations": l1, "level1_useful_instr": u["l1"],
                  "surviving_hypothesis_cell_pairs_all": wl["pairs"],
                  "surviving_hypothesis_cell_pairs_counted": wl["pairs_counted"], "level2_useful_instr": v2,

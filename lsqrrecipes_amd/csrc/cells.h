@@ -318,6 +318,11 @@ struct PlaneCell {
   typedef PlaneModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = 4 * D, ROW_F32 = 0, ROW2 = 0, ROW2_OFF = 0 };  // row = fp64 scan parameters
   enum { DEFAULT_CELL = 512, LDS_BROADCAST = 0, MIN_WAVES = 6 };  // measured best (tools/ab_cells.py)
+  // k_scan_pairs counts near-model hypotheses, 80 % of whose (hypothesis, cell) pairs take the full path: there the
+  // six v_readlane per pair are vector-issue slots the LDS broadcast gives back (0.84 -> 0.77 ms per step)
+  enum { LDS_BROADCAST_PAIRS = 1 };
+  // (1024-point cells / 8 packed pairs per lane, 4 waves per SIMD: second pass of the bounded scan 642 us against
+  // 510 us -- measured and not built; `enum { MAX_PP = 8 };` here brings the instantiation back)
   enum { USE_BOUND = 1 };  // bounded scan pays: a random plane still cuts ~13 % of the cells
   struct Hyp {
     double n[3], c;
@@ -716,7 +721,7 @@ __device__ __forceinline__ void cells_load(const double *__restrict__ sorted, co
 template <class CM, int PP, int CPT, int BS, bool LDSB = false>
 // CM::MIN_WAVES (default tile shape only): the register budget that buys the occupancy measured best -- plane
 // 80 VGPRs = 6 waves per SIMD (98 VGPRs / 4 waves without the hint: 1.44 -> 1.31 ms; 7 waves spill: 1.40 ms)
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? CM::MIN_WAVES : 1, 8))) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? (PP >= 8 ? 4 : CM::MIN_WAVES) : 1, 8))) void k_scan_cells(const double *__restrict__ sorted, size_t ns,
                                                     const CellBox *__restrict__ boxes,
                                                     uint32_t ncells, const double *__restrict__ sp,
                                                     const float *__restrict__ rows,
@@ -1174,7 +1179,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 }
 
 template <class CM, int PP, int BS, bool LDSB>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CM::MIN_WAVES, 8))) void k_scan_pairs(
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 : CM::MIN_WAVES, 8))) void k_scan_pairs(
     const double *__restrict__ sorted, size_t ns, const CellBox *__restrict__ boxes, uint32_t ncells,
     const double *__restrict__ sp, const float *__restrict__ rows, const float *__restrict__ spf, uint32_t H,
     ModelConsts mc, CellConsts cc, uint32_t *__restrict__ vpart, uint32_t vstride,

@@ -675,6 +675,16 @@ int run_scan_cells(lsqr_ctx *c) {
   return run_scan_cells<CM, PP, CPT>(c, b);
 }
 
+// cell size -> packed pairs per lane (PP = cell / 128); 1024-point cells only where the cell model is built for them
+template <class CM, class F>
+int with_pp(uint32_t cell_pts, F &&f) {
+  if constexpr (requires { CM::MAX_PP; }) {
+    if (cell_pts == 1024) return f(std::integral_constant<int, 8>{});
+  }
+  if (cell_pts == 512) return f(std::integral_constant<int, 4>{});
+  return f(std::integral_constant<int, 2>{});
+}
+
 // level 1 of the two-level scan alone over the current batch: d_ub[h] = vote bound, d_counter[4] = surviving pairs
 template <class CM, int PP>
 int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
@@ -725,7 +735,9 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
   hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
                      c->n_cells, d_cost, d_csum, b.votes);  // (also zeroes the batch's votes for k_votes_reduce)
   HIPCHK(c, hipGetLastError());
-  const bool ldsb = c->opt_block == 257 || (c->opt_block == 0 && CM::LDS_BROADCAST);
+  bool ldsb_default = CM::LDS_BROADCAST;
+  if constexpr (requires { CM::LDS_BROADCAST_PAIRS; }) ldsb_default = CM::LDS_BROADCAST_PAIRS;
+  const bool ldsb = c->opt_block == 257 || (c->opt_block == 0 && ldsb_default);
   constexpr int BS = 256, wpb = BS / 64;
   const size_t lds = (size_t)((Hc + 3) & ~3u) * sizeof(uint32_t) + (ldsb ? (size_t)wpb * 2048 : 0);
   auto launch = [&](auto kern) -> int {
@@ -967,7 +979,8 @@ int run_scan(lsqr_ctx *c) {
                            (c->opt_index == 1 && tuned_defaults &&
                             (c->index_valid || (c->n >= 65536 && to_come >= kIndexPaysAfter))));
         if (want) {
-          const uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : (uint32_t)CM::DEFAULT_CELL;
+          uint32_t cell_pts = c->opt_cell ? (uint32_t)c->opt_cell : (uint32_t)CM::DEFAULT_CELL;
+          if constexpr (!requires { CM::MAX_PP; }) cell_pts = cell_pts > 512 ? 512 : cell_pts;
           bool usable = true;
           if (!c->index_valid || c->cell_pts != cell_pts) {
             // the index is an accelerator: if it cannot be built (typically no memory for the sorted
@@ -985,16 +998,13 @@ int run_scan(lsqr_ctx *c) {
             // batch entry points: hypotheses that cannot become the running maximum are not counted (the extra
             // launches only pay for batches of >= 1024; the selection kernels handle <= 8192)
             if (CM::USE_BOUND && c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
-              if (cell_pts == 512) return run_scan_bounded<CM, 4>(c);
-              return run_scan_bounded<CM, 2>(c);
+              return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_bounded<CM, decltype(pp)::value>(c); });
             }
             if (c->opt_pairs == 1) {  // A/B: the statically balanced kernel for a plain scan too
               const ScanBatch b = {c->d_hparams, c->d_hparams_f32, c->H, c->d_votes, nullptr};
-              if (cell_pts == 512) return run_scan_pairs<CM, 4>(c, b);
-              return run_scan_pairs<CM, 2>(c, b);
+              return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_pairs<CM, decltype(pp)::value>(c, b); });
             }
-            if (cell_pts == 512) return run_scan_cells<CM, 4, 1>(c);
-            return run_scan_cells<CM, 2, 1>(c);
+            return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_cells<CM, decltype(pp)::value, 1>(c); });
           }
         }
       }
@@ -3417,8 +3427,8 @@ int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[8]) {
     typedef typename decltype(tag)::type M;
     if constexpr (requires { typename CellOf<M>::type; }) {
       typedef typename CellOf<M>::type CM;
-      if (c->cell_pts == 512) return run_cells_bounds<CM, 4>(c, c->d_ub, d_nc);
-      return run_cells_bounds<CM, 2>(c, c->d_ub, d_nc);
+      return with_pp<CM>(c->cell_pts,
+                         [&](auto pp) { return run_cells_bounds<CM, decltype(pp)::value>(c, c->d_ub, d_nc); });
     } else {
       return fail(c, LSQR_ERR_INVALID, "model has no two-level scan");
     }

@@ -21,8 +21,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402
 
-KERNEL = {"plane": "k_scan_cells", "sphere": "k_scan_cells", "line": "k_scan_cells", "us": "k_scan_us_f32",
-          "dense": "k_scan_dense_mfma"}
+# the kernels of the scan phase (bounded two-level scan: the level-1 passes and the balanced second level)
+CELLS = ("k_cells_bounds", "k_scan_pairs", "k_scan_cells")
+KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32",), "dense": ("k_scan_dense_mfma",)}
+
+
+def is_scan(w, name):
+    return any(k in name for k in KERNEL[w])
+
 LAUNCHES = 0
 SETS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM",
         "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
@@ -44,7 +50,7 @@ def run_pass(w, counters, d):
     acc = collections.defaultdict(float)
     launches = collections.defaultdict(int)
     for row in csv.DictReader(open(f[0])):
-        if KERNEL[w] in row["Kernel_Name"]:
+        if is_scan(w, row["Kernel_Name"]):
             acc[row["Counter_Name"]] += float(row["Counter_Value"])
             launches[row["Counter_Name"]] += 1
     global LAUNCHES
@@ -75,11 +81,11 @@ def main():
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
         tot = 0.0
         for row in csv.DictReader(open(f)):
-            if KERNEL[w] in row["Name"]:
+            if is_scan(w, row["Name"]):
                 tot += float(row["TotalDurationNs"])
         if tot:
             avg_ns = tot / 3.0        # per bench step (3 steps in this pass)
-    out = {"workload": w, "kernel": KERNEL[w], "kernel_source_hash": kernel_source_hash(),
+    out = {"workload": w, "kernel": " + ".join(KERNEL[w]), "kernel_source_hash": kernel_source_hash(),
            "collected_at": time.strftime("%Y-%m-%d %H:%M:%S"),
            "source": "tools/collect_counters.py %s: rocprofv3 --pmc passes (one counter set each, --kernel-trace only) of "
                      "tools/scan_once.py %s -- the bench's shapes and sampler stream, one step" % (w, w),
