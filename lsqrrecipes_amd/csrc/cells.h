@@ -649,7 +649,9 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
     // tin <= |v| < tout implies fl(|v| - tin) <= fl(tout - tin); flagging |v| == tout too only costs a re-check.
     // (Two compares per value with the mask logic and the counts on the scalar unit -- 36 vector and 40 scalar
     // instructions per pair instead of 59 and 25 -- measured SLOWER: 551 against 528 us in the second pass of the
-    // bounded plane scan, 1.67 against 1.39 ms for a plain 4096-hypothesis scan.)
+    // bounded plane scan, 1.67 against 1.39 ms for a plain 4096-hypothesis scan.  So did moving just the
+    // "filter off" test of t_out to integer arithmetic on the scalar unit: 3 vector instructions fewer, 8 scalar
+    // ones more, 0.794 against 0.779 ms per step.  The scalar unit is as busy as the vector unit in this loop.)
     unsigned long long in[2 * PP];
     uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll

@@ -1310,9 +1310,17 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           // result lands in pinned host memory and the host polls its sequence flag (no stream synchronisation,
           // no staging copies): per evaluation = the pass + one launch latency + a few hundred host flops
           // the consensus set, tight and in order (every evaluation then streams n_in records, all lanes busy)
+          // Compacting costs about as much as six evaluations through the mask save (10 M records, 38 % inliers:
+          // count + scan + host read-back + write = 130 us; a pass over the compacted set is 23 us against 43 us), and
+          // the sphere's geometric fit from the algebraic start typically needs three: the per-lane pass starts
+          // THROUGH THE MASK and the set is compacted once `kCompactAfter` evaluations have been spent.  The
+          // matrix-core pass (US: thousands of evaluations) reads compacted records only and compacts at once.
+          constexpr int kCompactAfter = 8;
+          const bool mfma_pass = c->opt_lm_mfma && M::NLM >= 8;
           const double *lm_data = c->d_data;
           size_t lm_stride = c->stride, cnt = c->n;
-          if (use_mask) {
+          bool through_mask = use_mask;
+          auto compact = [&]() -> int {
             int cb = grid_for(c->n, kBlock * 8, 1024);
             size_t cchunk = (c->n + cb - 1) / cb;
             cchunk = (cchunk + kBlock - 1) / kBlock * kBlock;
@@ -1324,22 +1332,35 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             HIPCHK(c, hipMemcpyAsync(pin + 200, d_off + cb, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             cnt = *(const uint32_t *)(pin + 200);
-            if ((st = ensure(c, &c->d_lmrec, &c->lmrec_cap, std::max<size_t>(cnt, 1) * M::ND)) != LSQR_OK) return st;
+            int st2 = ensure(c, &c->d_lmrec, &c->lmrec_cap, std::max<size_t>(cnt, 1) * M::ND);
+            if (st2 != LSQR_OK) return st2;
             hipLaunchKernelGGL((k_compact_write<M::ND>), dim3(cb), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
                                c->d_mask, c->n, cchunk, d_off, c->d_lmrec);
             HIPCHK(c, hipGetLastError());
             lm_data = c->d_lmrec;
             lm_stride = M::ND;
-          }
-          int nb = grid_for(cnt, kBlock * ((c->opt_lm_mfma && M::NLM >= 8) ? 2 : 8), kMaxPartials);
-          size_t chunk = (cnt + nb - 1) / nb;
-          chunk = (chunk + kBlock - 1) / kBlock * kBlock;
-          nb = (int)((cnt + chunk - 1) / chunk);
-          if (nb < 1) nb = 1;
+            through_mask = false;
+            return LSQR_OK;
+          };
+          int nb = 1;
+          size_t chunk = 0;
+          auto shape = [&]() {
+            nb = grid_for(cnt, kBlock * (mfma_pass ? 2 : 8), kMaxPartials);
+            chunk = (cnt + nb - 1) / nb;
+            chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+            nb = (int)((cnt + chunk - 1) / chunk);
+            if (nb < 1) nb = 1;
+          };
+          if (use_mask && mfma_pass && (st = compact()) != LSQR_OK) return st;
+          shape();
           volatile double *res = c->h_lmres;
           // the ticket word is zeroed per fit (an aborted launch must not poison the next one)
           HIPCHK(c, hipMemsetAsync(c->d_counter + 7, 0, sizeof(unsigned long long), c->stream));
           for (;;) {
+            if (through_mask && s.nfev >= kCompactAfter) {
+              if ((st = compact()) != LSQR_OK) return st;
+              shape();
+            }
             LmX xk;
             for (int j = 0; j < LM_NMAX; j++) xk.x[j] = j < n ? s.xtrial[j] : 0.0;
             const double seq = (c->lm_seq += 1.0);
@@ -1354,14 +1375,20 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
                 // the matrix-core pass pays when the (J | f) rows are wide (US: 12 / 9 columns, 78 / 45 sums); for the
                 // sphere's 5 columns the 16 x 16 tile is mostly padding and the instruction time alone (25 us at 3.8 M
                 // points) exceeds the per-lane version's whole pass
-                if (c->opt_lm_mfma && M::NLM >= 8) {
+                if (mfma_pass) {
                   typename M::LmCoef coef;
                   M::lm_coef(xk.x, coef);
                   hipLaunchKernelGGL((k_lm_pass_mfma<M>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
                                      cnt, coef, c->mc, c->d_partials);
-                } else
+                } else if (through_mask)
+                  hipLaunchKernelGGL((k_lm_pass<M, true>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
+                                     (size_t)0, cnt, chunk, (const uint8_t *)c->d_mask, xk, c->mc, c->d_partials);
+                else
                   hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
                                      (size_t)0, cnt, chunk, (const uint8_t *)nullptr, xk, c->mc, c->d_partials);
+              } else if (through_mask) {
+                hipLaunchKernelGGL((k_lm_pass<M, true>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
+                                   (size_t)0, cnt, chunk, (const uint8_t *)c->d_mask, xk, c->mc, c->d_partials);
               } else {
                 hipLaunchKernelGGL((k_lm_pass<M, false>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
                                    (size_t)0, cnt, chunk, (const uint8_t *)nullptr, xk, c->mc, c->d_partials);
