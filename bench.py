@@ -57,6 +57,9 @@ def parse():
                     help="final fit of the US workload: Levenberg-Marquardt with the reference's settings (BASELINE "
                          "config 5 as written: tolerances 1e-15, 5000 evaluations -- at 1 M frames MINPACK uses all "
                          "of them, see tests/golden/us_lm_vectors.npz) or the analytic estimate alone")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="single GPU, pipelined steps: HIP streams (lanes of lsqr_batch_fit_enqueue) the batches "
+                         "alternate over; batches of different streams overlap on the device (1 = one stream)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single GPU: one blocking lsqr_batch_fit per step instead of pipelined batches")
     ap.add_argument("--no-end-to-end", action="store_true",
@@ -198,6 +201,8 @@ def main():
         ctx.set_option("scan_filter", 0)
     if a.no_index:
         ctx.set_option("scan_index", 0)
+    a.streams = max(1, min(4, a.streams))
+    ctx.set_option("batch_lanes", a.streams)
     comm = Comm(dist, device)
     eng = ShardedRansac(ctx, comm)
     step_on_device = dist is not None and os.environ.get(
@@ -237,8 +242,41 @@ def main():
     closed_form = not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
     pipelined_dist = step_on_device and closed_form and not a.no_pipeline
 
+    cur_streams = [a.streams]
+
+    # multi-GPU with several streams: one engine per stream -- its own context (own upload and index), its own
+    # process group (an RCCL communicator serves one stream at a time) and its own torch stream
+    lanes = []
+    if pipelined_dist and a.streams > 1 and str(device) != "cpu":
+        import torch
+        for k in range(a.streams):
+            ck = ctx if k == 0 else Context(local)
+            if k:
+                ck.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
+                if a.no_filter:
+                    ck.set_option("scan_filter", 0)
+                if a.no_index:
+                    ck.set_option("scan_index", 0)
+            gk = dist.new_group(backend="nccl")        # every rank, same order
+            lanes.append((ShardedRansac(ck, Comm(dist, device, group=gk)), torch.cuda.Stream()))
+
     def run_steps(first_step, count):
         last = None
+        if pipelined_dist and lanes and cur_streams[0] > 1:
+            import torch
+            S = len(lanes)
+            ring = 2 * S
+            for i in range(count):
+                if i >= ring:
+                    j = i - ring
+                    last = lanes[j % S][0].step_device_wait((j // S) & 1)
+                with torch.cuda.stream(lanes[i % S][1]):
+                    lanes[i % S][0].step_device(seed, first_step + i, H, slot=(i // S) & 1)
+            for j in range(max(0, count - ring), count):
+                last = lanes[j % S][0].step_device_wait((j // S) & 1)
+            if last is None:
+                return None
+            return last[0], last[3], last[4]
         if pipelined_dist:   # multi-GPU: step i + 1 is enqueued (collectives included) before step i is read
             for i in range(count):
                 eng.step_device(seed, first_step + i, H, slot=i & 1)
@@ -253,17 +291,22 @@ def main():
             for i in range(count):
                 last = step(first_step + i)
             return last
+        # a ring of 2 * streams slots: slot s runs on stream (lane) s % streams, two batches deep per stream
+        ring = 2 * cur_streams[0]
         for i in range(count):
-            ctx.batch_fit_enqueue(seed, (first_step + i) * H, H, slot=i & 1)
-            if i:
-                last = ctx.batch_fit_wait((i - 1) & 1)
-        if count:
-            last = ctx.batch_fit_wait((count - 1) & 1)
+            if i >= ring:
+                last = ctx.batch_fit_wait((i - ring) % ring)
+            ctx.batch_fit_enqueue(seed, (first_step + i) * H, H, slot=i % ring)
+        for i in range(max(0, count - ring), count):
+            last = ctx.batch_fit_wait(i % ring)
         if last is None or last["info"].best_votes == 0:
             return None
         return int(last["info"].best_votes), last["params"], int(last["info"].fit.n_used)
 
     ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
+    multi_stream = a.streams > 1 and (pipelined or (pipelined_dist and bool(lanes)))
+    if multi_stream:
+        run_steps(0, 2 * a.streams)   # every stream builds its index / loads its code objects before the W steps
     run_steps(0, a.warmup)
     n_idx, ms_idx = ctx.profile_get("index")
     n_abs, ms_abs = ctx.profile_get("absmax")
@@ -276,12 +319,41 @@ def main():
     dt = comm.allreduce_max_f64(dt)
     prof = {k: ctx.profile_get(k) for k in ("scan", "mask", "moments", "estimate", "solve", "sample", "index")}
     ctx.profile(False)
+    single_stream = None
+    if multi_stream:
+        # Kernel durations measured while batches of several streams share the device overlap each other; the
+        # per-kernel figures (roofline, kernel_hbm, kernels_ms) come from the SAME steps run once more on one
+        # stream, right after the timed region.  `value` is the multi-stream figure of the timed region above.
+        if pipelined:
+            ctx.set_option("batch_lanes", 1)
+        cur_streams[0] = 1
+        k1 = min(a.steps, 20)
+        run_steps(a.warmup + a.steps, 2)
+        ctx.profile(True)
+        sync()
+        t1 = time.perf_counter()
+        run_steps(a.warmup + a.steps + 2, k1)
+        sync()
+        dt1 = comm.allreduce_max_f64(time.perf_counter() - t1)
+        prof1 = {k: ctx.profile_get(k) for k in ("scan", "mask", "moments", "estimate", "solve", "sample", "index")}
+        ctx.profile(False)
+        if pipelined:
+            ctx.set_option("batch_lanes", a.streams)
+        cur_streams[0] = a.streams
+        single_stream = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "value": H * a.gpus * k1 / dt1,
+                         "scan_ms_in_timed_region": prof["scan"][1] / max(prof["scan"][0], 1),
+                         "note": "the same chain on ONE stream, run right after the timed region: the source of the "
+                                 "per-kernel durations in roofline / kernel_hbm / kernels_ms (in the timed region "
+                                 "the kernels of %d streams overlap, so a kernel's own duration there includes the "
+                                 "time it shares the device)" % a.streams}
+        prof1["index"] = prof["index"]
+        prof = prof1
     idx = ctx.index_info()
 
     if rank == 0:
         out = report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx,
                      (n_idx, ms_idx), (n_abs, ms_abs), pipelined, pipelined_dist, step_on_device, force_dist,
-                     dist, model)
+                     dist, model, single_stream)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
@@ -459,7 +531,7 @@ def cold_call(a, L, Context, data, model, delta, ls_type, cpu):
 
 
 def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, idx_warm, abs_prof, pipelined,
-           pipelined_dist, step_on_device, force_dist, dist, model):
+           pipelined_dist, step_on_device, force_dist, dist, model, single_stream=None):
     from lsqrrecipes_amd import _lib as L
     from lsqrrecipes_amd.context import Context
     total_hyp = H * a.gpus * a.steps
@@ -489,14 +561,18 @@ def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, id
                    "world_size": comm.world,
                    "collectives": ("RCCL (torch.distributed nccl backend)" if dist is not None and comm.device != "cpu"
                                    else ("gloo (rehearsal)" if dist is not None else "none (single GPU)")),
-                   "step": ("lsqr_batch_fit_enqueue/_wait (one chain per step, next step enqueued before "
-                            "the previous one is read)" if pipelined
+                   "streams": a.streams if single_stream is not None else 1,
+                   "stream_priming_steps": 2 * a.streams if single_stream is not None else 0,
+                   "step": ("lsqr_batch_fit_enqueue/_wait (one chain per step; the steps alternate over %d HIP "
+                            "stream(s), two deep per stream, so chains of different streams overlap on the "
+                            "device)" % a.streams if pipelined
                             else "lsqr_batch_fit (one chain, one sync)" if single
                             else "step_device, pipelined (collectives on device buffers; step i + 1 enqueued "
                             "before step i is read)" if pipelined_dist
                             else "step_device (collectives on device buffers, one sync)" if step_on_device
                             else "step (exchanges staged through the host)")},
         "per_rank_hypotheses_per_s": value / a.gpus,
+        "single_stream": single_stream,
         "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),
                       "params": [float(x) for x in fit],
                       "abs_dot_true_normal": float(abs(np.dot(fit[:3], truth[:3])))

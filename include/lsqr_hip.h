@@ -237,12 +237,20 @@ LSQR_API int lsqr_ransac(lsqr_ctx *ctx, double p, uint64_t seed, const uint32_t 
 LSQR_API int lsqr_batch_fit(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H,
                             double *params_out, uint8_t *consensus_out, lsqr_ransac_info *info);
 /* lsqr_batch_fit split in two for pipelining: _enqueue chains the whole batch (sample .. fit and the copies
- * of the results into pinned slot `slot`, 0 or 1) on the stream and returns without waiting; _wait blocks on
- * that slot's event and returns what lsqr_batch_fit returns (no consensus copy: read it with lsqr_mask_*
- * before the next batch is enqueued if it is needed).  Batches execute in order on the one stream, so the
- * next batch can be enqueued before the previous one is read: the host's latency between steps disappears
- * behind the device's work.  Closed-form fits only (LSQR_ERR_INVALID for the iterative fits and the plane
- * phantom, whose final fit keeps the host in the loop). */
+ * of the results into a pinned slot) and returns without waiting; _wait blocks on that slot's event and returns
+ * what lsqr_batch_fit returns (no consensus copy: read it with lsqr_mask_* before the slot's lane gets its next
+ * batch if it is needed).  The next batches can be enqueued before the previous ones are read: the host's latency
+ * between steps disappears behind the device's work.
+ * Slots and lanes: the context runs L = option "batch_lanes" (1..4, default 4) LANES -- HIP streams with their own
+ * hypothesis / vote / mask buffers and their own spatial index, all reading the context's records -- and has 2 L
+ * slots: slot s is batch depth s / L (0 or 1) of lane s % L.  Batches on one lane execute in order; batches on
+ * different lanes OVERLAP on the device, which fills the time the dozen one-workgroup kernels of a batch (selection,
+ * winner, solve) and the tails of the large ones leave the chip idle: plane, 10 M points, 4096 hypotheses per
+ * batch: 0.81 ms per batch on one lane, 0.64 on two, 0.56 on four.  A caller that only uses slots 0 and 1 gets two
+ * lanes.  Results do not depend on the number of lanes (tests/test_gpu_parity.py::test_batch_lanes_*).  Replacing the
+ * records or the model (lsqr_upload / lsqr_attach / lsqr_set_model) waits for the lanes and voids unread slots.
+ * Closed-form fits only (LSQR_ERR_INVALID for the iterative fits and the plane phantom, whose final fit keeps the
+ * host in the loop). */
 LSQR_API int lsqr_batch_fit_enqueue(lsqr_ctx *ctx, uint64_t seed, uint64_t first_index, size_t H, int slot);
 LSQR_API int lsqr_batch_fit_wait(lsqr_ctx *ctx, int slot, double *params_out, lsqr_ransac_info *info);
 /* ---- multi-GPU step with device-resident exchange buffers ------------------------------------------
@@ -344,6 +352,9 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                hypothesis' votes from the cell boxes, a few early candidates counted first); the others
  *                report 0 votes -- winner, consensus set and iteration count are unchanged (RANSAC.hxx:94 abandons
  *                exactly such hypotheses).  0 = every hypothesis is counted.  lsqr_scan always counts all;
+ * "batch_lanes": streams (1..4, default 4) the slots of lsqr_batch_fit_enqueue / _wait are spread over (see there);
+ * "scan_pairs":  1 = plain (unbounded) scans of an indexed upload also go through the statically balanced kernel of
+ *                the bounded scan (k_scan_pairs) instead of k_scan_cells (A/B knob);
  * "dense_fast_solve": 1 (default) = the n x n minimal solves of the dense system use elimination with
  *                partial pivoting and only fall back to the SVD pseudo-inverse near the rank decision,
  *                0 = always the SVD pseudo-inverse;

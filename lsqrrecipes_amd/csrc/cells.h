@@ -948,12 +948,12 @@ __global__ __launch_bounds__(1024) void k_pick_rest(const uint32_t *__restrict__
     const uint32_t h = t * 8 + k;
     f[k] = 0;
     if (h < H && valid[h]) {
-      uint32_t before = 0;  // pilots with a smaller index
-      bool is_pilot = false;
-      for (uint32_t j = 0; j < np; j++) {
-        before += s_pi[j] < h ? 1u : 0u;
-        is_pilot = is_pilot || s_pi[j] == h;
-      }
+      uint32_t before = 0;  // pilots with a smaller index: lower bound in the sorted list (0xFFFFFFFF pads it)
+#pragma unroll
+      for (uint32_t step = kPilots / 2; step > 0; step >>= 1)
+        before += s_pi[before + step - 1] < h ? step : 0u;
+      before += (before < kPilots && s_pi[before] < h) ? 1u : 0u;
+      const bool is_pilot = before < kPilots && s_pi[before] == h;
       const uint32_t L = before ? s_pm[before - 1] : best_before;
       f[k] = (!is_pilot && ub[h] > L) ? 1u : 0u;
     }

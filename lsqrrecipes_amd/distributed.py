@@ -21,9 +21,11 @@ class Comm:
     The messages are tiny (8 B .. 17 KB) and latency-bound, so the device and pinned host staging
     buffers are allocated once and every exchange is copy-in, all_reduce, copy-out, one sync."""
 
-    def __init__(self, dist=None, device="cpu"):
+    def __init__(self, dist=None, device="cpu", group=None):
         self.dist = dist
         self.device = device
+        self.group = group    # process group of the collectives (None: the default group); one per stream when
+                              # steps of several streams are in flight: a communicator serves one stream at a time
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self._bufs = {}
@@ -44,7 +46,7 @@ class Comm:
         host.copy_(torch.as_tensor(values, dtype=dtype))
         if dev is not host:
             dev.copy_(host, non_blocking=True)
-        self.dist.all_reduce(dev, op=op)
+        self.dist.all_reduce(dev, op=op, group=self.group)
         if dev is not host:
             host.copy_(dev, non_blocking=True)
             torch.cuda.current_stream().synchronize()
@@ -71,7 +73,7 @@ class Comm:
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            self.dist.barrier(group=self.group)
 
 
 def slice_bounds(n, rank, world):
@@ -174,11 +176,11 @@ class ShardedRansac:
         first = (batch_index * c.world + c.rank) * H
         e.step_scan(seed, first, H, c.rank * H, packed.data_ptr())
         if c.dist is not None:
-            c.dist.all_reduce(packed, op=c.dist.ReduceOp.MAX)
+            c.dist.all_reduce(packed, op=c.dist.ReduceOp.MAX, group=c.group)
         lo, hi = slice_bounds(e.n, c.rank, c.world)
         e.step_winner(seed, batch_index * c.world * H, packed.data_ptr(), lo, hi, block.data_ptr())
         if c.dist is not None:
-            c.dist.all_reduce(block, op=c.dist.ReduceOp.SUM)
+            c.dist.all_reduce(block, op=c.dist.ReduceOp.SUM, group=c.group)
         if slot is not None:     # pipelined: results are fetched later with step_device_wait(slot)
             e.step_finish_enqueue(packed.data_ptr(), block.data_ptr(), slot)
             self._pending[slot] = (batch_index, H, lo, hi)
@@ -218,7 +220,7 @@ class ShardedRansac:
             while True:
                 e.moments_dev(xt[:e.P], self._lmbuf.data_ptr(), lo, hi, phase=1, use_mask=True)
                 if c.dist is not None:
-                    c.dist.all_reduce(self._lmbuf, op=c.dist.ReduceOp.SUM)
+                    c.dist.all_reduce(self._lmbuf, op=c.dist.ReduceOp.SUM, group=c.group)
                 cont, xt, fit, info = e.lm_step(self._lmbuf.cpu().numpy())
                 if not cont:
                     break

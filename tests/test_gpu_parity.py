@@ -1874,3 +1874,38 @@ def test_cell_scan_with_the_filter_switched_off_per_hypothesis(ctx):
         if valid[h]:
             assert plain[h] == O.scan(oc, par[h], pts)[0]
     assert plain.max() > 0.3 * n
+
+
+# ---- lanes of the pipelined batch entry points (lsqr_hip.h: lsqr_batch_fit_enqueue / _wait, option batch_lanes) ----
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3)])
+def test_batch_lanes_give_the_single_stream_results(ctx, model, dim):
+    """batches spread over three streams (each lane: own stream, buffers and index, attached to the context's records)
+    return exactly what one stream returns -- winner, votes, consensus size and fit of every batch -- also after the
+    records are replaced while lanes exist"""
+    n, H, nb = 200_000, 2048, 9
+    ls = L.LS_ALGEBRAIC if model == L.SPHERE else 0
+    for seed in (11, 12):                       # second round: re-upload with lanes alive
+        data = _data(model, dim, n, 900 + seed, outliers=0.6)
+        ctx.set_model(model, dim, 0.5, ls).upload(data)
+        ctx.set_option("scan_index", 2)
+        res = {}
+        for lanes in (1, 3):
+            ctx.set_option("batch_lanes", lanes)
+            ring, out = 2 * lanes, [None] * nb
+            for i in range(nb):
+                if i >= ring:
+                    out[i - ring] = ctx.batch_fit_wait((i - ring) % ring)
+                ctx.batch_fit_enqueue(seed, i * H, H, slot=i % ring)
+            for i in range(max(0, nb - ring), nb):
+                out[i] = ctx.batch_fit_wait(i % ring)
+            res[lanes] = [(r["info"].best_index, r["info"].best_votes, r["info"].fit.n_used, tuple(r["params"]))
+                          for r in out]
+        assert res[1] == res[3]
+        one = ctx.batch_fit(seed, 4 * H, H)     # the blocking entry point on the same batch
+        assert (one["info"].best_index, one["info"].best_votes, tuple(one["params"])) == \
+            (res[3][4][0], res[3][4][1], res[3][4][3])
+    ctx.set_option("batch_lanes", 3)
+    ctx.set_option("scan_index", 1)
+    with pytest.raises(Exception):
+        ctx.batch_fit_enqueue(1, 0, H, slot=6)  # three lanes: slots 0..5
+    ctx.set_option("batch_lanes", 4)            # the default
