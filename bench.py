@@ -201,8 +201,8 @@ def main():
         ctx.set_option("scan_filter", 0)
     if a.no_index:
         ctx.set_option("scan_index", 0)
-    a.streams = max(1, min(4, a.streams))
-    ctx.set_option("batch_lanes", a.streams)
+    a.streams = max(1, min(8, a.streams))      # the library's lanes go up to 4; host-threaded contexts up to 8
+    ctx.set_option("batch_lanes", min(4, a.streams))
     comm = Comm(dist, device)
     eng = ShardedRansac(ctx, comm)
     step_on_device = dist is not None and os.environ.get(
@@ -242,7 +242,25 @@ def main():
     closed_form = not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
     pipelined_dist = step_on_device and closed_form and not a.no_pipeline
 
+    if pipelined or pipelined_dist:
+        a.streams = min(4, a.streams)
     cur_streams = [a.streams]
+
+    # iterative final fits (sphere geometric, US iterative, phantom) keep the host in the loop -- MINPACK's control
+    # flow between device passes -- so a batch is a blocking call.  The library's threading model is one context per
+    # host thread (LsqrDevice.h); with several streams the steps are dealt to that many host threads, each driving
+    # its own context (own stream, own upload): while one thread waits for an evaluation, another one's scan runs.
+    threaded = (comm.world == 1 and not force_dist and not pipelined and a.streams > 1 and not a.no_pipeline)
+    tctx = [ctx]
+    if threaded:
+        for k in range(1, a.streams):
+            ck = Context(local)
+            ck.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
+            if a.no_filter:
+                ck.set_option("scan_filter", 0)
+            if a.no_index:
+                ck.set_option("scan_index", 0)
+            tctx.append(ck)
 
     # multi-GPU with several streams: one engine per stream -- its own context (own upload and index), its own
     # process group (an RCCL communicator serves one stream at a time) and its own torch stream
@@ -287,6 +305,28 @@ def main():
             if last is None:
                 return None
             return last[0], last[3], last[4]
+        if threaded and cur_streams[0] > 1:
+            import threading
+            S = len(tctx)
+            res = [None] * count
+            err = []
+
+            def work(k):
+                try:
+                    for i in range(k, count, S):
+                        r = tctx[k].batch_fit(seed, (first_step + i) * H, H)
+                        res[i] = (None if r["info"].best_votes == 0 else
+                                  (int(r["info"].best_votes), r["params"], int(r["info"].fit.n_used)))
+                except Exception as e:      # surfaced below: a failed step must fail the run
+                    err.append(e)
+            th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            if err:
+                raise err[0]
+            return res[-1] if count else None
         if not pipelined:
             for i in range(count):
                 last = step(first_step + i)
@@ -304,7 +344,7 @@ def main():
         return int(last["info"].best_votes), last["params"], int(last["info"].fit.n_used)
 
     ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
-    multi_stream = a.streams > 1 and (pipelined or (pipelined_dist and bool(lanes)))
+    multi_stream = a.streams > 1 and (pipelined or threaded or (pipelined_dist and bool(lanes)))
     if multi_stream:
         run_steps(0, 2 * a.streams)   # every stream builds its index / loads its code objects before the W steps
     run_steps(0, a.warmup)
@@ -338,7 +378,7 @@ def main():
         prof1 = {k: ctx.profile_get(k) for k in ("scan", "mask", "moments", "estimate", "solve", "sample", "index")}
         ctx.profile(False)
         if pipelined:
-            ctx.set_option("batch_lanes", a.streams)
+            ctx.set_option("batch_lanes", min(4, a.streams))
         cur_streams[0] = a.streams
         single_stream = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "value": H * a.gpus * k1 / dt1,
                          "scan_ms_in_timed_region": prof["scan"][1] / max(prof["scan"][0], 1),
@@ -488,6 +528,11 @@ def hbm_table(a, H, rec, prof, abs_prof, idx_prof, cnt):
     return rows
 
 
+def closed_form_fit(a, ls_type):
+    from lsqrrecipes_amd import _lib as L
+    return not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
+
+
 def cold_call(a, L, Context, data, model, delta, ls_type, cpu):
     """What a caller of RANSAC<T,S>::compute() (RANSAC.h:75-79) sees on data that is NOT yet on the device:
     lsqr_upload of the caller's pageable buffer + lsqr_ransac (adaptive, p = 0.999) + the consensus copy."""
@@ -542,6 +587,10 @@ def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, id
     rec = data.shape[1] * 8
     n_scan, ms_scan = prof["scan"]
     scan_ms = ms_scan / max(n_scan, 1)
+    if not single and a.workload in ("plane", "sphere", "line") and closed_form_fit(a, ls_type):
+        # the multi-GPU step leaves the re-derived winner (a batch of one) as the context's current batch: the work
+        # model of the roofline is taken on a full batch of this rank, as in the single-GPU run (untimed)
+        ctx.batch_fit(0xC0FFEE, comm.rank * H, H)
     n_idx = idx_warm[0] + prof["index"][0]
     ms_idx = idx_warm[1] + prof["index"][1]
     out = {
@@ -566,6 +615,9 @@ def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, id
                    "step": ("lsqr_batch_fit_enqueue/_wait (one chain per step; the steps alternate over %d HIP "
                             "stream(s), two deep per stream, so chains of different streams overlap on the "
                             "device)" % a.streams if pipelined
+                            else "lsqr_batch_fit (blocking: the iterative fit keeps the host in the loop), the steps "
+                            "dealt to %d host threads with one context (stream) each" % a.streams
+                            if (single and single_stream is not None)
                             else "lsqr_batch_fit (one chain, one sync)" if single
                             else "step_device, pipelined (collectives on device buffers; step i + 1 enqueued "
                             "before step i is read)" if pipelined_dist
