@@ -883,7 +883,7 @@ struct BoundSel {            // device-side state of one bounded scan
 __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict__ ub,
                                                       const uint8_t *__restrict__ valid, uint32_t H,
                                                       uint32_t *__restrict__ sel, BoundSel *__restrict__ st,
-                                                      uint32_t *__restrict__ votes) {
+                                                      uint32_t *__restrict__ votes, uint32_t best_before) {
   __shared__ uint32_t s_red[16], s_scan[1024];
   const int t = threadIdx.x;
   for (uint32_t h = t; h < H; h += 1024) votes[h] = 0;  // a hypothesis that is not counted reports 0 votes
@@ -920,7 +920,11 @@ __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict
       pos++;
     }
   if (t == 1023) {
-    st->n_pilot = s_scan[1023] < kPilots ? s_scan[1023] : kPilots;
+    // Pilots only exist to give the second pass a lower bound of the running maximum.  When an earlier batch of the
+    // same RANSAC run already holds a maximum of at least half the largest bound (the pilots' own entry level), that
+    // IS the bound: no pilots, the counting launches of the first pass find an empty cost table and return at once.
+    const bool known = best_before >= thr && best_before > 0;
+    st->n_pilot = known ? 0u : (s_scan[1023] < kPilots ? s_scan[1023] : kPilots);
     st->n_rest = 0;
   }
 }
@@ -1023,12 +1027,12 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
                                                       unsigned long long *__restrict__ total,
                                                       uint32_t *__restrict__ ncells_out,
                                                       uint8_t *__restrict__ cnt, uint32_t gstride,
-                                                      const uint32_t *__restrict__ h_dev) {
+                                                      const uint32_t *__restrict__ h_dev, uint32_t h_off) {
   typedef typename CM::M M;
   constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4, CP = 128 * PP;
   const int lane = threadIdx.x & 63;
   if (h_dev) {
-    const uint32_t hd = *h_dev;
+    const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection
     H = hd < H ? hd : H;
   }
   const uint32_t grp = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1140,10 +1144,10 @@ constexpr uint32_t kChunkCells = 128;
 __global__ __launch_bounds__(128) void k_tile_costs(const uint8_t *__restrict__ cnt, uint32_t gstride, uint32_t H,
                                                     const uint32_t *__restrict__ h_dev, uint32_t ncells,
                                                     uint32_t *__restrict__ cost, uint32_t *__restrict__ csum,
-                                                    uint32_t *__restrict__ votes) {
+                                                    uint32_t *__restrict__ votes, uint32_t h_off) {
   for (uint32_t i = blockIdx.x * kChunkCells + threadIdx.x; i < H; i += gridDim.x * kChunkCells) votes[i] = 0;
   if (h_dev) {
-    const uint32_t hd = *h_dev;
+    const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection
     H = hd < H ? hd : H;
   }
   const uint32_t G = (H + 63) / 64;
@@ -1186,13 +1190,13 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
     const double *__restrict__ sp, const float *__restrict__ rows, const float *__restrict__ spf, uint32_t H,
     ModelConsts mc, CellConsts cc, uint32_t *__restrict__ vpart, uint32_t vstride,
     const uint32_t *__restrict__ h_dev, const uint8_t *__restrict__ cnt, uint32_t gstride, const uint32_t *__restrict__ cost,
-    const uint32_t *__restrict__ csum, uint32_t nchunks) {
+    const uint32_t *__restrict__ csum, uint32_t nchunks, uint32_t h_off) {
   typedef typename CM::M M;
   constexpr int NB = CM::NB;
   constexpr int SPD = M::SP;
   constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4;
   if (h_dev) {
-    const uint32_t hd = *h_dev;
+    const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection
     H = hd < H ? hd : H;
   }
   extern __shared__ uint32_t s_cnt[];
@@ -1279,7 +1283,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
       cell += (uint32_t)__builtin_ctzll(nz);
     }
     pad(kCellPad);
-    // padded survivor counts of the cell's groups: lane g <-> group g
+    // padded survivor counts of the cell's groups: lane g <-> group g (the host cuts batches of more than 4096
+    // hypotheses into launches of 4096: a third loop level here costs the 4096 case 28 spilled registers)
     const uint32_t gc = (uint32_t)lane < G ? (uint32_t)cnt[(size_t)cell * gstride + lane] : 0u;
     unsigned long long gm = __ballot(gc != 0);
     // groups that lie before my range altogether
@@ -1316,18 +1321,19 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
           row2[4 * k] = nxt2[k].x, row2[4 * k + 1] = nxt2[k].y, row2[4 * k + 2] = nxt2[k].z,
                    row2[4 * k + 3] = nxt2[k].w;
       }
-      if (gm) load_rows((uint32_t)__builtin_ctzll(gm), nxt, nxt2);  // the next group's rows while this one is counted
+      if (gm) load_rows((uint32_t)__builtin_ctzll(gm), nxt, nxt2);  // the next group's rows meanwhile
       // my part [lo, hi) of the group's cost units; pair j sits at unit kGroupPad + j
       const uint32_t lo = skip, hi = cg < skip + budget ? cg : skip + budget;  // skip < cg here
       budget -= hi - lo;
       skip = 0;
-      const uint32_t jlo = (lo > kGroupPad ? lo : kGroupPad) - kGroupPad, jhi = (hi > kGroupPad ? hi : kGroupPad) - kGroupPad;
+      const uint32_t jlo = (lo > kGroupPad ? lo : kGroupPad) - kGroupPad,
+                     jhi = (hi > kGroupPad ? hi : kGroupPad) - kGroupPad;
       if (jhi <= jlo) continue;
       const uint32_t h0 = (uint32_t)g * 64, h = h0 + lane;
       typename CM::Hyp hy;
       CM::load(row, row2, h < H, cc, hy);
       float bc[NB];
-      unsigned long long surv = __ballot(CM::level1(hy, bx, ctr, cc, bc));  // == the counting pass: cg - kGroupPad bits
+      unsigned long long surv = __ballot(CM::level1(hy, bx, ctr, cc, bc));  // == the counting pass: cg - pad bits
       for (uint32_t k = 0; k < jlo; k++) surv &= surv - 1;                  // the first jlo are not mine
       if (jhi < cg - kGroupPad) {  // the tail belongs to the next wave: keep the lowest jhi - jlo bits
         unsigned long long keep = 0, m = surv;
@@ -1357,9 +1363,9 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
 __global__ __launch_bounds__(256) void k_votes_reduce(const uint32_t *__restrict__ vpart, uint32_t vstride,
                                                       uint32_t nparts, uint32_t H,
                                                       const uint32_t *__restrict__ h_dev,
-                                                      uint32_t *__restrict__ votes) {
+                                                      uint32_t *__restrict__ votes, uint32_t h_off) {
   if (h_dev) {
-    const uint32_t hd = *h_dev;
+    const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection
     H = hd < H ? hd : H;
   }
   const uint32_t h = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;

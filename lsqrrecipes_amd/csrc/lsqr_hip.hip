@@ -640,6 +640,7 @@ struct ScanBatch {
   size_t H;               // hypotheses (capacity when h_dev is set)
   uint32_t *votes;        // zeroed by the caller when h_dev is set
   const uint32_t *h_dev;  // device-side count (bounded scan) or null
+  uint32_t h_off = 0;     // the batch starts at hypothesis h_off of the device-side selection (k_scan_pairs chunks)
 };
 
 template <class CM, int PP, int CPT, int BS, bool LDSB = false>
@@ -724,7 +725,7 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
                      c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
                      (uint32_t)c->H, cc, per, d_ub, d_nc ? c->d_counter + 4 : (unsigned long long *)nullptr, d_nc,
-                     (uint8_t *)nullptr, 0u, (const uint32_t *)nullptr);  // (pair total: diagnostics only -- 8192
+                     (uint8_t *)nullptr, 0u, (const uint32_t *)nullptr, 0u);  // (pair total: diagnostics only -- 8192
                                                                            // atomics on one address are ~100 us)
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
@@ -733,7 +734,22 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
 // Level 2 of a (compacted) batch in statically balanced pieces (cells.h, "statically balanced level 2"): count the
 // survivors per (cell, group), sum them per cell and per chunk, then k_scan_pairs.  Chained on the stream.
 template <class CM, int PP>
-int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
+int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
+  typedef typename CM::M M;
+  // k_scan_pairs holds a cell's groups in the 64 lanes of a wave: batches of more than 4096 hypotheses are counted
+  // 4096 at a time (rare: the bounded scan's second pass is sized for the whole batch but holds ~1/8 of it, so the
+  // later launches find an empty cost table and return at once)
+  constexpr size_t kPairsChunk = 4096;  // 64 groups of 64
+  if (b0.H > kPairsChunk) {
+    for (size_t h0 = 0; h0 < b0.H; h0 += kPairsChunk) {
+      ScanBatch sub = {b0.sp + h0 * M::SP, b0.spf + h0 * M::SPF, std::min<size_t>(kPairsChunk, b0.H - h0),
+                       b0.votes + h0, b0.h_dev, (uint32_t)(b0.h_off + h0)};
+      int st = run_scan_pairs<CM, PP>(c, sub);
+      if (st != LSQR_OK) return st;
+    }
+    return LSQR_OK;
+  }
+  const ScanBatch &b = b0;
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
   if (c->n_cells == 0 || b.H == 0) {
     HIPCHK(c, hipMemsetAsync(b.votes, 0, b.H * sizeof(uint32_t), c->stream));
@@ -753,11 +769,11 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
     const unsigned gx = (c->n_cells + per - 1) / per;
     hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
                        c->n_sorted, rows, b.spf, Hc, cc, per, (uint32_t *)nullptr, (unsigned long long *)nullptr,
-                       (uint32_t *)nullptr, c->d_paircnt, gstride, b.h_dev);
+                       (uint32_t *)nullptr, c->d_paircnt, gstride, b.h_dev, b.h_off);
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
-                     c->n_cells, d_cost, d_csum, b.votes);  // (also zeroes the batch's votes for k_votes_reduce)
+                     c->n_cells, d_cost, d_csum, b.votes, b.h_off);  // (also zeroes the batch's votes)
   HIPCHK(c, hipGetLastError());
   bool ldsb_default = CM::LDS_BROADCAST;
   if constexpr (requires { CM::LDS_BROADCAST_PAIRS; }) ldsb_default = CM::LDS_BROADCAST_PAIRS;
@@ -778,10 +794,10 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b) {
     ProfScope ps(c, KID_SCAN);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BS), lds, c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
                        b.sp, rows, b.spf, Hc, c->mc, cc, c->d_vpart, Hc, b.h_dev, (const uint8_t *)c->d_paircnt, gstride,
-                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks);
+                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks, b.h_off);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_votes_reduce, dim3((Hc + 63) / 64, 48), dim3(256), 0, c->stream,
-                       (const uint32_t *)c->d_vpart, Hc, (uint32_t)blocks, Hc, b.h_dev, b.votes);
+                       (const uint32_t *)c->d_vpart, Hc, (uint32_t)blocks, Hc, b.h_dev, b.votes, b.h_off);
     HIPCHK(c, hipGetLastError());
     return LSQR_OK;
   };
@@ -809,7 +825,7 @@ int run_scan_bounded(lsqr_ctx *c) {
   double *sp_a = c->d_hparams2, *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
   float *spf_a = c->d_hparams2_f32, *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;
   hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel,
-                     c->d_votes);  // (also zeroes the batch's votes: skipped hypotheses report 0)
+                     c->d_votes, c->best_before);  // (also zeroes the batch's votes: skipped hypotheses report 0)
   hipLaunchKernelGGL(k_gather_rows, dim3(kPilots / 4), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
                      (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
   HIPCHK(c, hipGetLastError());

@@ -1909,3 +1909,67 @@ def test_batch_lanes_give_the_single_stream_results(ctx, model, dim):
     with pytest.raises(Exception):
         ctx.batch_fit_enqueue(1, 0, H, slot=6)  # three lanes: slots 0..5
     ctx.set_option("batch_lanes", 4)            # the default
+
+
+def _bounded_equals_full(ctx, model, dim, data, H, seed=77):
+    """scan_bound 1 against 0 on one batch: same valid flags, winner, consensus set, fit and replay state; every
+    hypothesis the bounded scan counted has its exact votes, every other one reports 0 and could not have become the
+    running maximum"""
+    n = len(data)
+    ls = L.LS_ALGEBRAIC if model == L.SPHERE else 0
+    ctx.set_model(model, dim, 0.5, ls).upload(data)
+    ctx.set_option("scan_index", 2)
+    res = {}
+    for bound in (0, 1):
+        ctx.set_option("scan_bound", bound)
+        r = ctx.batch_fit(seed, 0, H, want_consensus=True)
+        _, valid, votes = ctx.hypotheses(params=False)
+        subs = O.ctr_subsets(seed, 0, H, n, ctx.K)
+        res[bound] = (r, votes.copy(), valid.copy(), context_replay(n, ctx.K, 0.999, subs, valid, votes))
+    ctx.set_option("scan_bound", 1)
+    ctx.set_option("scan_index", 1)
+    (r0, v0, ok0, rp0), (r1, v1, ok1, rp1) = res[0], res[1]
+    assert np.array_equal(ok0, ok1)
+    assert (r0["info"].best_index, r0["info"].best_votes) == (r1["info"].best_index, r1["info"].best_votes)
+    if r0["info"].best_votes:
+        assert np.array_equal(r0["consensus"], r1["consensus"]) and np.array_equal(r0["params"], r1["params"])
+    runmax = np.maximum.accumulate(np.where(ok0 > 0, v0, 0))
+    skipped = v1 != v0
+    assert np.all(v1[skipped] == 0)
+    idx = np.flatnonzero(skipped)
+    assert np.all(v0[idx[idx > 0]] <= runmax[idx[idx > 0] - 1])
+    assert not skipped[0] or v0[0] == 0
+    assert rp0 == rp1
+    return r1, v1, skipped
+
+
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3), (L.LINE, 2), (L.SPHERE, 2)])
+@pytest.mark.parametrize("n,H,outliers", [(5_000, 1024, 0.5), (70_001, 1024, 0.0), (70_001, 8192, 0.3),
+                                          (130_000, 4096, 1.0), (66_000, 1027, 0.5)])
+def test_bounded_scan_shapes(ctx, model, dim, n, H, outliers):
+    """the statically balanced second level (k_scan_pairs) on the shapes that stress its bookkeeping: a handful of
+    cells, a last partial cell and chunk, every hypothesis a near-model one (no outliers: the second pass holds the
+    whole batch), no structure at all (only outliers), the largest batch the selection kernels take, a batch size
+    that is not a multiple of 64"""
+    data = _data(model, dim, n, 31337 + n + H, outliers=outliers)
+    r, votes, skipped = _bounded_equals_full(ctx, model, dim, data, H)
+    if r["info"].best_votes:   # the winner's votes against the oracle's scan of the same parameters
+        cfg = O.cfg({L.PLANE: O.PLANE, L.SPHERE: O.SPHERE, L.LINE: O.LINE}[model], dim, 0.5, O.LS_ALGEBRAIC)
+        subs = O.ctr_subsets(77, 0, H, n, ctx.K)
+        par = O.estimate(cfg, data[subs[r["info"].best_index]])
+        assert len(par) and O.scan(cfg, par, data)[0] == r["info"].best_votes
+
+
+def test_bounded_scan_duplicates_and_lattice(ctx):
+    """a lattice (thousands of identical coordinates per axis: degenerate cell boxes, equal Morton keys) and records
+    that occur twice: the cost table, the equal split and the exact re-checks of k_scan_pairs against counting
+    everything (non-finite records switch the filters and with them the two-level scan off: covered by
+    test_cell_scan_nonfinite_duplicate_and_flat_data)"""
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 40, size=(90_000, 3)).astype(np.float64)           # lattice, many duplicates
+    plane_pts = np.column_stack([rng.integers(0, 40, 60_000), rng.integers(0, 40, 60_000)]).astype(np.float64)
+    on = np.column_stack([plane_pts, 0.25 * plane_pts[:, 0] + 0.5 * plane_pts[:, 1] + rng.uniform(-0.4, 0.4, 60_000)])
+    data = np.vstack([g, on, on[:20_000]])
+    rng.shuffle(data)
+    r, votes, skipped = _bounded_equals_full(ctx, L.PLANE, 3, data, 2048, seed=9)
+    assert r["info"].best_votes > 50_000 and skipped.sum() > 0
