@@ -1973,3 +1973,27 @@ def test_bounded_scan_duplicates_and_lattice(ctx):
     rng.shuffle(data)
     r, votes, skipped = _bounded_equals_full(ctx, L.PLANE, 3, data, 2048, seed=9)
     assert r["info"].best_votes > 50_000 and skipped.sum() > 0
+
+
+def test_bounded_scan_with_filters_switched_off(ctx):
+    """the bounded path (batch entry point, 1024 hypotheses) on the data of the test above: most hypotheses have their
+    filter off, survive every cell (vote bound = N), and go the exact way through k_scan_pairs; delta 0.05"""
+    g = np.random.default_rng(12)
+    n = 70_000
+    c0 = np.array([3.0e6, -2.0e6, 1.0e6])
+    u = g.normal(size=(n, 3))
+    pts = c0 + 2.0 * u / np.linalg.norm(u, axis=1)[:, None] + g.normal(scale=0.01, size=(n, 3))
+    pts[::3] = c0 + g.uniform(-6, 6, size=(len(pts[::3]), 3))
+    ctx.set_model(L.SPHERE, 3, 0.05, L.LS_ALGEBRAIC).upload(pts)
+    ctx.set_option("scan_index", 2)
+    res = {}
+    for bound in (0, 1):
+        ctx.set_option("scan_bound", bound)
+        r = ctx.batch_fit(4, 0, 1024, want_consensus=True)
+        _, valid, votes = ctx.hypotheses(params=False)
+        res[bound] = (r["info"].best_index, r["info"].best_votes, r["consensus"].copy(), votes.copy())
+    ctx.set_option("scan_bound", 1)
+    ctx.set_option("scan_index", 1)
+    assert res[0][:2] == res[1][:2] and np.array_equal(res[0][2], res[1][2])
+    counted = res[1][3] != 0
+    assert np.array_equal(res[1][3][counted], res[0][3][counted]) and res[0][1] > 0.3 * n
