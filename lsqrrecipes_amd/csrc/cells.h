@@ -276,6 +276,51 @@ __global__ __launch_bounds__(256) void k_gather_boxes(const double *__restrict__
   }
 }
 
+// ---- coarser boxes for the vote bounds: one box per `merge` consecutive cells (Morton order keeps them close
+// together).  The bounds pass of the bounded scan only has to tell near-model hypotheses from the rest: with four
+// cells per box it evaluates a quarter of the (hypothesis, box) tests, and the bound -- the population of the
+// surviving boxes -- stays valid (a merged box contains its cells' boxes) if a little looser.
+template <int D>
+__global__ __launch_bounds__(256) void k_super_boxes(const CellBox *__restrict__ boxes, uint32_t ncells,
+                                                     CellBox *__restrict__ sboxes, uint32_t nsuper, uint32_t merge) {
+  const uint32_t sc = blockIdx.x * 256 + threadIdx.x;
+  if (sc >= nsuper) return;
+  double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()},
+         hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+  bool nan = false;
+  for (uint32_t c = sc * merge; c < (sc + 1) * merge && c < ncells; c++) {
+    const CellBox b = boxes[c];
+    for (int d = 0; d < D; d++) {  // the child box covers [c - h, c + h] (h already inflated); exact in fp64
+      const double l = (double)b.c[d] - (double)b.h[d], u = (double)b.c[d] + (double)b.h[d];
+      nan = nan || !(l == l) || !(u == u);
+      lo[d] = l < lo[d] ? l : lo[d];
+      hi[d] = u > hi[d] ? u : hi[d];
+    }
+  }
+  CellBox sb;
+  double r2 = 0.0;
+  for (int d = 0; d < 3; d++) {
+    if (d < D) {
+      float cf = (float)(0.5 * lo[d] + 0.5 * hi[d]);
+      if (!(__builtin_fabsf(cf) <= 3.4028234e38f)) cf = cf > 0 ? 3.4028234e38f : -3.4028234e38f;
+      const double hd = fmax(hi[d] - (double)cf, (double)cf - lo[d]) * (1.0 + 1e-12);
+      sb.c[d] = cf;
+      // a box nothing is known about (NaN child, overflow) must SURVIVE every test of a bound: the largest finite
+      // extent (not inf: 0 * inf would poison the plane's margin).  Cannot happen on an indexed upload (the index is
+      // only used when max |coordinate| <= 1e15 and holds finite records only); kept conservative all the same.
+      sb.h[d] = (!nan && hd <= 3.4e38) ? f32_up(hd) : 3.4028234e38f;
+      r2 += (double)sb.h[d] * (double)sb.h[d];
+    } else {
+      sb.c[d] = 0.0f;
+      sb.h[d] = 0.0f;
+    }
+  }
+  const double rad = sqrt(r2) * (1.0 + 1e-6);
+  sb.pad[0] = rad <= 3.4e38 ? f32_up(rad) : 3.4028234e38f;
+  sb.pad[1] = 0.0f;
+  sboxes[sc] = sb;
+}
+
 // ---- per-model cell logic ------------------------------------------------------------------------------
 // A cell model CM provides
 //   Hyp                      per-lane hypothesis state (lane = hypothesis), built by load() from the
@@ -324,6 +369,8 @@ struct PlaneCell {
   // (1024-point cells / 8 packed pairs per lane, 4 waves per SIMD: second pass of the bounded scan 642 us against
   // 510 us -- measured and not built; `enum { MAX_PP = 8 };` here brings the instantiation back)
   enum { USE_BOUND = 1 };  // bounded scan pays: a random plane still cuts ~13 % of the cells
+  // bounds on boxes of four cells: 47 -> 15 us for the bounds pass, the selection hardly changes (0.73 -> 0.71 ms / step)
+  enum { BOUND_MERGE = 4 };
   struct Hyp {
     double n[3], c;
     float nf[3], e0;
@@ -417,7 +464,7 @@ struct SphereCell {
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
   enum { MIN_WAVES = 4 };  // 72 VGPRs = 7 waves per SIMD as compiled
   enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // measured (tools/ab_cells.py): 1.9 ms; 512 / v_readlane 2.1 ms
-  enum { USE_BOUND = 1 };
+  enum { USE_BOUND = 1, BOUND_MERGE = 4 };  // the sphere's box test is 61 instructions: 0.29 -> 0.08 ms, 0.87 -> 0.70 ms / step
   struct Hyp {
     double c[3], mid;
     float half;
@@ -507,7 +554,7 @@ struct LineCell {
   // a line that misses the inliers touches < 1 % of the cells: the consensus candidates (a quarter of the batch at
   // 50 % outliers) are 99 % of the work with or without the bound; with the statically balanced second level the
   // bounded path is the faster one all the same (2.17 against 2.34 ms per 4096 hypotheses)
-  enum { USE_BOUND = 1 };
+  enum { USE_BOUND = 1, BOUND_MERGE = 4 };
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;
@@ -1027,9 +1074,11 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
                                                       unsigned long long *__restrict__ total,
                                                       uint32_t *__restrict__ ncells_out,
                                                       uint8_t *__restrict__ cnt, uint32_t gstride,
-                                                      const uint32_t *__restrict__ h_dev, uint32_t h_off) {
+                                                      const uint32_t *__restrict__ h_dev, uint32_t h_off,
+                                                      uint32_t box_pop) {
   typedef typename CM::M M;
-  constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4, CP = 128 * PP;
+  constexpr int ROW = CM::ROW, NR4 = ROW / 4, NR2 = CM::ROW2 / 4;
+  const size_t CP = box_pop;  // observations per box: 128 * PP for the cells, a multiple for merged boxes
   const int lane = threadIdx.x & 63;
   if (h_dev) {
     const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection

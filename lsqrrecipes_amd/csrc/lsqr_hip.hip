@@ -55,8 +55,10 @@ struct lsqr_ctx {
   // spatial index of the point models (cells.h): Morton-sorted copy + one fp32 box per 128 records
   double *d_sorted = nullptr;
   uint32_t *d_queues = nullptr;  // work-queue counters of k_scan_cells
-  CellBox *d_boxes = nullptr;
+  CellBox *d_boxes = nullptr;   // [n_cells cell boxes | merged boxes of the bounds pass (k_super_boxes)]
   size_t sorted_cap = 0, boxes_cap = 0;  // doubles / boxes allocated
+  uint32_t super_merge = 0;     // cells per merged box the second part currently holds (0: not built)
+  int opt_bound_merge = 0;      // 0: the cell model's default, 1: bounds on the cells themselves, 2 / 4 / 8
   size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
   uint32_t n_cells = 0, cell_pts = 0;
   bool index_valid = false;
@@ -611,7 +613,9 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   if ((st = ensure(c, &c->d_sorted, &c->sorted_cap, std::max<size_t>(n, 1) * D)) != LSQR_OK) return st;
   const size_t n_sorted = n - (size_t)hb.nonfinite;  // the non-finite records carry the largest key: they sort to the tail
   const uint32_t n_cells = (uint32_t)((n_sorted + cell_pts - 1) / cell_pts);
-  if ((st = ensure(c, &c->d_boxes, &c->boxes_cap, std::max<size_t>(n_cells, 1))) != LSQR_OK) return st;
+  if ((st = ensure(c, &c->d_boxes, &c->boxes_cap, std::max<size_t>((size_t)n_cells + n_cells / 2 + 2, 1))) != LSQR_OK)
+    return st;
+  c->super_merge = 0;
   // every buffer is in place (kept across uploads): from here on the build is device work only
   ProfScope ps(c, KID_INDEX);
   uint32_t *k_in = (uint32_t *)c->d_idx_scratch, *v_in = k_in + words, *k_out = v_in + words,
@@ -713,20 +717,41 @@ int with_pp(uint32_t cell_pts, F &&f) {
 // level 1 of the two-level scan alone over the current batch: d_ub[h] = vote bound, d_counter[4] = surviving pairs
 template <class CM, int PP>
 int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
+  typedef typename CM::M M;
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
   HIPCHK(c, hipMemsetAsync(d_ub, 0, c->H * sizeof(uint32_t), c->stream));
   if (d_nc) HIPCHK(c, hipMemsetAsync(d_nc, 0, c->H * sizeof(uint32_t), c->stream));
   if (d_nc) HIPCHK(c, hipMemsetAsync(c->d_counter + 4, 0, sizeof(unsigned long long), c->stream));
   if (c->n_cells == 0) return LSQR_OK;
+  // The bounds of the bounded scan are taken on merged boxes (a quarter of the tests; the bound stays valid);
+  // the diagnostics (d_nc: lsqr_scan_workload) count the surviving CELLS and stay on the cells.
+  // ... as long as a few thousand boxes remain: on a small upload coarse boxes cost the selection its teeth (300 k
+  // points in 147 boxes: 261 of 2048 hypotheses skipped instead of 1800)
+  uint32_t merge = c->opt_bound_merge ? (uint32_t)c->opt_bound_merge : (uint32_t)CM::BOUND_MERGE;
+  if (!c->opt_bound_merge)
+    while (merge > 1 && c->n_cells / merge < 4096) merge /= 2;
+  if (d_nc || merge < 2 || c->n_cells < 4 * merge) merge = 1;
+  const CellBox *boxes = c->d_boxes;
+  uint32_t nbox = c->n_cells;
+  if (merge > 1) {
+    nbox = (c->n_cells + merge - 1) / merge;
+    if (c->super_merge != merge) {
+      hipLaunchKernelGGL((k_super_boxes<M::ND>), dim3((nbox + 255) / 256), dim3(256), 0, c->stream, c->d_boxes,
+                         c->n_cells, c->d_boxes + c->n_cells, nbox, merge);
+      HIPCHK(c, hipGetLastError());
+      c->super_merge = merge;
+    }
+    boxes = c->d_boxes + c->n_cells;
+  }
   const unsigned gy = (unsigned)((c->H + 255) / 256);
-  unsigned gx = std::max(1u, std::min<unsigned>(c->n_cells, 2048u / gy));
-  const uint32_t per = (c->n_cells + gx - 1) / gx;
-  gx = (c->n_cells + per - 1) / per;
-  hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
-                     c->n_sorted, CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
+  unsigned gx = std::max(1u, std::min<unsigned>(nbox, 2048u / gy));
+  const uint32_t per = (nbox + gx - 1) / gx;
+  gx = (nbox + per - 1) / per;
+  hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, boxes, nbox, c->n_sorted,
+                     CM::ROW_F32 ? c->d_hparams_f32 : (const float *)c->d_hparams, c->d_hparams_f32,
                      (uint32_t)c->H, cc, per, d_ub, d_nc ? c->d_counter + 4 : (unsigned long long *)nullptr, d_nc,
-                     (uint8_t *)nullptr, 0u, (const uint32_t *)nullptr, 0u);  // (pair total: diagnostics only -- 8192
-                                                                           // atomics on one address are ~100 us)
+                     (uint8_t *)nullptr, 0u, (const uint32_t *)nullptr, 0u,  // (pair total: diagnostics only -- 8192
+                     (uint32_t)(128 * PP) * merge);                          // atomics on one address are ~100 us)
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
 }
@@ -769,7 +794,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
     const unsigned gx = (c->n_cells + per - 1) / per;
     hipLaunchKernelGGL((k_cells_bounds<CM, PP>), dim3(gx, gy), dim3(256), 0, c->stream, c->d_boxes, c->n_cells,
                        c->n_sorted, rows, b.spf, Hc, cc, per, (uint32_t *)nullptr, (unsigned long long *)nullptr,
-                       (uint32_t *)nullptr, c->d_paircnt, gstride, b.h_dev, b.h_off);
+                       (uint32_t *)nullptr, c->d_paircnt, gstride, b.h_dev, b.h_off, (uint32_t)(128 * PP));
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
@@ -3523,6 +3548,12 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   if (!strcmp(name, "scan_cpt")) {  // cells per wave tile of the two-level scan
     if (value != 0 && value != 1) return fail(c, LSQR_ERR_INVALID, "scan_cpt must be 0 or 1");
     c->opt_cpt = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_bound_merge")) {  // cells per box of the bounds pass (0 = the cell model's default)
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+      return fail(c, LSQR_ERR_INVALID, "scan_bound_merge must be 0, 1, 2, 4 or 8");
+    c->opt_bound_merge = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_pairs")) {  // 0: default, 1: k_scan_pairs for plain scans too (A/B)

@@ -1997,3 +1997,17 @@ def test_bounded_scan_with_filters_switched_off(ctx):
     assert res[0][:2] == res[1][:2] and np.array_equal(res[0][2], res[1][2])
     counted = res[1][3] != 0
     assert np.array_equal(res[1][3][counted], res[0][3][counted]) and res[0][1] > 0.3 * n
+
+
+@pytest.mark.parametrize("model,dim", [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3), (L.PLANE, 2)])
+@pytest.mark.parametrize("merge", [2, 4, 8])
+def test_bounded_scan_with_merged_bound_boxes(ctx, model, dim, merge):
+    """the vote bounds taken on boxes of 2 / 4 / 8 merged cells (the default only merges on uploads of millions of
+    records): looser bounds, the same winner, consensus set, fit and replay state as counting everything"""
+    data = _data(model, dim, 150_000, 4711 + merge, outliers=0.5)
+    ctx.set_option("scan_bound_merge", merge)
+    try:
+        r, votes, skipped = _bounded_equals_full(ctx, model, dim, data, 2048)
+    finally:
+        ctx.set_option("scan_bound_merge", 0)
+    assert r["info"].best_votes > 0.2 * len(data)
