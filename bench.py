@@ -41,8 +41,8 @@ FP64_VALU_MEASURED_GOPS = 33000.0  # tools/microbench.hip on this pool: v_add_f6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=0, help="observations (0 = the BASELINE.json size of "
                     "the workload: 10 M points, 2 M dense rows, 1 M US frames)")
     ap.add_argument("--batch", type=int, default=0, help="hypotheses per GPU per step (0 = 4096; "
