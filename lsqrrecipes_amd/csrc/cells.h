@@ -18,6 +18,15 @@
 // only observations that certainly do not agree (bound below), so votes are bit-identical to the
 // exhaustive kernels (tests/test_gpu_parity.py::test_cell_scan_*).
 //
+// Two drivers of the two levels:
+//   k_scan_cells   plain scan (lsqr_scan, small batches): a wave owns a tile (cell) for the whole hypothesis loop,
+//                  tiles handed out from shared atomic counters;
+//   bounded scan   (batch entry points, >= 1024 hypotheses): k_cells_bounds gives every hypothesis an upper bound on
+//                  its votes (level 1 alone, on boxes of four merged cells), a few pilots and then only the hypotheses
+//                  that can still become the running maximum are counted by k_scan_pairs -- level 1 is run first to
+//                  COUNT the surviving (hypothesis, cell) pairs, and every wave takes an equal share of them
+//                  ("statically balanced level 2" below).
+//
 // Index build, once per upload: k_bounds (min / max / max |x| in one pass) -> k_keys (Morton key + identity) ->
 // stable radix sort of the (key, index) pairs (sort.hip) -> k_gather_boxes (sorted copy + cell boxes).  No
 // per-record global atomics anywhere: the build time does not depend on how the observations cluster.

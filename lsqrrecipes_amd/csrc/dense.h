@@ -620,6 +620,169 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (tid == 0) amb_counts[blockIdx.x] = *s_amb;
 }
 
+// The same filter with the hypothesis fragments prefetched THROUGH LDS, two blocks ahead.  In k_scan_dense_mfma32 a
+// wave asks for the 64 bytes per lane of hypothesis block hb + 1 while it works on block hb -- 64 matrix instructions,
+// 2048 cycles -- and an L2 hit on another XCD's slice takes about as long: with two waves per SIMD nothing else hides
+// the rest of the wait, and there are no registers for a second block in flight (254 of 256).  global_load_lds writes
+// the rows straight into a per-wave ring in LDS (no staging registers, no waiting at issue): the loads for block
+// it + 2 are issued when block it is read out of its slot, so every fetch has two blocks' worth of matrix work
+// (~1.7 us) to land.  The thresholds of the whole batch sit in LDS as well.
+template <int NR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_scan_dense_mfma32r(
+    const double *__restrict__ data, size_t stride, size_t m, size_t rows_per_block,
+    const float *__restrict__ sp32, const float *__restrict__ thr, uint32_t H, int n,
+    uint32_t *__restrict__ votes, unsigned long long *__restrict__ amb_list,
+    unsigned int *__restrict__ amb_counts, uint32_t seg_cap, uint32_t hyp_base) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  static_assert(NR == 64, "fragment bookkeeping below assumes 64 padded unknowns");
+  extern __shared__ float smf[];
+  const uint32_t nhb = (H + 63) / 64, nhb2 = (nhb + 1) & ~1u;  // blocks past the batch: thresholds that never pass
+  float *ring = smf;                              // 4 waves x 2 slots x 4 chunks of 1 KiB (16-byte aligned: first)
+  float *At = ring + 4 * 2 * 1024;                // 64 rows x pitch
+  float *bv = At + 64 * kDmPitch32;               // 64 right-hand sides
+  float *thl = bv + 64;                           // (t_in, t_out) of every hypothesis of the launch
+  uint32_t *s_cnt = (uint32_t *)(thl + 2 * 64 * nhb2);
+  uint32_t *s_amb = s_cnt + H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, k4 = lane >> 4;
+  for (uint32_t h = tid; h < H; h += 256) s_cnt[h] = 0;
+  for (uint32_t h = tid; h < 64 * nhb2; h += 256) {
+    thl[2 * h] = h < H ? thr[2 * (size_t)h] : -1.0f;
+    thl[2 * h + 1] = h < H ? thr[2 * (size_t)h + 1] : -1.0f;
+  }
+  if (tid == 0) *s_amb = amb_counts[blockIdx.x];
+  size_t lo = (size_t)blockIdx.x * rows_per_block;
+  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
+  // hypothesis block hb -> slot: the rows of my 16 hypotheses in fragment order, 64 bytes per lane, as four
+  // 16-byte pieces; piece j of all lanes lands contiguously (lane * 16 bytes) in chunk j of the slot
+  auto issue = [&](uint32_t hb, uint32_t slot) {
+    const uint32_t h = hb * 64 + wave * 16 + c16;
+    const float *g = sp32 + (size_t)(h < H ? h : 0) * NR + k4 * 16;
+    float *dst = ring + ((wave * 2 + slot) * 4) * 256;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      __builtin_amdgcn_global_load_lds(g + 4 * j, (__attribute__((address_space(3))) void *)(dst + j * 256), 16, 0, 0);
+  };
+  uint32_t it = 0;  // hypothesis blocks this wave has started, over all tiles (slot = it & 1, block = it % nhb2)
+  // The NEXT tile of rows travels in registers while the current one is multiplied (the ring freed the registers the
+  // hypothesis fragments used to occupy): 16 coefficients and one right-hand side per thread, 17 loads per wave.
+  double pre[16], preb;
+  auto load_tile = [&](size_t base) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int idx = tid + 256 * i, r = idx >> 6, kk = idx & 63;
+      const size_t row = base + r;
+      pre[i] = data[(row < hi ? row : lo) * stride + (kk < n ? kk : 0)];
+    }
+    const size_t rowb = base + (tid & 63);
+    preb = data[(rowb < hi ? rowb : lo) * stride + n];
+  };
+  if (lo < hi) {
+    issue(0, 0);
+    issue(1 % nhb2, 1);
+    load_tile(lo);
+  }
+  for (size_t base = lo; base < hi; base += 64) {
+    __syncthreads();  // the previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int idx = tid + 256 * i, r = idx >> 6, kk = idx & 63;
+      At[r * kDmPitch32 + kk] = (base + r < hi && kk < n) ? (float)pre[i] : 0.0f;
+    }
+    if (tid < 64) bv[tid] = base + tid < hi ? (float)preb : __builtin_nanf("");  // NaN: row never counts
+    const bool more = base + 64 < hi;  // workgroup-uniform
+    if (more) load_tile(base + 64);    // in flight during the whole tile
+    __syncthreads();
+    float a[4][16];
+    {
+      const float *ap = At + c16 * kDmPitch32 + k4;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) a[t][q] = ap[t * 16 * kDmPitch32 + 4 * q];
+    }
+    // (the 16 right-hand sides of a lane are read from LDS where they are used: their registers carry the next tile)
+    // block `hb` out of its slot into registers, the slot handed to block it + 2, then the 64 matrix instructions
+    auto start_block = [&](f4(&acc)[4], uint32_t hb, float &ti, float &to) {
+      const uint32_t slot = it & 1u;
+      // My slot's four loads have landed.  Loads complete in order: younger than them are the four of block it + 1
+      // and, for the first two blocks of a tile, the 17 loads of the next tile issued at the top of this one.
+      if (more && hb < 2)
+        asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      float b[16];
+      const f4 *src = (const f4 *)(ring + ((wave * 2 + slot) * 4) * 256) + lane;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f4 v = src[j * 64];
+        b[4 * j] = v.x, b[4 * j + 1] = v.y, b[4 * j + 2] = v.z, b[4 * j + 3] = v.w;
+      }
+      const uint32_t h = hb * 64 + wave * 16 + c16;
+      ti = thl[2 * h];
+      to = thl[2 * h + 1];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be overwritten
+      issue((hb + 2) % nhb2, slot);
+      it++;
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][q], b[q], acc[t], 0, 0, 0);
+      }
+    };
+    auto count_block = [&](const f4(&acc)[4], float ti, float to, uint32_t hb) {
+      uint32_t c = 0, may = 0;
+      f4 rhs[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) rhs[t] = *(const f4 *)(bv + t * 16 + 4 * k4);
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const float res = __builtin_fabsf(acc[t][rg] - rhs[t][rg]);
+          c += res < ti ? 1u : 0u;
+          may += res < to ? 1u : 0u;
+        }
+      if (may != c) {  // rare: some pair sits in the band -> worklist, decided exactly by k_dense_recheck_seg
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const float res = __builtin_fabsf(acc[t][rg] - rhs[t][rg]);
+            if (res >= ti && res < to) {
+              const unsigned slot = atomicAdd(s_amb, 1u);
+              if (slot < seg_cap)
+                amb_list[(size_t)blockIdx.x * seg_cap + slot] =
+                    ((unsigned long long)(base + t * 16 + 4 * k4 + rg) << 32) |
+                    (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
+            }
+          }
+      }
+      c += __shfl_xor(c, 16);  // lanes l, l^16, l^32, l^48 hold the same hypothesis column
+      c += __shfl_xor(c, 32);
+      if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + wave * 16 + c16], c);
+    };
+    f4 accA[4], accB[4];
+    float tiA, toA, tiB, toB;
+    start_block(accA, 0, tiA, toA);
+    for (uint32_t hb = 0; hb < nhb2; hb += 2) {
+      start_block(accB, hb + 1, tiB, toB);
+      count_block(accA, tiA, toA, hb);
+      if (hb + 2 < nhb2) start_block(accA, hb + 2, tiA, toA);
+      count_block(accB, tiB, toB, hb + 1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS write of mine may still be in flight when the LDS is freed
+  __syncthreads();
+  for (uint32_t h = tid; h < H; h += 256) {
+    uint32_t c = s_cnt[h];
+    if (c) atomicAdd(&votes[h], c);
+  }
+  if (tid == 0) amb_counts[blockIdx.x] = *s_amb;
+}
+
 // exact decision of the segmented worklist (one block per segment); out_max[0] = largest segment fill (overflow check)
 template <int NR>
 __global__ __launch_bounds__(256) void k_dense_recheck_seg(const double *__restrict__ data, size_t stride,

@@ -72,7 +72,8 @@ struct lsqr_ctx {
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
   uint64_t hyp_expected = 0;      // hypotheses the caller still expects to scan on this upload (lsqr_ransac: numTries)
   unsigned dense_amb_max = 0;  // fullest worklist segment of the last fp32 dense scan (diagnostics)
-  int opt_dense_f32 = 1;  // dense scan filter on the fp32 matrix cores (worklist of ~1e-4 of the pairs); 0: fp64 MFMA
+  int opt_dense_f32 = 2;  // dense scan filter on the fp32 matrix cores (worklist of ~1e-4 of the pairs): 2 = hypothesis
+                          // fragments through an LDS ring + next tile in registers, 1 = fragments in registers; 0: fp64 MFMA
   int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
@@ -912,6 +913,18 @@ int run_scan(lsqr_ctx *c) {
                                    c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot,
                                    c->mc.absmax, d_thr32, d_sp32);
                 HIPCHK(c, hipGetLastError());
+                if (c->opt_dense_f32 == 2) {  // hypothesis fragments prefetched through an LDS ring (dense.h)
+                  constexpr size_t kRingChunk = 1024;  // 62.7 KiB of LDS per workgroup: two per CU
+                  for (size_t h0 = 0; h0 < c->H; h0 += kRingChunk) {
+                    uint32_t hc = (uint32_t)std::min<size_t>(kRingChunk, c->H - h0);
+                    const uint32_t nhb2 = (((hc + 63) / 64) + 1) & ~1u;
+                    size_t lds = sizeof(float) * (8192 + 64 * kDmPitch32 + 64 + 128 * nhb2) + sizeof(uint32_t) * (hc + 1);
+                    hipLaunchKernelGGL((k_scan_dense_mfma32r<64>), dim3((unsigned)nblk), dim3(256), lds, c->stream,
+                                       c->d_data, c->stride, c->n, rpb, d_sp32 + h0 * 64, d_thr32 + 2 * h0, hc,
+                                       (int)c->cfg.dim, c->d_votes + h0, c->d_amb, d_segcnt, seg_cap, (uint32_t)h0);
+                    HIPCHK(c, hipGetLastError());
+                  }
+                } else
                 for (size_t h0 = 0; h0 < c->H; h0 += kDmHypChunk) {
                   uint32_t hc = (uint32_t)std::min<size_t>(kDmHypChunk, c->H - h0);
                   size_t lds = sizeof(float) * (64 * kDmPitch32 + 64) + sizeof(uint32_t) * (hc + 1);
@@ -3586,7 +3599,7 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_f32")) {  // 1 (default): dense scan filter on the fp32 matrix cores; 0: fp64 MFMA filter
-    c->opt_dense_f32 = value != 0;
+    c->opt_dense_f32 = value < 0 ? 0 : (value > 2 ? 1 : value);  // 2: fragments through an LDS ring (A/B)
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_scan_v1")) {  // 1: first MFMA scan arrangement (hypothesis block through LDS)

@@ -870,10 +870,11 @@ def test_dense_mfma_filter_is_exact(ctx):
     for delta in (rho, np.nextafter(rho, np.inf), np.nextafter(rho, 0.0), 0.1):
         oc = O.cfg(O.DENSE, ncol, delta)
         want = None
-        for variant in ("mfma32", "mfma64", "plain", "transposed"):   # fp32 / fp64 matrix-core filters, exact VALU kernels
+        # fp32 (LDS ring, the default / fragments in registers) and fp64 matrix-core filters, exact VALU kernels
+        for variant in ("mfma32r", "mfma32", "mfma64", "plain", "transposed"):
             ctx.set_option("scan_filter", 0 if variant == "plain" else 1)
             ctx.set_option("dense_transposed", 1 if variant == "transposed" else 0)
-            ctx.set_option("dense_f32", 0 if variant == "mfma64" else 1)
+            ctx.set_option("dense_f32", {"mfma64": 0, "mfma32": 1}.get(variant, 2))
             ctx.set_model(L.DENSE, ncol, delta).upload(rows)
             ctx.hypotheses_from_subsets(subs)
             ctx.scan()
@@ -886,7 +887,7 @@ def test_dense_mfma_filter_is_exact(ctx):
         assert O.agree(oc, x, rows[777]) == (rho < delta)
     ctx.set_option("scan_filter", 1)
     ctx.set_option("dense_transposed", 0)
-    ctx.set_option("dense_f32", 1)
+    ctx.set_option("dense_f32", 2)
 
 
 # ---- two-level scan over the spatial index (csrc/cells.h) -------------------------------------------
@@ -1434,7 +1435,8 @@ def test_dense_mfma_scan_arrangements_agree(ctx):
     ctx.set_model(L.DENSE, 64, 0.1).upload(rows)
     ctx.hypotheses_sample(17, 0, 333)
     res = []
-    for v1, filt, f32 in ((0, 1, 0), (1, 1, 0), (0, 0, 0), (0, 1, 1)):   # last: the fp32 matrix-core filter (default)
+    # last two: the fp32 matrix-core filter, hypothesis fragments in registers / through the LDS ring
+    for v1, filt, f32 in ((0, 1, 0), (1, 1, 0), (0, 0, 0), (0, 1, 1), (0, 1, 2)):
         ctx.set_option("dense_scan_v1", v1)
         ctx.set_option("scan_filter", filt)
         ctx.set_option("dense_f32", f32)
@@ -1442,8 +1444,9 @@ def test_dense_mfma_scan_arrangements_agree(ctx):
         res.append(ctx.hypotheses(params=False)[2].copy())
     ctx.set_option("dense_scan_v1", 0)
     ctx.set_option("scan_filter", 1)
-    ctx.set_option("dense_f32", 1)
+    ctx.set_option("dense_f32", 2)
     assert np.array_equal(res[0], res[2]) and np.array_equal(res[1], res[2]) and np.array_equal(res[3], res[2])
+    assert np.array_equal(res[4], res[2])
     assert res[0].max() > 1000
 
 
