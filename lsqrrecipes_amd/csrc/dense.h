@@ -732,6 +732,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][q], b[q], acc[t], 0, 0, 0);
       }
     };
+    // The same with the branch-free part of the OTHER accumulator set's counting in the same basic block, and the
+    // scheduler told to alternate: a wave issues its instructions in order, so 64 matrix instructions in a row keep
+    // its own ~100 counting instructions out of their shadow (each occupies the matrix pipe for 32 cycles, the
+    // vector issue port for 4) -- only the second wave of the SIMD filled that gap.
+    auto start_and_count = [&](f4(&acc)[4], uint32_t hb, float &ti, float &to, const f4(&old)[4], float oti,
+                               float oto, uint32_t &c_out, uint32_t &may_out) {
+      const uint32_t slot = it & 1u;
+      if (more && hb < 2)
+        asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      float b[16];
+      const f4 *src = (const f4 *)(ring + ((wave * 2 + slot) * 4) * 256) + lane;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f4 v = src[j * 64];
+        b[4 * j] = v.x, b[4 * j + 1] = v.y, b[4 * j + 2] = v.z, b[4 * j + 3] = v.w;
+      }
+      const uint32_t h = hb * 64 + wave * 16 + c16;
+      ti = thl[2 * h];
+      to = thl[2 * h + 1];
+      f4 rhs[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) rhs[t] = *(const f4 *)(bv + t * 16 + 4 * k4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be overwritten
+      issue((hb + 2) % nhb2, slot);
+      it++;
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+      uint32_t c = 0, may = 0;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][q], b[q], acc[t], 0, 0, 0);
+        {  // one of the 16 residuals of the other set per four matrix instructions
+          const float res = __builtin_fabsf(old[q >> 2][q & 3] - rhs[q >> 2][q & 3]);
+          c += res < oti ? 1u : 0u;
+          may += res < oto ? 1u : 0u;
+        }
+      }
+      // (groups of 4 + 6; strict 1 : 1 alternation was measured slower than no interleaving at all: 3.35 against
+      // 3.20 ms; this pattern 3.11 ms)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 matrix instructions
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // the ~6 vector instructions of one residual
+      }
+      c_out = c;
+      may_out = may;
+    };
     auto count_block = [&](const f4(&acc)[4], float ti, float to, uint32_t hb) {
       uint32_t c = 0, may = 0;
       f4 rhs[4];
@@ -764,14 +814,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       c += __shfl_xor(c, 32);
       if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + wave * 16 + c16], c);
     };
+    // what is left of a block's counting once c / may are known: the rare worklist appends, the fold over the four
+    // lanes of a hypothesis column, one LDS atomic
+    auto count_tail = [&](const f4(&acc)[4], float ti, float to, uint32_t hb, uint32_t c, uint32_t may) {
+      if (may != c) {
+        f4 rhs[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) rhs[t] = *(const f4 *)(bv + t * 16 + 4 * k4);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const float res = __builtin_fabsf(acc[t][rg] - rhs[t][rg]);
+            if (res >= ti && res < to) {
+              const unsigned slot = atomicAdd(s_amb, 1u);
+              if (slot < seg_cap)
+                amb_list[(size_t)blockIdx.x * seg_cap + slot] =
+                    ((unsigned long long)(base + t * 16 + 4 * k4 + rg) << 32) |
+                    (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
+            }
+          }
+      }
+      c += __shfl_xor(c, 16);
+      c += __shfl_xor(c, 32);
+      if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + wave * 16 + c16], c);
+    };
     f4 accA[4], accB[4];
     float tiA, toA, tiB, toB;
+    uint32_t cc = 0, cm = 0;
     start_block(accA, 0, tiA, toA);
     for (uint32_t hb = 0; hb < nhb2; hb += 2) {
-      start_block(accB, hb + 1, tiB, toB);
-      count_block(accA, tiA, toA, hb);
-      if (hb + 2 < nhb2) start_block(accA, hb + 2, tiA, toA);
-      count_block(accB, tiB, toB, hb + 1);
+      start_and_count(accB, hb + 1, tiB, toB, accA, tiA, toA, cc, cm);
+      count_tail(accA, tiA, toA, hb, cc, cm);
+      if (hb + 2 < nhb2) {
+        start_and_count(accA, hb + 2, tiA, toA, accB, tiB, toB, cc, cm);
+        count_tail(accB, tiB, toB, hb + 1, cc, cm);
+      } else {
+        count_block(accB, tiB, toB, hb + 1);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS write of mine may still be in flight when the LDS is freed
