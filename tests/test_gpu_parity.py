@@ -2014,3 +2014,34 @@ def test_bounded_scan_with_merged_bound_boxes(ctx, model, dim, merge):
     finally:
         ctx.set_option("scan_bound_merge", 0)
     assert r["info"].best_votes > 0.2 * len(data)
+
+
+def test_lanes_and_bounded_scan_random_shapes(ctx):
+    """a dozen random (model, records, batch size, outlier share) combinations in a row on ONE context: every batch
+    through the lanes equals the blocking entry point with the bound switched off -- winner, votes of the winner,
+    consensus size, parameters"""
+    rng = np.random.default_rng(20260204)
+    models = [(L.PLANE, 3), (L.SPHERE, 3), (L.LINE, 3), (L.PLANE, 2), (L.LINE, 2)]
+    ctx.set_option("scan_index", 2)
+    for it in range(12):
+        model, dim = models[int(rng.integers(len(models)))]
+        n = int(rng.integers(3_000, 260_000))
+        H = int(rng.choice([1024, 1500, 2048, 4096, 6000]))
+        outl = float(rng.choice([0.0, 0.3, 0.5, 0.8]))
+        data = _data(model, dim, n, 5000 + it, outliers=outl)
+        ls = L.LS_ALGEBRAIC if model == L.SPHERE else 0
+        ctx.set_model(model, dim, 0.5, ls).upload(data)
+        nb = int(rng.integers(1, 7))
+        got = []
+        for i in range(nb):
+            ctx.batch_fit_enqueue(it, i * H, H, slot=i % 8)
+        for i in range(nb):
+            r = ctx.batch_fit_wait(i % 8)
+            got.append((r["info"].best_index, r["info"].best_votes, r["info"].fit.n_used, tuple(r["params"])))
+        ctx.set_option("scan_bound", 0)
+        for i in range(nb):
+            r = ctx.batch_fit(it, i * H, H)
+            assert got[i] == (r["info"].best_index, r["info"].best_votes, r["info"].fit.n_used,
+                              tuple(r["params"])), (it, i, model, dim, n, H, outl)
+        ctx.set_option("scan_bound", 1)
+    ctx.set_option("scan_index", 1)
