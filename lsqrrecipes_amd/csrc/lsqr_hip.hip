@@ -58,6 +58,9 @@ struct lsqr_ctx {
   CellBox *d_boxes = nullptr;   // [n_cells cell boxes | merged boxes of the bounds pass (k_super_boxes)]
   size_t sorted_cap = 0, boxes_cap = 0;  // doubles / boxes allocated
   uint32_t super_merge = 0;     // cells per merged box the second part currently holds (0: not built)
+  BoundSel *h_bsel = nullptr;   // pinned: selection counts of the last bounded scans (read without synchronising)
+  uint32_t h_bsel_H = 0;        // batch size those counts belong to
+  bool merge_off = false;       // this upload: merged boxes let too many hypotheses through, bounds stay on the cells
   int opt_bound_merge = 0;      // 0: the cell model's default, 1: bounds on the cells themselves, 2 / 4 / 8
   size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
   uint32_t n_cells = 0, cell_pts = 0;
@@ -728,9 +731,17 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   // the diagnostics (d_nc: lsqr_scan_workload) count the surviving CELLS and stay on the cells.
   // ... as long as a few thousand boxes remain: on a small upload coarse boxes cost the selection its teeth (300 k
   // points in 147 boxes: 261 of 2048 hypotheses skipped instead of 1800)
+  // ... and as long as the looser bound still prunes: a random plane cuts ~13 % of the cells but ~25 % of the merged
+  // boxes, and with few inliers (80 % outliers and up) that population exceeds the best model's votes -- every
+  // hypothesis would be counted.  The selection counts of earlier batches come back through pinned memory (no
+  // synchronisation; a stale value only delays the switch): once a second pass held more than a third of its batch,
+  // the bounds of this upload stay on the cells.
   uint32_t merge = c->opt_bound_merge ? (uint32_t)c->opt_bound_merge : (uint32_t)CM::BOUND_MERGE;
-  if (!c->opt_bound_merge)
+  if (!c->opt_bound_merge) {
     while (merge > 1 && c->n_cells / merge < 4096) merge /= 2;
+    if (c->h_bsel && c->h_bsel_H && (uint64_t)c->h_bsel->n_rest * 3 > c->h_bsel_H) c->merge_off = true;
+    if (c->merge_off) merge = 1;
+  }
   if (d_nc || merge < 2 || c->n_cells < 4 * merge) merge = 1;
   const CellBox *boxes = c->d_boxes;
   uint32_t nbox = c->n_cells;
@@ -871,6 +882,12 @@ int run_scan_bounded(lsqr_ctx *c) {
   HIPCHK(c, hipGetLastError());
   c->last_bound[0] = 1;
   c->last_bound[3] = H;
+  if (!c->h_bsel) {
+    HIPCHK(c, hipHostMalloc((void **)&c->h_bsel, 64));
+    memset(c->h_bsel, 0, 64);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_bsel, c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
+  c->h_bsel_H = H;
   return LSQR_OK;
 }
 
@@ -1781,6 +1798,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (c->h_bsel) (void)hipHostFree(c->h_bsel);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_lmres) (void)hipHostFree(c->h_lmres);
   if (c->h_batch) (void)hipHostFree(c->h_batch);
@@ -1908,6 +1926,8 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   if (count > 0xFFFFFFF0ull) return fail(c, LSQR_ERR_INVALID, "too many observations");
   lanes_quiesce(c);  // lanes read the records this call is about to replace
   c->data_epoch++;
+  c->merge_off = false;
+  c->h_bsel_H = 0;
   c->n = count;
   c->absmax_valid = false;
   c->bounds_valid = false;
