@@ -1692,7 +1692,61 @@ struct TupleLess {
     return a < b;  // lexicographic == RANSAC.h:135-149 SubSetIndexComparator
   }
 };
-typedef std::set<std::vector<uint32_t>, TupleLess> DedupSet;
+// The subsets already drawn (RANSAC.hxx:79: a std::set of sorted index tuples).  A set of heap-allocated vectors costs
+// ~250 ns per hypothesis -- 1 ms per batch of 4096, as long as the batch's scan on the device --, so tuples of up to
+// four indices (every point model, the rigid and ray estimators) live in an open-addressing table of 16-byte keys;
+// longer tuples (dense system, plane phantom) keep the ordered set.  Only membership is ever asked.
+struct DedupSet {
+  struct Key {
+    uint64_t a, b;  // four 32-bit indices (+1, sorted), zero padded: (0, 0) never occurs as a key
+  };
+  std::vector<Key> tab;
+  size_t used = 0;
+  std::set<std::vector<uint32_t>, TupleLess> big;
+  static uint64_t mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+  }
+  void grow() {
+    std::vector<Key> old;
+    old.swap(tab);
+    tab.assign(old.empty() ? 8192 : old.size() * 2, Key{0, 0});
+    used = 0;
+    for (const Key &k : old)
+      if (k.a | k.b) put(k);
+  }
+  bool put(const Key &k) {  // true: was not present
+    const size_t mask = tab.size() - 1;
+    size_t i = (size_t)(mix(k.a) ^ mix(k.b + 0x9e3779b97f4a7c15ULL)) & mask;
+    for (;; i = (i + 1) & mask) {
+      Key &s = tab[i];
+      if (!(s.a | s.b)) {
+        s = k;
+        used++;
+        return true;
+      }
+      if (s.a == k.a && s.b == k.b) return false;
+    }
+  }
+  // the k <= 4 indices + 1, sorted ascending
+  bool insert_small(const uint32_t *key, int k) {
+    if (tab.empty() || 2 * (used + 1) > tab.size()) grow();
+    Key q{0, 0};
+    for (int l = 0; l < k; l++) {
+      if (l < 2) q.a |= (uint64_t)key[l] << (32 * l);
+      else q.b |= (uint64_t)key[l] << (32 * (l - 2));
+    }
+    return put(q);
+  }
+  bool insert_sorted(const std::vector<uint32_t> &key) {
+    if (key.size() > 4) return big.insert(key).second;
+    return insert_small(key.data(), (int)key.size());
+  }
+};
 
 // C(n, m), the cap on numTries (RANSAC.hxx:41,110).  The reference evaluates it in double (:254-280): the
 // running product over the shorter of the two factor ranges, ascending, one division, saturation to UINT_MAX
@@ -2535,10 +2589,19 @@ size_t lsqr_replay(size_t n, int k, double p, const uint32_t *subsets, const uin
     }
     st[RS_I] = i + 1;
     bool fresh = true;
-    if (set) {
+    if (set && k <= 4) {
+      uint32_t kk[4] = {0, 0, 0, 0};
+      for (int l = 0; l < k; l++) {  // :71-76, insertion sort of at most four
+        uint32_t v = subsets[e * k + l] + 1;
+        int j = l;
+        for (; j > 0 && kk[j - 1] > v; j--) kk[j] = kk[j - 1];
+        kk[j] = v;
+      }
+      fresh = set->insert_small(kk, k);  // :79
+    } else if (set) {
       for (int l = 0; l < k; l++) key[l] = subsets[e * k + l] + 1;  // :71-76
       std::sort(key.begin(), key.end());
-      fresh = set->insert(key).second;  // :79
+      fresh = set->insert_sorted(key);  // :79
     }
     if (fresh && valid[e]) {            // :84-88
       unsigned int cur = votes[e];
