@@ -3,6 +3,7 @@ of the steps -- lanes of one context (closed-form fits), host threads with a con
 stream, and the RCCL path at world size 1 with one engine, process group and torch stream per stream."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -57,8 +58,16 @@ def test_bench_host_threads_for_the_iterative_fit():
     assert a["final_fit"]["winner_votes"] == b["final_fit"]["winner_votes"]
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def test_bench_rccl_path_with_one_engine_per_stream():
     j = _run(["--workload", "plane", "--streams", "2"],
-             env={"LSQR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29571"})
+             env={"LSQR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     _check(j, 2)
     assert j["config"]["world_size"] == 1 and "RCCL" in j["config"]["collectives"]
