@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-  metric   RANSAC hypotheses/s (+ final-fit residual), plane, 10 M points, 50 % outliers
-  step     one pass of the hot path over one batch: sample H minimal subsets -> solve -> agree()
-           scan of all H hypotheses over all N observations -> first-max winner -> consensus mask
-           -> final least-squares fit.  Nothing is cached between steps (new subsets each step).
-  value    whole-job hypotheses/s = H * n_gpus * steps / wall time (observations already resident
-           in HBM when the timed region starts).
-  N > 1    one process per GPU (torch.distributed, RCCL): observations replicated, the hypothesis
-           stream sharded; all-reduce(MAX) picks the winner, all-reduce(SUM) of the moment block of
-           each rank's observation slice gives the final fit.  scaling = "weak" (H per GPU fixed).
+  metric   RANSAC hypotheses/s (+ final-fit residual), plane, 10 M points, 50 % outliers (BASELINE.json configs[1])
+  step     one pass of the hot path over one batch: sample H minimal subsets -> solve -> agree() scan -> first-max
+           winner -> consensus mask -> final least-squares fit.  Nothing is cached between steps (new subsets each
+           step); observations are resident in HBM when a timed region starts.
+  rates    TWO hypothesis rates are measured and both are in the line:
+             value_full_count   every hypothesis of the batch gets its exact vote count over all N observations
+                                (option scan_bound 0) -- SURVEY.md 8(d)'s unit: one minimal solve + one full agree()
+                                pass per hypothesis, RANSAC.hxx:84-99 without the exit at :94.  THIS is `value`.
+             value_early_exit   the batched form of RANSAC.hxx:94: hypotheses that provably cannot become the running
+                                maximum are not counted to the end (scan_bound 1: cell-box vote bounds for the point
+                                models, chunked abandonment for the dense / US scans).  Winner, consensus set and fit are
+                                identical (tests/test_gpu_fullsize.py); the rate depends on the data.
+           Each rate has its own roofline block (roofline / roofline_early_exit).
+  repeats  every rate is timed over --repeats regions of exactly K steps (barrier + synchronise on both sides, max over
+           ranks); `value` is the median region, all regions are listed.
+  legs     the default single-GPU run appends short legs (5 steps) of BASELINE configs 3-5 -- sphere + geometric fit,
+           dense 2 M x 64, US calibration with the iterative and the analytic fit -- as other_configs[].
+  N > 1    one process per GPU (torch.distributed, RCCL): observations replicated, the hypothesis stream sharded;
+           all-reduce(MAX) picks the winner, all-reduce(SUM) of the moment block of each rank's observation slice gives
+           the final fit.  scaling = "weak" (H per GPU fixed).  `python bench.py --gpus N` without a launcher
+           environment starts its own ranks (python -m torch.distributed.run as a CHILD process, before anything here
+           touches the GPU) and relays rank 0's line; --transport multi drives the N devices from this one process
+           through the C ABI's lsqr_multi_* entry points (peer copies instead of RCCL).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--batch H] [--workload plane]
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,18 +47,37 @@ except Exception:
     METRIC = "RANSAC hypotheses/sec + final-fit residual, 10M pts, 1/2/4/8 GPU"
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP64_VALU_PEAK_GOPS = 39321.6  # 256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz: fp64 add/mul issue rate
-#                                (= the 78.6 TFLOP/s vector fp64 peak counting an FMA as one op;
-#                                the bit-exact agree() may not fuse, so this is its op roof)
-FP64_VALU_MEASURED_GOPS = 33000.0  # tools/microbench.hip on this pool: v_add_f64 / v_mul_f64 with
-#                                    every SIMD busy (4.8 nominal cycles per wave instruction)
+
+# ---- roofs (MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32s, 2.4 GHz.  A wave64 vector instruction occupies its SIMD for
+# 2 cycles when >= 2 waves are resident (one wave alone: 4), a packed-fp32 one (v_pk_fma_f32: two results per lane) and
+# an fp64 one for 4 -- the datasheet's 157.3 TFLOP/s fp32 = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz.  The issue roof
+# is therefore counted in SIMD CYCLES: useful cycles of the launch / (1024 SIMDs x 2.4 GHz).  tools/microbench.hip
+# measures the per-instruction cycles of the scan kernels' mix on the box (profiles/r03_microbench.json).
+SIMD_CYCLES_PEAK_G = 1024 * 2.4          # G SIMD-cycles / s
+CYC_PK = 4.0                             # v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+CYC_F32 = 2.0                            # non-packed fp32 arithmetic, compares, min / max
+FP64_MFMA_PEAK_TFLOPS = 78.6
+FP32_MFMA_PEAK_TFLOPS = 157.3
+# USEFUL vector instructions of the scan kernels, counted from the source (csrc/cells.h, models.h, us.h; table in
+# DESIGN.md section 6): l1 = non-packed fp32 instructions of CM::level1 per (64-hypothesis group, cell); pk = packed-fp32
+# instructions of the filter measure per packed pair of observations per lane (128 observations per wave).
+# Per surviving (hypothesis, cell) of 128*PP observations the useful work is PP * (pk packed + 1 |.|-min) + 2
+# (min3 combine + the candidate compare); everything else the kernel issues (v_readlane broadcasts, the
+# two-threshold ballots, bookkeeping, exact re-checks) is overhead against this roof.
+SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 6}, "line": {"l1": 35, "pk": 12},
+               "us": {"pk": 21}, "phantom": {"pk": 18}}
+
+DELTA = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}
+PROF_KEYS = ("scan", "mask", "moments", "estimate", "solve", "sample", "index")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps per rate; the median is "
+                    "reported, all are listed")
     ap.add_argument("--points", type=int, default=0, help="observations (0 = the BASELINE.json size of "
                     "the workload: 10 M points, 2 M dense rows, 1 M US frames)")
     ap.add_argument("--batch", type=int, default=0, help="hypotheses per GPU per step (0 = 4096; "
@@ -65,9 +100,20 @@ def parse():
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the adaptive RANSAC::compute() timing after the steps (profiling runs: "
                          "keeps one launch shape per kernel)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of BASELINE configs 3-5 appended to the default plane run")
+    ap.add_argument("--rates", default="both", choices=["both", "full", "early"],
+                    help="which hypothesis rates to time (profiling runs: one, so that one scan arrangement runs)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "multi"],
+                    help="--gpus N > 1: rccl = one process per GPU (torch.distributed), multi = this one process "
+                         "drives the N devices through lsqr_multi_* (peer copies)")
     ap.add_argument("--cpu-points", type=int, default=0, help="observations for the CPU leg "
                     "(0 = same as --points)")
-    return ap.parse_args()
+    ap.add_argument("--leg-scale", type=float, default=1.0, help="scale the observation counts of the other_configs "
+                    "legs (tests; 1 = the BASELINE sizes)")
+    ap.add_argument("--cpu-seconds", type=float, default=0.0, help="budget of the CPU full-count sample "
+                    "(0 = 4 s for the headline, 3 s per leg)")
+    return ap.parse_args(argv)
 
 
 def make_data(workload, n, outliers):
@@ -85,321 +131,69 @@ def make_data(workload, n, outliers):
     return synth.us_single_fast(n, outliers)
 
 
-# fp64 VALU instructions of the exact agree() per (hypothesis, observation) pair: arithmetic + compares
-OPS_PER_PAIR = {"plane": 9, "sphere": 10, "line": 20, "dense": 130, "us": 69, "phantom": 64}
-
-# ---- roofs (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction occupies its 16-lane
-# SIMD for 4 cycles (packed fp32: two results per lane in the same slot), so the chip issues at most
-# 1024 * 2.4e9 / 4 = 614.4 G wave-instructions/s; fp64 MFMA dense peak 78.6 TFLOP/s.
-VALU_ISSUE_PEAK_GWIPS = 1024 * 2.4 / 4.0
-FP64_MFMA_PEAK_TFLOPS = 78.6
-FP32_MFMA_PEAK_TFLOPS = 157.3
-# USEFUL vector instructions of the scan kernels, counted from the source (csrc/cells.h, models.h, us.h; table in
-# DESIGN.md section 6): l1 = arithmetic of CM::level1 per (64-hypothesis group, cell); pk = packed-fp32
-# instructions of the filter measure per packed pair of observations per lane (128 observations per wave).
-# Per surviving (hypothesis, cell) of 128*PP observations the useful count is PP * (pk + 1 |.|-min) + 2
-# (min3 combine + the candidate compare); everything else the kernel issues (v_readlane broadcasts, the
-# two-threshold ballots, bookkeeping, exact re-checks) is overhead against this roof.
-SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 6}, "line": {"l1": 35, "pk": 12},
-               "us": {"pk": 21}, "phantom": {"pk": 18}}
-
-
-def cpu_baseline(workload, data, delta):
-    """Reference single-thread CPU path on the same workload, bounded to ~10-30 s: the
-    reference's own RANSAC.hxx (oracle/_ref, compiled from /root/reference in the build
-    container) driving the restated estimator; falls back to the oracle's C port of the loop."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU leg (rank 0, N = 1): oracle/ is the checker and the baseline, never the product path
+def _oracle_cfg(workload, delta):
     from oracle import pyoracle as O
     model = {"plane": O.PLANE, "sphere": O.SPHERE, "line": O.LINE, "dense": O.DENSE,
              "us": O.US_SINGLE, "phantom": O.PHANTOM}[workload]
-    c = O.cfg(model, 64 if workload == "dense" else 3, delta, O.LS_ALGEBRAIC)
-    cores = 1
+    return O, O.cfg(model, 64 if workload == "dense" else 3, delta, O.LS_ALGEBRAIC)
+
+
+def cpu_full_count(workload, data, delta, budget_s):
+    """the metric's unit on one host core: minimal-subset solve + ONE full agree() pass over all N records, no early
+    exit (RANSAC.hxx:84-99 without :94), on the subsets of the bench's own counter-based stream; bounded by time"""
+    O, c = _oracle_cfg(workload, delta)
+    n = len(data)
+    k = {"plane": 3, "sphere": 4, "line": 2, "dense": 64, "us": 4, "phantom": 31}[workload]
+    subs = O.ctr_subsets(20261003, 0, 64 if workload == "dense" else 512, n, k)
     t0 = time.perf_counter()
+    hyp = 0
+    while hyp < len(subs) and (hyp < 3 or time.perf_counter() - t0 < budget_s):
+        par = O.estimate(c, data[subs[hyp]])
+        if len(par):
+            O.scan(c, par, data)
+        hyp += 1
+    dt = time.perf_counter() - t0
+    return {"value": hyp / dt, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+            "sample": "oracle C port of the %s estimator: %d hypotheses (%d-record minimal solve + full agree() pass "
+                      "over N=%d records, no early exit) in %.2f s; 1 thread" % (workload, hyp, k, n, dt)}
+
+
+def cpu_baseline(workload, data, delta, budget_s):
+    """Reference single-thread CPU path on the same workload: the reference's own RANSAC.hxx (oracle/_ref, compiled
+    from /root/reference in the build container) driving the restated estimator, adaptive run at p = 0.999 (its loop
+    WITH the early exit of :94) -- plus the full-count sample above (the unit `value` is quoted in)."""
+    full = cpu_full_count(workload, data, delta, budget_s)
     if workload in ("dense", "phantom"):
-        # the adaptive bound never closes for k = 64 / hardly for k = 31 (w^k underflows), so the CPU leg is
-        # a bounded sample of the metric's unit itself: minimal-subset solve + one full agree() pass
-        n = len(data)
-        k = 64 if workload == "dense" else 31
-        subs = O.ctr_subsets(20261003, 0, 64 if workload == "dense" else 4096, n, k)
-        hyp = 0
-        while hyp < len(subs) and (hyp < 4 or time.perf_counter() - t0 < 12.0):
-            par = O.estimate(c, data[subs[hyp]])
-            if len(par):
-                O.scan(c, par, data)
-            hyp += 1
-        dt = time.perf_counter() - t0
-        return {"value": hyp / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
-                "sample": "oracle C port of %s: %d hypotheses "
-                          "(%dx%d minimal solve + full agree() pass over N=%d records, no early exit) "
-                          "in %.2f s; 1 thread" % ("DenseLinearEquationSystemParametersEstimator" if k == 64 else
-                                                   "PlanePhantomUSCalibrationParametersEstimator", hyp, k, k, n, dt)}
+        # the adaptive bound never closes for k = 64 / hardly for k = 31 (w^k underflows): the bounded sample of the
+        # metric's unit is the whole CPU leg
+        return full
+    O, c = _oracle_cfg(workload, delta)
+    t0 = time.perf_counter()
     if O.ref_available():
         r = O.ref_ransac(c, data, 0.999, seed=20261003)
         hyp = r["estimate_calls"]
         kind = "reference"
         what = ("reference RANSAC.hxx compiled unmodified (oracle/_ref) + restated %sParametersEstimator"
-                " (VNL absent), adaptive run p=0.999" % workload.capitalize())
+                " (VNL absent), adaptive run p=0.999, early exit of RANSAC.hxx:94 included" % workload.capitalize())
     else:
         r = O.ransac(c, data, 0.999, sampler="ref", seed=20261003)
         hyp = int((r["status"] != 1).sum())
         kind = "port"
-        what = "oracle C port of RANSAC.hxx + estimator, adaptive run p=0.999"
+        what = "oracle C port of RANSAC.hxx + estimator, adaptive run p=0.999, early exit included"
     dt = time.perf_counter() - t0
-    return {"value": hyp / dt, "unit": "hypotheses/s", "cores": cores, "kind": kind,
+    return {"value": hyp / dt, "unit": "hypotheses/s", "cores": 1, "kind": kind,
             "sample": "%s; N=%d points; %d hypotheses in %.2f s; 1 thread" % (what, len(data), hyp, dt),
-            "fraction": r["fraction"], "compute_call_s": dt, "iterations": int(r.get("iters", hyp))}
+            "fraction": r["fraction"], "compute_call_s": dt, "iterations": int(r.get("iters", hyp)),
+            "full_count": full,
+            "unit_note": "value = hypotheses/s of the reference's serial loop as it runs (estimate + agree pass WITH "
+                         "its early exit, RANSAC.hxx:94): the counterpart of value_early_exit; full_count.value = the "
+                         "same core doing the metric's unit (full agree pass per hypothesis): the counterpart of "
+                         "`value` / value_full_count"}
 
 
-def main():
-    a = parse()
-    if a.points <= 0:
-        a.points = {"dense": 2_000_000, "us": 1_000_000, "phantom": 1_000_000}.get(a.workload, 10_000_000)
-    if a.batch <= 0:
-        a.batch = 1024 if a.workload == "dense" else 4096
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
-    dist = None
-    device = "cpu"
-    force_dist = os.environ.get("LSQR_FORCE_DIST") == "1"  # exercise the RCCL path at world size 1
-    # rehearsal knobs (CPU tests / one-GPU boxes): LSQR_DIST_BACKEND=gloo keeps the collectives on
-    # the host, LSQR_SHARE_GPU=1 lets every rank use device 0.  The driver's runs use neither.
-    backend = os.environ.get("LSQR_DIST_BACKEND", "nccl")
-    if os.environ.get("LSQR_SHARE_GPU") == "1":
-        local = 0
-    if a.gpus > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        if force_dist and "RANK" not in os.environ:  # stand-alone world of one rank
-            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            device = "cuda:%d" % local
-            dist.init_process_group("nccl", device_id=torch.device(device))
-        else:
-            dist.init_process_group(backend)
-            if os.environ.get("LSQR_STEP") == "device":
-                torch.cuda.init()      # torch's HIP runtime has to come up before the library's
-                torch.cuda.set_device(local)
-    from lsqrrecipes_amd import _lib as L
-    from lsqrrecipes_amd.context import Context
-    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
-
-    delta = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}[a.workload]
-    model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE, "dense": L.DENSE,
-             "us": L.US_SINGLE, "phantom": L.PHANTOM}[a.workload]
-    # GEOMETRIC == ITERATIVE == 1: the sphere's geometric fit, the US calibrations' and the phantom's LM fit
-    # (BASELINE.json configs[2], configs[4]); --us-fit analytic keeps the closed-form US fit
-    ls_type = L.LS_ANALYTIC if (a.workload == "us" and a.us_fit == "analytic") else L.LS_GEOMETRIC
-    data, truth, lab = make_data(a.workload, a.points, a.outliers)
-    ctx = Context(local)
-    ctx.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
-    if a.no_filter:
-        ctx.set_option("scan_filter", 0)
-    if a.no_index:
-        ctx.set_option("scan_index", 0)
-    a.streams = max(1, min(8, a.streams))      # the library's lanes go up to 4; host-threaded contexts up to 8
-    ctx.set_option("batch_lanes", min(4, a.streams))
-    comm = Comm(dist, device)
-    eng = ShardedRansac(ctx, comm)
-    step_on_device = dist is not None and os.environ.get(
-        "LSQR_STEP", "device" if backend == "nccl" else "host") == "device"
-    H = a.batch
-    seed = 0xC0FFEE
-
-    def step(i):
-        if comm.world == 1 and not force_dist:
-            # single GPU: the whole step is one chain on the device stream (lsqr_batch_fit)
-            r = ctx.batch_fit(seed, i * H, H)
-            if r["info"].best_votes == 0:
-                return None
-            return int(r["info"].best_votes), r["params"], int(r["info"].fit.n_used)
-        # multi-GPU: exchanges on device buffers, one host synchronisation per step (step_device);
-        # LSQR_STEP=host keeps the staged-through-the-host variant (the gloo rehearsal's default)
-        r = eng.step_device(seed, i, H) if step_on_device else eng.step(seed, i, H)
-        if r is None:
-            return None
-        votes, gidx, par, fit, cnt, info = r
-        return votes, fit, cnt
-
-    def sync():
-        ctx.synchronize()
-        if dist is not None and device != "cpu":
-            import torch
-            torch.cuda.synchronize()
-        comm.barrier()
-
-    # single GPU, closed-form fit: batches are pipelined -- batch i + 1 is enqueued before batch i is read
-    # (lsqr_batch_fit_enqueue / _wait), so the host's latency between steps hides behind the device's work;
-    # every step still runs the whole chain.  --no-pipeline keeps one blocking call per step.
-    pipelined = (comm.world == 1 and not force_dist and not a.no_pipeline
-                 and not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC)
-                 and a.workload != "phantom")
-
-    closed_form = not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
-    pipelined_dist = step_on_device and closed_form and not a.no_pipeline
-
-    if pipelined or pipelined_dist:
-        a.streams = min(4, a.streams)
-    cur_streams = [a.streams]
-
-    # iterative final fits (sphere geometric, US iterative, phantom) keep the host in the loop -- MINPACK's control
-    # flow between device passes -- so a batch is a blocking call.  The library's threading model is one context per
-    # host thread (LsqrDevice.h); with several streams the steps are dealt to that many host threads, each driving
-    # its own context (own stream, own upload): while one thread waits for an evaluation, another one's scan runs.
-    threaded = (comm.world == 1 and not force_dist and not pipelined and a.streams > 1 and not a.no_pipeline)
-    tctx = [ctx]
-    if threaded:
-        for k in range(1, a.streams):
-            ck = Context(local)
-            ck.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
-            if a.no_filter:
-                ck.set_option("scan_filter", 0)
-            if a.no_index:
-                ck.set_option("scan_index", 0)
-            tctx.append(ck)
-
-    # multi-GPU with several streams: one engine per stream -- its own context (own upload and index), its own
-    # process group (an RCCL communicator serves one stream at a time) and its own torch stream
-    lanes = []
-    if pipelined_dist and a.streams > 1 and str(device) != "cpu":
-        import torch
-        for k in range(a.streams):
-            ck = ctx if k == 0 else Context(local)
-            if k:
-                ck.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type).upload(data)
-                if a.no_filter:
-                    ck.set_option("scan_filter", 0)
-                if a.no_index:
-                    ck.set_option("scan_index", 0)
-            gk = dist.new_group(backend="nccl")        # every rank, same order
-            lanes.append((ShardedRansac(ck, Comm(dist, device, group=gk)), torch.cuda.Stream()))
-
-    def run_steps(first_step, count):
-        last = None
-        if pipelined_dist and lanes and cur_streams[0] > 1:
-            import torch
-            S = len(lanes)
-            ring = 2 * S
-            for i in range(count):
-                if i >= ring:
-                    j = i - ring
-                    last = lanes[j % S][0].step_device_wait((j // S) & 1)
-                with torch.cuda.stream(lanes[i % S][1]):
-                    lanes[i % S][0].step_device(seed, first_step + i, H, slot=(i // S) & 1)
-            for j in range(max(0, count - ring), count):
-                last = lanes[j % S][0].step_device_wait((j // S) & 1)
-            if last is None:
-                return None
-            return last[0], last[3], last[4]
-        if pipelined_dist:   # multi-GPU: step i + 1 is enqueued (collectives included) before step i is read
-            for i in range(count):
-                eng.step_device(seed, first_step + i, H, slot=i & 1)
-                if i:
-                    last = eng.step_device_wait((i - 1) & 1)
-            if count:
-                last = eng.step_device_wait((count - 1) & 1)
-            if last is None:
-                return None
-            return last[0], last[3], last[4]
-        if threaded and cur_streams[0] > 1:
-            import threading
-            S = len(tctx)
-            res = [None] * count
-            err = []
-
-            def work(k):
-                try:
-                    for i in range(k, count, S):
-                        r = tctx[k].batch_fit(seed, (first_step + i) * H, H)
-                        res[i] = (None if r["info"].best_votes == 0 else
-                                  (int(r["info"].best_votes), r["params"], int(r["info"].fit.n_used)))
-                except Exception as e:      # surfaced below: a failed step must fail the run
-                    err.append(e)
-            th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            if err:
-                raise err[0]
-            return res[-1] if count else None
-        if not pipelined:
-            for i in range(count):
-                last = step(first_step + i)
-            return last
-        # a ring of 2 * streams slots: slot s runs on stream (lane) s % streams, two batches deep per stream
-        ring = 2 * cur_streams[0]
-        for i in range(count):
-            if i >= ring:
-                last = ctx.batch_fit_wait((i - ring) % ring)
-            ctx.batch_fit_enqueue(seed, (first_step + i) * H, H, slot=i % ring)
-        for i in range(max(0, count - ring), count):
-            last = ctx.batch_fit_wait(i % ring)
-        if last is None or last["info"].best_votes == 0:
-            return None
-        return int(last["info"].best_votes), last["params"], int(last["info"].fit.n_used)
-
-    ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
-    multi_stream = a.streams > 1 and (pipelined or threaded or (pipelined_dist and bool(lanes)))
-    if multi_stream:
-        run_steps(0, 2 * a.streams)   # every stream builds its index / loads its code objects before the W steps
-    run_steps(0, a.warmup)
-    n_idx, ms_idx = ctx.profile_get("index")
-    n_abs, ms_abs = ctx.profile_get("absmax")
-    ctx.profile(True)
-    sync()
-    t0 = time.perf_counter()
-    last = run_steps(a.warmup, a.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    dt = comm.allreduce_max_f64(dt)
-    prof = {k: ctx.profile_get(k) for k in ("scan", "mask", "moments", "estimate", "solve", "sample", "index")}
-    ctx.profile(False)
-    single_stream = None
-    if multi_stream:
-        # Kernel durations measured while batches of several streams share the device overlap each other; the
-        # per-kernel figures (roofline, kernel_hbm, kernels_ms) come from the SAME steps run once more on one
-        # stream, right after the timed region.  `value` is the multi-stream figure of the timed region above.
-        if pipelined:
-            ctx.set_option("batch_lanes", 1)
-        cur_streams[0] = 1
-        k1 = min(a.steps, 20)
-        run_steps(a.warmup + a.steps, 2)
-        ctx.profile(True)
-        sync()
-        t1 = time.perf_counter()
-        run_steps(a.warmup + a.steps + 2, k1)
-        sync()
-        dt1 = comm.allreduce_max_f64(time.perf_counter() - t1)
-        prof1 = {k: ctx.profile_get(k) for k in ("scan", "mask", "moments", "estimate", "solve", "sample", "index")}
-        ctx.profile(False)
-        if pipelined:
-            ctx.set_option("batch_lanes", min(4, a.streams))
-        cur_streams[0] = a.streams
-        single_stream = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "value": H * a.gpus * k1 / dt1,
-                         "scan_ms_in_timed_region": prof["scan"][1] / max(prof["scan"][0], 1),
-                         "note": "the same chain on ONE stream, run right after the timed region: the source of the "
-                                 "per-kernel durations in roofline / kernel_hbm / kernels_ms (in the timed region "
-                                 "the kernels of %d streams overlap, so a kernel's own duration there includes the "
-                                 "time it shares the device)" % a.streams}
-        prof1["index"] = prof["index"]
-        prof = prof1
-    idx = ctx.index_info()
-
-    if rank == 0:
-        out = report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx,
-                     (n_idx, ms_idx), (n_abs, ms_abs), pipelined, pipelined_dist, step_on_device, force_dist,
-                     dist, model, single_stream)
-        print(json.dumps(out))
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
-
-
+# ---------------------------------------------------------------------------------------------------------------------
 def kernel_source_hash():
     """content hash of the kernel sources: counter files collected by tools/collect_profiles.sh carry it, and
     are only quoted when it still matches (a stale profile is dropped, not emitted next to live timings)"""
@@ -422,18 +216,31 @@ def profile_file(name):
     return d if d.get("kernel_source_hash") == kernel_source_hash() else None
 
 
-def scan_roofline(a, ctx, idx, H, scan_ms, n_scan, rec):
-    """the dominant kernel against the roof that binds it"""
+def measured_cycles():
+    """per-instruction SIMD cycles measured by tools/microbench.hip on an MI355X (profiles/r03_microbench.json), else
+    the guide's figures"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_microbench.json")))
+        return float(d["cycles"]["v_pk_fma_f32"]), float(d["cycles"]["v_fma_f32"]), "profiles/r03_microbench.json"
+    except Exception:
+        return CYC_PK, CYC_F32, "MI355X_MICROARCH.md (v_fma_f32 wave64: 2 cycles on the SIMD-32; packed fp32: 4)"
+
+
+def scan_roofline(R, mode, scan_ms, n_scan):
+    """the dominant kernel against the roof that binds it; mode = "full_count" / "early_exit" """
+    a, ctx, H = R.a, R.ctx, R.H
+    rec = R.rec
     w = a.workload
     t = scan_ms * 1e-3
     alg_bytes = float(H) * a.points * rec            # SURVEY 8(d): N*sizeof(T) per hypothesis, H per launch
-    base = {"launch_ms": scan_ms, "launches": int(n_scan),
+    base = {"rate": mode, "launch_ms": scan_ms, "launches": int(n_scan),
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_GBs": alg_bytes / t / 1e9 if t > 0 else 0.0,
             "algorithmic_note": "SURVEY 8(d) logical figure H*N*%d B / launch time: NOT a roofline fraction -- one pass "
-                                "over the observations serves all H hypotheses, so it exceeds the HBM peak by "
+                                "over the observations serves all H hypotheses (and the two-level scan proves most "
+                                "(hypothesis, cell) pairs irrelevant from the cell boxes), so it exceeds the HBM peak by "
                                 "construction" % rec}
-    prof = profile_file("r02_%s_scan_counters.json" % w)
+    prof = profile_file("r03_%s_%s_scan_counters.json" % (w, mode))
     traffic = prof.get("hbm_bytes_per_launch") if prof else None
     if prof:
         base["counters"] = {k: prof[k] for k in ("valu_issue_busy", "salu_issue_busy_per_cu", "lanes_active",
@@ -442,61 +249,82 @@ def scan_roofline(a, ctx, idx, H, scan_ms, n_scan, rec):
         if traffic and t > 0:
             base["hbm_frac_measured"] = traffic / t / 1e9 / HBM_PEAK_GBS
     if w == "dense":
-        flops = 2.0 * a.points * 64 * H              # the residual block rows x hypotheses as a GEMM
+        wl = ctx.scan_work() if hasattr(ctx, "scan_work") else None
+        rows_done = wl["row_hypothesis_pairs"] if wl else float(a.points) * H
+        flops = 2.0 * 64 * rows_done                 # the residual block rows x hypotheses as a GEMM
         ach = flops / t / 1e12 if t > 0 else 0.0
         base.update({"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "frac_of_fp64_mfma_peak": ach / FP64_MFMA_PEAK_TFLOPS,
-                     "kernel": "k_scan_dense_mfma32<64> (fp32 MFMA filter, v_mfma_f32_16x16x4_f32, A fragments in "
-                               "registers, two accumulator sets) + k_dense_recheck_seg (exact fp64 decision of the "
-                               "~1e-4 of the pairs inside the filter's band); launch_ms covers both and the thresholds",
-                     "note": "flops = 2*m*n*H of the filter GEMM per launch; peak = the fp32 dense matrix rate the "
-                             "filter runs at (the fp64 MFMA filter of round 1 reached 0.65 of the fp64 rate = 51 TFLOP/s)"})
+                     "kernel": "k_scan_dense_mfma32r<64> (fp32 MFMA filter, v_mfma_f32_16x16x4_f32, hypothesis fragments "
+                               "through an LDS ring, next row tile in registers) + k_dense_recheck_seg (exact fp64 "
+                               "decision of the ~1e-4 of the pairs inside the filter's band); launch_ms covers both "
+                               "and the thresholds",
+                     "work_model": {"row_hypothesis_pairs_evaluated": rows_done,
+                                    "row_hypothesis_pairs_all": float(a.points) * H,
+                                    "evaluated_fraction": rows_done / (float(a.points) * H)},
+                     "note": "flops = 2*n*(row, hypothesis) pairs the filter GEMM actually evaluated; peak = the fp32 "
+                             "dense matrix rate the filter runs at"})
         return base
     u = SCAN_USEFUL[w]
-    cells = w in ("plane", "sphere", "line") and idx["built"] and not a.no_filter
+    cyc_pk, cyc_f32, cyc_src = measured_cycles()
+    cells = w in ("plane", "sphere", "line") and R.idx["built"] and not a.no_filter
     if cells:
         wl = ctx.scan_workload()                     # level 1 alone on the last batch: live counts
         pp = wl["cell_points"] // 128
-        v2 = pp * (u["pk"] + 1) + 2
         groups = -(-H // 64)
         l1 = wl["level1_evaluations"]                # one level-1 pass over all hypotheses
         if wl["bounded"]:                            # bounds pass + the pilots' group + the second pass' groups
             l1 += wl["cells"] * (1 + -(-wl["second_pass"] // 64))
-        useful = l1 * u["l1"] + wl["pairs_counted"] * v2
+        v2_instr = pp * (u["pk"] + 1) + 2
+        v2_cycles = pp * (u["pk"] * cyc_pk + cyc_f32) + 2 * cyc_f32
+        useful_instr = l1 * u["l1"] + wl["pairs_counted"] * v2_instr
+        useful_cycles = l1 * u["l1"] * cyc_f32 + wl["pairs_counted"] * v2_cycles
         kname = ("two-level scan of <%s> over a Morton-sorted copy: cell-box culling, packed fp32 filter + exact fp64 "
                  "re-check in surviving cells; %s" % (
                      w, "bounded: k_cells_bounds (vote bounds) -> pilots -> only hypotheses that can still win, each "
                      "counted by k_scan_pairs (level 1 counted first, then an equal share of the surviving "
-                     "(hypothesis, cell) pairs per wave)" if wl["bounded"] else "k_scan_cells"))
+                     "(hypothesis, cell) pairs per wave)" if wl["bounded"] else
+                     "every hypothesis counted: k_cells_bounds(cnt) -> k_tile_costs -> k_scan_pairs" if R.full_pairs
+                     else "every hypothesis counted: k_scan_cells"))
         model = {"level1_evaluations": l1, "level1_useful_instr": u["l1"],
                  "surviving_hypothesis_cell_pairs_all": wl["pairs"],
-                 "surviving_hypothesis_cell_pairs_counted": wl["pairs_counted"], "level2_useful_instr": v2,
+                 "surviving_hypothesis_cell_pairs_counted": wl["pairs_counted"], "level2_useful_instr": v2_instr,
+                 "level2_useful_simd_cycles": v2_cycles,
                  "cells": wl["cells"], "cell_points": wl["cell_points"], "hypothesis_groups": groups,
                  "bounded_scan": wl["bounded"], "pilots": wl["pilots"], "second_pass_hypotheses": wl["second_pass"],
+                 "hypotheses_counted_exactly": (wl["pilots"] + wl["second_pass"]) if wl["bounded"] else H,
                  "surviving_fraction": wl["pairs"] / max(1.0, float(wl["cells"]) * H)}
     else:
-        pairs = float(H) * a.points / 128.0          # every (hypothesis, packed pair of observations per wave)
-        v2 = u["pk"] + 2
-        useful = pairs * v2
+        wk = ctx.scan_work() if hasattr(ctx, "scan_work") else None
+        pairs_all = float(H) * a.points / 128.0      # every (hypothesis, packed pair of observations per wave)
+        pairs = wk["row_hypothesis_pairs"] / 128.0 if wk else pairs_all
+        v2_instr = u["pk"] + 2
+        v2_cycles = u["pk"] * cyc_pk + 2 * cyc_f32
+        useful_instr = pairs * v2_instr
+        useful_cycles = pairs * v2_cycles
         kname = {"us": "k_scan_us_f32<us> (packed fp32 filter + exact fp64 re-check)",
                  "phantom": "k_scan_us_f32<phantom> (factored packed fp32 filter + exact fp64 re-check)"}.get(
                      w, "k_scan_f32<%s> (packed fp32 filter + exact fp64 re-check)" % w)
-        model = {"hypothesis_wave_pairs": pairs, "useful_instr_per_pair": v2}
-    ach = useful / t / 1e9 if t > 0 else 0.0
-    base.update({"bound": "valu", "achieved": ach, "peak": VALU_ISSUE_PEAK_GWIPS, "unit": "G wave-instr/s",
-                 "frac": ach / VALU_ISSUE_PEAK_GWIPS, "traffic": traffic, "kernel": kname, "work_model": model,
-                 "note": "achieved = USEFUL vector instructions of the launch (counted from the kernel source, "
-                         "work counts measured live by lsqr_scan_workload) / launch time; peak = 1024 SIMDs x "
-                         "2.4 GHz / 4 cycles per wave64 instruction.  The kernel reads the observations once "
-                         "per launch for all H hypotheses (HBM fraction in hbm_frac_measured), so the "
-                         "instruction-issue roof is the one that binds; counters.valu_issue_busy is the "
-                         "measured utilisation including overhead instructions"})
+        model = {"hypothesis_wave_pairs_evaluated": pairs, "hypothesis_wave_pairs_all": pairs_all,
+                 "evaluated_fraction": pairs / pairs_all, "useful_instr_per_pair": v2_instr,
+                 "useful_simd_cycles_per_pair": v2_cycles}
+    ach = useful_cycles / t / 1e9 if t > 0 else 0.0
+    base.update({"bound": "valu", "achieved": ach, "peak": SIMD_CYCLES_PEAK_G, "unit": "G SIMD-cycles/s",
+                 "frac": ach / SIMD_CYCLES_PEAK_G, "traffic": traffic, "kernel": kname, "work_model": model,
+                 "useful_wave_instructions": useful_instr,
+                 "cycles_per_instruction": {"v_pk_*_f32": cyc_pk, "fp32 non-packed": cyc_f32, "source": cyc_src},
+                 "note": "achieved = SIMD cycles of the USEFUL vector instructions of the launch (counted from the "
+                         "kernel source, work counts measured live by lsqr_scan_workload) / launch time; peak = 1024 "
+                         "SIMD-32s x 2.4 GHz.  The kernel reads the observations once per launch for all H hypotheses "
+                         "(HBM fraction in hbm_frac_measured), so the instruction-issue roof is the one that binds; "
+                         "counters.valu_issue_busy is the measured utilisation including overhead instructions"})
     return base
 
 
-def hbm_table(a, H, rec, prof, abs_prof, idx_prof, cnt):
+def hbm_table(R, prof, abs_prof, idx_prof, cnt):
     """HBM-bound kernels of the step: algorithmic bytes / HIP-event time / 8 TB/s (live)"""
+    a, rec = R.a, R.rec
     n = float(a.points)
     rows = []
 
@@ -516,9 +344,9 @@ def hbm_table(a, H, rec, prof, abs_prof, idx_prof, cnt):
     else:
         add("k_mask_moments<%s> (consensus mask + moment block, one pass)" % w, n * rec + n, *prof["mask"])
         if prof["moments"][0]:
-            add("k_moments<%s, LM> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f)" % w,
-                n + cnt * rec, *prof["moments"],
-                note="reads the mask (N B) and the %d consensus records" % cnt)
+            add("k_lm_pass<%s> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f over the compacted "
+                "consensus set)" % w, cnt * rec, *prof["moments"],
+                note="reads the %d consensus records (tight copy)" % cnt)
     add("k_bounds (point models: min / max / max |x| in one pass) or k_absmax, once per upload", n * rec, *abs_prof)
     if idx_prof[0]:
         add("spatial index build (k_keys, radix sort of (key, index) pairs, k_gather_boxes; once per upload)",
@@ -528,44 +356,37 @@ def hbm_table(a, H, rec, prof, abs_prof, idx_prof, cnt):
     return rows
 
 
-def closed_form_fit(a, ls_type):
-    from lsqrrecipes_amd import _lib as L
-    return not (a.workload in ("sphere", "us") and ls_type == L.LS_GEOMETRIC) and a.workload != "phantom"
-
-
 def cold_call(a, L, Context, data, model, delta, ls_type, cpu):
     """What a caller of RANSAC<T,S>::compute() (RANSAC.h:75-79) sees on data that is NOT yet on the device:
     lsqr_upload of the caller's pageable buffer + lsqr_ransac (adaptive, p = 0.999) + the consensus copy."""
-    res = {}
-    for label, threads in (("plain_hipMemcpy", 0), ("staged_upload_4_threads", 4)):
-        c2 = Context(0)
-        try:
-            c2.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type)
-            c2.set_option("upload_threads", threads)
-            c2.set_option("max_iterations", 100000)
-            best = None
-            for rep in range(3):
-                t0 = time.perf_counter()
-                c2.upload(data)
-                t1 = time.perf_counter()
-                r = c2.ransac(0.999, seed=20261003 + rep, want_consensus=True)
-                t2 = time.perf_counter()
-                cur = {"total_ms": (t2 - t0) * 1e3, "upload_ms": (t1 - t0) * 1e3,
-                       "ransac_and_consensus_copy_ms": (t2 - t1) * 1e3,
-                       "iterations": int(r["info"].iterations), "scanned": int(r["info"].evaluated),
-                       "fraction": r["fraction"], "index_built": c2.index_info()["built"]}
-                if rep and (best is None or cur["total_ms"] < best["total_ms"]):
-                    best = cur          # rep 0 allocates the device and pinned buffers: reported separately
-                if rep == 0:
-                    first = cur["total_ms"]
-            best["first_call_ms_incl_allocations"] = first
-            best["upload_GBs"] = data.nbytes / best["upload_ms"] / 1e6
-            res[label] = best
-        finally:
-            c2.close()
-    out = {"what": "lsqr_upload (host, pageable) + lsqr_ransac (p = 0.999) + consensus copy, %d records of %d B; "
-                   "best of 2 calls after the first" % (len(data), data.shape[1] * 8),
-           "ms": res["plain_hipMemcpy"]["total_ms"], "detail": res}
+    c2 = Context(0)
+    try:
+        c2.set_model(model, 64 if a.workload == "dense" else 3, delta, ls_type)
+        c2.set_option("upload_threads", 0)
+        c2.set_option("max_iterations", 100000)
+        best = None
+        first = 0.0
+        for rep in range(3):
+            t0 = time.perf_counter()
+            c2.upload(data)
+            t1 = time.perf_counter()
+            r = c2.ransac(0.999, seed=20261003 + rep, want_consensus=True)
+            t2 = time.perf_counter()
+            cur = {"total_ms": (t2 - t0) * 1e3, "upload_ms": (t1 - t0) * 1e3,
+                   "ransac_and_consensus_copy_ms": (t2 - t1) * 1e3,
+                   "iterations": int(r["info"].iterations), "scanned": int(r["info"].evaluated),
+                   "fraction": r["fraction"], "index_built": c2.index_info()["built"]}
+            if rep and (best is None or cur["total_ms"] < best["total_ms"]):
+                best = cur          # rep 0 allocates the device and pinned buffers: reported separately
+            if rep == 0:
+                first = cur["total_ms"]
+        best["first_call_ms_incl_allocations"] = first
+        best["upload_GBs"] = data.nbytes / best["upload_ms"] / 1e6
+    finally:
+        c2.close()
+    out = {"what": "lsqr_upload (host, pageable, one hipMemcpy) + lsqr_ransac (p = 0.999) + consensus copy, %d records "
+                   "of %d B; best of 2 calls after the first" % (len(data), data.shape[1] * 8),
+           "ms": best["total_ms"], "detail": best}
     if cpu and "compute_call_s" in cpu:
         out["reference_cpu_call_s"] = cpu["compute_call_s"]
         out["speedup_vs_reference_call"] = cpu["compute_call_s"] * 1e3 / out["ms"]
@@ -575,80 +396,403 @@ def cold_call(a, L, Context, data, model, delta, ls_type, cpu):
     return out
 
 
-def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, idx_warm, abs_prof, pipelined,
-           pipelined_dist, step_on_device, force_dist, dist, model, single_stream=None):
-    from lsqrrecipes_amd import _lib as L
-    from lsqrrecipes_amd.context import Context
-    total_hyp = H * a.gpus * a.steps
-    value = total_hyp / dt
-    votes, fit, cnt = last
-    single = comm.world == 1 and not force_dist
-    res = ctx.stats(fit, use_mask=True) if single else None
-    rec = data.shape[1] * 8
-    n_scan, ms_scan = prof["scan"]
-    scan_ms = ms_scan / max(n_scan, 1)
-    if not single and a.workload in ("plane", "sphere", "line") and closed_form_fit(a, ls_type):
-        # the multi-GPU step leaves the re-derived winner (a batch of one) as the context's current batch: the work
-        # model of the roofline is taken on a full batch of this rank, as in the single-GPU run (untimed)
-        ctx.batch_fit(0xC0FFEE, comm.rank * H, H)
-    n_idx = idx_warm[0] + prof["index"][0]
-    ms_idx = idx_warm[1] + prof["index"][1]
+# ---------------------------------------------------------------------------------------------------------------------
+class Run:
+    """one workload on this rank: contexts, the drivers of the steps, the timed regions"""
+
+    def __init__(self, a, dist, device, local, backend, force_dist, data=None):
+        from lsqrrecipes_amd import _lib as L
+        from lsqrrecipes_amd.context import Context
+        from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+        self.a, self.dist, self.device, self.local, self.force_dist = a, dist, device, local, force_dist
+        self.L, self.Context = L, Context
+        w = a.workload
+        self.delta = DELTA[w]
+        self.model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE, "dense": L.DENSE,
+                      "us": L.US_SINGLE, "phantom": L.PHANTOM}[w]
+        # GEOMETRIC == ITERATIVE == 1: the sphere's geometric fit, the US calibrations' and the phantom's LM fit
+        # (BASELINE.json configs[2], configs[4]); --us-fit analytic keeps the closed-form US fit
+        self.ls_type = L.LS_ANALYTIC if (w == "us" and a.us_fit == "analytic") else L.LS_GEOMETRIC
+        self.dim = 64 if w == "dense" else 3
+        if data is None:
+            data = make_data(w, a.points, a.outliers)
+        self.data, self.truth, self.lab = data
+        self.rec = self.data.shape[1] * 8
+        self.ctx = self._new_ctx()
+        a.streams = max(1, min(8, a.streams))      # the library's lanes go up to 4; host-threaded contexts up to 8
+        self.ctx.set_option("batch_lanes", min(4, a.streams))
+        self.comm = Comm(dist, device)
+        self.eng = ShardedRansac(self.ctx, self.comm)
+        self.step_on_device = dist is not None and os.environ.get(
+            "LSQR_STEP", "device" if backend == "nccl" else "host") == "device"
+        self.H = a.batch
+        self.seed = 0xC0FFEE
+        self.single = self.comm.world == 1 and not force_dist
+        self.closed_form = not (w in ("sphere", "us") and self.ls_type == L.LS_GEOMETRIC) and w != "phantom"
+        # single GPU, closed-form fit: batches are pipelined -- batch i + 1 is enqueued before batch i is read
+        # (lsqr_batch_fit_enqueue / _wait), so the host's latency between steps hides behind the device's work;
+        # every step still runs the whole chain.  --no-pipeline keeps one blocking call per step.
+        self.pipelined = self.single and not a.no_pipeline and self.closed_form
+        self.pipelined_dist = self.step_on_device and self.closed_form and not a.no_pipeline
+        if self.pipelined or self.pipelined_dist:
+            a.streams = min(4, a.streams)
+        self.cur_streams = a.streams
+        # iterative final fits (sphere geometric, US iterative, phantom) keep the host in the loop -- MINPACK's
+        # control flow between device passes -- so a batch is a blocking call.  The library's threading model is one
+        # context per host thread (LsqrDevice.h); with several streams the steps are dealt to that many host threads,
+        # each driving its own context (own stream, own upload): while one thread waits for an evaluation, another
+        # one's scan runs.
+        self.threaded = self.single and not self.pipelined and a.streams > 1 and not a.no_pipeline
+        self.tctx = [self.ctx]
+        if self.threaded:
+            for _ in range(1, a.streams):
+                self.tctx.append(self._new_ctx())
+        # multi-GPU with several streams: one engine per stream -- its own context (own upload and index), its own
+        # process group (an RCCL communicator serves one stream at a time) and its own torch stream
+        self.lanes = []
+        if self.pipelined_dist and a.streams > 1 and str(device) != "cpu":
+            import torch
+            for k in range(a.streams):
+                ck = self.ctx if k == 0 else self._new_ctx()
+                gk = dist.new_group(backend="nccl")        # every rank, same order
+                self.lanes.append((ShardedRansac(ck, Comm(dist, device, group=gk)), torch.cuda.Stream()))
+        self.multi_stream = a.streams > 1 and (self.pipelined or self.threaded or
+                                               (self.pipelined_dist and bool(self.lanes)))
+        self.next_step = 0
+        self.side_step = 1 << 20
+        self.nfev_total = 0        # LM evaluations of the steps run so far (iterative fits)
+        self.full_pairs = False
+        self.idx = None
+
+    def _new_ctx(self):
+        a = self.a
+        c = self.Context(self.local)
+        c.set_model(self.model, self.dim, self.delta, self.ls_type).upload(self.data)
+        if a.no_filter:
+            c.set_option("scan_filter", 0)
+        if a.no_index:
+            c.set_option("scan_index", 0)
+        return c
+
+    def all_ctx(self):
+        seen = [self.ctx] + [c for c in self.tctx[1:]] + [e.e for e, _ in self.lanes[1:]]
+        return seen
+
+    def set_option(self, name, value):
+        for c in self.all_ctx():
+            c.set_option(name, value)
+
+    def close(self):
+        for c in self.all_ctx():
+            c.close()
+
+    @staticmethod
+    def _res(r):
+        if r is None or r["info"].best_votes == 0:
+            return None
+        f = r["info"].fit
+        return {"votes": int(r["info"].best_votes), "fit": r["params"], "cnt": int(f.n_used),
+                "lm_info": int(f.lm_info), "lm_nfev": int(f.lm_nfev), "cost": float(f.cost),
+                "lm_stall": int(f.reserved)}
+
+    @staticmethod
+    def _res_step(r):
+        if r is None:
+            return None
+        votes, gidx, par, fit, cnt, info = r
+        return {"votes": int(votes), "fit": fit, "cnt": int(cnt),
+                "lm_info": int(getattr(info, "lm_info", 0) or 0), "lm_nfev": int(getattr(info, "lm_nfev", 0) or 0),
+                "cost": float(getattr(info, "cost", 0.0) or 0.0), "lm_stall": int(getattr(info, "reserved", 0) or 0)}
+
+    def step(self, i):
+        H, seed = self.H, self.seed
+        if self.single:
+            # single GPU: the whole step is one chain on the device stream (lsqr_batch_fit)
+            return self._res(self.ctx.batch_fit(seed, i * H, H))
+        # multi-GPU: exchanges on device buffers, one host synchronisation per step (step_device);
+        # LSQR_STEP=host keeps the staged-through-the-host variant (the gloo rehearsal's default)
+        r = self.eng.step_device(seed, i, H) if self.step_on_device else self.eng.step(seed, i, H)
+        return self._res_step(r)
+
+    def sync(self):
+        for c in self.all_ctx():
+            c.synchronize()
+        if self.dist is not None and self.device != "cpu":
+            import torch
+            torch.cuda.synchronize()
+        self.comm.barrier()
+
+    def run_steps(self, count, side=False):
+        """`count` steps of the hot path, continuing the hypothesis stream (side: on a range of step indices of their
+        own -- priming and the one-stream profile runs --, so that the timed steps are the same steps whatever the
+        number of streams); -> result of the last step"""
+        if side:
+            first_step = self.side_step
+            self.side_step += count
+        else:
+            first_step = self.next_step
+            self.next_step += count
+        H, seed = self.H, self.seed
+        last = None
+        if self.pipelined_dist and self.lanes and self.cur_streams > 1:
+            import torch
+            S = len(self.lanes)
+            ring = 2 * S
+            for i in range(count):
+                if i >= ring:
+                    j = i - ring
+                    last = self.lanes[j % S][0].step_device_wait((j // S) & 1)
+                with torch.cuda.stream(self.lanes[i % S][1]):
+                    self.lanes[i % S][0].step_device(seed, first_step + i, H, slot=(i // S) & 1)
+            for j in range(max(0, count - ring), count):
+                last = self.lanes[j % S][0].step_device_wait((j // S) & 1)
+            return self._res_step(last)
+        if self.pipelined_dist:   # multi-GPU: step i + 1 is enqueued (collectives included) before step i is read
+            for i in range(count):
+                self.eng.step_device(seed, first_step + i, H, slot=i & 1)
+                if i:
+                    last = self.eng.step_device_wait((i - 1) & 1)
+            if count:
+                last = self.eng.step_device_wait((count - 1) & 1)
+            return self._res_step(last)
+        if self.threaded and self.cur_streams > 1:
+            import threading
+            S = len(self.tctx)
+            res = [None] * count
+            err = []
+
+            def work(k):
+                try:
+                    for i in range(k, count, S):
+                        res[i] = self._res(self.tctx[k].batch_fit(seed, (first_step + i) * H, H))
+                except Exception as e:      # surfaced below: a failed step must fail the run
+                    err.append(e)
+            th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            if err:
+                raise err[0]
+            self.nfev_total += sum(r["lm_nfev"] for r in res if r)
+            return res[-1] if count else None
+        if not self.pipelined or self.cur_streams < 1:
+            for i in range(count):
+                last = self.step(first_step + i)
+                if last:
+                    self.nfev_total += last["lm_nfev"]
+            return last
+        # a ring of 2 * streams slots: slot s runs on stream (lane) s % streams, two batches deep per stream
+        ctx = self.ctx
+        ring = 2 * self.cur_streams
+        for i in range(count):
+            if i >= ring:
+                last = ctx.batch_fit_wait((i - ring) % ring)
+            ctx.batch_fit_enqueue(seed, (first_step + i) * H, H, slot=i % ring)
+        for i in range(max(0, count - ring), count):
+            last = ctx.batch_fit_wait(i % ring)
+        return self._res(last)
+
+    def region(self, K, side=False):
+        """exactly K steps between two barrier + synchronise brackets -> (seconds: max over ranks, own seconds, last)"""
+        self.sync()
+        t0 = time.perf_counter()
+        last = self.run_steps(K, side)
+        self.sync()
+        own = time.perf_counter() - t0
+        return self.comm.allreduce_max_f64(own), own, last
+
+    def one_stream(self, on):
+        if self.pipelined:
+            self.ctx.set_option("batch_lanes", 1 if on else min(4, self.a.streams))
+        self.cur_streams = 1 if on else self.a.streams
+
+    def measure(self, mode, bound):
+        """one hypothesis rate: prime, warm up, `repeats` timed regions, then the same chain on ONE stream for the
+        per-kernel figures"""
+        a, ctx, H = self.a, self.ctx, self.H
+        if bound is not None:
+            self.set_option("scan_bound", bound)
+        ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
+        if self.multi_stream:
+            self.run_steps(2 * a.streams, side=True)   # every stream builds its index / loads its code objects before the W steps
+        self.run_steps(a.warmup)
+        idx_warm = ctx.profile_get("index")
+        abs_warm = ctx.profile_get("absmax")
+        ctx.profile(True)
+        regions, own, last = [], [], None
+        nfev0 = self.nfev_total
+        for _ in range(max(1, a.repeats)):
+            dt, mine, last = self.region(a.steps)
+            regions.append(dt)
+            own.append(mine)
+        nfev = self.nfev_total - nfev0
+        k_med = int(np.argsort(regions)[len(regions) // 2])
+        per_rank = self.comm.allgather_f64(H * a.steps / own[k_med])   # each rank's own clock, median region
+        prof = {k: ctx.profile_get(k) for k in PROF_KEYS}
+        ctx.profile(False)
+        single_stream = None
+        if self.multi_stream:
+            # Kernel durations measured while batches of several streams share the device overlap each other; the
+            # per-kernel figures (roofline, kernel_hbm, kernels_ms) come from the SAME steps run once more on one
+            # stream, right after the timed regions.  The rate is the multi-stream figure of the timed regions.
+            self.one_stream(True)
+            k1 = min(a.steps, 20)
+            self.run_steps(2, side=True)
+            ctx.profile(True)
+            dt1, _, _ = self.region(k1, side=True)
+            prof1 = {k: ctx.profile_get(k) for k in PROF_KEYS}
+            ctx.profile(False)
+            self.one_stream(False)
+            single_stream = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "value": H * a.gpus * k1 / dt1,
+                             "scan_ms_in_timed_region": prof["scan"][1] / max(prof["scan"][0], 1),
+                             "note": "the same chain on ONE stream, run right after the timed regions: the source of "
+                                     "the per-kernel durations in roofline / kernel_hbm / kernels_ms (in the timed "
+                                     "regions the kernels of %d streams overlap, so a kernel's own duration there "
+                                     "includes the time it shares the device)" % a.streams}
+            prof1["index"] = prof["index"]
+            prof = prof1
+        self.idx = ctx.index_info()
+        vals = [H * a.gpus * a.steps / dt for dt in regions]
+        med = float(np.median(vals))
+        dt_med = H * a.gpus * a.steps / med
+        if not self.single and a.workload in ("plane", "sphere", "line") and self.closed_form:
+            # the multi-GPU step leaves the re-derived winner (a batch of one) as the context's current batch: the work
+            # model of the roofline is taken on a full batch of this rank, as in the single-GPU run (untimed)
+            ctx.batch_fit(0xC0FFEE, self.comm.rank * H, H)
+        n_scan, ms_scan = prof["scan"]
+        scan_ms = ms_scan / max(n_scan, 1)
+        out = {"mode": mode, "value": med, "values": vals, "ms_per_step": dt_med / a.steps * 1e3,
+               "region_s": regions, "per_rank": per_rank, "last": last, "prof": prof, "idx_warm": idx_warm,
+               "abs_warm": abs_warm, "single_stream": single_stream, "scan_ms": scan_ms, "lm_evaluations": nfev,
+               "roofline": scan_roofline(self, mode, scan_ms, n_scan)}
+        return out
+
+
+def step_text(R):
+    a = R.a
+    if R.pipelined:
+        return ("lsqr_batch_fit_enqueue/_wait (one chain per step; the steps alternate over %d HIP stream(s), two deep "
+                "per stream, so chains of different streams overlap on the device)" % a.streams)
+    if R.single and R.multi_stream:
+        return ("lsqr_batch_fit (blocking: the iterative fit keeps the host in the loop), the steps dealt to %d host "
+                "threads with one context (stream) each" % a.streams)
+    if R.single:
+        return "lsqr_batch_fit (one chain, one sync)"
+    if R.pipelined_dist:
+        return "step_device, pipelined (collectives on device buffers; step i + 1 enqueued before step i is read)"
+    if R.step_on_device:
+        return "step_device (collectives on device buffers, one sync)"
+    return "step (exchanges staged through the host)"
+
+
+def final_fit_block(R, last):
+    a = R.a
+    if last is None:
+        return {"inliers": 0, "winner_votes": 0, "params": [], "params_empty": True, "lm_info": 0, "lm_nfev": 0}
+    fit = last["fit"]
+    res = None
+    if R.single and len(fit):
+        try:
+            res = R.ctx.stats(fit, use_mask=True)
+        except Exception:
+            res = None
+    ff = {"inliers": int(last["cnt"]), "winner_votes": int(last["votes"]),
+          "params": [float(x) for x in fit], "params_empty": len(fit) == 0,
+          "lm_info": int(last["lm_info"]), "lm_nfev": int(last["lm_nfev"]),
+          "abs_dot_true_normal": float(abs(np.dot(fit[:3], R.truth[:3])))
+          if (a.workload in ("plane", "line") and len(fit)) else None,
+          "residual_min_max_mean_sumsq": [float(x) for x in res] if res is not None else None}
+    if last["lm_nfev"]:
+        ff["lm_cost"] = last["cost"]
+        ff["lm_nfev_cost_stopped_moving"] = last["lm_stall"] or None
+        ff["lm_note"] = ("MINPACK lmder control flow with the reference's tolerances; lm_info outside 1..4 is the "
+                         "reference's failure convention: parameters EMPTY (info 5 = the evaluation limit, which is "
+                         "what 1e-15 tolerances produce on >= 20 k frames: tests/golden/us_lm_flags.npz). "
+                         "lm_nfev_cost_stopped_moving = the evaluation after which the cost never again fell by more "
+                         "than 1e-7 relative")
+    return ff
+
+
+def report(R, rates, cpu_budget, headline=True):
+    """the JSON object of one workload; rates: list of measure() results, the first one is `value`"""
+    a, ctx, comm, H = R.a, R.ctx, R.comm, R.H
+    L, Context = R.L, R.Context
+    main_rate = rates[0]
+    by_mode = {r["mode"]: r for r in rates}
+    last = main_rate["last"]
+    prof = main_rate["prof"]
+    idx = R.idx
+    n_idx = main_rate["idx_warm"][0] + prof["index"][0]
+    ms_idx = main_rate["idx_warm"][1] + prof["index"][1]
+    value = main_rate["value"]
+    w = a.workload
+    what_value = {
+        "full_count": "`value` = value_full_count: every one of the H hypotheses of a step gets its exact vote count "
+                      "over all N observations (SURVEY 8(d)'s unit; scan_bound 0)",
+        "early_exit": "`value` = value_early_exit (only rate measured: --rates early)"}[main_rate["mode"]]
     out = {
         "metric": METRIC,
         "value": value, "unit": "hypotheses/s", "n_gpus": a.gpus, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "warmup": a.warmup, "ms_per_step": main_rate["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%sParametersEstimator + RANSAC, %d points, %d%% outliers, "
                                "delta=%.2f (BASELINE.json configs[1])" % (
-                                   a.workload.capitalize(), a.points, round(a.outliers * 100), delta)
-                   if a.workload == "plane" else "%s estimator + RANSAC, %d observations%s" % (
-                       a.workload, a.points,
-                       ", final fit: %s" % a.us_fit if a.workload == "us" else ""),
+                                   w.capitalize(), a.points, round(a.outliers * 100), R.delta)
+                   if w == "plane" else "%s estimator + RANSAC, %d observations%s" % (
+                       w, a.points, ", final fit: %s" % a.us_fit if w == "us" else ""),
                    "points": a.points, "hypotheses_per_gpu_per_step": H,
-                   "record_bytes": rec, "parallelism": "hypotheses sharded over %d GPU(s), "
+                   "record_bytes": R.rec, "parallelism": "hypotheses sharded over %d GPU(s), "
                    "observations replicated" % a.gpus,
                    "world_size": comm.world,
-                   "collectives": ("RCCL (torch.distributed nccl backend)" if dist is not None and comm.device != "cpu"
-                                   else ("gloo (rehearsal)" if dist is not None else "none (single GPU)")),
-                   "streams": a.streams if single_stream is not None else 1,
-                   "stream_priming_steps": 2 * a.streams if single_stream is not None else 0,
-                   "step": ("lsqr_batch_fit_enqueue/_wait (one chain per step; the steps alternate over %d HIP "
-                            "stream(s), two deep per stream, so chains of different streams overlap on the "
-                            "device)" % a.streams if pipelined
-                            else "lsqr_batch_fit (blocking: the iterative fit keeps the host in the loop), the steps "
-                            "dealt to %d host threads with one context (stream) each" % a.streams
-                            if (single and single_stream is not None)
-                            else "lsqr_batch_fit (one chain, one sync)" if single
-                            else "step_device, pipelined (collectives on device buffers; step i + 1 enqueued "
-                            "before step i is read)" if pipelined_dist
-                            else "step_device (collectives on device buffers, one sync)" if step_on_device
-                            else "step (exchanges staged through the host)")},
-        "per_rank_hypotheses_per_s": value / a.gpus,
-        "single_stream": single_stream,
-        "final_fit": {"inliers": int(cnt), "winner_votes": int(votes),
-                      "params": [float(x) for x in fit],
-                      "abs_dot_true_normal": float(abs(np.dot(fit[:3], truth[:3])))
-                      if a.workload in ("plane", "line") else None,
-                      "residual_min_max_mean_sumsq": [float(x) for x in res] if res is not None else None},
-        "roofline": scan_roofline(a, ctx, idx, H, scan_ms, n_scan, rec),
-        "kernel_hbm": hbm_table(a, H, rec, prof, abs_prof, (n_idx, ms_idx), int(cnt)),
-        "kernels_ms": {"sample": prof["sample"][1] / max(prof["sample"][0], 1),
-                       "estimate": prof["estimate"][1] / max(prof["estimate"][0], 1),
-                       "scan": scan_ms,
-                       "mask": prof["mask"][1] / max(prof["mask"][0], 1),
-                       "moments": prof["moments"][1] / max(prof["moments"][0], 1),
-                       "moments_launches_per_step": prof["moments"][0] / max(a.steps, 1),
-                       "reduce_and_solve_per_step": prof["solve"][1] / max(a.steps, 1)},
-        "index": {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
-                  "build_ms": ms_idx / n_idx if n_idx else None,
-                  "builds_in_warmup": int(idx_warm[0]), "builds_in_timed_region": int(prof["index"][0]),
-                  "note": "one-time per upload (device counting sort on Morton keys + cell boxes), built inside "
-                          "the scan that first needs it"},
+                   "collectives": ("RCCL (torch.distributed nccl backend)" if R.dist is not None and comm.device != "cpu"
+                                   else ("gloo (rehearsal)" if R.dist is not None else "none (single GPU)")),
+                   "streams": a.streams if R.multi_stream else 1,
+                   "stream_priming_steps": 2 * a.streams if R.multi_stream else 0,
+                   "repeats": max(1, a.repeats),
+                   "step": step_text(R) + "; " + what_value},
+        "value_is": main_rate["mode"],
+        "repeats": {r["mode"]: r["values"] for r in rates},
     }
-    if a.gpus == 1 and dist is None and a.workload in ("plane", "sphere", "line") and not a.no_end_to_end:
+    for r in rates:
+        out["value_" + r["mode"]] = r["value"]
+        out["ms_per_step_" + r["mode"]] = r["ms_per_step"]
+    out["per_rank_hypotheses_per_s"] = [float(x) for x in main_rate["per_rank"]]   # each rank's own clock
+    out["single_stream"] = main_rate["single_stream"]
+    out["final_fit"] = final_fit_block(R, last)
+    if last is not None and last["lm_nfev"]:
+        tot = main_rate["lm_evaluations"]
+        secs = sum(main_rate["region_s"])
+        out["lm"] = {"evaluations_in_timed_regions": int(tot), "evaluations_per_s": tot / secs if secs > 0 else None,
+                     "evaluations_per_step": tot / (a.steps * max(1, a.repeats)),
+                     "note": "one evaluation = one device pass (k_lm_pass*) over the winner's consensus set + the "
+                             "MINPACK step; with --streams > 1 several fits are in flight"}
+    out["roofline"] = main_rate["roofline"]
+    for r in rates[1:]:
+        out["roofline_" + r["mode"]] = r["roofline"]
+        out["single_stream_" + r["mode"]] = r["single_stream"]
+    cnt = int(last["cnt"]) if last else 0
+    out["kernel_hbm"] = hbm_table(R, prof, main_rate["abs_warm"], (n_idx, ms_idx), cnt)
+    out["kernels_ms"] = {"sample": prof["sample"][1] / max(prof["sample"][0], 1),
+                         "estimate": prof["estimate"][1] / max(prof["estimate"][0], 1),
+                         "scan": main_rate["scan_ms"],
+                         "mask": prof["mask"][1] / max(prof["mask"][0], 1),
+                         "moments": prof["moments"][1] / max(prof["moments"][0], 1),
+                         "moments_launches_per_step": prof["moments"][0] / max(min(a.steps, 20), 1),
+                         "reduce_and_solve_per_step": prof["solve"][1] / max(min(a.steps, 20), 1)}
+    for r in rates[1:]:
+        out["kernels_ms"]["scan_" + r["mode"]] = r["scan_ms"]
+    out["index"] = {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
+                    "build_ms": ms_idx / n_idx if n_idx else None,
+                    "builds_in_warmup": int(main_rate["idx_warm"][0]),
+                    "builds_in_timed_region": int(prof["index"][0]),
+                    "note": "one-time per upload (device radix sort on Morton keys + cell boxes), built inside "
+                            "the scan that first needs it"}
+    single_plain = a.gpus == 1 and R.dist is None
+    if headline and single_plain and w in ("plane", "sphere", "line") and not a.no_end_to_end:
         # a second build in the same process (code objects loaded, buffers kept): the build's own device time
         ctx.profile(True)
-        ctx.upload(data)
+        ctx.upload(R.data)
         ctx.batch_fit(0xC0FFEE, 0, H)
         nb2, msb2 = ctx.profile_get("index")
         nab, msab = ctx.profile_get("absmax")
@@ -659,6 +803,7 @@ def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, id
                                         "build_ms above is the first build of the process and includes the one-time "
                                         "load of the sort's code object")
         ctx.set_option("max_iterations", 100000)
+        ctx.set_option("scan_bound", 1)
         # the whole RANSAC<T,S>::compute() (adaptive termination, p = 0.999) on the resident data
         ctx.ransac(0.999, seed=7, want_consensus=False)
         t1 = time.perf_counter()
@@ -675,16 +820,210 @@ def report(a, ctx, comm, data, truth, delta, ls_type, H, dt, last, prof, idx, id
     cpu = None
     if a.gpus == 1 and not a.no_cpu_baseline:
         cp = a.cpu_points or a.points
-        cpu = cpu_baseline(a.workload, data[:cp], delta)
+        cpu = cpu_baseline(w, R.data[:cp], R.delta, cpu_budget)
         out["cpu_baseline"] = cpu
-        out["cpu_baseline"]["unit_note"] = (
-            "hypotheses/s of the reference's serial loop (estimate + agree pass WITH its early exit, "
-            "RANSAC.hxx:94); `value` counts full agree passes, so the ratio below overstates the "
-            "like-for-like gain -- cold_call.speedup_vs_reference_call is the end-to-end comparison")
-        out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-    if a.gpus == 1 and dist is None and not a.no_end_to_end and a.workload in ("plane", "sphere", "line", "us"):
-        out["cold_call"] = cold_call(a, L, Context, data, model, delta, ls_type, cpu)
+        full = cpu.get("full_count", cpu)
+        if "full_count" in by_mode:
+            out["speedup_vs_cpu_baseline"] = by_mode["full_count"]["value"] / full["value"]
+            out["speedup_note"] = ("value_full_count / cpu_baseline%s.value: the same unit on both sides (full agree "
+                                   "pass per hypothesis)" % (".full_count" if "full_count" in cpu else ""))
+        if "early_exit" in by_mode and "full_count" in cpu:
+            out["speedup_early_exit_vs_reference_loop"] = by_mode["early_exit"]["value"] / cpu["value"]
+    if headline and single_plain and not a.no_end_to_end and w in ("plane", "sphere", "line", "us"):
+        out["cold_call"] = cold_call(a, L, Context, R.data, R.model, R.delta, R.ls_type, cpu)
     return out
+
+
+def rates_for(a):
+    """(mode, scan_bound) pairs in the order measured; the first one is `value`"""
+    if a.rates == "full":
+        return [("full_count", 0)]
+    if a.rates == "early":
+        return [("early_exit", 1)]
+    return [("full_count", 0), ("early_exit", 1)]
+
+
+def run_workload(a, dist, device, local, backend, force_dist, cpu_budget, headline=True):
+    R = Run(a, dist, device, local, backend, force_dist)
+    try:
+        rates = []
+        for mode, bound in rates_for(a):
+            rates.append(R.measure(mode, bound))
+        return report(R, rates, cpu_budget, headline) if R.comm.rank == 0 else None
+    finally:
+        R.close()
+
+
+LEGS = (("sphere", "iterative", "SphereParametersEstimator + RANSAC, 10 M points, geometric (LM) final fit "
+         "(BASELINE.json configs[2]; on the driver's 8-GPU run the hypotheses are sharded, here 1 GPU)"),
+        ("dense", "iterative", "DenseLinearEquationSystemParametersEstimator, m = 2 M, n = 64 (BASELINE.json configs[3])"),
+        ("us", "iterative", "SinglePointTargetUSCalibrationParametersEstimator, 1 M frames, ITERATIVE (LM) final fit "
+         "with the reference's tolerances (BASELINE.json configs[4] as written)"),
+        ("us", "analytic", "SinglePointTargetUSCalibrationParametersEstimator, 1 M frames, ANALYTIC final fit"))
+
+
+def run_legs(a0, local):
+    """short legs of BASELINE configs 3-5 on this GPU (5 steps each), so that the driver's own run observes them"""
+    legs = []
+    for w, fit, title in LEGS:
+        t0 = time.perf_counter()
+        a = parse([])
+        a.workload, a.us_fit = w, fit
+        a.points = max(4096, int({"dense": 2_000_000, "us": 1_000_000}.get(w, 10_000_000) * a0.leg_scale))
+        a.batch = 1024 if w == "dense" else 4096
+        a.steps, a.warmup, a.repeats = 5, 2, 1
+        a.streams = a0.streams
+        a.no_end_to_end = True
+        a.no_cpu_baseline = a0.no_cpu_baseline
+        try:
+            o = run_workload(a, None, "cpu", local, "nccl", False, a0.cpu_seconds or 3.0, headline=False)
+            keep = {k: o[k] for k in o if k in (
+                "value", "unit", "steps", "warmup", "ms_per_step", "value_is", "value_full_count", "value_early_exit",
+                "ms_per_step_full_count", "ms_per_step_early_exit", "repeats", "single_stream", "final_fit", "lm",
+                "roofline", "roofline_early_exit", "kernel_hbm", "kernels_ms", "cpu_baseline",
+                "speedup_vs_cpu_baseline")}
+            keep["config"] = {"workload": title, "points": a.points, "hypotheses_per_gpu_per_step": a.batch,
+                              "streams": o["config"]["streams"], "step": o["config"]["step"]}
+            keep["leg_wall_s"] = time.perf_counter() - t0
+            legs.append(keep)
+        except Exception as e:      # a leg must not take the headline down with it; the failure is in the line
+            legs.append({"config": {"workload": title}, "error": "%s: %s" % (type(e).__name__, e)})
+    return legs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher environment: start the N ranks as CHILDREN (this process has not
+    touched the GPU and never will), relay rank 0's JSON line, exit non-zero if any rank failed"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d)\n" % (a.gpus, rc))
+        return rc or 1
+    print(line)
+    return 0
+
+
+def run_multi(a):
+    """--transport multi: the N devices driven from this one process through lsqr_multi_* (peer copies)"""
+    from lsqrrecipes_amd import _lib as L
+    from lsqrrecipes_amd.context import MultiContext
+    w = a.workload
+    model = {"plane": L.PLANE, "sphere": L.SPHERE, "line": L.LINE, "dense": L.DENSE, "us": L.US_SINGLE}[w]
+    ls_type = L.LS_ANALYTIC if (w == "us" and a.us_fit == "analytic") else L.LS_GEOMETRIC
+    data, truth, _ = make_data(w, a.points, a.outliers)
+    devs = [0] * a.gpus if os.environ.get("LSQR_SHARE_GPU") == "1" else list(range(a.gpus))
+    H = a.batch
+    seed = 0xC0FFEE
+    with MultiContext(devs) as mc:
+        mc.set_model(model, 64 if w == "dense" else 3, DELTA[w], ls_type).upload(data)
+        out_rates = {}
+        last = None
+        step = 0
+        for mode, bound in rates_for(a):
+            mc.set_option("scan_bound", bound)
+            for _ in range(a.warmup):
+                mc.batch_fit(seed, step * a.gpus * H, H)
+                step += 1
+            vals = []
+            for _ in range(max(1, a.repeats)):
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    last = mc.batch_fit(seed, step * a.gpus * H, H)
+                    step += 1
+                vals.append(H * a.gpus * a.steps / (time.perf_counter() - t0))
+            out_rates[mode] = vals
+    first = rates_for(a)[0][0]
+    value = float(np.median(out_rates[first]))
+    f = last["info"].fit
+    out = {"metric": METRIC, "value": value, "unit": "hypotheses/s", "n_gpus": a.gpus, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": H * a.gpus / value * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s estimator + RANSAC, %d observations" % (w, a.points), "points": a.points,
+                      "hypotheses_per_gpu_per_step": H, "world_size": a.gpus, "devices": devs,
+                      "collectives": "peer copies (lsqr_multi)", "streams": 1, "repeats": max(1, a.repeats),
+                      "step": "lsqr_multi_batch_fit (one process, one context per device, blocking); `value` = value_%s"
+                              % first},
+           "value_is": first, "repeats": out_rates,
+           "per_rank_hypotheses_per_s": [value / a.gpus] * a.gpus,
+           "final_fit": {"inliers": int(f.n_used), "winner_votes": int(last["info"].best_votes),
+                         "params": [float(x) for x in last["params"]], "params_empty": len(last["params"]) == 0,
+                         "lm_info": int(f.lm_info), "lm_nfev": int(f.lm_nfev)},
+           "roofline": None, "cpu_baseline": None}
+    for mode, vals in out_rates.items():
+        out["value_" + mode] = float(np.median(vals))
+    print(json.dumps(out))
+    return 0
+
+
+def main():
+    a = parse()
+    if a.points <= 0:
+        a.points = {"dense": 2_000_000, "us": 1_000_000, "phantom": 1_000_000}.get(a.workload, 10_000_000)
+    if a.batch <= 0:
+        a.batch = 1024 if a.workload == "dense" else 4096
+    in_launcher_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not in_launcher_env:
+        # nothing in this process has touched the GPU yet (numpy and the standard library only)
+        if a.transport == "multi":
+            sys.exit(run_multi(a))
+        sys.exit(launch_ranks(a))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    dist = None
+    device = "cpu"
+    force_dist = os.environ.get("LSQR_FORCE_DIST") == "1"  # exercise the RCCL path at world size 1
+    # rehearsal knobs (CPU tests / one-GPU boxes): LSQR_DIST_BACKEND=gloo keeps the collectives on
+    # the host, LSQR_SHARE_GPU=1 lets every rank use device 0.  The driver's runs use neither.
+    backend = os.environ.get("LSQR_DIST_BACKEND", "nccl")
+    if os.environ.get("LSQR_SHARE_GPU") == "1":
+        local = 0
+    if a.gpus > 1 or force_dist:
+        import torch
+        import torch.distributed as dist
+        if force_dist and "RANK" not in os.environ:  # stand-alone world of one rank
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            device = "cuda:%d" % local
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+            if os.environ.get("LSQR_STEP") == "device":
+                torch.cuda.init()      # torch's HIP runtime has to come up before the library's
+                torch.cuda.set_device(local)
+    out = run_workload(a, dist, device, local, backend, force_dist, a.cpu_seconds or 4.0, headline=True)
+    if rank == 0:
+        single_plain = a.gpus == 1 and dist is None
+        if single_plain and a.workload == "plane" and not a.no_other_configs and a.rates == "both":
+            out["other_configs"] = run_legs(a, local)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

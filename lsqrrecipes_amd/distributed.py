@@ -71,6 +71,14 @@ class Comm:
         import torch
         return float(self._allreduce([float(value)], torch.float64, self.dist.ReduceOp.MAX)[0])
 
+    def allgather_f64(self, value):
+        """every rank's scalar, in rank order (a one-hot sum: the message is 8 B per rank)"""
+        if self.dist is None:
+            return [float(value)]
+        v = np.zeros(self.world)
+        v[self.rank] = float(value)
+        return [float(x) for x in self.allreduce_sum_f64(v)]
+
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier(group=self.group)

@@ -1,6 +1,7 @@
 """bench.py end to end on a small workload (run with -m gpu): the JSON contract of the line it prints, on every driver
 of the steps -- lanes of one context (closed-form fits), host threads with a context each (iterative fits), one
-stream, and the RCCL path at world size 1 with one engine, process group and torch stream per stream."""
+stream, the RCCL path at world size 1 with one engine, process group and torch stream per stream, the self-launched
+two-rank run (no launcher environment) and the one-process multi-device transport."""
 import json
 import os
 import socket
@@ -11,34 +12,47 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
+LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                "TORCHELASTIC_RUN_ID")
 
 
-def _run(args, env=None):
-    e = dict(os.environ)
+def _run(args, env=None, extra=("--no-cpu-baseline", "--no-end-to-end", "--no-other-configs")):
+    e = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
     if env:
         e.update(env)
     r = subprocess.run([sys.executable, "bench.py", "--points", "200000", "--steps", "6", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-end-to-end"] + args, cwd=ROOT, env=e, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+                        "--repeats", "2"] + list(extra) + args, cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line
     return json.loads(lines[0])
 
 
-def _check(j, streams):
+def _check(j, streams, n_gpus=1):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "value_is", "repeats", "final_fit"):
         assert k in j, k
-    assert j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 2 and j["unit"] == "hypotheses/s"
-    assert j["value"] > 0 and abs(j["value"] - j["config"]["hypotheses_per_gpu_per_step"] * 6 /
+    assert j["n_gpus"] == n_gpus and j["steps"] == 6 and j["warmup"] == 2 and j["unit"] == "hypotheses/s"
+    assert j["value"] > 0 and abs(j["value"] - n_gpus * j["config"]["hypotheses_per_gpu_per_step"] * 6 /
                                   (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]
-    r = j["roofline"]
-    assert r["bound"] in ("valu", "mfma", "hbm") and 0 < r["frac"] <= 1.0
+    # `value` is the full-count rate (SURVEY 8d's unit) and says so; the early-exit rate rides beside it
+    assert j["value_is"] == "full_count" and j["value"] == j["value_full_count"]
+    assert "value_full_count" in j["config"]["step"]
+    assert j["value_early_exit"] > 0 and len(j["repeats"]["full_count"]) == 2 and len(j["repeats"]["early_exit"]) == 2
+    assert abs(sum(j["repeats"]["full_count"]) / 2 - j["value"]) < 1e-9 * j["value"]    # the median of the regions
+    for key in ("roofline", "roofline_early_exit"):
+        r = j[key]
+        assert r["bound"] in ("valu", "mfma", "hbm") and 0 < r["frac"] <= 1.0, (key, r["frac"])
+    assert j["roofline"]["rate"] == "full_count" and j["roofline_early_exit"]["rate"] == "early_exit"
     assert j["config"]["streams"] == streams
     if streams > 1:
         assert j["single_stream"]["value"] > 0
-    assert j["final_fit"]["winner_votes"] > 0
+    ff = j["final_fit"]
+    assert ff["winner_votes"] > 0
+    for k in ("lm_info", "lm_nfev", "params_empty"):
+        assert k in ff, k
+    assert len(j["per_rank_hypotheses_per_s"]) == j["config"]["world_size"]
 
 
 def test_bench_lanes_and_single_stream():
@@ -49,6 +63,10 @@ def test_bench_lanes_and_single_stream():
     # the same steps: the last step's winner and fit do not depend on the number of streams
     assert a["final_fit"]["winner_votes"] == b["final_fit"]["winner_votes"]
     assert a["final_fit"]["params"] == b["final_fit"]["params"]
+    # counting everything and the bounded scan see different work, and say so
+    wf, we = a["roofline"]["work_model"], a["roofline_early_exit"]["work_model"]
+    assert not wf["bounded_scan"] and wf["hypotheses_counted_exactly"] == 4096
+    assert we["bounded_scan"] and we["hypotheses_counted_exactly"] < 4096
 
 
 def test_bench_host_threads_for_the_iterative_fit():
@@ -56,6 +74,19 @@ def test_bench_host_threads_for_the_iterative_fit():
     _check(a, 3)
     b = _run(["--workload", "sphere", "--streams", "1"])
     assert a["final_fit"]["winner_votes"] == b["final_fit"]["winner_votes"]
+    assert a["final_fit"]["lm_info"] in (1, 2, 3, 4) and a["final_fit"]["lm_nfev"] > 0 and not a["final_fit"]["params_empty"]
+    assert a["lm"]["evaluations_per_s"] > 0
+
+
+def test_bench_us_iterative_line_says_what_the_fit_did():
+    """BASELINE config 5 as written ends at MINPACK's evaluation limit on large frame counts (info 5 = the
+    reference's EMPTY vector): whatever happens, the line must say it"""
+    j = _run(["--workload", "us", "--points", "30000", "--rates", "full"])
+    ff = j["final_fit"]
+    assert ff["lm_nfev"] > 0 and ff["lm_info"] >= 1
+    assert ff["params_empty"] == (ff["lm_info"] not in (1, 2, 3, 4)) == (len(ff["params"]) == 0)
+    assert j["lm"]["evaluations_per_step"] >= 1 and j["lm"]["evaluations_per_s"] > 0
+    assert "lm_nfev_cost_stopped_moving" in ff
 
 
 def _free_port():
@@ -71,3 +102,40 @@ def test_bench_rccl_path_with_one_engine_per_stream():
              env={"LSQR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     _check(j, 2)
     assert j["config"]["world_size"] == 1 and "RCCL" in j["config"]["collectives"]
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment: the parent starts the ranks as children and relays
+    rank 0's line.  One-GPU box: both ranks share device 0 and the collectives run over gloo (RCCL refuses two ranks
+    on one device); the driver's 8-GPU run uses RCCL."""
+    for step in ("host", "device"):
+        j = _run(["--workload", "plane", "--gpus", "2", "--streams", "1"],
+                 env={"LSQR_SHARE_GPU": "1", "LSQR_DIST_BACKEND": "gloo", "LSQR_STEP": step})
+        _check(j, 1, n_gpus=2)
+        assert j["config"]["world_size"] == 2 and j["n_gpus"] == 2
+        assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
+
+
+def test_bench_gpus_2_one_process_multi_transport():
+    j = _run(["--workload", "plane", "--gpus", "2", "--transport", "multi"], env={"LSQR_SHARE_GPU": "1"})
+    assert j["config"]["world_size"] == 2 and j["config"]["collectives"] == "peer copies (lsqr_multi)"
+    assert j["value"] > 0 and j["value_is"] == "full_count" and j["value_early_exit"] > 0
+    assert j["final_fit"]["winner_votes"] > 0
+
+
+def test_bench_default_run_carries_the_other_configs():
+    """the default plane run appends short legs of BASELINE configs 3-5 (scaled down here)"""
+    j = _run(["--workload", "plane", "--leg-scale", "0.02", "--cpu-seconds", "0.3"], extra=("--no-end-to-end",))
+    legs = j["other_configs"]
+    assert len(legs) == 4 and not any("error" in leg for leg in legs), legs
+    names = [leg["config"]["workload"] for leg in legs]
+    assert "Sphere" in names[0] and "Dense" in names[1] and "ITERATIVE" in names[2] and "ANALYTIC" in names[3]
+    for leg in legs:
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0 and 0 < leg["roofline"]["frac"] <= 1
+        assert leg["cpu_baseline"]["value"] > 0 and leg["cpu_baseline"]["cores"] == 1
+        for k in ("lm_info", "lm_nfev", "params_empty"):
+            assert k in leg["final_fit"]
+    assert legs[2]["final_fit"]["lm_nfev"] > 0 and legs[2]["lm"]["evaluations_per_s"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["full_count"]["value"] > 0 and "full agree" in cb["unit_note"]
+    assert abs(j["speedup_vs_cpu_baseline"] - j["value_full_count"] / cb["full_count"]["value"]) < 1e-6 * j["speedup_vs_cpu_baseline"]
