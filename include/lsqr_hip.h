@@ -91,7 +91,8 @@ typedef struct {
   int32_t n_params;     /* 0 when status is LSQR_EMPTY */
   int32_t lm_info;      /* MINPACK info code of the LM run (0 when no LM) */
   int32_t lm_nfev;      /* LM function evaluations (= device passes) */
-  int32_t reserved;
+  int32_t reserved;     /* LM runs: the evaluation after which the cost never again fell by more than 1e-7
+                           relative (diagnostics: where a run that ends at the evaluation limit stopped gaining) */
   uint64_t n_used;      /* observations that entered the fit */
   double cost;          /* final sum of squared residuals where the model defines one, else 0 */
 } lsqr_fit_info;
@@ -351,7 +352,9 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                upload count only hypotheses that can still become the running maximum (an upper bound on every
  *                hypothesis' votes from the cell boxes, a few early candidates counted first); the others
  *                report 0 votes -- winner, consensus set and iteration count are unchanged (RANSAC.hxx:94 abandons
- *                exactly such hypotheses).  0 = every hypothesis is counted.  lsqr_scan always counts all;
+ *                exactly such hypotheses).  Dense system (n > 32) and US calibrations: the observations are scanned in
+ *                chunks and a hypothesis stops being counted once it cannot win any more (lsqr_scan_work; it reports
+ *                its partial count).  0 = every hypothesis is counted.  lsqr_scan always counts all;
  * "batch_lanes": streams (1..4, default 4) the slots of lsqr_batch_fit_enqueue / _wait are spread over (see there);
  * "scan_pairs":  1 = plain (unbounded) scans of an indexed upload also go through the statically balanced kernel of
  *                the bounded scan (k_scan_pairs) instead of k_scan_cells (A/B knob); "scan_pairs_waves": workgroups
@@ -379,6 +382,16 @@ LSQR_API int lsqr_index_info(const lsqr_ctx *ctx, uint64_t out[4]);
  * hypothesis the summed population of its surviving cells: an upper bound on its votes.  LSQR_ERR_STATE when the
  * upload has no index.  Used by bench.py to price the scan against the instruction-issue roof. */
 LSQR_API int lsqr_scan_workload(lsqr_ctx *ctx, uint32_t *bound_out, uint64_t out[8]);
+
+/* Work of the LAST scan of the current batch for the models without a spatial index (dense system, US calibrations,
+ * plane phantom).  The batch entry points (lsqr_batch_fit*, lsqr_step_scan, lsqr_ransac) scan the observations in
+ * chunks and stop counting a hypothesis once  votes so far + observations still to come  cannot exceed a lower bound
+ * of the running maximum at its index (option "scan_bound" 1, the batched form of RANSAC.hxx:94; csrc/earlyexit.h) --
+ * winner, consensus set and iteration count are unchanged, an abandoned hypothesis reports its partial count.
+ * out[0..5] = {1 if that path ran (0: every pair was evaluated), (observation, hypothesis) pairs handed to the scan
+ * kernels, pairs of a full scan = H * N, candidates counted to the end first, hypotheses abandoned at the first
+ * selection, hypotheses still alive after the last one}.  Used by bench.py to price the scan. */
+LSQR_API int lsqr_scan_work(lsqr_ctx *ctx, uint64_t out[6]);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream.  kernel ids: 0 sample, 1 estimate,

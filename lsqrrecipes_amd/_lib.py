@@ -122,6 +122,7 @@ SIGNATURES = {
     "lsqr_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
     "lsqr_index_info": (C.c_int, [_ctx, _u64p]),
     "lsqr_scan_workload": (C.c_int, [_ctx, C.c_void_p, _u64p]),
+    "lsqr_scan_work": (C.c_int, [_ctx, _u64p]),
     "lsqr_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "lsqr_profile_get": (C.c_int, [_ctx, C.c_int, _u64p, _dp]),
     "lsqr_profile_reset": (C.c_int, [_ctx]),

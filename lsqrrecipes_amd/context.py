@@ -328,6 +328,13 @@ class Context:
             r["bounds"] = ub
         return r
 
+    def scan_work(self):
+        """what the last scan of the current batch evaluated (lsqr_scan_work): models without a spatial index"""
+        out = (C.c_uint64 * 6)()
+        self._chk(self._lib.lsqr_scan_work(self._h, out))
+        return {"early_exit": bool(out[0]), "row_hypothesis_pairs": int(out[1]), "row_hypothesis_pairs_all": int(out[2]),
+                "candidates": int(out[3]), "dropped_first": int(out[4]), "alive_at_end": int(out[5])}
+
     def synchronize(self):
         self._chk(self._lib.lsqr_synchronize(self._h))
 

@@ -629,13 +629,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (~1.7 us) to land.  The thresholds of the whole batch sit in LDS as well.
 template <int NR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_scan_dense_mfma32r(
-    const double *__restrict__ data, size_t stride, size_t m, size_t rows_per_block,
+    const double *__restrict__ data, size_t stride, size_t row_begin, size_t row_end, size_t rows_per_block,
     const float *__restrict__ sp32, const float *__restrict__ thr, uint32_t H, int n,
     uint32_t *__restrict__ votes, unsigned long long *__restrict__ amb_list,
-    unsigned int *__restrict__ amb_counts, uint32_t seg_cap, uint32_t hyp_base) {
+    unsigned int *__restrict__ amb_counts, uint32_t seg_cap, uint32_t hyp_base,
+    const uint32_t *__restrict__ h_dev, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ range_dev) {
+  // (range_dev: the row range comes from device memory -- planned by k_ee_plan -- and is cut into gridDim.x equal runs
+  // of whole tiles here)
+  if (range_dev) {
+    row_begin = range_dev[0];
+    row_end = range_dev[1];
+    if (row_begin >= row_end) return;  // workgroup-uniform
+    const size_t tiles = (row_end - row_begin + 63) / 64;
+    rows_per_block = (tiles + gridDim.x - 1) / gridDim.x * 64;
+  }
+  // Rows [row_begin, row_end) against hypotheses [hyp_base, hyp_base + H) of a batch -- the context's batch itself
+  // (sel == null: hypothesis index = position) or a compacted selection of it (early exit, earlyexit.h: sel[] maps
+  // positions to hypothesis indices, *h_dev is the selection's size; sp32 / thr are the selection's compact rows,
+  // already offset to hyp_base).  Votes and worklist entries carry hypothesis indices.
   typedef float f4 __attribute__((ext_vector_type(4)));
   static_assert(NR == 64, "fragment bookkeeping below assumes 64 padded unknowns");
   extern __shared__ float smf[];
+  if (h_dev) {
+    const uint32_t ht = *h_dev, hd = ht > hyp_base ? ht - hyp_base : 0u;
+    H = hd < H ? hd : H;
+    if (H == 0) return;  // workgroup-uniform
+  }
   const uint32_t nhb = (H + 63) / 64, nhb2 = (nhb + 1) & ~1u;  // blocks past the batch: thresholds that never pass
   float *ring = smf;                              // 4 waves x 2 slots x 4 chunks of 1 KiB (16-byte aligned: first)
   float *At = ring + 4 * 2 * 1024;                // 64 rows x pitch
@@ -651,8 +670,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     thl[2 * h + 1] = h < H ? thr[2 * (size_t)h + 1] : -1.0f;
   }
   if (tid == 0) *s_amb = amb_counts[blockIdx.x];
-  size_t lo = (size_t)blockIdx.x * rows_per_block;
-  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
+  size_t lo = row_begin + (size_t)blockIdx.x * rows_per_block;
+  size_t hi = lo + rows_per_block < row_end ? lo + rows_per_block : row_end;
+  if (lo > hi) lo = hi;
+  auto hyp_id = [&](uint32_t h) -> uint32_t { return sel ? sel[hyp_base + h] : hyp_base + h; };
   // hypothesis block hb -> slot: the rows of my 16 hypotheses in fragment order, 64 bytes per lane, as four
   // 16-byte pieces; piece j of all lanes lands contiguously (lane * 16 bytes) in chunk j of the slot
   auto issue = [&](uint32_t hb, uint32_t slot) {
@@ -806,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               if (slot < seg_cap)
                 amb_list[(size_t)blockIdx.x * seg_cap + slot] =
                     ((unsigned long long)(base + t * 16 + 4 * k4 + rg) << 32) |
-                    (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
+                    (unsigned long long)hyp_id(hb * 64 + wave * 16 + c16);
             }
           }
       }
@@ -831,7 +852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               if (slot < seg_cap)
                 amb_list[(size_t)blockIdx.x * seg_cap + slot] =
                     ((unsigned long long)(base + t * 16 + 4 * k4 + rg) << 32) |
-                    (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
+                    (unsigned long long)hyp_id(hb * 64 + wave * 16 + c16);
             }
           }
       }
@@ -858,7 +879,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
   for (uint32_t h = tid; h < H; h += 256) {
     uint32_t c = s_cnt[h];
-    if (c) atomicAdd(&votes[h], c);
+    if (c) atomicAdd(&votes[hyp_id(h)], c);
   }
   if (tid == 0) amb_counts[blockIdx.x] = *s_amb;
 }
@@ -868,12 +889,13 @@ template <int NR>
 __global__ __launch_bounds__(256) void k_dense_recheck_seg(const double *__restrict__ data, size_t stride,
                                                            const double *__restrict__ sp, ModelConsts mc,
                                                            const unsigned long long *__restrict__ amb_list,
-                                                           const unsigned int *__restrict__ amb_counts,
+                                                           unsigned int *__restrict__ amb_counts,
                                                            uint32_t seg_cap, uint32_t *__restrict__ votes,
                                                            unsigned int *__restrict__ out_max) {
   typedef DenseModel<NR> M;
   const unsigned filled = amb_counts[blockIdx.x];
-  if (threadIdx.x == 0 && filled) atomicMax(out_max, filled);
+  if (filled == 0) return;
+  if (threadIdx.x == 0) atomicMax(out_max, filled);
   const unsigned total = filled < seg_cap ? filled : seg_cap;
   for (unsigned e = threadIdx.x; e < total; e += 256) {
     unsigned long long v = amb_list[(size_t)blockIdx.x * seg_cap + e];
@@ -883,6 +905,8 @@ __global__ __launch_bounds__(256) void k_dense_recheck_seg(const double *__restr
     M::load(data + row * stride, mc, x);
     if (M::agree(sp + (size_t)h * NR, x, mc)) atomicAdd(&votes[h], 1u);
   }
+  __syncthreads();  // every thread has read `filled`
+  if (threadIdx.x == 0) amb_counts[blockIdx.x] = 0;  // decided: the segment is free for the next chunk's appends
 }
 
 // exact decision of the pairs the MFMA filter could not classify
@@ -1068,6 +1092,196 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
     if (i <= j && j < nz) out[i * nz - i * (i - 1) / 2 + (j - i)] = fold[pos];
   }
   if (threadIdx.x == 0) out[ne] = (double)(s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3]);
+}
+
+// K3 + K4 dense in ONE pass over the rows: consensus mask of the model `par` (bit-identical to DenseModel::agree: the
+// reference's running sum, one row per lane) and, from the same rows while they sit in LDS, the block of sums
+// sum z z^T over the agreeing rows on the matrix cores (same partial layout as k_syrk_mfma).  Tight records only
+// (stride == n + 1), so that a tile of 16 rows is one contiguous run of 128 (n + 1) bytes:
+//   * every wave owns a ring of four 16-row tile buffers in LDS and fills them with global_load_lds (16 bytes per
+//     lane, no staging registers): the LDS image is the memory image, and because a row is an ODD number of doubles
+//     the lanes that walk one row each hit distinct bank pairs -- no padding needed.  Three tiles are in flight while
+//     one is evaluated (counted s_waitcnt vmcnt): 4 waves x 25 KB per CU outstanding at all times -- with one tile in
+//     flight per wave the kernel ran at the latency of a tile, 3.4 TB/s;
+//   * lane r < 16 evaluates row r; the ballot of the decisions is the tile's piece of the mask;
+//   * only the agreeing rows are multiplied: their indices are compacted (rank of the lane's bit) and fed four at a
+//     time to v_mfma_f64_16x16x4 -- lane (k, c) holds z_k[16 b + c] for block b: at once the A operand of block-row
+//     b and the B operand of block-column b (as k_syrk_mfma).  With 30 % of the rows agreeing that is a third of the
+//     matrix work of the unconditional SYRK, and the rows are read from HBM once instead of twice.
+template <int NB16, int NBUF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 2 : 1, NBUF == 2 ? 2 : 1))) void k_mask_syrk_dense(
+    const double *__restrict__ data, size_t begin, size_t end, size_t chunk, int n, const double *__restrict__ par,
+    double delta, uint8_t *__restrict__ mask, unsigned long long *__restrict__ counter, int pstride,
+    double *__restrict__ partials, double amax, double bmax, double band_scale, int diag) {
+  constexpr int TR = 16;   // rows per tile: lane r < 16 walks row r
+  // NBUF = ring of tile buffers per wave.  2: two workgroups (eight waves) per CU, one tile in flight per wave while
+  // the other is evaluated -- the second wave of a SIMD fills the matrix pipe while the first walks its rows (the
+  // phases of one wave do not overlap: loads 0.19 ms, + rows 0.28 ms, + matrix 0.41 ms with four waves per CU);
+  // 4: one workgroup per CU, three tiles in flight (A/B)
+  extern __shared__ double smd[];
+  __shared__ unsigned s_rows[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k4 = lane >> 4, c16 = lane & 15;
+  const int nz = n + 1;
+  const int tile_d = TR * nz;                       // doubles per tile
+  double *ring = smd + (size_t)wave * NBUF * tile_d;
+  double *xs = smd + (size_t)4 * NBUF * tile_d;     // the model, read with uniform addresses (64 doubles)
+  unsigned char *list = (unsigned char *)(xs + 64) + wave * 32;  // compacted row indices of the tile
+  if (threadIdx.x < 64) xs[threadIdx.x] = (int)threadIdx.x < n ? par[threadIdx.x] : 0.0;
+  __syncthreads();
+  // Band of the four-chain evaluation below against the reference's single running sum: both add the same 64 rounded
+  // products, in different orders; each order is within (n - 1) u sum |p_i| (1 + O(u)) of the exact sum, u = 2^-53,
+  // and sum |p_i| <= Amax ||x||_1.  E = 2.2 n u (Amax ||x||_1 + Bmax) covers both and the final subtraction.
+  // Non-finite magnitudes (or a NaN model) give E = NaN / inf: every tile takes the serial evaluation.
+  double l1 = 0.0;
+  for (int i = 0; i < 64; i++) l1 += fabs(xs[i]);
+  const double eband = band_scale * 2.2 * 64.0 * 1.1102230246251565e-16 * (amax * l1 + bmax);
+  constexpr int NT = NB16 * (NB16 + 1) / 2;
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  int off[NB16];
+  bool colok[NB16];
+#pragma unroll
+  for (int b = 0; b < NB16; b++) {
+    colok[b] = 16 * b + c16 < nz;
+    off[b] = colok[b] ? 16 * b + c16 : 0;
+  }
+  const size_t lo = begin + (size_t)blockIdx.x * chunk;
+  const size_t hi = lo + chunk < end ? lo + chunk : end;
+  unsigned rows_used = 0;
+  // a tile = TR consecutive rows = one contiguous run of bytes; 16-byte pieces straight into LDS (a whole tile is a
+  // multiple of 16 bytes; the last, shorter tile of a range may end in one 8-byte piece)
+  auto issue = [&](size_t base, double *dst) {
+    const size_t rows = hi - base < (size_t)TR ? hi - base : (size_t)TR;
+    const size_t bytes = rows * (size_t)nz * 8;
+    const char *g = (const char *)(data + base * (size_t)nz);
+    for (size_t o = 0; o < bytes; o += 1024) {      // wave-uniform trip count
+      const size_t mine = o + (size_t)lane * 16;
+      if (mine + 16 <= bytes)
+        __builtin_amdgcn_global_load_lds((const void *)(g + mine),
+                                         (__attribute__((address_space(3))) void *)((char *)dst + o), 16, 0, 0);
+      else if (mine + 8 <= bytes)
+        ((double *)dst)[mine / 8] = *(const double *)(g + mine);
+    }
+  };
+  // tile j of this wave: rows [lo + (4 j + wave) * TR, + TR)
+  const size_t step = (size_t)4 * TR;
+  size_t base = lo + (size_t)wave * TR;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (base + p * step < hi) issue(base + p * step, ring + (size_t)p * tile_d);
+  for (unsigned j = 0; base < hi; base += step, j++) {
+    double *tile = ring + (size_t)(j % NBUF) * tile_d;
+    const size_t ahead = base + (size_t)(NBUF - 1) * step;
+    // My tile has landed when all but the operations issued after it are done.  Loads, LDS-DMA and stores retire in
+    // order; after tile j's pieces came, per later iteration, one mask store and the pieces of one more tile.  Only
+    // the full case (n = 64: nine pieces per 16-row tile, every later tile whole) is counted; anything else drains.
+    if (NBUF == 4 && NB16 == 5 && ahead + TR <= hi)
+      asm volatile("s_waitcnt vmcnt(21) lgkmcnt(0)" ::: "memory");   // 2 x (1 store + 9 pieces) + 1 store
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (ahead < hi) issue(ahead, ring + (size_t)((j + NBUF - 1) % NBUF) * tile_d);  // the buffer read last iteration
+    const int rows = (int)(hi - base < (size_t)TR ? hi - base : (size_t)TR);
+    bool a;
+    {
+      // every lane walks a row (lanes past the tile's rows walk row 0: no divergence, their result is dropped); the
+      // reference's running sum in its order, multiply and add unfused (-ffp-contract=off)
+      const double *row = tile + (lane < rows ? lane : 0) * nz;
+      // A single running sum is one chain of 128 dependent fp64 operations -- with one wave per SIMD its latency IS
+      // the kernel (measured: 3000 cycles per tile).  Four interleaved chains give the residual up to the band E
+      // above; only a tile with a row inside |  |r| - delta | <= E (one in ~1e11 rows) is walked again serially.
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if (diag & 2) {  // timing diagnostics: no evaluation
+        s0 = row[0];
+      } else if constexpr (NB16 == 5) {  // n = 64
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+          s0 += row[i] * xs[i];
+          s1 += row[i + 1] * xs[i + 1];
+          s2 += row[i + 2] * xs[i + 2];
+          s3 += row[i + 3] * xs[i + 3];
+        }
+      } else {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+          s0 += row[i] * xs[i];
+          s1 += row[i + 1] * xs[i + 1];
+          s2 += row[i + 2] * xs[i + 2];
+          s3 += row[i + 3] * xs[i + 3];
+        }
+        for (; i < n; i++) s0 += row[i] * xs[i];
+      }
+      const double rq = fabs(((s0 + s1) + (s2 + s3)) - row[n]);
+      a = rq < delta;
+      const bool unsure = !(fabs(rq - delta) > eband);      // also true for NaN
+      if (__ballot(unsure && lane < rows)) {                // wave-uniform, rare: the reference's own order
+        double sum = 0.0;
+        for (int i = 0; i < n; i++) sum += row[i] * xs[i];
+        sum -= row[n];
+        a = fabs(sum) < delta;
+      }
+      a = a && lane < rows;
+      if (lane < rows) mask[base + lane] = a ? 1 : 0;
+    }
+    const unsigned long long in = __ballot(a);
+    const int cnt = __builtin_popcountll(in);
+    rows_used += (unsigned)cnt;
+    if (a) list[__builtin_popcountll(in & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int g0 = 0; g0 < ((diag & 1) ? 0 : cnt); g0 += 4) {           // wave-uniform
+      const bool live = g0 + k4 < cnt;
+      const int r = live ? list[g0 + k4] : 0;
+      double zc[NB16];
+#pragma unroll
+      for (int b = 0; b < NB16; b++) {
+        const double v = tile[r * nz + off[b]];
+        zc[b] = (live && colok[b]) ? v : 0.0;
+      }
+      int t = 0;
+#pragma unroll
+      for (int bi = 0; bi < NB16; bi++)
+#pragma unroll
+        for (int bj = bi; bj < NB16; bj++, t++)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[bi], zc[bj], acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // every wave is done with its tiles: the LDS becomes the fold area
+  double *fold = smd;
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int pos = t * 256 + (k4 + 4 * rg) * 16 + c16;
+          fold[pos] = (w == 0 ? 0.0 : fold[pos]) + acc[t][rg];
+        }
+      if (lane == 0) s_rows[w] = rows_used;
+    }
+    __syncthreads();
+  }
+  double *out = partials + (size_t)blockIdx.x * pstride;
+  const int ne = nz * (nz + 1) / 2;
+  for (int pos = threadIdx.x; pos < NT * 256; pos += 256) {
+    const int t = pos >> 8, r = (pos >> 4) & 15, cc = pos & 15;
+    int bi = 0, rem = t;
+    while (rem >= NB16 - bi) {
+      rem -= NB16 - bi;
+      bi++;
+    }
+    const int bj = bi + rem;
+    const int i = 16 * bi + r, j = 16 * bj + cc;
+    if (i <= j && j < nz) out[i * nz - i * (i - 1) / 2 + (j - i)] = fold[pos];
+  }
+  if (threadIdx.x == 0) {
+    const unsigned tot = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
+    out[ne] = (double)tot;
+    if (tot) atomicAdd(counter, (unsigned long long)tot);
+  }
 }
 
 // K5 dense: x = pinv(A) b from the normal equations block (DenseLinear...Estimator.hxx:64-96:

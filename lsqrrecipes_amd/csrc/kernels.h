@@ -298,17 +298,30 @@ __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ da
     const size_t cnt = rows * stride;
     const double *base = data + r0 * stride;
     uint32_t d = (uint32_t)(threadIdx.x % stride);
-    for (size_t e = threadIdx.x; e < cnt; e += kBlock) {
-      if ((int)d < nd && (int)d != skip) {  // US records: slot 12 holds an int + padding, not a double
-        double v = fabs(base[e]);
-        unsigned long long b;
-        if (!(v == v)) v = __builtin_inf();  // NaN observation: disables the filter
-        __builtin_memcpy(&b, &v, 8);
-        m = b > m ? b : m;
-        if ((int)d < nrot) mr = b > mr ? b : mr;
+    // eight loads per lane in flight (one at a time ran at 1.7 TB/s: nothing else covers the HBM latency of a pass
+    // that does no arithmetic); slots that hold no double (skip) are loaded and dropped
+    constexpr int U = 8;
+    for (size_t e = threadIdx.x; e < cnt; e += (size_t)U * kBlock) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const size_t eu = e + (size_t)u * kBlock;
+        v[u] = base[eu < cnt ? eu : cnt - 1];
       }
-      d += step;
-      if (d >= st) d -= st;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool in = e + (size_t)u * kBlock < cnt;
+        if (in && (int)d < nd && (int)d != skip) {  // US records: slot 12 holds an int + padding, not a double
+          double a = fabs(v[u]);
+          unsigned long long b;
+          if (!(a == a)) a = __builtin_inf();  // NaN observation: disables the filter
+          __builtin_memcpy(&b, &a, 8);
+          m = b > m ? b : m;
+          if ((int)d < nrot) mr = b > mr ? b : mr;
+        }
+        d += step;
+        if (d >= st) d -= st;
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -678,23 +691,31 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass_mfma(const double *__restric
   }
 }
 
-// grid = nmom blocks of one wave.  out: host-visible (or device) buffer of nmom + 1 doubles, out[nmom] = seq flag.
+// grid = nmom blocks of one wave.  out: host-visible pinned memory, 2 * nmom 8-byte GRANULES: moment k is published
+// as {high word | seq} and {low word | seq}, each one aligned 8-byte store -- a granule is valid the moment its tag
+// equals the sequence number of the evaluation the host is waiting for, so no fence, no ticket and no flag ordering
+// are needed (r02 published doubles + a flag behind __threadfence_system() per block and an agent-scope ticket:
+// 10.7 us per evaluation; MI355X_MICROARCH.md, "handoff-1to1": data-tagged granules).
 __global__ __launch_bounds__(64) void k_lm_publish(const double *__restrict__ partials, int nblocks, int nmom,
-                                                   unsigned int *__restrict__ ticket, double *__restrict__ out,
-                                                   double seq) {
+                                                   unsigned long long *__restrict__ out, uint32_t seq) {
   const int k = blockIdx.x;
   double t = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 64) t += partials[(size_t)b * MOM_MAX + k];
+  // fixed order: lane l sums blocks l, l + 64, ...; four loads in flight per lane
+  int b = threadIdx.x;
+  for (; b + 192 < nblocks; b += 256) {
+    const double a0 = partials[(size_t)b * MOM_MAX + k], a1 = partials[(size_t)(b + 64) * MOM_MAX + k],
+                 a2 = partials[(size_t)(b + 128) * MOM_MAX + k], a3 = partials[(size_t)(b + 192) * MOM_MAX + k];
+    t += a0;
+    t += a1;
+    t += a2;
+    t += a3;
+  }
+  for (; b < nblocks; b += 64) t += partials[(size_t)b * MOM_MAX + k];
   for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
   if (threadIdx.x != 0) return;
-  out[k] = t;
-  __threadfence_system();  // this sum is visible (host memory) before the ticket says so
-  const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (prev == (unsigned int)nmom - 1u) {
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next evaluation (stream order)
-    __threadfence_system();
-    __hip_atomic_store(&out[nmom], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, t);
+  __hip_atomic_store(&out[2 * k], (bits & 0xFFFFFFFF00000000ULL) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&out[2 * k + 1], (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // fixed-order sum of the per-block partials -> mom[0..nmom): one wave per moment, lane-strided
@@ -766,6 +787,7 @@ __global__ __launch_bounds__(64) void k_lm_advance(LmState *st, const double *__
     out->cont = cont ? 1 : 0;
     out->lm_info = s.info;
     out->lm_nfev = s.nfev;
+    out->pad = s.stall;
     if (!cont) {
       bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
       out->ok = ok ? 1 : 0;

@@ -21,11 +21,13 @@ enum { LM_NMAX = 11, LM_MOM_MAX = 1 + LM_NMAX * (LM_NMAX + 1) / 2 + LM_NMAX };
 
 struct LmState {
   int n, iter, nfev, info, maxfev, started;
+  int stall, pad0;  // stall: the last evaluation at which the cost still fell by more than 1e-7 relative (diagnostics)
   double ftol, xtol, gtol, factor;
   double x[LM_NMAX], xtrial[LM_NMAX], diag[LM_NMAX], qtf[LM_NMAX], acnorm[LM_NMAX], p[LM_NMAX];
   double r[LM_NMAX * LM_NMAX];
   int ipvt[LM_NMAX];
   double fnorm, par, delta, xnorm, gnorm, pnorm;
+  double cstall;    // the cost at `stall`
 };
 
 LSQR_HD int lm_mom_len(int n) { return 1 + n * (n + 1) / 2 + n; }
@@ -275,6 +277,9 @@ LSQR_HD void lm_init(LmState &s, int n, const double *x0, double ftol, double xt
   s.info = 0;
   s.maxfev = maxfev;
   s.started = 0;
+  s.stall = 0;
+  s.pad0 = 0;
+  s.cstall = 0.0;
   s.ftol = ftol;
   s.xtol = xtol;
   s.gtol = gtol;
@@ -294,6 +299,8 @@ LSQR_HD bool lm_advance(LmState &s, const double *mom) {
   if (!s.started) {
     s.started = 1;
     s.fnorm = sqrt(mom[0]);
+    s.stall = s.nfev;
+    s.cstall = mom[0];
     if (!lm_outer(s, mom)) return false;
     lm_trial(s);
     return true;
@@ -336,6 +343,10 @@ LSQR_HD bool lm_advance(LmState &s, const double *mom) {
     s.xnorm = lm_enorm(n, wa2);
     s.fnorm = fnorm1;
     s.iter++;
+    if (mom[0] < s.cstall * (1.0 - 1e-7)) {
+      s.cstall = mom[0];
+      s.stall = s.nfev;
+    }
   }
   bool small = fabs(actred) <= s.ftol && prered <= s.ftol && 0.5 * ratio <= 1.0;
   if (small) s.info = 1;

@@ -25,6 +25,7 @@
 #include "dense.h"
 #include "us_kernels.h"
 #include "cells.h"
+#include "earlyexit.h"
 #include "sort.h"
 #include "rigid.h"
 #include "phantom.h"
@@ -96,6 +97,11 @@ struct lsqr_ctx {
   uint32_t best_before = 0;         // exact votes of the best hypothesis of earlier batches (lsqr_ransac)
   bool allow_bound = false;         // set by the batch entry points around run_scan (lsqr_scan always counts all)
   uint64_t last_bound[4] = {0, 0, 0, 0};  // diagnostics of the last bounded scan: {used, pilots, rest, H}
+  // chunked early exit of the dense / US scans (earlyexit.h)
+  void *d_ee = nullptr;             // [EeState | sel_c | sel_o x 2 | compact thresholds | compact fp32 rows]
+  EeState *h_ee = nullptr;          // pinned copy of the last early-exit scan's state (read without synchronising)
+  bool ee_last = false;             // the last scan of this context took the early-exit path
+  uint64_t ee_H = 0, ee_n = 0;      // its batch size and observation count
   bool scanned = false;
   bool external_stream = false;
   // lsqr_batch_fit_enqueue / _wait run on LANES: independent contexts on the same device, each with its own stream
@@ -137,12 +143,15 @@ struct lsqr_ctx {
   bool origin_valid = false;
   int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1, opt_syrk_diag = 0;
   int opt_fuse_mask = 1;  // winner's mask + moment block in one pass (0: two kernels, for A/B runs)
+  int opt_mask_ring = 2;  // k_mask_syrk_dense: tile buffers per wave (2: two workgroups per CU; 4: one, three tiles in flight)
+  int opt_mask_diag = 0;  // timing diagnostics of k_mask_syrk_dense: 1 = no matrix instructions, 2 = no row evaluation
+  int opt_mask_band = 0;  // tests: scale factor of the dense fused mask's band (forces its serial re-evaluation path)
   long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
   LmState h_lm;  // host copy of the LM state (opt_lm_host)
   double *d_lmrec = nullptr;  // consensus set copied tight and in order for the iterative fits (k_compact_*)
   size_t lmrec_cap = 0;
-  double *h_lmres = nullptr;  // pinned, device-visible: {moment block, sequence flag} written by k_lm_pass
-  double lm_seq = 0.0;        // sequence number of the last evaluation (the flag value the host polls for)
+  unsigned long long *h_lmres = nullptr;  // pinned, device-visible: tagged granules written by k_lm_publish
+  uint32_t lm_seq = 0;        // sequence number of the last evaluation (the tag the host polls for)
   int opt_lm_mfma = 1;        // 1: the LM pass accumulates (J | f)^T (J | f) on the matrix cores; 0: per-lane sums
   int opt_lm_fused = 1;       // 1: one launch per LM evaluation, result polled in pinned memory; 0: r01 path
 
@@ -891,8 +900,192 @@ int run_scan_bounded(lsqr_ctx *c) {
   return LSQR_OK;
 }
 
+// ---- chunked early exit (earlyexit.h) ---------------------------------------------------------------------
+constexpr size_t kEeCap = 8192;  // hypotheses per batch the selection kernels handle
+struct EeBuf {
+  EeState *st;
+  uint32_t *sel_c, *sel_o[2];
+  float *thr_c, *rows_c;
+};
+int ee_buffers(lsqr_ctx *c, EeBuf *b) {
+  const size_t bytes = 256 + 3 * kEeCap * sizeof(uint32_t) + (2 + 64) * (kEeCap + 64) * sizeof(float);
+  if (!c->d_ee) HIPCHK(c, hipMalloc(&c->d_ee, bytes));
+  if (!c->h_ee) {
+    HIPCHK(c, hipHostMalloc((void **)&c->h_ee, 64));
+    memset(c->h_ee, 0, 64);
+  }
+  char *p = (char *)c->d_ee;
+  b->st = (EeState *)p;
+  b->sel_c = (uint32_t *)(p + 256);
+  b->sel_o[0] = b->sel_c + kEeCap;
+  b->sel_o[1] = b->sel_o[0] + kEeCap;
+  b->thr_c = (float *)(b->sel_o[1] + kEeCap);
+  b->rows_c = b->thr_c + 2 * (kEeCap + 64);
+  return LSQR_OK;
+}
+// scan(row_begin, row_end, range_dev, h_dev, sel): sel == null -> the context's whole batch over [row_begin, row_end),
+// else the compact selection the last gather(sel, n_dev) produced, over the device-side range range_dev (launch sized
+// for [row_begin, row_end)).  Everything is chained on the stream; no host round trip.
+template <class Scan, class Gather>
+int run_early_exit(lsqr_ctx *c, size_t align, const EeBuf &b, Scan &&scan, Gather &&gather) {
+  const size_t n = c->n;
+  const uint32_t H = (uint32_t)c->H;
+  size_t b1 = (n / 16 + align - 1) / align * align;
+  if (b1 > n) b1 = n;
+  int st;
+  HIPCHK(c, hipMemsetAsync(c->d_votes, 0, H * sizeof(uint32_t), c->stream));
+  // A: the first sixteenth, every hypothesis
+  if ((st = scan(0, b1, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr)) != LSQR_OK)
+    return st;
+  hipLaunchKernelGGL(k_ee_split, dim3(1), dim3(1024), 0, c->stream, c->d_votes, c->d_valid, H, b.sel_c, b.sel_o[0], b.st,
+                     (uint32_t)b1, (uint32_t)n);
+  HIPCHK(c, hipGetLastError());
+  if (b1 < n) {
+    // B: the candidates to the end
+    if ((st = gather(b.sel_c, &b.st->n_cand)) != LSQR_OK) return st;
+    if ((st = scan(b1, n, &b.st->rng[0][0], &b.st->n_cand, b.sel_c)) != LSQR_OK) return st;
+    hipLaunchKernelGGL(k_ee_plan, dim3(1), dim3(1024), 0, c->stream, c->d_votes, b.sel_c, b.st, c->best_before,
+                       (uint32_t)b1, (uint32_t)n, (uint32_t)align);
+    HIPCHK(c, hipGetLastError());
+    // C: the others over the planned ranges
+    int cur = 0;
+    for (int k = 1; k <= kEeChunksC; k++) {
+      if ((st = gather(b.sel_o[cur], &b.st->n_alive)) != LSQR_OK) return st;
+      if ((st = scan(b1, n, &b.st->rng[k][0], &b.st->n_alive, b.sel_o[cur])) != LSQR_OK) return st;
+      if (k < kEeChunksC) {
+        hipLaunchKernelGGL(k_ee_select, dim3(1), dim3(1024), 0, c->stream, c->d_votes, c->d_valid, H, (uint32_t)n, k,
+                           c->best_before, b.sel_o[cur], b.sel_o[cur ^ 1], b.st);
+        HIPCHK(c, hipGetLastError());
+        cur ^= 1;
+      }
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_ee, b.st, sizeof(EeState), hipMemcpyDeviceToHost, c->stream));
+  c->ee_last = true;
+  c->ee_H = H;
+  c->ee_n = n;
+  return LSQR_OK;
+}
+
+// dense system, n > 32: the fp32 matrix-core filter (dense.h: k_scan_dense_mfma32r) over row chunks and compacted
+// selections; the band of every chunk is decided exactly (k_dense_recheck_seg) before the next selection looks at the
+// votes.  Returns LSQR_OK with *done = false when a worklist segment overflowed (the caller counts everything with
+// the fp64 filter instead).
+int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
+  *done = false;
+  EeBuf b;
+  int st = ee_buffers(c, &b);
+  if (st != LSQR_OK) return st;
+  const uint32_t H = (uint32_t)c->H;
+  const uint32_t seg_cap = kAmbCap / 1024;
+  float *d_thr32 = (float *)c->d_partials;
+  float *d_sp32 = (float *)c->d_partials + 2 * 8192;
+  unsigned int *d_segcnt = (unsigned int *)((float *)c->d_partials + 2 * 8192 + 64 * 8192);
+  ProfScope whole(c, KID_SCAN);
+  struct Mute {
+    lsqr_ctx *c;
+    bool was;
+    ~Mute() { c->prof = was; }
+  } mute{c, c->prof};
+  c->prof = false;
+  HIPCHK(c, hipMemsetAsync(d_segcnt, 0, 1024 * sizeof(unsigned int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_dense_thresholds32, dim3((H + 255) / 256), dim3(256), 0, c->stream, c->d_hparams, H,
+                     (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot, c->mc.absmax, d_thr32, d_sp32);
+  HIPCHK(c, hipGetLastError());
+  auto scan = [&](size_t rb, size_t re, const uint32_t *range_dev, const uint32_t *h_dev, const uint32_t *sel) -> int {
+    if (rb >= re) return LSQR_OK;
+    const size_t tiles = (re - rb + 63) / 64;
+    const size_t nb2 = std::min<size_t>(tiles, 512);  // two workgroups per CU
+    const size_t rpb = (tiles + nb2 - 1) / nb2 * 64;
+    const size_t nblk = (re - rb + rpb - 1) / rpb;
+    const float *rows = sel ? b.rows_c : d_sp32, *thr = sel ? b.thr_c : d_thr32;
+    constexpr size_t kRingChunk = 1024;  // 62.7 KiB of LDS per workgroup: two per CU
+    for (size_t h0 = 0; h0 < H; h0 += kRingChunk) {
+      const uint32_t hc = (uint32_t)std::min<size_t>(kRingChunk, H - h0);
+      const uint32_t nhb2 = (((hc + 63) / 64) + 1) & ~1u;
+      const size_t lds = sizeof(float) * (8192 + 64 * kDmPitch32 + 64 + 128 * nhb2) + sizeof(uint32_t) * (hc + 1);
+      hipLaunchKernelGGL((k_scan_dense_mfma32r<64>), dim3((unsigned)nblk), dim3(256), lds, c->stream, c->d_data,
+                         c->stride, rb, re, rpb, rows + h0 * 64, thr + 2 * h0, hc, (int)c->cfg.dim, c->d_votes,
+                         c->d_amb, d_segcnt, seg_cap, (uint32_t)h0, h_dev, sel, range_dev);
+      HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_dense_recheck_seg<64>), dim3(512), dim3(256), 0, c->stream, c->d_data, c->stride,
+                       c->d_hparams, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes, (unsigned int *)(c->d_counter + 3));
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  };
+  auto gather = [&](const uint32_t *sel, const uint32_t *n_dev) -> int {
+    hipLaunchKernelGGL(k_ee_gather_f32, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel, n_dev, H,
+                       (const float *)d_sp32, 64, b.rows_c, (const float *)d_thr32, 2, b.thr_c, -1.0f);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  };
+  if ((st = run_early_exit(c, 64, b, scan, gather)) != LSQR_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->dense_amb_max = *(unsigned int *)c->h_pin;
+  if (c->dense_amb_max <= seg_cap) {
+    *done = true;
+    return LSQR_OK;
+  }
+  c->ee_last = false;
+  (void)fail(c, LSQR_OK, "dense fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used", c->dense_amb_max,
+             seg_cap);
+  return LSQR_OK;
+}
+
+// US calibrations / plane phantom: k_scan_us_f32 over frame chunks and compacted selections
+template <class M>
+int run_scan_us_ee(lsqr_ctx *c) {
+  EeBuf b;
+  int st = ee_buffers(c, &b);
+  if (st != LSQR_OK) return st;
+  const uint32_t H = (uint32_t)c->H;
+  const int np = c->opt_ppl == 2 ? 1 : 2;
+  const size_t tile = (size_t)kBlock * 2 * np;
+  ProfScope whole(c, KID_SCAN);
+  struct Mute {
+    lsqr_ctx *c;
+    bool was;
+    ~Mute() { c->prof = was; }
+  } mute{c, c->prof};
+  c->prof = false;
+  auto scan = [&](size_t rb, size_t re, const uint32_t *range_dev, const uint32_t *h_dev, const uint32_t *sel) -> int {
+    if (rb >= re) return LSQR_OK;
+    const size_t tiles = (re - rb + tile - 1) / tile;
+    const size_t lds = (size_t)H * sizeof(uint32_t);
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    const size_t max_blocks = (size_t)256 * per_cu;
+    const size_t tpb = (tiles + max_blocks - 1) / max_blocks;
+    const int grid = (int)((tiles + tpb - 1) / tpb);
+    unsigned ysplit = (unsigned)std::min<size_t>(std::max<size_t>(1, (size_t)256 * 5 / (size_t)grid),
+                                                 std::max<size_t>(1, H / 256));
+    if (c->opt_hsplit > 0) ysplit = (unsigned)c->opt_hsplit;
+    const double *sp = sel ? c->d_hparams2 : c->d_hparams;
+    const float *spf = sel ? c->d_hparams2_f32 : c->d_hparams_f32;
+    if (np == 1)
+      hipLaunchKernelGGL((k_scan_us_f32<M, 1>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream, c->d_data, c->stride,
+                         rb, re, sp, spf, H, c->mc, c->d_votes, h_dev, sel, range_dev);
+    else
+      hipLaunchKernelGGL((k_scan_us_f32<M, 2>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream, c->d_data, c->stride,
+                         rb, re, sp, spf, H, c->mc, c->d_votes, h_dev, sel, range_dev);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  };
+  auto gather = [&](const uint32_t *sel, const uint32_t *n_dev) -> int {
+    hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel, n_dev, H, c->d_hparams,
+                       (int)M::SP, c->d_hparams_f32, (int)M::SPF, c->d_hparams2, c->d_hparams2_f32);
+    HIPCHK(c, hipGetLastError());
+    return LSQR_OK;
+  };
+  return run_early_exit(c, tile, b, scan, gather);
+}
+
 int run_scan(lsqr_ctx *c) {
   c->hyp_since_upload += c->H;
+  c->ee_last = false;
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     if constexpr (M::IS_DENSE) {  // default: MFMA filter + exact recheck of ambiguous pairs
@@ -901,6 +1094,16 @@ int run_scan(lsqr_ctx *c) {
         if (st != LSQR_OK) return st;
         if (!c->d_amb) HIPCHK(c, hipMalloc((void **)&c->d_amb, sizeof(unsigned long long) * kAmbCap));
         if (c->mc.absmax <= 1e100) {  // finite, sane magnitudes: the filter's bound applies
+          if constexpr (M::NR == 64) {
+            // batch entry points: chunked early exit (earlyexit.h) -- hypotheses that can no longer become the running
+            // maximum stop being counted
+            if (c->allow_bound && c->opt_bound && c->opt_dense_f32 == 2 && !c->opt_dense_v1 && c->H >= 128 &&
+                c->H <= kEeCap && c->n >= 65536 && c->mc.absmax < 1e15) {
+              bool done = false;
+              if ((st = run_scan_dense_ee(c, &done)) != LSQR_OK) return st;
+              if (done) return LSQR_OK;
+            }
+          }
           HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
           HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
           double *d_thr = c->d_partials;  // scratch: 2 doubles per hypothesis (H <= 2^20 checked)
@@ -937,8 +1140,9 @@ int run_scan(lsqr_ctx *c) {
                     const uint32_t nhb2 = (((hc + 63) / 64) + 1) & ~1u;
                     size_t lds = sizeof(float) * (8192 + 64 * kDmPitch32 + 64 + 128 * nhb2) + sizeof(uint32_t) * (hc + 1);
                     hipLaunchKernelGGL((k_scan_dense_mfma32r<64>), dim3((unsigned)nblk), dim3(256), lds, c->stream,
-                                       c->d_data, c->stride, c->n, rpb, d_sp32 + h0 * 64, d_thr32 + 2 * h0, hc,
-                                       (int)c->cfg.dim, c->d_votes + h0, c->d_amb, d_segcnt, seg_cap, (uint32_t)h0);
+                                       c->d_data, c->stride, (size_t)0, c->n, rpb, d_sp32 + h0 * 64, d_thr32 + 2 * h0, hc,
+                                       (int)c->cfg.dim, c->d_votes, c->d_amb, d_segcnt, seg_cap, (uint32_t)h0,
+                                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
                     HIPCHK(c, hipGetLastError());
                   }
                 } else
@@ -1025,6 +1229,9 @@ int run_scan(lsqr_ctx *c) {
     }
     if constexpr (requires { M::NF32; }) {  // packed fp32 pre-filter (scan_filter 1); US: 2 = the fused fp64 filter
       if (c->opt_filter == 1 && c->absmax_valid && c->mc.absmax <= 1e15) {
+        c->ee_last = false;
+        if (c->allow_bound && c->opt_bound && c->H >= 256 && c->H <= kEeCap && c->n >= 65536)
+          return run_scan_us_ee<M>(c);  // batch entry points: chunked early exit (earlyexit.h)
         const int np = c->opt_ppl == 2 ? 1 : 2;  // pairs of frames per lane (scan_ppl 2 / 4)
         HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
         size_t tiles = (c->n + (size_t)kBlock * 2 * np - 1) / ((size_t)kBlock * 2 * np);
@@ -1043,12 +1250,14 @@ int run_scan(lsqr_ctx *c) {
           ProfScope ps(c, KID_SCAN);
           if (np == 1)
             hipLaunchKernelGGL((k_scan_us_f32<M, 1>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
-                               c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
-                               c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
+                               c->d_data, c->stride, (size_t)0, c->n, c->d_hparams + h0 * M::SP,
+                               c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr);
           else
             hipLaunchKernelGGL((k_scan_us_f32<M, 2>), dim3(grid, ysplit), dim3(kBlock), lds, c->stream,
-                               c->d_data, c->stride, c->n, c->d_hparams + h0 * M::SP,
-                               c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0);
+                               c->d_data, c->stride, (size_t)0, c->n, c->d_hparams + h0 * M::SP,
+                               c->d_hparams_f32 + h0 * M::SPF, hc, c->mc, c->d_votes + h0, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr);
           HIPCHK(c, hipGetLastError());
         }
         return LSQR_OK;
@@ -1326,7 +1535,7 @@ int enqueue_fit(lsqr_ctx *c, int use_mask, bool have_moments = false) {
     typedef typename decltype(tag)::type M;
     int nmom = 0, st;
     if constexpr (M::IS_DENSE) {
-      if ((st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
+      if (!have_moments && (st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
       return launch_solve_dense(c);
     } else {
       if (!have_moments) {
@@ -1364,7 +1573,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
       phantom_solve_block(c->cfg, (const double *)c->h_pin, out);
       return LSQR_OK;
     } else if constexpr (M::IS_DENSE) {
-      if ((st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
+      if (!have_moments && (st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
       if ((st = launch_solve_dense(c)) != LSQR_OK) return st;
       return read_out(c, out);
     } else {
@@ -1448,9 +1657,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           };
           if (use_mask && mfma_pass && (st = compact()) != LSQR_OK) return st;
           shape();
-          volatile double *res = c->h_lmres;
-          // the ticket word is zeroed per fit (an aborted launch must not poison the next one)
-          HIPCHK(c, hipMemsetAsync(c->d_counter + 7, 0, sizeof(unsigned long long), c->stream));
+          volatile unsigned long long *res = c->h_lmres;
           for (;;) {
             if (through_mask && s.nfev >= kCompactAfter) {
               if ((st = compact()) != LSQR_OK) return st;
@@ -1458,7 +1665,8 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             }
             LmX xk;
             for (int j = 0; j < LM_NMAX; j++) xk.x[j] = j < n ? s.xtrial[j] : 0.0;
-            const double seq = (c->lm_seq += 1.0);
+            uint32_t seq = ++c->lm_seq;
+            if (seq == 0) seq = c->lm_seq = 1;  // (the zero-initialised granules carry tag 0)
             // profiling: every 16th evaluation carries event pairs (four event records per evaluation would cost
             // more host time than the evaluation's own launches); lsqr_profile_get's averages are unaffected
             const bool timed = c->prof && (s.nfev & 15) == 0;
@@ -1493,23 +1701,27 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             {
               ProfScope ps(c, KID_SOLVE);
               hipLaunchKernelGGL(k_lm_publish, dim3((unsigned)M::NMOM_LM), dim3(64), 0, c->stream, c->d_partials, nb,
-                                 (int)M::NMOM_LM, (unsigned int *)(c->d_counter + 7), c->h_lmres, seq);
+                                 (int)M::NMOM_LM, c->h_lmres, seq);
               HIPCHK(c, hipGetLastError());
             }
             c->prof = prof_saved;
+            // poll the granules in order: each one is valid as soon as its tag is this evaluation's
             unsigned long long spins = 0;
-            while (res[M::NMOM_LM] != seq) {
-              if ((++spins & 0xFFFF) == 0) {  // every 65 k polls: is the stream still alive?
-                hipError_t q = hipStreamQuery(c->stream);
-                if (q != hipSuccess && q != hipErrorNotReady)
-                  return fail(c, LSQR_ERR_HIP, "LM pass failed: %s", hipGetErrorString(q));
-                if (q == hipSuccess && res[M::NMOM_LM] != seq)
-                  return fail(c, LSQR_ERR_HIP, "LM pass finished without publishing its result");
-              }
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
             double blk[LM_MOM_MAX];
-            for (int j = 0; j < (int)M::NMOM_LM; j++) blk[j] = res[j];
+            for (int j = 0; j < (int)M::NMOM_LM; j++) {
+              unsigned long long g0, g1;
+              while ((uint32_t)(g0 = res[2 * j]) != seq || (uint32_t)(g1 = res[2 * j + 1]) != seq) {
+                if ((++spins & 0xFFFF) == 0) {  // every 65 k polls: is the stream still alive?
+                  hipError_t q = hipStreamQuery(c->stream);
+                  if (q != hipSuccess && q != hipErrorNotReady)
+                    return fail(c, LSQR_ERR_HIP, "LM pass failed: %s", hipGetErrorString(q));
+                  if (q == hipSuccess && ((uint32_t)res[2 * j] != seq || (uint32_t)res[2 * j + 1] != seq))
+                    return fail(c, LSQR_ERR_HIP, "LM pass finished without publishing its result");
+                }
+              }
+              const unsigned long long bits = (g0 & 0xFFFFFFFF00000000ULL) | (g1 >> 32);
+              memcpy(&blk[j], &bits, 8);
+            }
             if (!lm_advance(s, blk)) break;
           }
           HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1529,6 +1741,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
         out->cont = 0;
         out->lm_info = s.info;
         out->lm_nfev = s.nfev;
+        out->pad = s.stall;
         out->cost = s.fnorm * s.fnorm;
         int np = M::lm_finalize(s.x, out->params);
         out->n_params = ok ? np : 0;
@@ -1589,9 +1802,13 @@ int launch_mask(lsqr_ctx *c, size_t begin, size_t end) {
   return LSQR_OK;
 }
 
+int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *fused);
 int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t *count_out) {
-  int st = launch_mask(c, begin, end);
-  if (st != LSQR_OK) return st;
+  int st, nm = 0;
+  bool fused = false;
+  // dense system: the one-pass kernel (mask + block of sums, dense.h: k_mask_syrk_dense) is the faster mask as well
+  if (c->cfg.model == LSQR_MODEL_DENSE && (st = launch_mask_moments(c, begin, end, &nm, &fused)) != LSQR_OK) return st;
+  if (!fused && (st = launch_mask(c, begin, end)) != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
   if (mask_out)
@@ -1607,10 +1824,58 @@ int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t 
 // whose moments are not a per-record accumulate (dense: SYRK on the matrix cores; phantom: Gram of the rows).
 int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *fused) {
   *fused = false;
-  if (c->cfg.model == LSQR_MODEL_DENSE || c->cfg.model == LSQR_MODEL_PHANTOM || !c->opt_fuse_mask)
-    return LSQR_OK;
+  if (c->cfg.model == LSQR_MODEL_PHANTOM || !c->opt_fuse_mask) return LSQR_OK;
   int st = ensure(c, &c->d_mask, &c->mask_cap, c->n);
   if (st != LSQR_OK) return st;
+  if (c->cfg.model == LSQR_MODEL_DENSE) {
+    // dense system: mask + sum z z^T of the agreeing rows in one pass (dense.h: k_mask_syrk_dense); tight records
+    // and the matrix-core path only -- anything else keeps the two kernels
+    const int n = c->cfg.dim, nz = n + 1;
+    if (c->stride != (size_t)nz || !c->opt_filter || c->opt_syrk_diag || end <= begin ||
+        ((uintptr_t)c->d_data & 15) != 0 || ((begin * (size_t)nz) & 1) != 0)  // 16-byte pieces from the first row on
+      return LSQR_OK;
+    if ((st = ensure_absmax(c)) != LSQR_OK) return st;  // magnitudes for the band of the four-chain evaluation
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    const size_t cnt = end - begin;
+    const int nbuf = (c->opt_mask_ring == 4 && n == 64) ? 4 : 2;
+    int nb = grid_for(cnt, 64 * 4, nbuf == 2 ? 512 : 256);   // two workgroups per CU / one
+    size_t chunk = (cnt + nb - 1) / nb;
+    chunk = (chunk + 63) / 64 * 64;                 // whole rounds of the four waves' 16-row tiles
+    nb = (int)((cnt + chunk - 1) / chunk);
+    const int ps = dense_pstride(n), nb16 = (nz + 15) / 16;
+    const size_t lds = std::max<size_t>(sizeof(double) * (4 * nbuf * 16 * nz + 64) + 128, sizeof(double) * 15 * 256);
+    if ((size_t)nb * ps > (size_t)2 * kDenseBlocks * 2160) return LSQR_OK;  // (partials area: 512 x 2160 doubles)
+    *nmom = dense_ne(n) + 1;
+    {
+      ProfScope ps_(c, KID_MASK);
+      auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, c->stream, c->d_data, begin, end, chunk, n, c->d_par,
+                           c->mc.delta, c->d_mask, c->d_counter, ps, c->d_partials, c->mc.absmax_rot, c->mc.absmax,
+                           c->opt_mask_band > 0 ? (double)c->opt_mask_band : 1.0, c->opt_mask_diag);
+      };
+      if (nbuf == 4) {
+        launch(k_mask_syrk_dense<5, 4>);   // (A/B arrangement, n = 64 only)
+      } else
+      switch (nb16) {
+        case 1: launch(k_mask_syrk_dense<1, 2>); break;
+        case 2: launch(k_mask_syrk_dense<2, 2>); break;
+        case 3: launch(k_mask_syrk_dense<3, 2>); break;
+        case 4: launch(k_mask_syrk_dense<4, 2>); break;
+        default: launch(k_mask_syrk_dense<5, 2>); break;
+      }
+      HIPCHK(c, hipGetLastError());
+    }
+    {
+      ProfScope ps_(c, KID_SOLVE);
+      hipLaunchKernelGGL(k_reduce, dim3(*nmom), dim3(64), 0, c->stream, c->d_partials, nb, ps, *nmom, c->d_mom);
+      HIPCHK(c, hipGetLastError());
+    }
+    c->mask_valid = true;
+    c->origin_valid = true;
+    *fused = true;
+    return LSQR_OK;
+  }
   st = dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     if constexpr (M::IS_DENSE || requires { M::IS_PHANTOM; }) {
@@ -1815,7 +2080,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
   c->device = device;
   bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipMalloc((void **)&c->d_partials, sizeof(double) * kDenseBlocks * 2160) == hipSuccess &&
+            hipMalloc((void **)&c->d_partials, sizeof(double) * 2 * kDenseBlocks * 2160) == hipSuccess &&
             hipMalloc((void **)&c->d_mom, sizeof(double) * 4096) == hipSuccess &&
             hipMalloc((void **)&c->d_vec, sizeof(double) * 128) == hipSuccess &&
             hipMalloc((void **)&c->d_par, sizeof(double) * 128) == hipSuccess &&
@@ -1824,9 +2089,9 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
             hipMalloc((void **)&c->d_out, sizeof(SolveOut)) == hipSuccess &&
             hipMalloc((void **)&c->d_counter, 64) == hipSuccess &&
             hipHostMalloc(&c->h_pin, 1 << 16) == hipSuccess &&
-            hipHostMalloc((void **)&c->h_lmres, sizeof(double) * 128, hipHostMallocCoherent) == hipSuccess;
+            hipHostMalloc((void **)&c->h_lmres, sizeof(unsigned long long) * 256, hipHostMallocCoherent) == hipSuccess;
   if (ok) {
-    memset(c->h_lmres, 0, sizeof(double) * 128);
+    memset(c->h_lmres, 0, sizeof(unsigned long long) * 256);
     ok = hipMemsetAsync(c->d_counter, 0, 64, c->own_stream) == hipSuccess;
   }
   c->stream = c->own_stream;
@@ -2331,6 +2596,7 @@ static void fill_info(const SolveOut &out, lsqr_fit_info *info) {
   info->n_params = out.n_params;
   info->lm_info = out.lm_info;
   info->lm_nfev = out.lm_nfev;
+  info->reserved = out.pad;  // LM: the evaluation after which the cost never again fell by more than 1e-7 relative
   info->cost = out.cost;
 }
 
@@ -2432,6 +2698,7 @@ int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *con
     memset(&fi, 0, sizeof fi);
     fi.lm_info = s.info;
     fi.lm_nfev = s.nfev;
+    fi.reserved = s.stall;
     fi.cost = s.fnorm * s.fnorm;
     if (go) {
       if (x_trial_out)
@@ -2659,6 +2926,7 @@ static int finish_ransac(lsqr_ctx *c, bool has_best, uint32_t best_votes, double
   info->fit.n_params = out.ok ? out.n_params : 0;
   info->fit.lm_info = out.lm_info;
   info->fit.lm_nfev = out.lm_nfev;
+  info->fit.reserved = out.pad;
   info->fit.cost = out.cost;
   info->fit.n_used = cnt;
   if (!out.ok) return LSQR_EMPTY;
@@ -2842,6 +3110,7 @@ int lsqr_batch_fit(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H, double 
     info->fit.n_params = info->n_params;
     info->fit.lm_info = out.lm_info;
     info->fit.lm_nfev = out.lm_nfev;
+    info->fit.reserved = out.pad;
     info->fit.n_used = cnt;
     info->fit.cost = out.cost;
   }
@@ -3159,6 +3428,7 @@ int lsqr_step_finish_wait(lsqr_ctx *c, int slot, double *winner_out, double *par
     info->fit.n_params = info->n_params;
     info->fit.lm_info = out.lm_info;
     info->fit.lm_nfev = out.lm_nfev;
+    info->fit.reserved = out.pad;
     info->fit.cost = out.cost;
     info->fit.n_used = (uint64_t)(count + 0.5);
     info->fraction = c->n ? count / (double)c->n : 0.0;
@@ -3665,6 +3935,18 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     c->opt_hsplit = value;
     return LSQR_OK;
   }
+  if (!strcmp(name, "dense_mask_ring")) {  // A/B: 2 (default) or 4 tile buffers per wave
+    c->opt_mask_ring = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_mask_diag")) {  // timing diagnostics (wrong results): 1 no MFMA, 2 no row evaluation
+    c->opt_mask_diag = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_mask_band")) {  // tests: widen the band of k_mask_syrk_dense's four-chain evaluation
+    c->opt_mask_band = value;
+    return LSQR_OK;
+  }
   if (!strcmp(name, "fuse_mask")) {  // winner's mask + moment block in one pass (default) or two kernels
     c->opt_fuse_mask = value != 0;
     return LSQR_OK;
@@ -3747,6 +4029,27 @@ int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[8]) {
   out[5] = h_sel[0];
   out[6] = h_sel[1];
   out[7] = bounded ? pin[1] : pin[0];
+  return LSQR_OK;
+}
+
+int lsqr_scan_work(lsqr_ctx *c, uint64_t out[6]) {
+  int st = need_ready(c, true);
+  if (st != LSQR_OK) return st;
+  if (!out) return fail(c, LSQR_ERR_INVALID, "null argument");
+  if (c->H == 0 || !c->scanned) return fail(c, LSQR_ERR_STATE, "no scanned batch");
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the state of the last early-exit scan has landed in h_ee
+  const uint64_t all = (uint64_t)c->H * (uint64_t)c->n;
+  memset(out, 0, 6 * sizeof(uint64_t));
+  out[2] = all;
+  if (c->ee_last && c->h_ee && c->ee_H == c->H && c->ee_n == c->n) {
+    out[0] = 1;
+    out[1] = c->h_ee->work;
+    out[3] = c->h_ee->n_cand;
+    out[4] = c->h_ee->n_drop_first;
+    out[5] = c->h_ee->n_alive;
+  } else {
+    out[1] = all;
+  }
   return LSQR_OK;
 }
 

@@ -74,26 +74,41 @@ __global__ __launch_bounds__(256) void k_prepare_f32_us(const double *__restrict
 // records and evaluate the exact predicate (bit-identical votes; same counting scheme as k_scan).
 template <class M, int NP>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_scan_us_f32(const double *__restrict__ data, size_t stride,
-                                                        size_t n, const double *__restrict__ sp,
+                                                        size_t n_begin, size_t n, const double *__restrict__ sp,
                                                         const float *__restrict__ spf, uint32_t H,
-                                                        ModelConsts mc, uint32_t *__restrict__ votes) {
+                                                        ModelConsts mc, uint32_t *__restrict__ votes,
+                                                        const uint32_t *__restrict__ h_dev,
+                                                        const uint32_t *__restrict__ sel,
+                                                        const uint32_t *__restrict__ range_dev) {
+  if (range_dev) {  // the frame range comes from device memory (planned by k_ee_plan)
+    n_begin = range_dev[0];
+    n = range_dev[1];
+  }
+  // Frames [n_begin, n) against the batch's hypotheses -- the context's batch itself (sel == null) or a compacted
+  // selection of it (early exit, earlyexit.h: sp / spf are the selection's compact rows, sel[] maps positions to
+  // hypothesis indices, *h_dev is the selection's size).  votes[] is indexed by hypothesis index.
   constexpr int NFLD = M::NFLD, NF = M::NF32;
   extern __shared__ uint32_t s_cnt[];
+  if (h_dev) {
+    const uint32_t hd = *h_dev;
+    H = hd < H ? hd : H;
+  }
   // blockIdx.y selects a segment of the hypothesis range: more resident waves when the observations
   // alone give fewer tiles than the chip has wave slots
+  uint32_t hb0;
   {
     const uint32_t hseg = (H + gridDim.y - 1) / gridDim.y, hb = blockIdx.y * hseg;
     if (hb >= H) return;
     sp += (size_t)hb * M::SP;
     spf += (size_t)hb * M::SPF;
-    votes += hb;
+    hb0 = hb;
     H = hb + hseg < H ? hseg : H - hb;
   }
   for (uint32_t h = threadIdx.x; h < H; h += kBlock) s_cnt[h] = 0;
   __syncthreads();
   const size_t tile = (size_t)kBlock * 2 * NP;
   const bool leader = (threadIdx.x & 63) == 0;
-  for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
+  for (size_t base = n_begin + (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
     v2f xs[NP][NFLD];
 #pragma unroll
     for (int q = 0; q < NP; q++) {
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
   __syncthreads();
   for (uint32_t h = threadIdx.x; h < H; h += kBlock) {
     uint32_t c = s_cnt[h];
-    if (c) atomicAdd(&votes[h], c);
+    if (c) atomicAdd(&votes[sel ? sel[hb0 + h] : hb0 + h], c);
   }
 }
 

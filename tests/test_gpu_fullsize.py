@@ -44,6 +44,26 @@ def _pick(votes, valid, bi, n_good, n_total, seed):
     return out[:max(n_total, 3 + n_good)]
 
 
+def _early_exit_equals_full(ctx, r_full, valid, votes, H, n):
+    """the same batch through the chunked early exit (scan_bound 1, what bench.py times as value_early_exit): winner,
+    consensus set and fit identical; an abandoned hypothesis reports a partial count that is inert in the replay"""
+    ctx.set_option("scan_bound", 1)
+    r = ctx.batch_fit(SEED, 0, H, want_consensus=True)
+    w = ctx.scan_work()
+    _, valid1, v1 = ctx.hypotheses(params=False)
+    assert w["early_exit"] and w["row_hypothesis_pairs"] < H * n
+    assert r["info"].best_index == r_full["info"].best_index and r["info"].best_votes == r_full["info"].best_votes
+    assert np.array_equal(r["consensus"], r_full["consensus"]) and np.array_equal(r["params"], r_full["params"])
+    assert np.array_equal(valid1, valid) and np.all(v1 <= votes)
+    run = np.maximum.accumulate(np.where(valid > 0, votes, 0))
+    prev = np.concatenate([[0], run[:-1]])
+    rec = (valid > 0) & (votes > prev)                     # the serial loop's new maxima (strict '>')
+    assert np.array_equal(v1[rec], votes[rec])
+    part = v1 != votes
+    assert np.all(votes[part] <= prev[part])
+    return w
+
+
 def _point_model_fullsize(ctx, model, omodel, gen, ls_type, expect_cell):
     n, H = 10_000_000, 4096
     data, truth, lab = gen(n, 0.5)                       # bench.py: make_data(workload, 10 M, 0.5)
@@ -80,6 +100,19 @@ def _point_model_fullsize(ctx, model, omodel, gen, ls_type, expect_cell):
     wcnt, wmask = O.scan(oc, par[bi], data)
     assert wcnt == info.best_votes == info.fit.n_used
     assert np.array_equal(r["consensus"], wmask), "winner's consensus mask differs from the oracle"
+    # the same batch with every hypothesis counted (scan_bound 0: bench.py's `value` = value_full_count): every vote
+    # of the sample exact, winner / consensus / fit identical
+    ctx.set_option("scan_bound", 0)
+    r0 = ctx.batch_fit(SEED, 0, H, want_consensus=True)
+    _, valid0, votes0 = ctx.hypotheses(params=False)
+    ctx.set_option("scan_bound", 1)
+    assert np.array_equal(valid0, valid)
+    for h in checked:
+        if valid[h]:
+            assert votes0[h] == O.scan(oc, par[h], data)[0], "full count differs at h=%d" % h
+    assert np.all(votes <= votes0) and np.all((votes == votes0) | (votes == 0))
+    assert r0["info"].best_index == info.best_index and r0["info"].best_votes == info.best_votes
+    assert np.array_equal(r0["consensus"], r["consensus"]) and np.array_equal(r0["params"], r["params"])
     want = O.ls(oc, data, wmask)
     assert len(want) == len(r["params"]) > 0
     return r, want, truth, lab, wmask
@@ -103,6 +136,26 @@ def test_config2_plane_10M_batch_on_bench_path(ctx):
     data = synth.plane(10_000_000, 0.5)[0]
     wcnt, wm = O.scan(oc, par[bi], data)
     assert wcnt == votes[bi] == r2["info"].best_votes and np.array_equal(r2["consensus"], wm)
+    # bench.py's timed region drives the steps through lsqr_batch_fit_enqueue / _wait on FOUR lanes (streams with
+    # their own buffers and index): at full size, both rates, every lane's step must be the blocking call's step --
+    # whose winner mask is compared with the oracle
+    for bound in (1, 0):
+        ctx.set_option("scan_bound", bound)
+        ctx.set_option("batch_lanes", 4)
+        for sl in range(4):
+            ctx.batch_fit_enqueue(SEED, sl * 4096, 4096, slot=sl)
+        lanes = [ctx.batch_fit_wait(sl) for sl in range(4)]
+        for sl in range(4):
+            rb = ctx.batch_fit(SEED, sl * 4096, 4096, want_consensus=True)
+            parb, _, votesb = ctx.hypotheses()
+            bib = int(rb["info"].best_index) - sl * 4096
+            cnt, mask = O.scan(oc, parb[bib], data)
+            assert cnt == rb["info"].best_votes and np.array_equal(rb["consensus"], mask), (bound, sl)
+            la = lanes[sl]["info"]
+            assert (la.best_index, la.best_votes, la.fit.n_used) == (
+                rb["info"].best_index, rb["info"].best_votes, rb["info"].fit.n_used), (bound, sl)
+            assert np.array_equal(lanes[sl]["params"], rb["params"]), (bound, sl)
+    ctx.set_option("scan_bound", 1)
 
 
 def test_config3_sphere_10M_geometric_on_bench_path(ctx):
@@ -125,6 +178,7 @@ def test_config4_dense_2Mx64_on_bench_path(ctx):
     rows, x_true, lab = synth.dense(m, ncol, 0.05)               # bench.py: make_data("dense", 2 M, .)
     oc = O.cfg(O.DENSE, ncol, 0.1)
     ctx.set_model(L.DENSE, ncol, 0.1, L.LS_GEOMETRIC).upload(rows)
+    ctx.set_option("scan_bound", 0)                               # bench.py's value_full_count: every vote exact
     r = ctx.batch_fit(SEED, 0, H, want_consensus=True)
     assert r["status"] == L.OK
     info = r["info"]
@@ -149,6 +203,7 @@ def test_config4_dense_2Mx64_on_bench_path(ctx):
     want = np.linalg.lstsq(sel[:, :ncol], sel[:, ncol], rcond=None)[0]
     scale = max(1.0, np.abs(want).max())
     assert np.abs(r["params"] - want).max() <= REL * scale
+    _early_exit_equals_full(ctx, r, valid, votes, H, m)           # bench.py's value_early_exit on the same batch
     # the oracle's restatement on a subset of the consensus set, device fit of the same subset
     sub = np.ascontiguousarray(sel[:100_000])
     ctx.upload(sub)
@@ -166,6 +221,7 @@ def test_config5_us_1M_frames_on_bench_path(ctx):
     rec, truth, lab = synth.us_single_fast(n, 0.5)              # bench.py: make_data("us", 1 M, 0.5)
     oc = O.cfg(O.US_SINGLE, 0, 3.0, 0)
     ctx.set_model(L.US_SINGLE, 3, 3.0, L.LS_ANALYTIC).upload(rec)
+    ctx.set_option("scan_bound", 0)                               # bench.py's value_full_count: every vote exact
     r = ctx.batch_fit(SEED, 0, H, want_consensus=True)
     assert r["status"] == L.OK
     info = r["info"]
@@ -189,6 +245,8 @@ def test_config5_us_1M_frames_on_bench_path(ctx):
     assert len(want) == len(r["params"]) == 20
     assert np.allclose(r["params"], want, rtol=REL, atol=REL * np.abs(want).max())
     assert (wmask.astype(bool) & ~lab).sum() <= 0.02 * n
+    w = _early_exit_equals_full(ctx, r, valid, votes, H, n)       # bench.py's value_early_exit on the same batch
+    assert w["row_hypothesis_pairs"] < 0.7 * H * n                # 50 % inliers: the wrong models go at half time
 
 
 def test_config5_us_iterative_fit_against_minpack_fixtures(ctx, golden_dir):
