@@ -149,6 +149,18 @@ LSQR_API int lsqr_hypotheses_sample(lsqr_ctx *ctx, uint64_t seed, uint64_t first
  * of lsqrrecipes_amd/include/RANSAC.h), so that host and device paths walk one subset stream. */
 LSQR_API int lsqr_sample_subsets(uint64_t seed, uint64_t first_index, size_t H, uint64_t n, int k,
                                  uint32_t *subsets_out);
+/* ---- single-datum calls, evaluated on the HOST (no context, no device) --------------------------------
+ * ParametersEstimator<T,S>::agree(parameters, datum) (ParametersEstimator.h:55; a ten-flop inline in the reference,
+ * PlaneParametersEstimator.hxx:196-203) and estimate() of one minimal subset (ParametersEstimator.h:41-43) for the
+ * closed-form models: the library's own per-model code (the code the kernels run, compiled for the host; bit-identical
+ * results) without an upload and a kernel launch per call.  record(s): the caller's record(s) as laid out for
+ * lsqr_upload.  lsqr_estimate_host: `count` >= lsqr_min_subset records in draw order; returns LSQR_EMPTY
+ * (*n_params_out = 0) for a degenerate subset.  Both return LSQR_ERR_INVALID when the model has no host form for
+ * the call (minimal solves of the dense system, the US calibrations and the plane phantom are device kernels). */
+LSQR_API int lsqr_agree_host(const lsqr_model_cfg *cfg, const double *params, const void *record, int *agree_out);
+LSQR_API int lsqr_estimate_host(const lsqr_model_cfg *cfg, const void *records, size_t count, size_t stride_bytes,
+                                double *params_out, int *n_params_out);
+
 /* ---- agree() scan over all observations (RANSAC.hxx:94-99, without the early exit) ---------- */
 LSQR_API int lsqr_scan(lsqr_ctx *ctx);
 /* Results of the current batch: any pointer may be NULL.  params: H*P doubles; valid: H bytes

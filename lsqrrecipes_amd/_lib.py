@@ -65,6 +65,9 @@ SIGNATURES = {
     "lsqr_hypotheses_from_subsets": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "lsqr_hypotheses_sample": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p]),
     "lsqr_sample_subsets": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint64, C.c_int, C.c_void_p]),
+    "lsqr_agree_host": (C.c_int, [C.POINTER(ModelCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "lsqr_estimate_host": (C.c_int, [C.POINTER(ModelCfg), C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                     C.POINTER(C.c_int)]),
     "lsqr_scan": (C.c_int, [_ctx]),
     "lsqr_get_hypotheses": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lsqr_num_hypotheses": (C.c_size_t, [_ctx]),

@@ -310,6 +310,19 @@ int dense_ne(int n) { return (n + 1) * (n + 2) / 2; }
 constexpr int kDenseBlocks = 256;
 int dense_pstride(int n) { return (dense_ne(n) + 1 + 7) & ~7; }
 
+// the per-model constants a configuration implies (what the reference's constructors / setters store)
+void model_consts(const lsqr_model_cfg &cfg, ModelConsts *mc) {
+  mc->delta = cfg.delta;
+  mc->delta_sq = cfg.delta * cfg.delta;
+  mc->dim = cfg.dim;
+  mc->ls_type = cfg.ls_type;
+  mc->thr = square_threshold(mc->delta_sq);
+  const double ce = sin(cfg.aux);  // RayIntersectionParametersEstimator.cxx:13-14
+  mc->aux = ce * ce;
+  mc->absmax = 0.0;
+  mc->absmax_rot = 0.0;
+}
+
 bool cfg_supported(const lsqr_model_cfg &cfg) {
   return dispatch(cfg, [](auto) { return (int)LSQR_OK; }) == LSQR_OK;
 }
@@ -2210,25 +2223,27 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
     return fail(c, LSQR_ERR_INVALID, "invalid sphere least squares type %d", cfg->ls_type);
   lanes_quiesce(c);
   c->data_epoch++;
+  // The same estimator type with another threshold / fit type (RANSAC<T,S>::compute() again on resident records,
+  // lsqrRecipes::ResidentData): what was derived from the records alone -- their bounds and magnitudes, the spatial
+  // index -- stays valid.
+  const bool same_shape = c->has_model && c->cfg.model == cfg->model && c->cfg.dim == cfg->dim;
+  const double absmax_keep = c->mc.absmax, absrot_keep = c->mc.absmax_rot;
   c->cfg = *cfg;
-  c->mc.delta = cfg->delta;
-  c->mc.delta_sq = cfg->delta * cfg->delta;
-  c->mc.dim = cfg->dim;
-  c->mc.ls_type = cfg->ls_type;
-  c->mc.thr = square_threshold(c->mc.delta_sq);
-  {  // RayIntersectionParametersEstimator.cxx:13-14
-    double ce = sin(cfg->aux);
-    c->mc.aux = ce * ce;
-  }
-  c->mc.absmax = 0.0;
+  model_consts(*cfg, &c->mc);
   c->K = lsqr_min_subset(cfg);
   c->P = lsqr_num_params(cfg);
   c->ND = lsqr_record_doubles(cfg);
   c->HS = dispatch(*cfg, [](auto tag) { return (int)decltype(tag)::type::SP; });
   c->has_model = true;
-  drop_index(c);
-  c->absmax_valid = false;
-  c->bounds_valid = false;
+  if (c->n && c->stride < (size_t)c->ND) c->n = 0;  // the resident records cannot be read as this model's
+  if (same_shape && c->n) {
+    c->mc.absmax = absmax_keep;
+    c->mc.absmax_rot = absrot_keep;
+  } else {
+    drop_index(c);
+    c->absmax_valid = false;
+    c->bounds_valid = false;
+  }
   c->rows_valid = false;
   c->H = 0;
   c->scanned = false;
@@ -4030,6 +4045,56 @@ int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[8]) {
   out[6] = h_sel[1];
   out[7] = bounded ? pin[1] : pin[0];
   return LSQR_OK;
+}
+
+// ---- single-datum calls on the HOST ------------------------------------------------------------------------
+// ParametersEstimator::agree(parameters, datum) is a ten-flop inline in the reference (PlaneParametersEstimator
+// .hxx:196-203) that user code may call in a loop, and estimate() of a minimal subset a closed form: an upload and a
+// kernel launch per call would cost microseconds each.  These two evaluate the SAME per-model code the kernels run
+// (models.h, models_nd.h, rigid.h, us.h -- LSQR_HD, compiled here for the host with -ffp-contract=off; tests/
+// test_host_math.py and tests/test_host_calls.py hold host and device to the same bits).  No context, no device.
+// LSQR_ERR_INVALID: the model has no host form for that call (minimal solves that are wave kernels: dense, US,
+// phantom) -- the caller then takes the device path.
+int lsqr_agree_host(const lsqr_model_cfg *cfg, const double *params, const void *record, int *agree_out) {
+  if (!cfg || !params || !record || !agree_out || !cfg_supported(*cfg)) return LSQR_ERR_INVALID;
+  ModelConsts mc;
+  model_consts(*cfg, &mc);
+  return dispatch(*cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    double sp[128];
+    for (int j = 0; j < 128; j++) sp[j] = 0.0;
+    for (int j = 0; j < (int)M::P; j++) sp[j] = params[j];
+    M::prepare(sp, mc);
+    double x[M::REC > 0 ? M::REC : 1];
+    M::load((const double *)record, mc, x);
+    *agree_out = M::agree(sp, x, mc) ? 1 : 0;
+    return LSQR_OK;
+  });
+}
+
+int lsqr_estimate_host(const lsqr_model_cfg *cfg, const void *records, size_t count, size_t stride_bytes,
+                       double *params_out, int *n_params_out) {
+  if (!cfg || !records || !params_out || !n_params_out || !cfg_supported(*cfg) || stride_bytes % sizeof(double))
+    return LSQR_ERR_INVALID;
+  ModelConsts mc;
+  model_consts(*cfg, &mc);
+  const size_t stride = stride_bytes / sizeof(double);
+  return dispatch(*cfg, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type M;
+    if constexpr (M::IS_DENSE || M::IS_US || requires { M::IS_PHANTOM; }) {
+      return LSQR_ERR_INVALID;  // wave / workgroup kernels: device only
+    } else {
+      if (count < (size_t)M::K || stride < (size_t)M::ND) return LSQR_ERR_INVALID;
+      double r[M::K][M::ND];
+      for (int l = 0; l < (int)M::K; l++)
+        for (int j = 0; j < (int)M::ND; j++) r[l][j] = ((const double *)records)[l * stride + j];
+      double par[M::P];
+      const bool ok = M::estimate(r, mc, par);
+      *n_params_out = ok ? (int)M::P : 0;
+      for (int j = 0; j < (int)M::P; j++) params_out[j] = ok ? par[j] : 0.0;
+      return ok ? LSQR_OK : LSQR_EMPTY;
+    }
+  });
 }
 
 int lsqr_scan_work(lsqr_ctx *c, uint64_t out[6]) {

@@ -67,6 +67,29 @@ class RANSAC {
     return finish(ok, info, p, cons, parameters, consensusSet);
   }
 
+  // the same on records that are already resident on the device (lsqrRecipes::ResidentData, LsqrDevice.h): no
+  // upload; repeat with other thresholds / probabilities / seeds / estimators of the same record type
+  static double compute(std::vector<S> &parameters, ParametersEstimator<T, S> *paramEstimator,
+                        ResidentData<T> &data, double desiredProbabilityForNoOutliers,
+                        std::vector<bool> *consensusSet = NULL) {
+    lsqr_model_cfg cfg;
+    if (!paramEstimator) throw std::invalid_argument("lsqrRecipes::RANSAC: null estimator");
+    if (data.size() < paramEstimator->numForEstimate() || desiredProbabilityForNoOutliers >= 1.0 ||
+        desiredProbabilityForNoOutliers <= 0.0)
+      return 0;
+    if (!paramEstimator->deviceModel(cfg))
+      throw std::invalid_argument("lsqrRecipes::RANSAC: ResidentData needs an estimator with a device model");
+    lsqr_ctx *ctx = data.attach(cfg);
+    std::vector<double> p(64);
+    std::vector<uint8_t> cons(consensusSet ? data.size() : 0);
+    lsqr_ransac_info info;
+    parameters.clear();
+    bool ok = data.check(lsqr_ransac(ctx, desiredProbabilityForNoOutliers, seed(), NULL, 0, &p[0],
+                                     consensusSet ? &cons[0] : NULL, &info));
+    lastInfo() = info;
+    return finish(ok, info, p, cons, parameters, consensusSet);
+  }
+
   // exhaustive search over all subsets, reference RANSAC.h:111-113
   static double compute(std::vector<S> &parameters, ParametersEstimator<T, S> *paramEstimator,
                         std::vector<T> &data, std::vector<bool> *consensusSet = NULL) {

@@ -857,9 +857,75 @@ static void weightedAbsoluteOrientationTest() {  // AbsoluteOrientationParameter
   CHECK(p1.empty());
 }
 
+// records resident across compute() calls (lsqrRecipes::ResidentData): same results as the vector overload,
+// whatever the order of the calls; agree() / estimate() on the host give what the device gives
+static void residentTest() {
+  typedef Point<double, 3> P;
+  std::vector<P> pts;
+  const double n[3] = {0.6, -0.48, 0.64}, a[3] = {10, 20, -30};
+  for (int i = 0; i < 200000; i++) {
+    P p;
+    for (int j = 0; j < 3; j++) p[j] = U(-300, 300);
+    if (i % 2) {
+      double d = 0;
+      for (int j = 0; j < 3; j++) d += (p[j] - a[j]) * n[j];
+      for (int j = 0; j < 3; j++) p[j] += -d * n[j] + N(0.3);
+    }
+    pts.push_back(p);
+  }
+  ResidentData<P> resident(pts);
+  const double deltas[3] = {0.5, 1.0, 0.25};
+  for (int rep = 0; rep < 3; rep++) {
+    PlaneParametersEstimator<3> est(deltas[rep]);
+    std::vector<double> pv, pr;
+    std::vector<bool> cv, cr;
+    RANSAC<P, double>::seed() = 5 + rep;
+    double fv = RANSAC<P, double>::compute(pv, &est, pts, 0.999, &cv);
+    lsqr_ransac_info iv = RANSAC<P, double>::lastInfo();
+    RANSAC<P, double>::seed() = 5 + rep;
+    double fr = RANSAC<P, double>::compute(pr, &est, resident, 0.999, &cr);
+    lsqr_ransac_info ir = RANSAC<P, double>::lastInfo();
+    CHECK(fv == fr && cv == cr && pv == pr && pv.size() == 6);
+    CHECK(iv.iterations == ir.iterations && iv.best_index == ir.best_index && iv.best_votes == ir.best_votes);
+    CHECK(fr > 0.2);
+    // agree() per datum (host) against the consensus set of the device run, estimate() of a subset (host) against
+    // the device's minimal solve
+    if (pr.size() == 6 && cr.size() == pts.size()) {
+      std::vector<double> winner;
+      std::vector<P *> sub;
+      // (the winner's own parameters are not returned by compute(): check agree() with the fitted model's mask
+      //  computed by the device)
+      int bad = 0;
+      lsqr_model_cfg cfg;
+      est.deviceModel(cfg);
+      lsqr_ctx *ctx = resident.attach(cfg);
+      std::vector<uint8_t> m(pts.size());
+      resident.check(lsqr_mask(ctx, &pr[0], 0, pts.size(), &m[0], 0));
+      for (size_t i = 0; i < pts.size(); i += 97) bad += (est.agree(pr, pts[i]) != (m[i] != 0));
+      CHECK(bad == 0);
+      sub.push_back(&pts[3]), sub.push_back(&pts[1001]), sub.push_back(&pts[77777]);
+      est.estimate(sub, winner);
+      uint32_t idx[3] = {3, 1001, 77777};
+      double hp[6];
+      uint8_t valid = 0;
+      resident.check(lsqr_hypotheses_from_subsets(ctx, idx, 1));
+      resident.check(lsqr_get_hypothesis(ctx, 0, hp, &valid));
+      CHECK(valid && winner.size() == 6);
+      if (winner.size() == 6)
+        for (int j = 0; j < 6; j++) CHECK(winner[j] == hp[j]);
+    }
+  }
+  // another estimator of the same record type on the same resident records
+  SphereParametersEstimator<3> sph(0.5);
+  std::vector<double> ps;
+  RANSAC<P, double>::compute(ps, &sph, resident, 0.9);
+  CHECK(ps.empty() || ps.size() == 4);
+}
+
 int main(int argc, char *argv[]) {
   try {
     planeTest();
+    residentTest();
     sphereTest();
     lineTest();
     denseTest(argc > 1 ? argv[1] : 0);

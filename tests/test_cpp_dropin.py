@@ -157,6 +157,21 @@ def test_example_data_file_programs_on_gpu():
 
 
 @pytest.mark.gpu
+def test_pointer_us_calibration_example(tmp_path):
+    """examples/pointerUSCalibration.cxx (the reference's examples/pointerUSCalibration.cxx:30-112): simulated probe
+    frames of a tracked pointer tip, one frame in six an outlier; RANSAC with the CalibratedPointerTarget estimator"""
+    xml = str(tmp_path / "pointer.xml")
+    out = _run(["pointerUSCalibration"])
+    assert "60 frames" in out
+    used = _numbers(out, "Percentage of frames used:")[-1][0]
+    assert 0.7 <= used <= 0.84                      # 50 of 60 frames are consistent
+    dist = _numbers(out, "distance to the pointer tip over the consensus set: min")[-1]
+    assert dist[1] < 2.0                            # max over the consensus set below the threshold
+    par = _vector_after(out, "RANSAC calibration [t3, wz, wy, wx, mx, my, mx r1, my r2, r3]")
+    assert len(par) == 17 and abs(par[6] - 0.143) < 5e-3 and abs(par[7] - 0.139) < 5e-3   # the scale factors
+
+
+@pytest.mark.gpu
 def test_crosswire_writes_igstk_xml(tmp_path):
     """the reference example's output wire format (examples/crosswireUSCalibration.cxx:181-210)"""
     xml = tmp_path / "calibration.xml"
