@@ -48,14 +48,12 @@ except Exception:
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# ---- roofs (MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32s, 2.4 GHz.  A wave64 vector instruction occupies its SIMD for
-# 2 cycles when >= 2 waves are resident (one wave alone: 4), a packed-fp32 one (v_pk_fma_f32: two results per lane) and
-# an fp64 one for 4 -- the datasheet's 157.3 TFLOP/s fp32 = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz.  The issue roof
-# is therefore counted in SIMD CYCLES: useful cycles of the launch / (1024 SIMDs x 2.4 GHz).  tools/microbench.hip
-# measures the per-instruction cycles of the scan kernels' mix on the box (profiles/r03_microbench.json).
-SIMD_CYCLES_PEAK_G = 1024 * 2.4          # G SIMD-cycles / s
-CYC_PK = 4.0                             # v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
-CYC_F32 = 2.0                            # non-packed fp32 arithmetic, compares, min / max
+# ---- roofs: 256 CUs x 4 SIMDs, 2.4 GHz.  A wave64 vector instruction occupies its SIMD for 4 cycles -- packed fp32
+# (two results per lane), non-packed fp32, fp64 and cross-lane alike: tools/microbench.hip measures 4.1 - 4.8 nominal
+# cycles for every instruction of the scan kernels' mix at 2 - 8 waves per SIMD (profiles/r03_microbench.json; the
+# 2-cycle figure MI355X_MICROARCH.md gives for non-packed fp32 on the SIMD-32 is not reached by these streams), so the
+# chip issues at most 1024 * 2.4e9 / 4 = 614.4 G wave-instructions/s.
+VALU_ISSUE_PEAK_GWIPS = 1024 * 2.4 / 4.0
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
 # USEFUL vector instructions of the scan kernels, counted from the source (csrc/cells.h, models.h, us.h; table in
@@ -217,13 +215,14 @@ def profile_file(name):
 
 
 def measured_cycles():
-    """per-instruction SIMD cycles measured by tools/microbench.hip on an MI355X (profiles/r03_microbench.json), else
-    the guide's figures"""
+    """the microbenchmark's per-instruction cycles (profiles/r03_microbench.json), quoted beside the roof"""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r03_microbench.json")))
-        return float(d["cycles"]["v_pk_fma_f32"]), float(d["cycles"]["v_fma_f32"]), "profiles/r03_microbench.json"
+        return {"v_fma_f32": d["cycles"]["v_fma_f32"], "v_pk_fma_f32": d["cycles"]["v_pk_fma_f32"],
+                "level2_mix": d["cycles"]["level2_mix"], "source": "profiles/r03_microbench.json (tools/microbench.hip, "
+                "8 waves per SIMD, nominal cycles at 2.4 GHz)"}
     except Exception:
-        return CYC_PK, CYC_F32, "MI355X_MICROARCH.md (v_fma_f32 wave64: 2 cycles on the SIMD-32; packed fp32: 4)"
+        return None
 
 
 def scan_roofline(R, mode, scan_ms, n_scan):
@@ -267,7 +266,6 @@ def scan_roofline(R, mode, scan_ms, n_scan):
                              "dense matrix rate the filter runs at"})
         return base
     u = SCAN_USEFUL[w]
-    cyc_pk, cyc_f32, cyc_src = measured_cycles()
     cells = w in ("plane", "sphere", "line") and R.idx["built"] and not a.no_filter
     if cells:
         wl = ctx.scan_workload()                     # level 1 alone on the last batch: live counts
@@ -277,9 +275,7 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         if wl["bounded"]:                            # bounds pass + the pilots' group + the second pass' groups
             l1 += wl["cells"] * (1 + -(-wl["second_pass"] // 64))
         v2_instr = pp * (u["pk"] + 1) + 2
-        v2_cycles = pp * (u["pk"] * cyc_pk + cyc_f32) + 2 * cyc_f32
         useful_instr = l1 * u["l1"] + wl["pairs_counted"] * v2_instr
-        useful_cycles = l1 * u["l1"] * cyc_f32 + wl["pairs_counted"] * v2_cycles
         kname = ("two-level scan of <%s> over a Morton-sorted copy: cell-box culling, packed fp32 filter + exact fp64 "
                  "re-check in surviving cells; %s" % (
                      w, "bounded: k_cells_bounds (vote bounds) -> pilots -> only hypotheses that can still win, each "
@@ -290,7 +286,6 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         model = {"level1_evaluations": l1, "level1_useful_instr": u["l1"],
                  "surviving_hypothesis_cell_pairs_all": wl["pairs"],
                  "surviving_hypothesis_cell_pairs_counted": wl["pairs_counted"], "level2_useful_instr": v2_instr,
-                 "level2_useful_simd_cycles": v2_cycles,
                  "cells": wl["cells"], "cell_points": wl["cell_points"], "hypothesis_groups": groups,
                  "bounded_scan": wl["bounded"], "pilots": wl["pilots"], "second_pass_hypotheses": wl["second_pass"],
                  "hypotheses_counted_exactly": (wl["pilots"] + wl["second_pass"]) if wl["bounded"] else H,
@@ -300,24 +295,21 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         pairs_all = float(H) * a.points / 128.0      # every (hypothesis, packed pair of observations per wave)
         pairs = wk["row_hypothesis_pairs"] / 128.0 if wk else pairs_all
         v2_instr = u["pk"] + 2
-        v2_cycles = u["pk"] * cyc_pk + 2 * cyc_f32
         useful_instr = pairs * v2_instr
-        useful_cycles = pairs * v2_cycles
         kname = {"us": "k_scan_us_f32<us> (packed fp32 filter + exact fp64 re-check)",
                  "phantom": "k_scan_us_f32<phantom> (factored packed fp32 filter + exact fp64 re-check)"}.get(
                      w, "k_scan_f32<%s> (packed fp32 filter + exact fp64 re-check)" % w)
         model = {"hypothesis_wave_pairs_evaluated": pairs, "hypothesis_wave_pairs_all": pairs_all,
-                 "evaluated_fraction": pairs / pairs_all, "useful_instr_per_pair": v2_instr,
-                 "useful_simd_cycles_per_pair": v2_cycles}
-    ach = useful_cycles / t / 1e9 if t > 0 else 0.0
-    base.update({"bound": "valu", "achieved": ach, "peak": SIMD_CYCLES_PEAK_G, "unit": "G SIMD-cycles/s",
-                 "frac": ach / SIMD_CYCLES_PEAK_G, "traffic": traffic, "kernel": kname, "work_model": model,
-                 "useful_wave_instructions": useful_instr,
-                 "cycles_per_instruction": {"v_pk_*_f32": cyc_pk, "fp32 non-packed": cyc_f32, "source": cyc_src},
-                 "note": "achieved = SIMD cycles of the USEFUL vector instructions of the launch (counted from the "
-                         "kernel source, work counts measured live by lsqr_scan_workload) / launch time; peak = 1024 "
-                         "SIMD-32s x 2.4 GHz.  The kernel reads the observations once per launch for all H hypotheses "
-                         "(HBM fraction in hbm_frac_measured), so the instruction-issue roof is the one that binds; "
+                 "evaluated_fraction": pairs / pairs_all, "useful_instr_per_pair": v2_instr}
+    ach = useful_instr / t / 1e9 if t > 0 else 0.0
+    base.update({"bound": "valu", "achieved": ach, "peak": VALU_ISSUE_PEAK_GWIPS, "unit": "G wave-instr/s",
+                 "frac": ach / VALU_ISSUE_PEAK_GWIPS, "traffic": traffic, "kernel": kname, "work_model": model,
+                 "measured_cycles_per_instruction": measured_cycles(),
+                 "note": "achieved = USEFUL vector instructions of the launch (counted from the kernel source, work "
+                         "counts measured live by lsqr_scan_workload / lsqr_scan_work) / launch time; peak = 1024 SIMDs "
+                         "x 2.4 GHz / 4 cycles per wave64 instruction (measured: profiles/r03_microbench.json).  The "
+                         "kernel reads the observations once per launch for all H hypotheses (HBM fraction in "
+                         "hbm_frac_measured), so the instruction-issue roof is the one that binds; "
                          "counters.valu_issue_busy is the measured utilisation including overhead instructions"})
     return base
 
@@ -461,7 +453,7 @@ class Run:
         self.next_step = 0
         self.side_step = 1 << 20
         self.nfev_total = 0        # LM evaluations of the steps run so far (iterative fits)
-        self.full_pairs = False
+        self.full_pairs = w == "plane" and a.batch >= 1024   # cells.h: PlaneCell::FULL_COUNT_PAIRS
         self.idx = None
 
     def _new_ctx(self):

@@ -368,18 +368,17 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                chunks and a hypothesis stops being counted once it cannot win any more (lsqr_scan_work; it reports
  *                its partial count).  0 = every hypothesis is counted.  lsqr_scan always counts all;
  * "batch_lanes": streams (1..4, default 4) the slots of lsqr_batch_fit_enqueue / _wait are spread over (see there);
- * "scan_pairs":  1 = plain (unbounded) scans of an indexed upload also go through the statically balanced kernel of
- *                the bounded scan (k_scan_pairs) instead of k_scan_cells (A/B knob); "scan_pairs_waves": workgroups
+ * "scan_pairs":  plain (unbounded) scans of an indexed upload: 0 (default) = the model's measured choice (plane, batches
+ *                of >= 1024: the statically balanced kernel of the bounded scan, k_scan_pairs; else k_scan_cells),
+ *                1 = always k_scan_pairs, 2 = always k_scan_cells (A/B knob); "scan_pairs_waves": workgroups
  *                per CU of that kernel (0 = what fits); "scan_bound_merge": cells per box of the vote bounds
  *                (0 = default: 4 while >= 4096 boxes remain, 1 = the cells themselves, 2 / 4 / 8);
- * "dense_f32":   dense scan filter at n > 32: 2 (default) = fp32 matrix cores, hypothesis fragments prefetched through
- *                an LDS ring (global_load_lds) and the next tile of rows in registers, 1 = fp32 matrix cores, fragments
- *                in registers, 0 = fp64 matrix cores.  Votes are identical (the band is decided exactly);
+ * "dense_f32":   dense scan filter at n > 32: 1 (default) = fp32 matrix cores, hypothesis fragments prefetched through
+ *                an LDS ring (global_load_lds) and the next tile of rows in registers, 0 = fp64 matrix cores.  Votes are
+ *                identical (the band is decided exactly);
  * "dense_fast_solve": 1 (default) = the n x n minimal solves of the dense system use elimination with
  *                partial pivoting and only fall back to the SVD pseudo-inverse near the rank decision,
- *                0 = always the SVD pseudo-inverse;
- * "dense_transposed": 1 = dense scan with one hypothesis per lane and rows broadcast from LDS
- *                (k_scan_dense_t), 0 = rows in registers, hypotheses through the scalar cache. */
+ *                0 = always the SVD pseudo-inverse. */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
 
 /* State of the spatial index of the current upload ("scan_index"): out = {built (0/1), indexed

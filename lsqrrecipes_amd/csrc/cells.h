@@ -375,6 +375,7 @@ struct PlaneCell {
   // k_scan_pairs counts near-model hypotheses, 80 % of whose (hypothesis, cell) pairs take the full path: there the
   // six v_readlane per pair are vector-issue slots the LDS broadcast gives back (0.84 -> 0.77 ms per step)
   enum { LDS_BROADCAST_PAIRS = 1 };
+  enum { FULL_COUNT_PAIRS = 1 };  // plain scans of >= 1024 hypotheses through k_scan_pairs too (r03: 1.24 -> 1.13 ms)
   // (1024-point cells / 8 packed pairs per lane, 4 waves per SIMD: second pass of the bounded scan 642 us against
   // 510 us -- measured and not built; `enum { MAX_PP = 8 };` here brings the instantiation back)
   enum { USE_BOUND = 1 };  // bounded scan pays: a random plane still cuts ~13 % of the cells

@@ -153,71 +153,6 @@ __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict
   if (lane == 0) valid[h] = ok ? 1 : 0;
 }
 
-// K2 dense, transposed: one hypothesis per LANE (its x in VGPRs, its own vote counter), the rows of
-// a tile staged once per workgroup in LDS (coalesced 16-byte loads) and broadcast to every lane with
-// uniform-address ds_read_b128.  No scalar loads, ballots or per-hypothesis atomics in the loop; the
-// per-pair arithmetic is the reference's (running sum of a_i*x_i from 0, minus b, |.| < delta).
-constexpr int kDenseTile = 32;  // rows per LDS tile
-
-template <int NR>
-__global__ __launch_bounds__(256) void k_scan_dense_t(const double *__restrict__ data,
-                                                      size_t stride, size_t m, size_t rows_per_block,
-                                                      const double *__restrict__ sp, uint32_t H, int n,
-                                                      double delta, uint32_t *__restrict__ votes) {
-  constexpr int LDW = NR + 2;  // 16-byte aligned row pitch in LDS; slot NR holds b
-  __shared__ __attribute__((aligned(16))) double tile[kDenseTile * LDW];
-  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
-  double x[NR];
-  {
-    const double *hp = sp + (size_t)(h < H ? h : 0) * NR;
-    const double qnan = __builtin_nan("");
-#pragma unroll
-    for (int i = 0; i < NR; i++) x[i] = h < H ? hp[i] : qnan;
-  }
-  uint32_t cnt = 0;
-  size_t lo = (size_t)blockIdx.y * rows_per_block;
-  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
-  for (size_t base = lo; base < hi; base += kDenseTile) {
-    int rows = (int)((hi - base) < (size_t)kDenseTile ? (hi - base) : (size_t)kDenseTile);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < rows * LDW; idx += 256) {
-      int r = idx / LDW, c = idx % LDW;
-      double v = 0.0;
-      if (c < n) v = data[(base + r) * stride + c];
-      else if (c == NR) v = data[(base + r) * stride + n];
-      tile[idx] = v;
-    }
-    __syncthreads();
-    // RU rows at a time: RU independent running sums per lane, so that a dependent v_add_f64 is
-    // RU*2 instructions behind its producer (one row alone stalls on the fp64 pipeline latency)
-    constexpr int RU = 4;
-    int r = 0;
-    for (; r + RU <= rows; r += RU) {
-      double sum[RU];
-#pragma unroll
-      for (int u = 0; u < RU; u++) sum[u] = 0.0;
-#pragma unroll
-      for (int i = 0; i < NR; i++) {
-#pragma unroll
-        for (int u = 0; u < RU; u++) sum[u] += tile[(r + u) * LDW + i] * x[i];
-      }
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        double t = sum[u] - tile[(r + u) * LDW + NR];
-        cnt += (fabs(t) < delta) ? 1u : 0u;
-      }
-    }
-    for (; r < rows; r++) {
-      const double *row = tile + r * LDW;
-      double sum = 0.0;
-#pragma unroll
-      for (int i = 0; i < NR; i++) sum += row[i] * x[i];
-      sum -= row[NR];
-      cnt += (fabs(sum) < delta) ? 1u : 0u;
-    }
-  }
-  if (h < H && cnt) atomicAdd(&votes[h], cnt);
-}
 
 // K2 dense on the matrix cores.  The residuals of a block of rows against a block of hypotheses are
 // a GEMM; v_mfma_f64_16x16x4 evaluates it with fused multiply-adds, which round differently from the
@@ -483,144 +418,9 @@ __global__ void k_dense_thresholds32(const double *__restrict__ sp, uint32_t H, 
 }
 
 constexpr int kDmPitch32 = 68;  // floats: the 16 x 4 fragment reads of a wave hit 64 distinct banks
-template <int NR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_scan_dense_mfma32(
-    const double *__restrict__ data, size_t stride, size_t m, size_t rows_per_block,
-    const float *__restrict__ sp32, const float *__restrict__ thr, uint32_t H, int n,
-    uint32_t *__restrict__ votes, unsigned long long *__restrict__ amb_list,
-    unsigned int *__restrict__ amb_counts, uint32_t seg_cap, uint32_t hyp_base) {
-  // the worklist is one segment per workgroup with its counter in LDS: a single global counter would take ~14 ns
-  // per (same-address) append, seconds' worth at the ~1e5..1e6 ambiguous pairs of the fp32 band
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  static_assert(NR == 64, "fragment bookkeeping below assumes 64 padded unknowns");
-  extern __shared__ float smf[];
-  float *At = smf;                    // 64 rows x pitch
-  float *bv = At + 64 * kDmPitch32;   // 64 right-hand sides
-  uint32_t *s_cnt = (uint32_t *)(bv + 64);
-  uint32_t *s_amb = s_cnt + H;        // entries of this workgroup's worklist segment so far
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c16 = lane & 15, k4 = lane >> 4;
-  const uint32_t nhb = (H + 63) / 64;
-  for (uint32_t h = tid; h < H; h += 256) s_cnt[h] = 0;
-  if (tid == 0) *s_amb = amb_counts[blockIdx.x];
-  size_t lo = (size_t)blockIdx.x * rows_per_block;
-  size_t hi = lo + rows_per_block < m ? lo + rows_per_block : m;
-  float nb[16], nti = -1.0f, nto = -1.0f;
-  auto fetch_hyp = [&](uint32_t hb) {
-    const uint32_t h = hb * 64 + wave * 16 + c16;
-    const uint32_t hc = h < H ? h : 0;  // loads are unconditional (no divergent branches in the loop) ...
-    const f4 *row = (const f4 *)(sp32 + (size_t)hc * NR + k4 * 16);  // fragment order (k_dense_thresholds32)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const f4 v = row[j];
-      nb[4 * j] = v.x, nb[4 * j + 1] = v.y, nb[4 * j + 2] = v.z, nb[4 * j + 3] = v.w;  // (columns >= n are 0)
-    }
-    nti = h < H ? thr[2 * (size_t)hc] : -1.0f;            // ... a lane past the batch gets thresholds that never pass
-    nto = h < H ? thr[2 * (size_t)hc + 1] : -1.0f;
-  };
-  if (lo < hi) fetch_hyp(0);
-  for (size_t base = lo; base < hi; base += 64) {
-    __syncthreads();  // the previous tile's fragment reads are done
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-      int r = idx >> 6, kk = idx & 63;
-      size_t row = base + r;
-      At[r * kDmPitch32 + kk] = (row < hi && kk < n) ? (float)data[row * stride + kk] : 0.0f;
-    }
-    if (tid < 64) {
-      size_t row = base + tid;
-      bv[tid] = row < hi ? (float)data[row * stride + n] : __builtin_nanf("");  // NaN: row never counts
-    }
-    __syncthreads();
-    // The wave's A fragments of the whole tile (64 floats per lane) and its 16 right-hand sides are read from LDS
-    // ONCE and stay in registers for all hypothesis blocks.  The hypothesis loop is software-pipelined over two
-    // accumulator sets: while the matrix pipe works through the 64 instructions of block hb + 1, the same wave
-    // issues the (branch-free) counting of block hb in their shadow -- with two waves per SIMD nothing else hides it.
-    float a[4][16], bvr[16];
-    {
-      const float *ap = At + c16 * kDmPitch32 + k4;
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) a[t][q] = ap[t * 16 * kDmPitch32 + 4 * q];
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) bvr[4 * t + rg] = bv[t * 16 + 4 * k4 + rg];
-    }
-    auto mfma_block = [&](f4(&acc)[4], const float(&b)[16]) {
-#pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][q], b[q], acc[t], 0, 0, 0);
-      }
-    };
-    // D layout of the fp32 instruction: column (hypothesis) = lane & 15, row = 4 * (lane >> 4) + reg (+ 16 * row
-    // group) -- four CONSECUTIVE rows per lane, unlike the fp64 instruction's (lane >> 4) + 4 * reg
-    auto count_block = [&](const f4(&acc)[4], float ti, float to, uint32_t hb) {
-      uint32_t c = 0, may = 0;
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const float res = __builtin_fabsf(acc[t][rg] - bvr[4 * t + rg]);
-          c += res < ti ? 1u : 0u;
-          may += res < to ? 1u : 0u;
-        }
-      if (may != c) {  // rare: some pair sits in the band -> worklist, decided exactly by k_dense_recheck_seg
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const float res = __builtin_fabsf(acc[t][rg] - bvr[4 * t + rg]);
-            if (res >= ti && res < to) {
-              const unsigned slot = atomicAdd(s_amb, 1u);
-              if (slot < seg_cap)
-                amb_list[(size_t)blockIdx.x * seg_cap + slot] =
-                    ((unsigned long long)(base + t * 16 + 4 * k4 + rg) << 32) |
-                    (unsigned long long)(hyp_base + hb * 64 + wave * 16 + c16);
-            }
-          }
-      }
-      c += __shfl_xor(c, 16);  // lanes l, l^16, l^32, l^48 hold the same hypothesis column
-      c += __shfl_xor(c, 32);
-      if (k4 == 0 && c) atomicAdd(&s_cnt[hb * 64 + wave * 16 + c16], c);
-    };
-    const uint32_t nhb2 = (nhb + 1) & ~1u;  // blocks past the batch carry thresholds that never pass
-    f4 accA[4], accB[4];
-    float bA[16], bB[16], tiA, toA, tiB, toB;
-#pragma unroll
-    for (int q = 0; q < 16; q++) bA[q] = nb[q];
-    tiA = nti, toA = nto;
-    fetch_hyp(1);
-    mfma_block(accA, bA);
-    for (uint32_t hb = 0; hb < nhb2; hb += 2) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) bB[q] = nb[q];
-      tiB = nti, toB = nto;
-      fetch_hyp(hb + 2 < nhb2 ? hb + 2 : 0);
-      mfma_block(accB, bB);
-      count_block(accA, tiA, toA, hb);
-      if (hb + 2 < nhb2) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) bA[q] = nb[q];
-        tiA = nti, toA = nto;
-        fetch_hyp(hb + 3 < nhb2 ? hb + 3 : 0);
-        mfma_block(accA, bA);
-      }
-      count_block(accB, tiB, toB, hb + 1);
-    }
-  }
-  __syncthreads();
-  for (uint32_t h = tid; h < H; h += 256) {
-    uint32_t c = s_cnt[h];
-    if (c) atomicAdd(&votes[h], c);
-  }
-  if (tid == 0) amb_counts[blockIdx.x] = *s_amb;
-}
-
-// The same filter with the hypothesis fragments prefetched THROUGH LDS, two blocks ahead.  In k_scan_dense_mfma32 a
+// The fp32 filter with the hypothesis fragments prefetched THROUGH LDS, two blocks ahead.  (Its predecessor kept the
+// fragments in registers -- 64 floats of A per lane read once per tile, two accumulator sets so that the counting of
+// block hb runs beside the 64 matrix instructions of block hb + 1; removed in r03, 3.27 against 2.99 ms.)  There a
 // wave asks for the 64 bytes per lane of hypothesis block hb + 1 while it works on block hb -- 64 matrix instructions,
 // 2048 cycles -- and an L2 hit on another XCD's slice takes about as long: with two waves per SIMD nothing else hides
 // the rest of the wait, and there are no registers for a second block in flight (254 of 256).  global_load_lds writes

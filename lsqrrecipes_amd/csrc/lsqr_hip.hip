@@ -76,9 +76,9 @@ struct lsqr_ctx {
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
   uint64_t hyp_expected = 0;      // hypotheses the caller still expects to scan on this upload (lsqr_ransac: numTries)
   unsigned dense_amb_max = 0;  // fullest worklist segment of the last fp32 dense scan (diagnostics)
-  int opt_dense_f32 = 2;  // dense scan filter on the fp32 matrix cores (worklist of ~1e-4 of the pairs): 2 = hypothesis
-                          // fragments through an LDS ring + next tile in registers, 1 = fragments in registers; 0: fp64 MFMA
-  int opt_dense_fast = 1, opt_dense_v1 = 0;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_dense_f32 = 1;  // dense scan filter at n = 64: 1 = fp32 matrix cores (worklist of ~1e-4 of the pairs, hypothesis
+                          // fragments through an LDS ring + next tile in registers), 0 = fp64 matrix cores
+  int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
@@ -141,7 +141,7 @@ struct lsqr_ctx {
   SolveOut *d_out = nullptr;
   unsigned long long *d_counter = nullptr;
   bool origin_valid = false;
-  int opt_ppl = 0, opt_filter = 1, opt_dense_t = 0, opt_lm_host = 1, opt_syrk_diag = 0;
+  int opt_ppl = 0, opt_filter = 1, opt_lm_host = 1, opt_syrk_diag = 0;
   int opt_fuse_mask = 1;  // winner's mask + moment block in one pass (0: two kernels, for A/B runs)
   int opt_mask_ring = 2;  // k_mask_syrk_dense: tile buffers per wave (2: two workgroups per CU; 4: one, three tiles in flight)
   int opt_mask_diag = 0;  // timing diagnostics of k_mask_syrk_dense: 1 = no matrix instructions, 2 = no row evaluation
@@ -1102,7 +1102,7 @@ int run_scan(lsqr_ctx *c) {
   return dispatch(c->cfg, [&](auto tag) -> int {
     typedef typename decltype(tag)::type M;
     if constexpr (M::IS_DENSE) {  // default: MFMA filter + exact recheck of ambiguous pairs
-      if (c->opt_filter && !c->opt_dense_t) {
+      if (c->opt_filter) {
         int st = ensure_absmax(c);
         if (st != LSQR_OK) return st;
         if (!c->d_amb) HIPCHK(c, hipMalloc((void **)&c->d_amb, sizeof(unsigned long long) * kAmbCap));
@@ -1110,7 +1110,7 @@ int run_scan(lsqr_ctx *c) {
           if constexpr (M::NR == 64) {
             // batch entry points: chunked early exit (earlyexit.h) -- hypotheses that can no longer become the running
             // maximum stop being counted
-            if (c->allow_bound && c->opt_bound && c->opt_dense_f32 == 2 && !c->opt_dense_v1 && c->H >= 128 &&
+            if (c->allow_bound && c->opt_bound && c->opt_dense_f32 && c->H >= 128 &&
                 c->H <= kEeCap && c->n >= 65536 && c->mc.absmax < 1e15) {
               bool done = false;
               if ((st = run_scan_dense_ee(c, &done)) != LSQR_OK) return st;
@@ -1122,14 +1122,14 @@ int run_scan(lsqr_ctx *c) {
           double *d_thr = c->d_partials;  // scratch: 2 doubles per hypothesis (H <= 2^20 checked)
           if (c->H * 2 > (size_t)kDenseBlocks * 2160) return fail(c, LSQR_ERR_INVALID, "batch too large");
           size_t tiles = (c->n + 63) / 64;
-          size_t nblk = std::min<size_t>(tiles, c->opt_dense_v1 ? 512 : 768);  // 2 / 3 workgroups per CU
+          size_t nblk = std::min<size_t>(tiles, 768);  // 3 workgroups per CU
           size_t rpb = (tiles + nblk - 1) / nblk * 64;
           nblk = (c->n + rpb - 1) / rpb;
           if constexpr (M::NR == 64) {
             // default at n > 32: the filter in fp32 on the matrix cores (twice the fp64 MFMA rate); its band holds
             // ~1e-4 of the pairs, decided exactly from a per-workgroup worklist.  A segment overflow (not seen)
             // falls through to the fp64 filter below.
-            if (c->opt_dense_f32 && !c->opt_dense_v1 && c->H <= 8192 && c->mc.absmax < 1e15) {
+            if (c->opt_dense_f32 && c->H <= 8192 && c->mc.absmax < 1e15) {
               const uint32_t seg_cap = kAmbCap / 1024;  // <= 512 segments
               {  // two waves per SIMD (the A fragments live in registers): exactly two workgroups per CU
                 size_t nb2 = std::min<size_t>(tiles, 512);
@@ -1146,7 +1146,7 @@ int run_scan(lsqr_ctx *c) {
                                    c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot,
                                    c->mc.absmax, d_thr32, d_sp32);
                 HIPCHK(c, hipGetLastError());
-                if (c->opt_dense_f32 == 2) {  // hypothesis fragments prefetched through an LDS ring (dense.h)
+                {  // hypothesis fragments prefetched through an LDS ring (dense.h)
                   constexpr size_t kRingChunk = 1024;  // 62.7 KiB of LDS per workgroup: two per CU
                   for (size_t h0 = 0; h0 < c->H; h0 += kRingChunk) {
                     uint32_t hc = (uint32_t)std::min<size_t>(kRingChunk, c->H - h0);
@@ -1158,14 +1158,6 @@ int run_scan(lsqr_ctx *c) {
                                        (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
                     HIPCHK(c, hipGetLastError());
                   }
-                } else
-                for (size_t h0 = 0; h0 < c->H; h0 += kDmHypChunk) {
-                  uint32_t hc = (uint32_t)std::min<size_t>(kDmHypChunk, c->H - h0);
-                  size_t lds = sizeof(float) * (64 * kDmPitch32 + 64) + sizeof(uint32_t) * (hc + 1);
-                  hipLaunchKernelGGL((k_scan_dense_mfma32<64>), dim3((unsigned)nblk), dim3(256), lds, c->stream,
-                                     c->d_data, c->stride, c->n, rpb, d_sp32 + h0 * 64, d_thr32 + 2 * h0, hc,
-                                     (int)c->cfg.dim, c->d_votes + h0, c->d_amb, d_segcnt, seg_cap, (uint32_t)h0);
-                  HIPCHK(c, hipGetLastError());
                 }
                 hipLaunchKernelGGL((k_dense_recheck_seg<64>), dim3((unsigned)nblk), dim3(256), 0, c->stream, c->d_data,
                                    c->stride, c->d_hparams, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes,
@@ -1192,7 +1184,7 @@ int run_scan(lsqr_ctx *c) {
             for (size_t h0 = 0; h0 < c->H; h0 += kDmHypChunk) {
               uint32_t hc = (uint32_t)std::min<size_t>(kDmHypChunk, c->H - h0);
               if constexpr (M::NR == 64) {
-                if (!c->opt_dense_v1) {  // default: B fragments in registers, no barriers per block
+                {  // n = 64: B fragments in registers, no barriers per block
                   size_t lds2 = sizeof(double) * (64 * kDmPitch + 64) + sizeof(uint32_t) * hc;
                   hipLaunchKernelGGL((k_scan_dense_mfma2<64>), dim3((unsigned)nblk), dim3(256), lds2,
                                      c->stream, c->d_data, c->stride, c->n, rpb,
@@ -1222,22 +1214,6 @@ int run_scan(lsqr_ctx *c) {
           HIPCHK(c, hipStreamSynchronize(c->stream));
           if (*(unsigned int *)c->h_pin <= kAmbCap) return LSQR_OK;
         }
-      }
-    }
-    if constexpr (M::IS_DENSE) {  // hypotheses in lanes, rows broadcast from LDS (A/B variant)
-      if (c->opt_dense_t) {
-        HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
-        unsigned hb = (unsigned)((c->H + 255) / 256);
-        size_t chunks = std::max<size_t>(1, 512 / hb);
-        size_t rpb = (c->n + chunks - 1) / chunks;
-        rpb = (rpb + kDenseTile - 1) / kDenseTile * kDenseTile;
-        chunks = (c->n + rpb - 1) / rpb;
-        ProfScope ps(c, KID_SCAN);
-        hipLaunchKernelGGL((k_scan_dense_t<M::NR>), dim3(hb, (unsigned)chunks), dim3(256), 0,
-                           c->stream, c->d_data, c->stride, c->n, rpb, c->d_hparams,
-                           (uint32_t)c->H, (int)c->cfg.dim, c->mc.delta, c->d_votes);
-        HIPCHK(c, hipGetLastError());
-        return LSQR_OK;
       }
     }
     if constexpr (requires { M::NF32; }) {  // packed fp32 pre-filter (scan_filter 1); US: 2 = the fused fp64 filter
@@ -1317,7 +1293,12 @@ int run_scan(lsqr_ctx *c) {
             if (CM::USE_BOUND && c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
               return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_bounded<CM, decltype(pp)::value>(c); });
             }
-            if (c->opt_pairs == 1) {  // A/B: the statically balanced kernel for a plain scan too
+            // plain scans of a large batch: the statically balanced kernel where it measured faster (plane, 10 M x
+            // 4096: 1.13 against 1.24 ms; sphere and line are faster with tiles handed out dynamically);
+            // "scan_pairs" 1 / 2 force one or the other (A/B)
+            bool full_pairs = false;
+            if constexpr (requires { CM::FULL_COUNT_PAIRS; }) full_pairs = c->opt_pairs == 0 && c->H >= 1024;
+            if (c->opt_pairs == 1 || full_pairs) {
               const ScanBatch b = {c->d_hparams, c->d_hparams_f32, c->H, c->d_votes, nullptr};
               return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_pairs<CM, decltype(pp)::value>(c, b); });
             }
@@ -3979,19 +3960,11 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_f32")) {  // 1 (default): dense scan filter on the fp32 matrix cores; 0: fp64 MFMA filter
-    c->opt_dense_f32 = value < 0 ? 0 : (value > 2 ? 1 : value);  // 2: fragments through an LDS ring (A/B)
-    return LSQR_OK;
-  }
-  if (!strcmp(name, "dense_scan_v1")) {  // 1: first MFMA scan arrangement (hypothesis block through LDS)
-    c->opt_dense_v1 = value != 0;
+    c->opt_dense_f32 = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
     c->opt_dense_fast = value != 0;
-    return LSQR_OK;
-  }
-  if (!strcmp(name, "dense_transposed")) {
-    c->opt_dense_t = value != 0;
     return LSQR_OK;
   }
   return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);

@@ -12,7 +12,7 @@
  *
  * PARITY PINNING.  RANSAC.hxx itself is pinned against the real reference: oracle/_ref
  * compiles /root/reference/parametersEstimators/RANSAC.hxx unmodified (ref_driver.cxx) and
- * tests/test_oracle_vs_ref.py checks this restatement against it on identical rand()
+ * tests/test_oracle_ransac.py checks this restatement against it on identical rand()
  * streams.  The estimators' third-party numerics live in VNL (VXL/ITK, version unpinned
  * by the reference's CMakeLists.txt:36,58 and absent from /root/reference):
  * vnl_svd / vnl_matrix_inverse (LINPACK dsvdc), vnl_symmetric_eigensystem (EISPACK rs),

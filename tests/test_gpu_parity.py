@@ -870,11 +870,10 @@ def test_dense_mfma_filter_is_exact(ctx):
     for delta in (rho, np.nextafter(rho, np.inf), np.nextafter(rho, 0.0), 0.1):
         oc = O.cfg(O.DENSE, ncol, delta)
         want = None
-        # fp32 (LDS ring, the default / fragments in registers) and fp64 matrix-core filters, exact VALU kernels
-        for variant in ("mfma32r", "mfma32", "mfma64", "plain", "transposed"):
+        # fp32 (LDS ring: the default) and fp64 matrix-core filters, exact VALU kernel
+        for variant in ("mfma32r", "mfma64", "plain"):
             ctx.set_option("scan_filter", 0 if variant == "plain" else 1)
-            ctx.set_option("dense_transposed", 1 if variant == "transposed" else 0)
-            ctx.set_option("dense_f32", {"mfma64": 0, "mfma32": 1}.get(variant, 2))
+            ctx.set_option("dense_f32", 0 if variant == "mfma64" else 1)
             ctx.set_model(L.DENSE, ncol, delta).upload(rows)
             ctx.hypotheses_from_subsets(subs)
             ctx.scan()
@@ -886,8 +885,7 @@ def test_dense_mfma_filter_is_exact(ctx):
         # the boundary row itself: strict '<'
         assert O.agree(oc, x, rows[777]) == (rho < delta)
     ctx.set_option("scan_filter", 1)
-    ctx.set_option("dense_transposed", 0)
-    ctx.set_option("dense_f32", 2)
+    ctx.set_option("dense_f32", 1)
 
 
 # ---- two-level scan over the spatial index (csrc/cells.h) -------------------------------------------
@@ -1429,24 +1427,20 @@ def test_filters_and_cell_scan_across_scales(ctx, model):
 
 
 def test_dense_mfma_scan_arrangements_agree(ctx):
-    """both arrangements of the fp64 MFMA filter scan (hypothesis block through LDS / B fragments in
-    registers) and the exact VALU kernel count the same votes; ragged row and hypothesis counts"""
+    """the fp64 and the fp32 matrix-core filter scans and the exact VALU kernel count the same votes; ragged row and
+    hypothesis counts"""
     rows = synth.dense(70_013, 64, 0.05, seed=313)[0]
     ctx.set_model(L.DENSE, 64, 0.1).upload(rows)
     ctx.hypotheses_sample(17, 0, 333)
     res = []
-    # last two: the fp32 matrix-core filter, hypothesis fragments in registers / through the LDS ring
-    for v1, filt, f32 in ((0, 1, 0), (1, 1, 0), (0, 0, 0), (0, 1, 1), (0, 1, 2)):
-        ctx.set_option("dense_scan_v1", v1)
+    for filt, f32 in ((1, 0), (0, 0), (1, 1)):
         ctx.set_option("scan_filter", filt)
         ctx.set_option("dense_f32", f32)
         ctx.scan()
         res.append(ctx.hypotheses(params=False)[2].copy())
-    ctx.set_option("dense_scan_v1", 0)
     ctx.set_option("scan_filter", 1)
-    ctx.set_option("dense_f32", 2)
-    assert np.array_equal(res[0], res[2]) and np.array_equal(res[1], res[2]) and np.array_equal(res[3], res[2])
-    assert np.array_equal(res[4], res[2])
+    ctx.set_option("dense_f32", 1)
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[2], res[1])
     assert res[0].max() > 1000
 
 

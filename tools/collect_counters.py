@@ -3,7 +3,7 @@
 box and write profiles-ready JSON (stamped with the content hash of the kernel sources, which bench.py checks
 before quoting it):
 
-    python3 tools/collect_counters.py plane [out_dir]      # -> out_dir/r02_plane_scan_counters.json
+    python3 tools/collect_counters.py plane [out_dir] [full_count|early_exit]   # -> out_dir/r03_plane_<rate>_scan_counters.json
 
 Six separate rocprofv3 passes (counters only + --kernel-trace, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 WRITE_SIZE each in their own pass, gfx950 correction FETCH_SIZE x 2) of `tools/scan_once.py <workload>`, plus one
@@ -23,7 +23,8 @@ from bench import kernel_source_hash  # noqa: E402
 
 # the kernels of the scan phase (bounded two-level scan: the level-1 passes and the balanced second level)
 CELLS = ("k_cells_bounds", "k_scan_pairs", "k_scan_cells")
-KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32",), "dense": ("k_scan_dense_mfma",)}
+KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32",),
+          "dense": ("k_scan_dense_mfma", "k_dense_recheck")}
 
 
 def is_scan(w, name):
@@ -38,9 +39,12 @@ SETS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM",
 MFMA_SETS = ["SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES"]
 
 
+BOUND = "1"
+
+
 def run_pass(w, counters, d):
     cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "-d", d, "--output-format", "csv", "--",
-                                                       "python3", "tools/scan_once.py", w]
+                                                       "python3", "tools/scan_once.py", w, "1", BOUND]
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
     if r.returncode != 0:
         return None
@@ -59,11 +63,14 @@ def run_pass(w, counters, d):
 
 
 def main():
+    global BOUND
     w = sys.argv[1]
     out_dir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
+    mode = sys.argv[3] if len(sys.argv) > 3 else "early_exit"
+    BOUND = "0" if mode == "full_count" else "1"
     os.makedirs(out_dir, exist_ok=True)
     os.environ.setdefault("TMPDIR", "/tmp")
-    scratch = os.path.join(out_dir, "pmc_%s" % w)
+    scratch = os.path.join(out_dir, "pmc_%s_%s" % (w, mode))
     c = {}
     for i, s in enumerate(SETS + (MFMA_SETS if w == "dense" else [])):
         got = run_pass(w, s, os.path.join(scratch, "p%d" % i))
@@ -75,7 +82,7 @@ def main():
     # kernel duration from a --kernel-trace --stats pass of the same command (3 launches)
     d = os.path.join(scratch, "stats")
     subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "--output-format", "csv", "--", "python3",
-                    "tools/scan_once.py", w, "3"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                    "tools/scan_once.py", w, "3", BOUND], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                    timeout=300)
     avg_ns = None
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
@@ -85,10 +92,11 @@ def main():
                 tot += float(row["TotalDurationNs"])
         if tot:
             avg_ns = tot / 3.0        # per bench step (3 steps in this pass)
-    out = {"workload": w, "kernel": " + ".join(KERNEL[w]), "kernel_source_hash": kernel_source_hash(),
+    out = {"workload": w, "rate": mode, "kernel": " + ".join(KERNEL[w]), "kernel_source_hash": kernel_source_hash(),
            "collected_at": time.strftime("%Y-%m-%d %H:%M:%S"),
-           "source": "tools/collect_counters.py %s: rocprofv3 --pmc passes (one counter set each, --kernel-trace only) of "
-                     "tools/scan_once.py %s -- the bench's shapes and sampler stream, one step" % (w, w),
+           "source": "tools/collect_counters.py %s %s: rocprofv3 --pmc passes (one counter set each, --kernel-trace only) of "
+                     "tools/scan_once.py %s 1 %s -- the bench's shapes and sampler stream, one step, scan_bound %s" % (
+                         w, mode, w, BOUND, BOUND),
            "counters_per_launch_sum_over_chip": c, "scan_launches_per_step": LAUNCHES,
            "kernel_avg_ms": avg_ns / 1e6 if avg_ns else None,
            "note": "counters and kernel time are SUMS over the scan launches of ONE bench step (lsqr_batch_fit)"}
@@ -110,7 +118,7 @@ def main():
         out["hbm_write_bytes"] = wr
         out["hbm_bytes_per_launch"] = rd + wr
         out["hbm_note"] = "FETCH_SIZE_KB*1024*2 (gfx950 correction) + WRITE_SIZE_KB*1024, separate passes"
-    path = os.path.join(out_dir, "r02_%s_scan_counters.json" % w)
+    path = os.path.join(out_dir, "r03_%s_%s_scan_counters.json" % (w, mode))
     json.dump(out, open(path, "w"), indent=1)
     print(path)
     subprocess.run(["rm", "-rf", scratch])

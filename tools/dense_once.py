@@ -1,4 +1,4 @@
-# dense scan launches for timing / rocprof:  python3 tools/dense_once.py [f32=1|0] [H]
+# dense scan launches for timing / rocprof:  python3 tools/dense_once.py [f32=1|0] [H]   (1: fp32 matrix cores, 0: fp64)
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 from lsqrrecipes_amd import _lib as L, synth

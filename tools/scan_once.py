@@ -1,11 +1,12 @@
 # one bench step (lsqr_batch_fit) of a BASELINE workload on the bench's shapes and seed (for rocprofv3 --pmc passes):
-#   python3 tools/scan_once.py plane|sphere|line|us|dense [launches]
+#   python3 tools/scan_once.py plane|sphere|line|us|dense [launches] [scan_bound: 0 = full count, 1 = early exit]
 import sys
 sys.path.insert(0, '.')
 from lsqrrecipes_amd import _lib as L, synth
 from lsqrrecipes_amd.context import Context
 wl = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+bound = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 N = {'dense': 2_000_000, 'us': 1_000_000}.get(wl, 10_000_000)
 H = 1024 if wl == 'dense' else 4096
 gen = {'plane': synth.plane, 'sphere': synth.sphere, 'line': synth.line, 'us': synth.us_single_fast}
@@ -16,7 +17,8 @@ ctx = Context(0)
 ctx.set_model(model, 64 if wl == 'dense' else 3, delta, L.LS_ANALYTIC).upload(data)
 if wl in ('plane', 'sphere', 'line'):
     ctx.set_option('scan_index', 2)
+ctx.set_option('scan_bound', bound)
 for _ in range(reps):
-    # one bench step: sample, solve, scan (bounded for plane / sphere), winner, mask, closed-form fit
+    # one bench step: sample, solve, scan, winner, mask, closed-form fit
     ctx.batch_fit(0xC0FFEE, 0, H)
     ctx.synchronize()
