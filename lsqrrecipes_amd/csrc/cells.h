@@ -932,7 +932,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? (
 constexpr int kPilots = 64;
 struct BoundSel {            // device-side state of one bounded scan
   uint32_t n_pilot, n_rest;  // number of selected hypotheses of the two passes
-  uint32_t pad[2];
+  uint32_t n_cand;           // rank bounds (axis.h): hypotheses whose bounds were refined by rank (n_pilot is 0 then)
+  uint32_t pad;
 };
 
 // single block of 1024 threads, H <= 8192: pilots = the first kPilots valid hypotheses (index order) whose bound is
@@ -983,6 +984,7 @@ __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict
     const bool known = best_before >= thr && best_before > 0;
     st->n_pilot = known ? 0u : (s_scan[1023] < kPilots ? s_scan[1023] : kPilots);
     st->n_rest = 0;
+    st->n_cand = 0;
   }
 }
 
@@ -1203,8 +1205,10 @@ constexpr uint32_t kChunkCells = 128;
 __global__ __launch_bounds__(128) void k_tile_costs(const uint8_t *__restrict__ cnt, uint32_t gstride, uint32_t H,
                                                     const uint32_t *__restrict__ h_dev, uint32_t ncells,
                                                     uint32_t *__restrict__ cost, uint32_t *__restrict__ csum,
-                                                    uint32_t *__restrict__ votes, uint32_t h_off) {
-  for (uint32_t i = blockIdx.x * kChunkCells + threadIdx.x; i < H; i += gridDim.x * kChunkCells) votes[i] = 0;
+                                                    uint32_t *__restrict__ votes, uint32_t h_off, int zero_votes) {
+  // (zero_votes = 0: the counting pass has already put counts there -- axis.h: k_count_axis)
+  if (zero_votes)
+    for (uint32_t i = blockIdx.x * kChunkCells + threadIdx.x; i < H; i += gridDim.x * kChunkCells) votes[i] = 0;
   if (h_dev) {
     const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection
     H = hd < H ? hd : H;
@@ -1249,7 +1253,9 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
     const double *__restrict__ sp, const float *__restrict__ rows, const float *__restrict__ spf, uint32_t H,
     ModelConsts mc, CellConsts cc, uint32_t *__restrict__ vpart, uint32_t vstride,
     const uint32_t *__restrict__ h_dev, const uint8_t *__restrict__ cnt, uint32_t gstride, const uint32_t *__restrict__ cost,
-    const uint32_t *__restrict__ csum, uint32_t nchunks, uint32_t h_off) {
+    const uint32_t *__restrict__ csum, uint32_t nchunks, uint32_t h_off, const unsigned long long *__restrict__ pmask) {
+  // pmask (nullable): survivor masks per (cell, group) written by the counting pass when it settles pairs itself
+  // (axis.h: k_count_axis) -- then the survivors are what that pass left, not everything level 1 lets through
   typedef typename CM::M M;
   constexpr int NB = CM::NB;
   constexpr int SPD = M::SP;
@@ -1392,7 +1398,9 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
       typename CM::Hyp hy;
       CM::load(row, row2, h < H, cc, hy);
       float bc[NB];
-      unsigned long long surv = __ballot(CM::level1(hy, bx, ctr, cc, bc));  // == the counting pass: cg - pad bits
+      const bool l1 = CM::level1(hy, bx, ctr, cc, bc);
+      unsigned long long surv = __ballot(l1);  // == the counting pass: cg - pad bits
+      if (pmask) surv = pmask[(size_t)cell * gstride + g];  // (wave-uniform address: a scalar load)
       for (uint32_t k = 0; k < jlo; k++) surv &= surv - 1;                  // the first jlo are not mine
       if (jhi < cg - kGroupPad) {  // the tail belongs to the next wave: keep the lowest jhi - jlo bits
         unsigned long long keep = 0, m = surv;

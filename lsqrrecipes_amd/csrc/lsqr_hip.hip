@@ -26,6 +26,7 @@
 #include "us_kernels.h"
 #include "cells.h"
 #include "earlyexit.h"
+#include "axis.h"
 #include "sort.h"
 #include "rigid.h"
 #include "phantom.h"
@@ -83,12 +84,20 @@ struct lsqr_ctx {
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
   uint32_t *d_ub = nullptr;  // per-hypothesis vote bound of the two-level scan's first level (k_cells_bounds)
+  // axis-sorted cells (axis.h; plane, 3-D): per-cell axis, the cells' sorted projections
+  CellAxis *d_axis = nullptr;
+  float *d_cellT = nullptr;
+  size_t axis_cap = 0, cellT_cap = 0;
+  bool axis_valid = false;
+  int opt_axis = 1;               // 1: the bounded scan of the plane takes its vote bounds by rank (k_bound_axis)
+  uint32_t *d_ub2 = nullptr, *d_lb2 = nullptr;  // rank bounds of the candidates (compact order), H_cap each
   uint8_t *d_paircnt = nullptr;   // k_scan_pairs: survivors per (cell, group of 64 hypotheses)
   uint32_t *d_paircost = nullptr; // [n_cells cell costs | chunk sums]
   uint32_t *d_vpart = nullptr;    // per-workgroup partial votes of k_scan_pairs
   size_t paircnt_cap = 0, paircost_cap = 0, vpart_cap = 0;
   // bounded scan (cells.h: k_pick_*): the selected hypotheses as a compact batch
   uint32_t *d_sel = nullptr;        // [kPilots pilots | H_cap rest]
+  bool pick_exact_lds = false;
   BoundSel *d_bsel = nullptr;
   double *d_hparams2 = nullptr;
   float *d_hparams2_f32 = nullptr;
@@ -349,6 +358,9 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   if (c->d_votes) (void)hipFree(c->d_votes);
   if (c->d_ub) (void)hipFree(c->d_ub);
   c->d_ub = nullptr;
+  if (c->d_ub2) (void)hipFree(c->d_ub2);
+  if (c->d_lb2) (void)hipFree(c->d_lb2);
+  c->d_ub2 = c->d_lb2 = nullptr;  // (allocated by the first bounded scan with rank bounds)
   for (void *b : {(void *)c->d_sel, (void *)c->d_bsel, (void *)c->d_hparams2, (void *)c->d_hparams2_f32, (void *)c->d_votes2})
     if (b) (void)hipFree(b);
   c->d_sel = nullptr; c->d_bsel = nullptr; c->d_hparams2 = nullptr; c->d_hparams2_f32 = nullptr; c->d_votes2 = nullptr;
@@ -554,6 +566,7 @@ void drop_index(lsqr_ctx *c) {
   c->n_sorted = 0;
   c->n_cells = 0;
   c->index_valid = false;
+  c->axis_valid = false;
 }
 void free_index(lsqr_ctx *c) {
   if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -657,6 +670,34 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
     hipLaunchKernelGGL((k_gather_boxes<D>), dim3((c->n_cells + 3) / 4), dim3(256), 0, c->stream, c->d_data,
                        c->stride, v_out, c->n_sorted, c->n_cells, cell_pts, c->d_sorted, c->d_boxes);
     IDXCHK(hipGetLastError());
+  }
+  // axis-sorted cells (axis.h): plane in 3-D, cells of 256 / 512 records
+  c->axis_valid = false;
+  if (D == 3 && c->opt_axis && c->cfg.model == LSQR_MODEL_PLANE && c->n_cells && (cell_pts == 512 || cell_pts == 256)) {
+    if ((st = ensure(c, &c->d_axis, &c->axis_cap, (size_t)c->n_cells)) != LSQR_OK) return st;
+    if ((st = ensure(c, &c->d_cellT, &c->cellT_cap, (size_t)c->n_cells * cell_pts)) != LSQR_OK) return st;
+    double *d_cmom = (double *)c->d_idx_scratch;  // 80 B per cell: the sort's scratch is free again (16 B per record)
+    if ((size_t)c->n_cells * 10 * sizeof(double) <= c->idx_scratch_cap) {
+      const unsigned gc = (c->n_cells + 3) / 4;
+      if (cell_pts == 512) {
+        hipLaunchKernelGGL((k_cell_moments<8>), dim3(gc), dim3(256), 0, c->stream, c->d_sorted, c->n_sorted, c->n_cells,
+                           c->d_boxes, d_cmom);
+      } else {
+        hipLaunchKernelGGL((k_cell_moments<4>), dim3(gc), dim3(256), 0, c->stream, c->d_sorted, c->n_sorted, c->n_cells,
+                           c->d_boxes, d_cmom);
+      }
+      const unsigned ngrp = (c->n_cells + kAxisGroup - 1) / kAxisGroup;
+      hipLaunchKernelGGL(k_cell_axes, dim3((ngrp + 255) / 256), dim3(256), 0, c->stream, d_cmom, c->d_boxes, c->n_cells,
+                         c->d_axis);
+      if (cell_pts == 512)
+        hipLaunchKernelGGL((k_cell_sort<8>), dim3(gc), dim3(256), 0, c->stream, c->d_sorted, c->n_sorted, c->n_cells,
+                           c->d_boxes, c->d_axis, c->d_cellT);
+      else
+        hipLaunchKernelGGL((k_cell_sort<4>), dim3(gc), dim3(256), 0, c->stream, c->d_sorted, c->n_sorted, c->n_cells,
+                           c->d_boxes, c->d_axis, c->d_cellT);
+      IDXCHK(hipGetLastError());
+      c->axis_valid = true;
+    }
   }
 #undef IDXCHK
   c->index_valid = true;
@@ -822,7 +863,9 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
   if ((st = ensure(c, &c->d_paircost, &c->paircost_cap, (size_t)c->n_cells + nchunks)) != LSQR_OK) return st;
   uint32_t *d_cost = c->d_paircost, *d_csum = c->d_paircost + c->n_cells;
   const float *rows = CM::ROW_F32 ? b.spf : (const float *)b.sp;
-  {  // counting pass: waves past the device-side H leave at once, so the grid is cut finely in x
+  const unsigned long long *pmask = nullptr;  // (survivor masks from a counting pass that settles pairs itself: none)
+  const bool by_rank = false;
+  if (!by_rank) {  // counting pass: waves past the device-side H leave at once, so the grid is cut finely in x
     const unsigned gy = (Hc + 255) / 256;
     const uint32_t per = std::max<uint32_t>(8, (c->n_cells + 1023) / 1024);
     const unsigned gx = (c->n_cells + per - 1) / per;
@@ -832,7 +875,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
-                     c->n_cells, d_cost, d_csum, b.votes, b.h_off);  // (also zeroes the batch's votes)
+                     c->n_cells, d_cost, d_csum, b.votes, b.h_off, by_rank ? 0 : 1);  // (zeroes the batch's votes)
   HIPCHK(c, hipGetLastError());
   bool ldsb_default = CM::LDS_BROADCAST;
   if constexpr (requires { CM::LDS_BROADCAST_PAIRS; }) ldsb_default = CM::LDS_BROADCAST_PAIRS;
@@ -853,7 +896,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
     ProfScope ps(c, KID_SCAN);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BS), lds, c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
                        b.sp, rows, b.spf, Hc, c->mc, cc, c->d_vpart, Hc, b.h_dev, (const uint8_t *)c->d_paircnt, gstride,
-                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks, b.h_off);
+                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks, b.h_off, pmask);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_votes_reduce, dim3((Hc + 63) / 64, 48), dim3(256), 0, c->stream,
                        (const uint32_t *)c->d_vpart, Hc, (uint32_t)blocks, Hc, b.h_dev, b.votes, b.h_off);
@@ -863,11 +906,93 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
   return ldsb ? launch(k_scan_pairs<CM, PP, BS, true>) : launch(k_scan_pairs<CM, PP, BS, false>);
 }
 
+// The bounded scan with vote bounds by rank (axis.h; plane in 3-D over axis-sorted cells): box-population bounds ->
+// candidates -> their upper AND lower vote bounds by rank (k_bound_axis: no observation is evaluated) -> only the
+// hypotheses whose upper bound exceeds the best lower bound before them are counted exactly.  No pilots.
+template <int PP>
+int run_scan_bounded_rank(lsqr_ctx *c) {
+  typedef PlaneCell<3> CM;
+  typedef typename CM::M M;
+  ProfScope whole(c, KID_SCAN);
+  struct Mute {
+    lsqr_ctx *c;
+    bool was;
+    ~Mute() { c->prof = was; }
+  } mute{c, c->prof};
+  c->prof = false;
+  int st = run_cells_bounds<CM, PP>(c, c->d_ub);
+  if (st != LSQR_OK) return st;
+  const uint32_t H = (uint32_t)c->H;
+  if (!c->d_ub2) {
+    HIPCHK(c, hipMalloc((void **)&c->d_ub2, c->H_cap * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_lb2, c->H_cap * sizeof(uint32_t)));
+  }
+  const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
+  uint32_t *sel_a = c->d_sel, *sel_b = c->d_sel + kPilots;          // candidates / counted (both <= H entries:
+  double *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;           //  sel_a overlays the head of the area, the
+  float *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;      //  candidate list lives in d_votes2's tail)
+  uint32_t *votes_b = c->d_votes2 + kPilots;
+  // the candidate list may hold up to H entries: it cannot share d_sel's 64-entry head -- it goes to d_vpart scratch
+  if ((st = ensure(c, &c->d_vpart, &c->vpart_cap, (size_t)H)) != LSQR_OK) return st;
+  uint32_t *cand = c->d_vpart;  // (free until run_scan_pairs below, which is after the last reader of cand)
+  (void)sel_a;
+  hipLaunchKernelGGL(k_pick_cands, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, c->best_before, cand,
+                     c->d_bsel, c->d_votes, c->d_ub2, c->d_lb2);
+  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, cand, &c->d_bsel->n_pilot, H,
+                     c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
+  HIPCHK(c, hipGetLastError());
+  {
+    const unsigned gy = (H + 511) / 512;  // (workgroups past the device-side candidate count return at once)
+    const uint32_t per = std::max<uint32_t>(8, ((c->n_cells + 767) / 768 + 7) / 8 * 8);
+    const unsigned gx = (c->n_cells + per - 1) / per;
+    float thr_up = (float)c->mc.thr, thr_dn = thr_up;
+    if ((double)thr_up < c->mc.thr) thr_up = nextafterf(thr_up, INFINITY);
+    if ((double)thr_dn > c->mc.thr) thr_dn = nextafterf(thr_dn, -INFINITY);
+    float xabs = (float)c->mc.absmax;
+    if ((double)xabs < c->mc.absmax) xabs = nextafterf(xabs, INFINITY);
+    hipLaunchKernelGGL((k_bound_axis<PP>), dim3(gx, gy), dim3(512), 0, c->stream, c->d_boxes, c->d_axis, c->d_cellT,
+                       c->n_sorted, c->n_cells, (const float *)sp_b, H, &c->d_bsel->n_pilot, cc, thr_up, thr_dn, xabs, per,
+                       c->d_ub2, c->d_lb2);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    const size_t lds = (2 * (size_t)((H + 7) & ~7u) + 1024) * sizeof(uint32_t);
+    if (lds > 64 * 1024 && !c->pick_exact_lds) {
+      HIPCHK(c, hipFuncSetAttribute((const void *)k_pick_exact, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      c->pick_exact_lds = true;
+    }
+    hipLaunchKernelGGL(k_pick_exact, dim3(1), dim3(1024), lds, c->stream, c->d_ub, c->d_valid, H, c->best_before, cand,
+                       c->d_ub2, c->d_lb2, sel_b, c->d_bsel);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, H,
+                     c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
+  HIPCHK(c, hipGetLastError());
+  const ScanBatch pb = {sp_b, spf_b, (size_t)H, votes_b, &c->d_bsel->n_rest};
+  if ((st = run_scan_pairs<CM, PP>(c, pb)) != LSQR_OK) return st;
+  hipLaunchKernelGGL(k_scatter_one, dim3((H + 255) / 256), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, votes_b,
+                     c->d_votes);
+  HIPCHK(c, hipGetLastError());
+  c->last_bound[0] = 1;
+  c->last_bound[3] = H;
+  if (!c->h_bsel) {
+    HIPCHK(c, hipHostMalloc((void **)&c->h_bsel, 64));
+    memset(c->h_bsel, 0, 64);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_bsel, c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
+  c->h_bsel_H = H;
+  return LSQR_OK;
+}
+
 // The bounded scan of the current batch over the index (cells.h, "bounded scan"): bounds, pilots counted exactly,
 // then only the hypotheses that can still become the running maximum.  Everything is chained on the stream.
 template <class CM, int PP>
 int run_scan_bounded(lsqr_ctx *c) {
   typedef typename CM::M M;
+  if constexpr (std::is_same<CM, PlaneCell<3>>::value && (PP == 4 || PP == 2)) {
+    if (c->axis_valid && c->opt_axis && c->cell_pts == (uint32_t)(128 * PP) && c->H <= 8192)
+      return run_scan_bounded_rank<PP>(c);
+  }
   // profiling: ONE scope over the whole scan phase (bounds, selections, both counting launches)
   ProfScope whole(c, KID_SCAN);
   struct Mute {
@@ -2107,7 +2232,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     }
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_ub2, c->d_lb2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -3922,6 +4047,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     c->opt_pairs = value;
     return LSQR_OK;
   }
+  if (!strcmp(name, "scan_axis")) {  // 1 (default): axis-sorted cells + vote bounds by rank (plane, 3-D); 0: off
+    c->opt_axis = value != 0;
+    return LSQR_OK;
+  }
   if (!strcmp(name, "scan_pairs_waves")) {  // workgroups per CU of k_scan_pairs (0 = what fits)
     c->opt_pairs_waves = value;
     return LSQR_OK;
@@ -4087,6 +4216,8 @@ int lsqr_scan_work(lsqr_ctx *c, uint64_t out[6]) {
     out[5] = c->h_ee->n_alive;
   } else {
     out[1] = all;
+    if (c->last_bound[0] && c->last_bound[3] == c->H && c->h_bsel && c->h_bsel_H == c->H)
+      out[3] = c->h_bsel->n_cand;  // bounded plane scan with rank bounds: the hypotheses whose bounds were refined
   }
   return LSQR_OK;
 }
