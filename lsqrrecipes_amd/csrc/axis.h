@@ -342,14 +342,15 @@ __global__ __launch_bounds__(512) void k_bound_axis(const CellBox *__restrict__ 
 }
 
 // candidates of the rank bounds: valid hypotheses whose box-population bound is at least half the largest one and
-// above the best of earlier batches (index order); st->n_pilot = their number
+// above the best of earlier batches (index order); st->n_cand = their number
 __global__ __launch_bounds__(1024) void k_pick_cands(const uint32_t *__restrict__ ub, const uint8_t *__restrict__ valid,
                                                      uint32_t H, uint32_t best_before, uint32_t *__restrict__ sel,
                                                      BoundSel *__restrict__ st, uint32_t *__restrict__ votes,
-                                                     uint32_t *__restrict__ ub2, uint32_t *__restrict__ lb2) {
+                                                     uint32_t *__restrict__ ub2, uint32_t *__restrict__ lb2,
+                                                     uint32_t *__restrict__ lo) {
   __shared__ uint32_t s_red[16], s_scan[1024];
   const int t = threadIdx.x;
-  for (uint32_t h = t; h < H; h += 1024) votes[h] = 0, ub2[h] = 0, lb2[h] = 0;  // (uncounted hypotheses report 0)
+  for (uint32_t h = t; h < H; h += 1024) votes[h] = 0, ub2[h] = 0, lb2[h] = 0, lo[h] = 0;  // (uncounted hypotheses report 0)
   uint32_t mx = 0;
   for (uint32_t h = t; h < H; h += 1024) mx = valid[h] && ub[h] > mx ? ub[h] : mx;
   for (int o = 32; o > 0; o >>= 1) {
@@ -379,82 +380,29 @@ __global__ __launch_bounds__(1024) void k_pick_cands(const uint32_t *__restrict_
   for (int k = 0; k < 8; k++)
     if (f[k]) sel[pos++] = t * 8 + k;
   if (t == 1023) {
-    st->n_pilot = s_scan[1023];
+    st->n_cand = s_scan[1023];
+    st->n_pilot = 0;
     st->n_rest = 0;
   }
 }
 
-// The hypotheses to count exactly.  U[h] / Lo[h]: vote bounds of hypothesis h -- the rank bounds (ub2 / lb2, compact
-// order of `cand`) for a candidate, (box population, 0) for the others.  h is counted iff  U[h] > L[h],
-// L[h] = max(best of earlier batches, max over h' < h of Lo[h'])  -- a lower bound of the serial loop's running maximum
-// when it reaches h.  A hypothesis left out has votes <= U[h] <= L[h] <= running maximum: no update there (strict '>');
-// a hypothesis the serial loop DOES update on has votes > every earlier count >= every earlier Lo, so U >= votes > L:
-// it is counted.  Winner, iteration count and consensus set are those of counting everything.
-__global__ __launch_bounds__(1024) void k_pick_exact(const uint32_t *__restrict__ ub, const uint8_t *__restrict__ valid,
-                                                     uint32_t H, uint32_t best_before, const uint32_t *__restrict__ cand,
-                                                     const uint32_t *__restrict__ ub2, const uint32_t *__restrict__ lb2,
-                                                     uint32_t *__restrict__ sel, BoundSel *__restrict__ st) {
-  extern __shared__ uint32_t s_ul[];  // [U (H) | Lo (H) | scan (1024)]
-  const int t = threadIdx.x;
-  const uint32_t Hp = (H + 7) & ~7u;
-  uint32_t *U = s_ul, *Lo = s_ul + Hp, *s_scan = s_ul + 2 * Hp;
-  for (uint32_t h = t; h < Hp; h += 1024) U[h] = (h < H && valid[h]) ? ub[h] : 0u, Lo[h] = 0u;
-  __syncthreads();
-  const uint32_t nc = st->n_pilot;
-  for (uint32_t j = t; j < nc; j += 1024) {
-    const uint32_t h = cand[j];
-    U[h] = ub2[j] < U[h] ? ub2[j] : U[h];  // (both are valid upper bounds)
-    Lo[h] = lb2[j];
-  }
-  __syncthreads();
-  uint32_t pre[8], lm = 0;
-  for (int k = 0; k < 8; k++) {
-    const uint32_t h = t * 8 + k;
-    pre[k] = lm;
-    const uint32_t v = h < H ? Lo[h] : 0u;
-    lm = v > lm ? v : lm;
-  }
-  s_scan[t] = lm;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const uint32_t a = t >= o ? s_scan[t - o] : 0u;
-    __syncthreads();
-    s_scan[t] = a > s_scan[t] ? a : s_scan[t];
-    __syncthreads();
-  }
-  const uint32_t before = t ? s_scan[t - 1] : 0u;
-  __syncthreads();
-  uint32_t f[8], cnt = 0;
-  for (int k = 0; k < 8; k++) {
-    const uint32_t h = t * 8 + k;
-    uint32_t L = before > pre[k] ? before : pre[k];
-    L = best_before > L ? best_before : L;
-    f[k] = (h < H && valid[h] && U[h] > L) ? 1u : 0u;
-    cnt += f[k];
-  }
-  s_scan[t] = cnt;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const uint32_t a = t >= o ? s_scan[t - o] : 0u;
-    __syncthreads();
-    s_scan[t] += a;
-    __syncthreads();
-  }
-  uint32_t pos = s_scan[t] - cnt;
-  for (int k = 0; k < 8; k++)
-    if (f[k]) sel[pos++] = t * 8 + k;
-  if (t == 1023) {
-    st->n_rest = s_scan[1023];
-    st->n_cand = nc;
-    st->n_pilot = 0;  // nothing was counted in a first pass (lsqr_scan_workload)
-  }
-}
-
-// exact votes of the counted selection back to their places in the batch
-__global__ __launch_bounds__(256) void k_scatter_one(const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel,
-                                                     const uint32_t *__restrict__ v, uint32_t *__restrict__ votes) {
+// The rank bounds of the candidates (compact order of `cand`) folded into per-hypothesis bounds: ub[h] = min(box
+// population, rank upper bound) -- both are valid upper bounds -- and lo[h] = rank lower bound (0 for the others:
+// zeroed by k_pick_cands).  k_pick_pilots / k_pick_rest (cells.h) then select on these: h is counted iff
+//   ub[h] > L[h],   L[h] = max(best of earlier batches, max over h' < h of lo[h'], exact votes of pilots before h)
+// -- a lower bound of the serial loop's running maximum when it reaches h.  A hypothesis left out has votes <= ub[h]
+// <= L[h] <= running maximum: no update there (strict '>'); a hypothesis the serial loop DOES update on has votes >
+// every earlier count >= every earlier lo, so ub >= votes > L: it is counted.  Winner, iteration count and consensus
+// set are those of counting everything.  Pilots are only counted when the rank lower bounds are weak (max lo below
+// half the largest upper bound: sparse uploads, whose cells are not flat enough for rank bounds).
+__global__ __launch_bounds__(256) void k_refine_bounds(const uint32_t *__restrict__ cand, const BoundSel *__restrict__ st,
+                                                       const uint32_t *__restrict__ ub2, const uint32_t *__restrict__ lb2,
+                                                       uint32_t *__restrict__ ub, uint32_t *__restrict__ lo) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j < *n_sel) votes[sel[j]] = v[j];
+  if (j >= st->n_cand) return;
+  const uint32_t h = cand[j];
+  ub[h] = ub2[j] < ub[h] ? ub2[j] : ub[h];
+  lo[h] = lb2[j];
 }
 
 }  // namespace lsqr

@@ -641,6 +641,30 @@ inline CellConsts cell_consts(const LineCell<D> *, const ModelConsts &mc) {
 // ---- level 2 of one (cell, group of 64 hypotheses): the surviving hypotheses of the group (bits of `surv`) against
 // the cell's observations held in registers.  bc[] are the lane's (= hypothesis') per-cell constants from level 1;
 // votes are added to lane b of accv for hypothesis b of the group.
+//
+// The filter works on SQUARES (r03; the |v| form it replaces cost 50 vector instructions a pair, this one 32 -- the
+// loop is bound by vector issue, every wave64 instruction taking 4 cycles: profiles/r03_microbench.json):
+//   level 1 gives t_in <= t_out with  |v32| < t_in => agrees,  |v32| >= t_out => does not.  With
+//   a = RD(t_in^2) (0 when t_in <= 0: nothing is certain) and c = RU(t_out^2):
+//     d = fma(v32, v32, -a)  has the sign of v32^2 - a exactly (one rounding), so  d < 0  =>  v32^2 < a <= t_in^2: a
+//     certain inlier (float compare: NaN rows never count);  an observation outside the certain set is AMBIGUOUS iff
+//     v32^2 < c, and  v32^2 < c  =>  d = RN(v32^2 - a) <= RN(c - a) =: band  (rounding is monotone) -- tested once per
+//     lane on the unsigned minimum of the bit patterns of d (a negative d has its sign bit set and looks huge, a NaN
+//     larger than any finite number).  Flagging a few observations with v32^2 >= c too only costs a re-check.
+//   A hypothesis whose filter is off (t_out = +inf or NaN: literal-formula sphere, |n_i| > 1, out-of-range magnitudes)
+//   gets a = 0 and band = 0xFFFFFFFF: every cell it survives in takes the exact predicate, whatever v32 is.
+// cells_filter_squares() turns level 1's (t_in, t_out) in bc[NB-2], bc[NB-1] into (a, band bits).
+template <int NB>
+__device__ __forceinline__ void cells_filter_squares(float (&bc)[NB]) {
+  const float tin = bc[NB - 2], tout = bc[NB - 1];
+  const bool off = !(tout < __builtin_inff());
+  const float a = tin > 0.0f ? (tin * tin) * 0.9999998f : 0.0f;  // RD with room: fl(t^2)(1 - 2^-22) <= t^2
+  const float c = (tout * tout) * 1.0000002f;                    // RU with room (inf when it overflows: band = inf)
+  const float band = c - a;
+  bc[NB - 2] = off ? 0.0f : a;
+  bc[NB - 1] = off ? __builtin_bit_cast(float, 0xFFFFFFFFu) : band;
+}
+
 template <class CM, int PP, bool LDSB>
 __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const float (&bc)[CM::NB], float *s_bc,
                                                 unsigned long long surv, const int lane,
@@ -662,17 +686,17 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
   while (surv) {
     const int b = __builtin_ctzll(surv);
     asm("s_bitset0_b64 %0, %1" : "+s"(surv) : "s"(b));  // surv &= ~(1 << b)
-    v2f fp[NV];
-    float btout, btin_l = 0.0f;
+    v2f fp[NV], na;
+    uint32_t band;
     if (LDSB) {
       static_assert(NB <= 8, "broadcast area holds 8 floats per lane");
       const float4 r0 = ((const float4 *)s_bc)[2 * b], r1 = ((const float4 *)s_bc)[2 * b + 1];
       const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
       for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
-      // (the same value in every lane; said explicitly so that the control flow below stays scalar)
-      btout = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rb[NB - 1])));
-      btin_l = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rb[NB - 2])));
+      na.x = -rb[NB - 2], na.y = -rb[NB - 2];
+      // (the same value in every lane; said explicitly so that the compare below takes it from a scalar register)
+      band = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rb[NB - 1]));
     } else {
 #pragma unroll
       for (int k = 0; k < NV; k++) {
@@ -681,47 +705,31 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
         fp[k].x = v;
         fp[k].y = v;
       }
-      btout = __builtin_bit_cast(
-          float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b));
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 2]), b));
+      na.x = -a, na.y = -a;
+      band = (uint32_t)__builtin_amdgcn_readlane(__builtin_bit_cast(int, bc[NB - 1]), b);
     }
-    // candidate test on the smallest |value| of the lane: NaN rows are ignored by min
-    v2f s[PP];
-    float m = __builtin_inff();
-#pragma unroll
-    for (int p = 0; p < PP; p++) {
-      s[p] = CM::value(xs[p], fp);
-      m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(s[p].x), __builtin_fabsf(s[p].y)));
-    }
-    // a hypothesis whose filter is off (t_out = +inf: literal-formula sphere, |n_i| > 1, out-of-range magnitudes)
-    // takes the exact predicate for the whole cell whatever the fp32 measure says -- it may be inf or NaN there
-    const bool exact_all = !(btout < __builtin_inff());
-    if (__ballot(exact_all || m < btout) == 0) continue;  // (ballots keep the control flow wave-uniform)
-    const float btin = LDSB ? btin_l
-                            : __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                                            __builtin_bit_cast(int, bc[NB - 2]), b));
-    // Does any observation sit in the band tin <= |v| < tout?  One ballot instead of one per value: the
-    // smallest NON-NEGATIVE difference |v| - tin of the lane, found as the unsigned minimum of the bit patterns
-    // (a negative difference -- a certain inlier -- has its sign bit set and looks huge; a NaN row looks
-    // larger than any finite number), against fl(tout - tin).  Conservative: rounding is monotone, so
-    // tin <= |v| < tout implies fl(|v| - tin) <= fl(tout - tin); flagging |v| == tout too only costs a re-check.
-    // (Two compares per value with the mask logic and the counts on the scalar unit -- 36 vector and 40 scalar
-    // instructions per pair instead of 59 and 25 -- measured SLOWER: 551 against 528 us in the second pass of the
-    // bounded plane scan, 1.67 against 1.39 ms for a plain 4096-hypothesis scan.  So did moving just the
-    // "filter off" test of t_out to integer arithmetic on the scalar unit: 3 vector instructions fewer, 8 scalar
-    // ones more, 0.794 against 0.779 ms per step.  The scalar unit is as busy as the vector unit in this loop.)
+    // (An early test "does any observation of the cell come near?" before the ballots -- the |v| form had one -- is
+    // not made: at the bench's thresholds nearly every pair that survives level 1 holds candidates, and after d the
+    // rest of the body is 13 instructions.  Two compares per value with the mask logic and the counts on the scalar
+    // unit measured SLOWER in r02: the scalar unit is nearly as busy as the vector unit in this loop.)
     unsigned long long in[2 * PP];
     uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
     for (int p = 0; p < PP; p++) {
-      const float ax = __builtin_fabsf(s[p].x), ay = __builtin_fabsf(s[p].y);
-      in[2 * p] = __ballot(ax < btin);
-      in[2 * p + 1] = __ballot(ay < btin);
-      const uint32_t dx = __builtin_bit_cast(uint32_t, ax - btin), dy = __builtin_bit_cast(uint32_t, ay - btin);
-      dmin = dx < dmin ? dx : dmin;
-      dmin = dy < dmin ? dy : dmin;
+      const v2f s = CM::value(xs[p], fp);
+      const v2f d = __builtin_elementwise_fma(s, s, na);
+      in[2 * p] = __ballot(d.x < 0.0f);
+      in[2 * p + 1] = __ballot(d.y < 0.0f);
+      // (the two halves are compared with each other FIRST: written as two running minima -- dmin = min(dmin, dx),
+      // dmin = min(dmin, dy) -- hipcc 7.2 drops the high half of a packed fma's result from the chain; seen in the
+      // ISA, a standalone kernel reproduces it, 50 votes in 4 M were lost)
+      typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+      const v2u du = __builtin_bit_cast(v2u, d);
+      const uint32_t m = du.x < du.y ? du.x : du.y;
+      dmin = m < dmin ? m : dmin;
     }
-    const unsigned long long amb =
-        __ballot(exact_all || dmin <= __builtin_bit_cast(uint32_t, btout - btin));
+    const unsigned long long amb = __ballot(dmin <= band);
     if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
       const double *hp = spg + (size_t)b * SPD;  // wave-uniform -> scalar loads
 #pragma unroll
@@ -903,6 +911,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? (
       for (int q = 0; q < CPT; q++) {
         float bc[NB];
         unsigned long long surv = __ballot(CM::level1(hy, bx[q], ctr[q], cc, bc));
+        cells_filter_squares(bc);
         cells_survivors<CM, PP, LDSB>(xs[q], bc, s_bc, surv, lane, sorted, ns, (size_t)(wt * CPT + q),
                                       sp + (size_t)h0 * SPD, mc, accv);
       }
@@ -937,24 +946,30 @@ struct BoundSel {            // device-side state of one bounded scan
 };
 
 // single block of 1024 threads, H <= 8192: pilots = the first kPilots valid hypotheses (index order) whose bound is
-// at least half the largest bound
+// at least half the largest bound.  lo (nullable): per-hypothesis LOWER vote bounds (rank bounds, axis.h) -- they
+// count as known lower bounds of the running maximum like the best of earlier batches.
 __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict__ ub,
                                                       const uint8_t *__restrict__ valid, uint32_t H,
                                                       uint32_t *__restrict__ sel, BoundSel *__restrict__ st,
-                                                      uint32_t *__restrict__ votes, uint32_t best_before) {
-  __shared__ uint32_t s_red[16], s_scan[1024];
+                                                      uint32_t *__restrict__ votes, uint32_t best_before,
+                                                      const uint32_t *__restrict__ lo) {
+  __shared__ uint32_t s_red[16], s_redl[16], s_scan[1024];
   const int t = threadIdx.x;
   for (uint32_t h = t; h < H; h += 1024) votes[h] = 0;  // a hypothesis that is not counted reports 0 votes
-  uint32_t mx = 0;
-  for (uint32_t h = t; h < H; h += 1024) mx = valid[h] && ub[h] > mx ? ub[h] : mx;
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t a = __shfl_down(mx, o);
-    mx = a > mx ? a : mx;
+  uint32_t mx = 0, ml = 0;
+  for (uint32_t h = t; h < H; h += 1024) {
+    mx = valid[h] && ub[h] > mx ? ub[h] : mx;
+    if (lo) ml = valid[h] && lo[h] > ml ? lo[h] : ml;
   }
-  if ((t & 63) == 0) s_red[t >> 6] = mx;
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = __shfl_down(mx, o), b = __shfl_down(ml, o);
+    mx = a > mx ? a : mx;
+    ml = b > ml ? b : ml;
+  }
+  if ((t & 63) == 0) s_red[t >> 6] = mx, s_redl[t >> 6] = ml;
   __syncthreads();
-  mx = 0;
-  for (int w = 0; w < 16; w++) mx = s_red[w] > mx ? s_red[w] : mx;
+  mx = 0, ml = best_before;
+  for (int w = 0; w < 16; w++) mx = s_red[w] > mx ? s_red[w] : mx, ml = s_redl[w] > ml ? s_redl[w] : ml;
   const uint32_t thr = mx - mx / 2;  // ceil(mx / 2)
   // each thread owns 8 consecutive hypotheses: flags, block-wide exclusive scan, ordered write
   uint32_t f[8], cnt = 0;
@@ -981,10 +996,11 @@ __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict
     // Pilots only exist to give the second pass a lower bound of the running maximum.  When an earlier batch of the
     // same RANSAC run already holds a maximum of at least half the largest bound (the pilots' own entry level), that
     // IS the bound: no pilots, the counting launches of the first pass find an empty cost table and return at once.
-    const bool known = best_before >= thr && best_before > 0;
+    // (The rank bounds' lower bounds count the same way.)
+    const bool known = ml >= thr && ml > 0;
     st->n_pilot = known ? 0u : (s_scan[1023] < kPilots ? s_scan[1023] : kPilots);
     st->n_rest = 0;
-    st->n_cand = 0;
+    if (!lo) st->n_cand = 0;
   }
 }
 
@@ -993,10 +1009,33 @@ __global__ __launch_bounds__(1024) void k_pick_rest(const uint32_t *__restrict__
                                                     const uint8_t *__restrict__ valid, uint32_t H,
                                                     const uint32_t *__restrict__ pilots,
                                                     const uint32_t *__restrict__ pilot_votes, uint32_t best_before,
-                                                    uint32_t *__restrict__ sel, BoundSel *__restrict__ st) {
+                                                    uint32_t *__restrict__ sel, BoundSel *__restrict__ st,
+                                                    const uint32_t *__restrict__ lo) {
   __shared__ uint32_t s_pi[kPilots], s_pm[kPilots], s_scan[1024];
   const int t = threadIdx.x;
   const uint32_t np = st->n_pilot;
+  // lo (nullable): lower vote bounds per hypothesis; lob[k] = max of lo over the hypotheses before t * 8 + k
+  uint32_t lob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lo) {
+    uint32_t lm = 0;
+    for (int k = 0; k < 8; k++) {
+      const uint32_t h = t * 8 + k;
+      lob[k] = lm;
+      const uint32_t v = (h < H && valid[h]) ? lo[h] : 0u;
+      lm = v > lm ? v : lm;
+    }
+    s_scan[t] = lm;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const uint32_t a = t >= o ? s_scan[t - o] : 0u;
+      __syncthreads();
+      s_scan[t] = a > s_scan[t] ? a : s_scan[t];
+      __syncthreads();
+    }
+    const uint32_t before = t ? s_scan[t - 1] : 0u;
+    __syncthreads();
+    for (int k = 0; k < 8; k++) lob[k] = before > lob[k] ? before : lob[k];
+  }
   if (t < kPilots) s_pi[t] = t < (int)np ? pilots[t] : 0xFFFFFFFFu;
   if (t == 0) {  // running maximum over the pilots in index order (they are sorted by index)
     uint32_t m = best_before;
@@ -1017,7 +1056,8 @@ __global__ __launch_bounds__(1024) void k_pick_rest(const uint32_t *__restrict__
         before += s_pi[before + step - 1] < h ? step : 0u;
       before += (before < kPilots && s_pi[before] < h) ? 1u : 0u;
       const bool is_pilot = before < kPilots && s_pi[before] == h;
-      const uint32_t L = before ? s_pm[before - 1] : best_before;
+      uint32_t L = before ? s_pm[before - 1] : best_before;
+      L = lob[k] > L ? lob[k] : L;
       f[k] = (!is_pilot && ub[h] > L) ? 1u : 0u;
     }
     cnt += f[k];
@@ -1400,7 +1440,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
       float bc[NB];
       const bool l1 = CM::level1(hy, bx, ctr, cc, bc);
       unsigned long long surv = __ballot(l1);  // == the counting pass: cg - pad bits
-      if (pmask) surv = pmask[(size_t)cell * gstride + g];  // (wave-uniform address: a scalar load)
+      cells_filter_squares(bc);
       for (uint32_t k = 0; k < jlo; k++) surv &= surv - 1;                  // the first jlo are not mine
       if (jhi < cg - kGroupPad) {  // the tail belongs to the next wave: keep the lowest jhi - jlo bits
         unsigned long long keep = 0, m = surv;

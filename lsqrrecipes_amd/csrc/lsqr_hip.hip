@@ -90,14 +90,13 @@ struct lsqr_ctx {
   size_t axis_cap = 0, cellT_cap = 0;
   bool axis_valid = false;
   int opt_axis = 1;               // 1: the bounded scan of the plane takes its vote bounds by rank (k_bound_axis)
-  uint32_t *d_ub2 = nullptr, *d_lb2 = nullptr;  // rank bounds of the candidates (compact order), H_cap each
+  uint32_t *d_ub2 = nullptr;  // rank bounds: [upper | lower] of the candidates (compact order) | lower per hypothesis
   uint8_t *d_paircnt = nullptr;   // k_scan_pairs: survivors per (cell, group of 64 hypotheses)
   uint32_t *d_paircost = nullptr; // [n_cells cell costs | chunk sums]
   uint32_t *d_vpart = nullptr;    // per-workgroup partial votes of k_scan_pairs
   size_t paircnt_cap = 0, paircost_cap = 0, vpart_cap = 0;
   // bounded scan (cells.h: k_pick_*): the selected hypotheses as a compact batch
   uint32_t *d_sel = nullptr;        // [kPilots pilots | H_cap rest]
-  bool pick_exact_lds = false;
   BoundSel *d_bsel = nullptr;
   double *d_hparams2 = nullptr;
   float *d_hparams2_f32 = nullptr;
@@ -359,8 +358,7 @@ int ensure_hyp(lsqr_ctx *c, size_t H) {
   if (c->d_ub) (void)hipFree(c->d_ub);
   c->d_ub = nullptr;
   if (c->d_ub2) (void)hipFree(c->d_ub2);
-  if (c->d_lb2) (void)hipFree(c->d_lb2);
-  c->d_ub2 = c->d_lb2 = nullptr;  // (allocated by the first bounded scan with rank bounds)
+  c->d_ub2 = nullptr;  // (allocated by the first bounded scan with rank bounds)
   for (void *b : {(void *)c->d_sel, (void *)c->d_bsel, (void *)c->d_hparams2, (void *)c->d_hparams2_f32, (void *)c->d_votes2})
     if (b) (void)hipFree(b);
   c->d_sel = nullptr; c->d_bsel = nullptr; c->d_hparams2 = nullptr; c->d_hparams2_f32 = nullptr; c->d_votes2 = nullptr;
@@ -906,81 +904,43 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
   return ldsb ? launch(k_scan_pairs<CM, PP, BS, true>) : launch(k_scan_pairs<CM, PP, BS, false>);
 }
 
-// The bounded scan with vote bounds by rank (axis.h; plane in 3-D over axis-sorted cells): box-population bounds ->
-// candidates -> their upper AND lower vote bounds by rank (k_bound_axis: no observation is evaluated) -> only the
-// hypotheses whose upper bound exceeds the best lower bound before them are counted exactly.  No pilots.
+// Vote bounds by rank (axis.h; plane in 3-D over axis-sorted cells) on top of the box-population bounds in d_ub:
+// candidates -> their upper AND lower vote bounds by rank (k_bound_axis: no observation is evaluated) -> d_ub refined
+// in place, *lo_out = per-hypothesis lower bounds for the selections of the bounded scan.
 template <int PP>
-int run_scan_bounded_rank(lsqr_ctx *c) {
+int run_rank_bounds(lsqr_ctx *c, const uint32_t **lo_out) {
   typedef PlaneCell<3> CM;
   typedef typename CM::M M;
-  ProfScope whole(c, KID_SCAN);
-  struct Mute {
-    lsqr_ctx *c;
-    bool was;
-    ~Mute() { c->prof = was; }
-  } mute{c, c->prof};
-  c->prof = false;
-  int st = run_cells_bounds<CM, PP>(c, c->d_ub);
-  if (st != LSQR_OK) return st;
   const uint32_t H = (uint32_t)c->H;
-  if (!c->d_ub2) {
-    HIPCHK(c, hipMalloc((void **)&c->d_ub2, c->H_cap * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->d_lb2, c->H_cap * sizeof(uint32_t)));
-  }
+  int st;
+  if (!c->d_ub2) HIPCHK(c, hipMalloc((void **)&c->d_ub2, 3 * c->H_cap * sizeof(uint32_t)));  // [ub2 | lb2 | lo]
+  uint32_t *ub2 = c->d_ub2, *lb2 = c->d_ub2 + c->H_cap, *lo = c->d_ub2 + 2 * c->H_cap;
   const CellConsts cc = cell_consts((const CM *)nullptr, c->mc);
-  uint32_t *sel_a = c->d_sel, *sel_b = c->d_sel + kPilots;          // candidates / counted (both <= H entries:
-  double *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;           //  sel_a overlays the head of the area, the
-  float *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;      //  candidate list lives in d_votes2's tail)
-  uint32_t *votes_b = c->d_votes2 + kPilots;
-  // the candidate list may hold up to H entries: it cannot share d_sel's 64-entry head -- it goes to d_vpart scratch
-  if ((st = ensure(c, &c->d_vpart, &c->vpart_cap, (size_t)H)) != LSQR_OK) return st;
-  uint32_t *cand = c->d_vpart;  // (free until run_scan_pairs below, which is after the last reader of cand)
-  (void)sel_a;
+  // (the candidate list and their rows use the second pass's areas: free until the pilots have been counted)
+  uint32_t *cand = c->d_sel + kPilots;
+  double *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
+  float *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;
   hipLaunchKernelGGL(k_pick_cands, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, c->best_before, cand,
-                     c->d_bsel, c->d_votes, c->d_ub2, c->d_lb2);
-  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, cand, &c->d_bsel->n_pilot, H,
+                     c->d_bsel, c->d_votes, ub2, lb2, lo);
+  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, cand, &c->d_bsel->n_cand, H,
                      c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
   HIPCHK(c, hipGetLastError());
-  {
-    const unsigned gy = (H + 511) / 512;  // (workgroups past the device-side candidate count return at once)
-    const uint32_t per = std::max<uint32_t>(8, ((c->n_cells + 767) / 768 + 7) / 8 * 8);
-    const unsigned gx = (c->n_cells + per - 1) / per;
-    float thr_up = (float)c->mc.thr, thr_dn = thr_up;
-    if ((double)thr_up < c->mc.thr) thr_up = nextafterf(thr_up, INFINITY);
-    if ((double)thr_dn > c->mc.thr) thr_dn = nextafterf(thr_dn, -INFINITY);
-    float xabs = (float)c->mc.absmax;
-    if ((double)xabs < c->mc.absmax) xabs = nextafterf(xabs, INFINITY);
-    hipLaunchKernelGGL((k_bound_axis<PP>), dim3(gx, gy), dim3(512), 0, c->stream, c->d_boxes, c->d_axis, c->d_cellT,
-                       c->n_sorted, c->n_cells, (const float *)sp_b, H, &c->d_bsel->n_pilot, cc, thr_up, thr_dn, xabs, per,
-                       c->d_ub2, c->d_lb2);
-    HIPCHK(c, hipGetLastError());
-  }
-  {
-    const size_t lds = (2 * (size_t)((H + 7) & ~7u) + 1024) * sizeof(uint32_t);
-    if (lds > 64 * 1024 && !c->pick_exact_lds) {
-      HIPCHK(c, hipFuncSetAttribute((const void *)k_pick_exact, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      c->pick_exact_lds = true;
-    }
-    hipLaunchKernelGGL(k_pick_exact, dim3(1), dim3(1024), lds, c->stream, c->d_ub, c->d_valid, H, c->best_before, cand,
-                       c->d_ub2, c->d_lb2, sel_b, c->d_bsel);
-    HIPCHK(c, hipGetLastError());
-  }
-  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, H,
-                     c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
+  const unsigned gy = (H + 511) / 512;  // (workgroups past the device-side candidate count return at once)
+  const uint32_t per = std::max<uint32_t>(8, ((c->n_cells + 767) / 768 + 7) / 8 * 8);
+  const unsigned gx = (c->n_cells + per - 1) / per;
+  float thr_up = (float)c->mc.thr, thr_dn = thr_up;
+  if ((double)thr_up < c->mc.thr) thr_up = nextafterf(thr_up, INFINITY);
+  if ((double)thr_dn > c->mc.thr) thr_dn = nextafterf(thr_dn, -INFINITY);
+  float xabs = (float)c->mc.absmax;
+  if ((double)xabs < c->mc.absmax) xabs = nextafterf(xabs, INFINITY);
+  hipLaunchKernelGGL((k_bound_axis<PP>), dim3(gx, gy), dim3(512), 0, c->stream, c->d_boxes, c->d_axis, c->d_cellT,
+                     c->n_sorted, c->n_cells, (const float *)sp_b, H, &c->d_bsel->n_cand, cc, thr_up, thr_dn, xabs, per,
+                     ub2, lb2);
+  hipLaunchKernelGGL(k_refine_bounds, dim3((H + 255) / 256), dim3(256), 0, c->stream, cand, c->d_bsel, ub2, lb2,
+                     c->d_ub, lo);
   HIPCHK(c, hipGetLastError());
-  const ScanBatch pb = {sp_b, spf_b, (size_t)H, votes_b, &c->d_bsel->n_rest};
-  if ((st = run_scan_pairs<CM, PP>(c, pb)) != LSQR_OK) return st;
-  hipLaunchKernelGGL(k_scatter_one, dim3((H + 255) / 256), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, votes_b,
-                     c->d_votes);
-  HIPCHK(c, hipGetLastError());
-  c->last_bound[0] = 1;
-  c->last_bound[3] = H;
-  if (!c->h_bsel) {
-    HIPCHK(c, hipHostMalloc((void **)&c->h_bsel, 64));
-    memset(c->h_bsel, 0, 64);
-  }
-  HIPCHK(c, hipMemcpyAsync(c->h_bsel, c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
-  c->h_bsel_H = H;
+  (void)st;
+  *lo_out = lo;
   return LSQR_OK;
 }
 
@@ -989,10 +949,6 @@ int run_scan_bounded_rank(lsqr_ctx *c) {
 template <class CM, int PP>
 int run_scan_bounded(lsqr_ctx *c) {
   typedef typename CM::M M;
-  if constexpr (std::is_same<CM, PlaneCell<3>>::value && (PP == 4 || PP == 2)) {
-    if (c->axis_valid && c->opt_axis && c->cell_pts == (uint32_t)(128 * PP) && c->H <= 8192)
-      return run_scan_bounded_rank<PP>(c);
-  }
   // profiling: ONE scope over the whole scan phase (bounds, selections, both counting launches)
   ProfScope whole(c, KID_SCAN);
   struct Mute {
@@ -1008,8 +964,13 @@ int run_scan_bounded(lsqr_ctx *c) {
   uint32_t *votes_a = c->d_votes2, *votes_b = c->d_votes2 + kPilots;
   double *sp_a = c->d_hparams2, *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
   float *spf_a = c->d_hparams2_f32, *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;
+  const uint32_t *lo = nullptr;  // lower vote bounds (rank bounds of the plane), or none
+  if constexpr (std::is_same<CM, PlaneCell<3>>::value && (PP == 4 || PP == 2)) {
+    if (c->axis_valid && c->opt_axis && c->cell_pts == (uint32_t)(128 * PP))
+      if ((st = run_rank_bounds<PP>(c, &lo)) != LSQR_OK) return st;
+  }
   hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel,
-                     c->d_votes, c->best_before);  // (also zeroes the batch's votes: skipped hypotheses report 0)
+                     c->d_votes, c->best_before, lo);  // (also zeroes the batch's votes: skipped hypotheses report 0)
   hipLaunchKernelGGL(k_gather_rows, dim3(kPilots / 4), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
                      (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
   HIPCHK(c, hipGetLastError());
@@ -1017,7 +978,7 @@ int run_scan_bounded(lsqr_ctx *c) {
   if ((st = run_scan_pairs<CM, PP>(c, pa)) != LSQR_OK) return st;
 
   hipLaunchKernelGGL(k_pick_rest, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, votes_a,
-                     c->best_before, sel_b, c->d_bsel);
+                     c->best_before, sel_b, c->d_bsel, lo);
   hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel_b, &c->d_bsel->n_rest, H,
                      c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
   HIPCHK(c, hipGetLastError());
@@ -2232,7 +2193,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     }
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_ub2, c->d_lb2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
