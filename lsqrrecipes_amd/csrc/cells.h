@@ -1245,10 +1245,8 @@ constexpr uint32_t kChunkCells = 128;
 __global__ __launch_bounds__(128) void k_tile_costs(const uint8_t *__restrict__ cnt, uint32_t gstride, uint32_t H,
                                                     const uint32_t *__restrict__ h_dev, uint32_t ncells,
                                                     uint32_t *__restrict__ cost, uint32_t *__restrict__ csum,
-                                                    uint32_t *__restrict__ votes, uint32_t h_off, int zero_votes) {
-  // (zero_votes = 0: the counting pass has already put counts there -- axis.h: k_count_axis)
-  if (zero_votes)
-    for (uint32_t i = blockIdx.x * kChunkCells + threadIdx.x; i < H; i += gridDim.x * kChunkCells) votes[i] = 0;
+                                                    uint32_t *__restrict__ votes, uint32_t h_off) {
+  for (uint32_t i = blockIdx.x * kChunkCells + threadIdx.x; i < H; i += gridDim.x * kChunkCells) votes[i] = 0;
   if (h_dev) {
     const uint32_t hd = *h_dev > h_off ? *h_dev - h_off : 0u;  // hypotheses [h_off, h_off + H) of the selection
     H = hd < H ? hd : H;
@@ -1293,9 +1291,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
     const double *__restrict__ sp, const float *__restrict__ rows, const float *__restrict__ spf, uint32_t H,
     ModelConsts mc, CellConsts cc, uint32_t *__restrict__ vpart, uint32_t vstride,
     const uint32_t *__restrict__ h_dev, const uint8_t *__restrict__ cnt, uint32_t gstride, const uint32_t *__restrict__ cost,
-    const uint32_t *__restrict__ csum, uint32_t nchunks, uint32_t h_off, const unsigned long long *__restrict__ pmask) {
-  // pmask (nullable): survivor masks per (cell, group) written by the counting pass when it settles pairs itself
-  // (axis.h: k_count_axis) -- then the survivors are what that pass left, not everything level 1 lets through
+    const uint32_t *__restrict__ csum, uint32_t nchunks, uint32_t h_off) {
   typedef typename CM::M M;
   constexpr int NB = CM::NB;
   constexpr int SPD = M::SP;

@@ -861,9 +861,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
   if ((st = ensure(c, &c->d_paircost, &c->paircost_cap, (size_t)c->n_cells + nchunks)) != LSQR_OK) return st;
   uint32_t *d_cost = c->d_paircost, *d_csum = c->d_paircost + c->n_cells;
   const float *rows = CM::ROW_F32 ? b.spf : (const float *)b.sp;
-  const unsigned long long *pmask = nullptr;  // (survivor masks from a counting pass that settles pairs itself: none)
-  const bool by_rank = false;
-  if (!by_rank) {  // counting pass: waves past the device-side H leave at once, so the grid is cut finely in x
+  {  // counting pass: waves past the device-side H leave at once, so the grid is cut finely in x
     const unsigned gy = (Hc + 255) / 256;
     const uint32_t per = std::max<uint32_t>(8, (c->n_cells + 1023) / 1024);
     const unsigned gx = (c->n_cells + per - 1) / per;
@@ -873,7 +871,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(k_tile_costs, dim3(nchunks), dim3(kChunkCells), 0, c->stream, c->d_paircnt, gstride, Hc, b.h_dev,
-                     c->n_cells, d_cost, d_csum, b.votes, b.h_off, by_rank ? 0 : 1);  // (zeroes the batch's votes)
+                     c->n_cells, d_cost, d_csum, b.votes, b.h_off);  // (zeroes the batch's votes)
   HIPCHK(c, hipGetLastError());
   bool ldsb_default = CM::LDS_BROADCAST;
   if constexpr (requires { CM::LDS_BROADCAST_PAIRS; }) ldsb_default = CM::LDS_BROADCAST_PAIRS;
@@ -894,7 +892,7 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
     ProfScope ps(c, KID_SCAN);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BS), lds, c->stream, c->d_sorted, c->n_sorted, c->d_boxes, c->n_cells,
                        b.sp, rows, b.spf, Hc, c->mc, cc, c->d_vpart, Hc, b.h_dev, (const uint8_t *)c->d_paircnt, gstride,
-                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks, b.h_off, pmask);
+                       (const uint32_t *)d_cost, (const uint32_t *)d_csum, nchunks, b.h_off);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_votes_reduce, dim3((Hc + 63) / 64, 48), dim3(256), 0, c->stream,
                        (const uint32_t *)c->d_vpart, Hc, (uint32_t)blocks, Hc, b.h_dev, b.votes, b.h_off);
