@@ -59,9 +59,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 # USEFUL vector instructions of the scan kernels, counted from the source (csrc/cells.h, models.h, us.h; table in
 # DESIGN.md section 6): l1 = non-packed fp32 instructions of CM::level1 per (64-hypothesis group, cell); pk = packed-fp32
 # instructions of the filter measure per packed pair of observations per lane (128 observations per wave).
-# Per surviving (hypothesis, cell) of 128*PP observations the useful work is PP * (pk packed + 1 |.|-min) + 2
-# (min3 combine + the candidate compare); everything else the kernel issues (v_readlane broadcasts, the
-# two-threshold ballots, bookkeeping, exact re-checks) is overhead against this roof.
+# Per surviving (hypothesis, cell) of 128*PP observations the useful work is PP * (pk packed + 1 threshold operation:
+# the packed square-minus-threshold) + 2 (combine + the band compare); everything else the kernel issues (the
+# per-observation compares behind the ballots, the band minimum, broadcasts, bookkeeping, exact re-checks) is overhead
+# against this roof.  (Same count as in r01 / r02, whose filter spent the threshold operation on a |.|-minimum.)
 SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 6}, "line": {"l1": 35, "pk": 12},
                "us": {"pk": 21}, "phantom": {"pk": 18}}
 
@@ -272,13 +273,16 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         pp = wl["cell_points"] // 128
         groups = -(-H // 64)
         l1 = wl["level1_evaluations"]                # one level-1 pass over all hypotheses
-        if wl["bounded"]:                            # bounds pass + the pilots' group + the second pass' groups
-            l1 += wl["cells"] * (1 + -(-wl["second_pass"] // 64))
+        cand = 0
+        if wl["bounded"]:        # bounds pass + the groups of the rank-bound candidates, the pilots, the second pass
+            cand = ctx.scan_work()["candidates"] if w == "plane" else 0
+            l1 += wl["cells"] * (-(-cand // 64) + -(-wl["pilots"] // 64) + -(-wl["second_pass"] // 64))
         v2_instr = pp * (u["pk"] + 1) + 2
         useful_instr = l1 * u["l1"] + wl["pairs_counted"] * v2_instr
         kname = ("two-level scan of <%s> over a Morton-sorted copy: cell-box culling, packed fp32 filter + exact fp64 "
                  "re-check in surviving cells; %s" % (
-                     w, "bounded: k_cells_bounds (vote bounds) -> pilots -> only hypotheses that can still win, each "
+                     w, "bounded: k_cells_bounds (vote bounds) -> rank bounds of the candidates (plane: k_bound_axis) "
+                     "-> pilots when those are weak -> only hypotheses that can still win, each "
                      "counted by k_scan_pairs (level 1 counted first, then an equal share of the surviving "
                      "(hypothesis, cell) pairs per wave)" if wl["bounded"] else
                      "every hypothesis counted: k_cells_bounds(cnt) -> k_tile_costs -> k_scan_pairs" if R.full_pairs
@@ -287,7 +291,8 @@ def scan_roofline(R, mode, scan_ms, n_scan):
                  "surviving_hypothesis_cell_pairs_all": wl["pairs"],
                  "surviving_hypothesis_cell_pairs_counted": wl["pairs_counted"], "level2_useful_instr": v2_instr,
                  "cells": wl["cells"], "cell_points": wl["cell_points"], "hypothesis_groups": groups,
-                 "bounded_scan": wl["bounded"], "pilots": wl["pilots"], "second_pass_hypotheses": wl["second_pass"],
+                 "bounded_scan": wl["bounded"], "rank_bound_candidates": cand, "pilots": wl["pilots"],
+                 "second_pass_hypotheses": wl["second_pass"],
                  "hypotheses_counted_exactly": (wl["pilots"] + wl["second_pass"]) if wl["bounded"] else H,
                  "surviving_fraction": wl["pairs"] / max(1.0, float(wl["cells"]) * H)}
     else:
