@@ -319,7 +319,7 @@ def scan_roofline(R, mode, scan_ms, n_scan):
     return base
 
 
-def hbm_table(R, prof, abs_prof, idx_prof, cnt):
+def hbm_table(R, prof, abs_prof, idx_prof, cnt, lm_nfev=0):
     """HBM-bound kernels of the step: algorithmic bytes / HIP-event time / 8 TB/s (live)"""
     a, rec = R.a, R.rec
     n = float(a.points)
@@ -332,18 +332,24 @@ def hbm_table(R, prof, abs_prof, idx_prof, cnt):
                          "frac_of_hbm_peak": byts / t / 1e6 / HBM_PEAK_GBS, "launches": int(nl), "note": note})
     w = a.workload
     if w == "dense":
-        add("k_mask_dense (winner's consensus mask)", n * rec + n, *prof["mask"])
-        add("k_syrk_mfma (A^T A | A^T b over the consensus set)", n * rec + n, *prof["moments"],
-            note="also 2*m*65*66/2*... fp64 MFMA flops: see DESIGN.md")
+        add("k_mask_syrk_dense (winner's consensus mask and A^T A | A^T b over the consensus rows in ONE pass: "
+            "rows through an LDS ring, agreeing rows to fp64 MFMAs)", n * rec + n, *prof["mask"],
+            note="also 2*m_in*65*66/2 fp64 MFMA flops: see DESIGN.md")
+        add("k_syrk_mfma (A^T A | A^T b over the consensus set, separate pass: only when the fused pass did not run)",
+            n * rec + n, *prof["moments"])
     elif w == "phantom":
         add("k_mask<phantom>", n * rec + n, *prof["mask"])
         add("k_phantom_rows / k_syrk_mfma (Gram block)", n * 256 + n, *prof["moments"])
     else:
         add("k_mask_moments<%s> (consensus mask + moment block, one pass)" % w, n * rec + n, *prof["mask"])
         if prof["moments"][0]:
-            add("k_lm_pass<%s> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f over the compacted "
-                "consensus set)" % w, cnt * rec, *prof["moments"],
-                note="reads the %d consensus records (tight copy)" % cnt)
+            # the set is compacted before the first evaluation for the matrix-core pass (US) and otherwise after 8
+            # evaluations through the mask (csrc/lsqr_hip.hip: kCompactAfter)
+            tight = w in ("us", "phantom") or lm_nfev >= 8
+            add("k_lm_pass<%s> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f over the consensus set)" % w,
+                cnt * rec if tight else n * rec + n, *prof["moments"],
+                note=("reads the %d consensus records (tight copy)" % cnt) if tight else
+                "fewer than 8 evaluations: every evaluation reads all records through the mask (no compaction pass)")
     add("k_bounds (point models: min / max / max |x| in one pass) or k_absmax, once per upload", n * rec, *abs_prof)
     if idx_prof[0]:
         add("spatial index build (k_keys, radix sort of (key, index) pairs, k_gather_boxes; once per upload)",
@@ -769,7 +775,8 @@ def report(R, rates, cpu_budget, headline=True):
         out["roofline_" + r["mode"]] = r["roofline"]
         out["single_stream_" + r["mode"]] = r["single_stream"]
     cnt = int(last["cnt"]) if last else 0
-    out["kernel_hbm"] = hbm_table(R, prof, main_rate["abs_warm"], (n_idx, ms_idx), cnt)
+    out["kernel_hbm"] = hbm_table(R, prof, main_rate["abs_warm"], (n_idx, ms_idx), cnt,
+                                  int(last["lm_nfev"]) if last else 0)
     out["kernels_ms"] = {"sample": prof["sample"][1] / max(prof["sample"][0], 1),
                          "estimate": prof["estimate"][1] / max(prof["estimate"][0], 1),
                          "scan": main_rate["scan_ms"],

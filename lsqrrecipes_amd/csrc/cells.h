@@ -79,16 +79,12 @@ __global__ __launch_bounds__(256) void k_bounds(const double *__restrict__ data,
                                                 size_t n, BoundsRow *__restrict__ rows) {
   unsigned long long mn[D], mx[D], am = 0, bad = 0;
   for (int d = 0; d < D; d++) mn[d] = ~0ULL, mx[d] = 0ULL;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    double x[D];
+  auto one = [&](const double(&x)[D]) {
     bool fin = true;
-    for (int d = 0; d < D; d++) {
-      x[d] = data[i * stride + d];
-      fin = fin && (fabs(x[d]) <= 1.7976931348623157e308);  // false for NaN and inf
-    }
+    for (int d = 0; d < D; d++) fin = fin && (fabs(x[d]) <= 1.7976931348623157e308);  // false for NaN and inf
     if (!fin) {
       bad++;
-      continue;
+      return;
     }
     for (int d = 0; d < D; d++) {
       unsigned long long o = ord_u64(x[d]);
@@ -97,6 +93,22 @@ __global__ __launch_bounds__(256) void k_bounds(const double *__restrict__ data,
       const unsigned long long a = (unsigned long long)__builtin_bit_cast(long long, fabs(x[d]));
       am = a > am ? a : am;  // bit patterns of non-negative doubles are ordered like the values
     }
+  };
+  // four records per lane in flight (a minimum / maximum does not care about the order)
+  const size_t step = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * step < n; i += 4 * step) {
+    double x[4][D];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      for (int d = 0; d < D; d++) x[u][d] = data[(i + u * step) * stride + d];
+#pragma unroll
+    for (int u = 0; u < 4; u++) one(x[u]);
+  }
+  for (; i < n; i += step) {
+    double x[D];
+    for (int d = 0; d < D; d++) x[d] = data[i * stride + d];
+    one(x);
   }
   __shared__ unsigned long long s_v[4][2 * D + 2];
   for (int o = 32; o > 0; o >>= 1) {

@@ -26,6 +26,12 @@ namespace lsqr {
 
 constexpr int kBlock = 256;       // 4 waves
 constexpr int kMaxPartials = 1024;  // blocks of the moment reduction
+// smallest chunk of a block of the mask / moment passes: 1 M records still make ~1000 workgroups (r03; 16 * kBlock
+// left a 1 M-frame pass with 244 workgroups of four waves -- one per CU -- at a quarter of the HBM rate)
+constexpr int kMomChunk = kBlock * 4;
+// ... except where a block's own reduction is long (US / phantom: 80 - 150 sums, a shuffle tree each): 977 instead of
+// 244 workgroups made the 1 M-frame mask + moments pass SLOWER (60 -> 88 us)
+constexpr int kMomChunkWide = kBlock * 16;
 
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t first, uint32_t H,
@@ -450,7 +456,30 @@ __global__ __launch_bounds__(kBlock) void k_mask_moments(const double *__restric
   uint32_t local = 0;
   size_t lo = begin + (size_t)blockIdx.x * chunk;
   size_t hi = lo + chunk < end ? lo + chunk : end;
-  for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+  // small records: the loads of U records are issued before the first is used (one 24-byte record per lane in
+  // flight is 24 KB per CU at 16 waves, a third of what 8 TB/s x the memory latency needs); the records are still
+  // accumulated one by one in index order, so the sums keep their bits
+  constexpr int U = M::REC <= 4 ? 4 : 1;
+  size_t i = lo + threadIdx.x;
+  if constexpr (U > 1) {
+    for (; i + (size_t)(U - 1) * kBlock < hi; i += (size_t)U * kBlock) {
+      double x[U][M::REC];
+#pragma unroll
+      for (int u = 0; u < U; u++) M::load(data + (i + (size_t)u * kBlock) * stride, mc, x[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool a = M::agree(sp, x[u], mc);
+        mask[i + (size_t)u * kBlock] = a ? 1 : 0;
+        if (a) {
+          local++;
+          A::acc(x[u], cv, acc);
+        }
+      }
+    }
+  }
+  // (Wide records -- US: 120 B / 144 B -- staged through LDS as a coalesced stream, as k_lm_pass_mfma does, measured
+  // SLOWER here: 74 us against 45 us for the 1 M-frame pass; tools/mask_time.py.)
+  for (; i < hi; i += kBlock) {
     double x[M::REC];
     M::load(data + i * stride, mc, x);
     const bool a = M::agree(sp, x, mc);
@@ -579,7 +608,24 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const double *__restrict__ d
       M::accumulate_lm_fast(x, coef, acc);
     }
   } else {
-    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    // small records: U loads in flight per lane (see k_mask_moments); accumulated one by one in index order
+    constexpr int U = M::REC <= 4 ? 4 : 1;
+    size_t i = lo + threadIdx.x;
+    if constexpr (U > 1) {
+      for (; i + (size_t)(U - 1) * kBlock < hi; i += (size_t)U * kBlock) {
+        double x[U][M::REC];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          in[u] = !USE_MASK || mask[i + (size_t)u * kBlock];
+          M::load(data + (i + (size_t)u * kBlock) * stride, mc, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (in[u]) M::accumulate_lm(x[u], xk.x, acc);
+      }
+    }
+    for (; i < hi; i += kBlock) {
       if (USE_MASK && !mask[i]) continue;
       double x[M::REC];
       M::load(data + i * stride, mc, x);

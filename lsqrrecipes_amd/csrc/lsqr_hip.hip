@@ -89,6 +89,7 @@ struct lsqr_ctx {
   float *d_cellT = nullptr;
   size_t axis_cap = 0, cellT_cap = 0;
   bool axis_valid = false;
+  int opt_mom_chunk = 0;          // chunk of the mask / moment passes in units of kBlock records (0 = default; A/B)
   int opt_axis = 1;               // 1: the bounded scan of the plane takes its vote bounds by rank (k_bound_axis)
   uint32_t *d_ub2 = nullptr;  // rank bounds: [upper | lower] of the candidates (compact order) | lower per hypothesis
   uint8_t *d_paircnt = nullptr;   // k_scan_pairs: survivors per (cell, group of 64 hypotheses)
@@ -388,6 +389,12 @@ int need_ready(lsqr_ctx *c, bool need_data) {
   return LSQR_OK;
 }
 
+// smallest chunk per block of the mask / moment passes (kernels.h: kMomChunk)
+static inline int mom_chunk(const lsqr_ctx *c) {
+  if (c->opt_mom_chunk > 0) return c->opt_mom_chunk * kBlock;
+  const int m = c->cfg.model;
+  return (m == LSQR_MODEL_US_SINGLE || m == LSQR_MODEL_US_POINTER || m == LSQR_MODEL_PHANTOM) ? kMomChunkWide : kMomChunk;
+}
 int grid_for(size_t items, int per_block, int max_blocks) {
   size_t b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -1521,7 +1528,7 @@ int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phas
     return launch_moments_dense(c, use_mask, begin, end, nmom);
   } else {
   size_t cnt = end - begin;
-  int nb = grid_for(cnt, kBlock * 16, kMaxPartials);
+  int nb = grid_for(cnt, mom_chunk(c), kMaxPartials);
   size_t chunk = (cnt + nb - 1) / nb;
   chunk = (chunk + kBlock - 1) / kBlock * kBlock;
   nb = (int)((cnt + chunk - 1) / chunk);
@@ -1965,7 +1972,7 @@ int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *
         HIPCHK(c, hipGetLastError());
       }
       size_t cnt = end - begin;
-      int nb = grid_for(cnt, kBlock * 16, kMaxPartials);  // the chunking of launch_moments
+      int nb = grid_for(cnt, mom_chunk(c), kMaxPartials);  // the chunking of launch_moments
       size_t chunk = (cnt + nb - 1) / nb;
       chunk = (chunk + kBlock - 1) / kBlock * kBlock;
       nb = (int)((cnt + chunk - 1) / chunk);
@@ -2842,7 +2849,7 @@ int lsqr_stats(lsqr_ctx *c, const double *params, int use_mask, double out[4]) {
   HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice,
                            c->stream));
-  int nb = grid_for(c->n, kBlock * 16, kMaxPartials);
+  int nb = grid_for(c->n, mom_chunk(c), kMaxPartials);
   size_t chunk = (c->n + nb - 1) / nb;
   chunk = (chunk + kBlock - 1) / kBlock * kBlock;
   nb = (int)((c->n + chunk - 1) / chunk);
@@ -4008,6 +4015,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_axis")) {  // 1 (default): axis-sorted cells + vote bounds by rank (plane, 3-D); 0: off
     c->opt_axis = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "mom_chunk")) {
+    c->opt_mom_chunk = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_pairs_waves")) {  // workgroups per CU of k_scan_pairs (0 = what fits)
