@@ -903,21 +903,21 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
 //     the lanes that walk one row each hit distinct bank pairs -- no padding needed.  Three tiles are in flight while
 //     one is evaluated (counted s_waitcnt vmcnt): 4 waves x 25 KB per CU outstanding at all times -- with one tile in
 //     flight per wave the kernel ran at the latency of a tile, 3.4 TB/s;
-//   * lane r < 16 evaluates row r; the ballot of the decisions is the tile's piece of the mask;
+//   * four lanes evaluate a row (one interleaved chain of 16 columns each); the ballot of the decisions is the tile's
+//     piece of the mask;
 //   * only the agreeing rows are multiplied: their indices are compacted (rank of the lane's bit) and fed four at a
 //     time to v_mfma_f64_16x16x4 -- lane (k, c) holds z_k[16 b + c] for block b: at once the A operand of block-row
 //     b and the B operand of block-column b (as k_syrk_mfma).  With 30 % of the rows agreeing that is a third of the
 //     matrix work of the unconditional SYRK, and the rows are read from HBM once instead of twice.
-template <int NB16, int NBUF>
+template <int NA16, int NBUF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 2 : 1, NBUF == 2 ? 2 : 1))) void k_mask_syrk_dense(
     const double *__restrict__ data, size_t begin, size_t end, size_t chunk, int n, const double *__restrict__ par,
     double delta, uint8_t *__restrict__ mask, unsigned long long *__restrict__ counter, int pstride,
     double *__restrict__ partials, double amax, double bmax, double band_scale, int diag) {
-  constexpr int TR = 16;   // rows per tile: lane r < 16 walks row r
-  // NBUF = ring of tile buffers per wave.  2: two workgroups (eight waves) per CU, one tile in flight per wave while
-  // the other is evaluated -- the second wave of a SIMD fills the matrix pipe while the first walks its rows (the
-  // phases of one wave do not overlap: loads 0.19 ms, + rows 0.28 ms, + matrix 0.41 ms with four waves per CU);
-  // 4: one workgroup per CU, three tiles in flight (A/B)
+  constexpr int TR = 16;   // rows per tile
+  // NBUF = ring of tile buffers per wave.  4: one workgroup per CU, three tiles in flight per wave (n = 64); 2: two
+  // workgroups (eight waves) per CU, one tile in flight per wave while the other is evaluated.
+  // NA16 = 16-column blocks that cover the n columns of A; the right-hand side b = z[n] is not a matrix block (below).
   extern __shared__ double smd[];
   __shared__ unsigned s_rows[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
   const int tile_d = TR * nz;                       // doubles per tile
   double *ring = smd + (size_t)wave * NBUF * tile_d;
   double *xs = smd + (size_t)4 * NBUF * tile_d;     // the model, read with uniform addresses (64 doubles)
-  unsigned char *list = (unsigned char *)(xs + 64) + wave * 32;  // compacted row indices of the tile
+  double *pend = xs + 64 + (size_t)wave * 3 * nz;           // up to three agreeing rows waiting for a full group
   if (threadIdx.x < 64) xs[threadIdx.x] = (int)threadIdx.x < n ? par[threadIdx.x] : 0.0;
   __syncthreads();
   // Band of the four-chain evaluation below against the reference's single running sum: both add the same 64 rounded
@@ -935,21 +935,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
   // Non-finite magnitudes (or a NaN model) give E = NaN / inf: every tile takes the serial evaluation.
   double l1 = 0.0;
   for (int i = 0; i < 64; i++) l1 += fabs(xs[i]);
+  double xq[16];  // the model entries of this lane's chain (columns q, q + 4, ...), in registers for the whole pass
+#pragma unroll
+  for (int i = 0; i < 16; i++) xq[i] = xs[4 * i + (lane & 3)];
   const double eband = band_scale * 2.2 * 64.0 * 1.1102230246251565e-16 * (amax * l1 + bmax);
-  constexpr int NT = NB16 * (NB16 + 1) / 2;
+  constexpr int NT = NA16 * (NA16 + 1) / 2;
   d4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-  int off[NB16];
-  bool colok[NB16];
+  double vb = 0.0, bb = 0.0;  // A^T b (lane = column) and b^T b, on the vector unit: see group()
+  int off[NA16];
+  bool colok[NA16];
 #pragma unroll
-  for (int b = 0; b < NB16; b++) {
-    colok[b] = 16 * b + c16 < nz;
+  for (int b = 0; b < NA16; b++) {
+    colok[b] = 16 * b + c16 < n;
     off[b] = colok[b] ? 16 * b + c16 : 0;
   }
   const size_t lo = begin + (size_t)blockIdx.x * chunk;
   const size_t hi = lo + chunk < end ? lo + chunk : end;
   unsigned rows_used = 0;
+  int npend = 0;
   // a tile = TR consecutive rows = one contiguous run of bytes; 16-byte pieces straight into LDS (a whole tile is a
   // multiple of 16 bytes; the last, shorter tile of a range may end in one 8-byte piece)
   auto issue = [&](size_t base, double *dst) {
@@ -965,6 +970,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
         ((double *)dst)[mine / 8] = *(const double *)(g + mine);
     }
   };
+  // Four agreeing rows -- the waiting ones first, then rows of the tile in index order -- into the sums:
+  //   A^T A (the NA16 (NA16 + 1) / 2 upper 16 x 16 blocks) on the matrix cores: lane (k, c) holds z_k[16 b + c] for
+  //   block b, at once the A operand of block-row b and the B operand of block-column b (as k_syrk_mfma);
+  //   A^T b and b^T b on the vector unit, lane = column: one fused multiply-add per row.  As a fifth block row /
+  //   column of the matrix product (r03 before) the right-hand side cost 5 of 15 MFMAs for 65 useful entries.
+  // The group's rows are `nlive` <= 4 wave-uniform LDS pointers p[]: no index list in memory, no dependent reads --
+  // with one wave per SIMD every LDS round trip in front of the MFMAs is idle time (r03: an index list in LDS and a
+  // row loop around the vector part cost 1100 cycles a tile on top of the 640 of the MFMAs).
+  auto group = [&](const double *const (&p)[4], int nlive) {
+    const double *rp = k4 == 0 ? p[0] : k4 == 1 ? p[1] : k4 == 2 ? p[2] : p[3];
+    const bool live = k4 < nlive;
+    double zc[NA16], zl[4], zb[4];
+#pragma unroll
+    for (int b = 0; b < NA16; b++) zc[b] = rp[off[b]];
+#pragma unroll
+    for (int j = 0; j < 4; j++) zl[j] = p[j][lane < n ? lane : 0], zb[j] = p[j][n];
+#pragma unroll
+    for (int b = 0; b < NA16; b++) zc[b] = (live && colok[b]) ? zc[b] : 0.0;
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NA16; bi++)
+#pragma unroll
+      for (int bj = bi; bj < NA16; bj++, t++)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[bi], zc[bj], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double l = (j < nlive && lane < n) ? zl[j] : 0.0, r = j < nlive ? zb[j] : 0.0;
+      vb = fma(l, r, vb);  // (a dead slot adds 0 * 0)
+      bb = fma(r, r, bb);
+    }
+  };
   // tile j of this wave: rows [lo + (4 j + wave) * TR, + TR)
   const size_t step = (size_t)4 * TR;
   size_t base = lo + (size_t)wave * TR;
@@ -977,7 +1013,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
     // My tile has landed when all but the operations issued after it are done.  Loads, LDS-DMA and stores retire in
     // order; after tile j's pieces came, per later iteration, one mask store and the pieces of one more tile.  Only
     // the full case (n = 64: nine pieces per 16-row tile, every later tile whole) is counted; anything else drains.
-    if (NBUF == 4 && NB16 == 5 && ahead + TR <= hi)
+    if (NBUF == 4 && NA16 == 4 && n == 64 && ahead + TR <= hi)
       asm volatile("s_waitcnt vmcnt(21) lgkmcnt(0)" ::: "memory");   // 2 x (1 store + 9 pieces) + 1 store
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -985,72 +1021,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
     const int rows = (int)(hi - base < (size_t)TR ? hi - base : (size_t)TR);
     bool a;
     {
-      // every lane walks a row (lanes past the tile's rows walk row 0: no divergence, their result is dropped); the
-      // reference's running sum in its order, multiply and add unfused (-ffp-contract=off)
-      const double *row = tile + (lane < rows ? lane : 0) * nz;
-      // A single running sum is one chain of 128 dependent fp64 operations -- with one wave per SIMD its latency IS
-      // the kernel (measured: 3000 cycles per tile).  Four interleaved chains give the residual up to the band E
-      // above; only a tile with a row inside |  |r| - delta | <= E (one in ~1e11 rows) is walked again serially.
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      // FOUR lanes walk a row: lane 4 r + q takes the columns i = q (mod 4) of row r -- one of the four interleaved
+      // chains (rows past the tile's end walk row 0: no divergence, their result is dropped); multiply and add
+      // unfused (-ffp-contract=off).  The reference's single running sum is one chain of 128 dependent fp64
+      // operations; the four chains, combined as (s0 + s1) + (s2 + s3), give the residual up to the band E above, and
+      // only a tile with a row inside |  |r| - delta | <= E (one in ~1e11 rows) is walked again serially.  (r03: one
+      // lane per row walked all four chains itself, 16 of the 64 lanes busy for 128 operations: 1770 cycles a tile.)
+      const int rr = lane >> 2, q = lane & 3;
+      const double *row = tile + (rr < rows ? rr : 0) * nz;
+      double sq = 0.0;
       if (diag & 2) {  // timing diagnostics: no evaluation
-        s0 = row[0];
-      } else if constexpr (NB16 == 5) {  // n = 64
+        sq = row[0];
+      } else if (NA16 == 4 && n == 64) {
 #pragma unroll
-        for (int i = 0; i < 64; i += 4) {
-          s0 += row[i] * xs[i];
-          s1 += row[i + 1] * xs[i + 1];
-          s2 += row[i + 2] * xs[i + 2];
-          s3 += row[i + 3] * xs[i + 3];
-        }
+        for (int i = 0; i < 16; i++) sq += row[4 * i + q] * xq[i];
       } else {
-        int i = 0;
-        for (; i + 4 <= n; i += 4) {
-          s0 += row[i] * xs[i];
-          s1 += row[i + 1] * xs[i + 1];
-          s2 += row[i + 2] * xs[i + 2];
-          s3 += row[i + 3] * xs[i + 3];
-        }
-        for (; i < n; i++) s0 += row[i] * xs[i];
+        for (int i = 0; 4 * i + q < (n & ~3); i++) sq += row[4 * i + q] * xq[i];
+        if (q == 0)
+          for (int i = n & ~3; i < n; i++) sq += row[i] * xs[i];  // (the tail rides on chain 0)
       }
-      const double rq = fabs(((s0 + s1) + (s2 + s3)) - row[n]);
+      const double s01 = sq + __shfl_down(sq, 1);     // q = 0: s0 + s1,  q = 2: s2 + s3
+      const double s = s01 + __shfl_down(s01, 2);     // q = 0: (s0 + s1) + (s2 + s3)
+      const double rq = fabs(s - row[n]);
+      const bool mine = q == 0 && rr < rows;
       a = rq < delta;
       const bool unsure = !(fabs(rq - delta) > eband);      // also true for NaN
-      if (__ballot(unsure && lane < rows)) {                // wave-uniform, rare: the reference's own order
+      if (__ballot(unsure && mine)) {                       // wave-uniform, rare: the reference's own order
         double sum = 0.0;
         for (int i = 0; i < n; i++) sum += row[i] * xs[i];
         sum -= row[n];
         a = fabs(sum) < delta;
       }
-      a = a && lane < rows;
-      if (lane < rows) mask[base + lane] = a ? 1 : 0;
+      a = a && mine;
+      if (mine) mask[base + rr] = a ? 1 : 0;
     }
-    const unsigned long long in = __ballot(a);
+    const unsigned long long in = __ballot(a);   // bit 4 r: row r agrees
     const int cnt = __builtin_popcountll(in);
     rows_used += (unsigned)cnt;
-    if (a) list[__builtin_popcountll(in & ((1ull << lane) - 1ull))] = (unsigned char)lane;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int g0 = 0; g0 < ((diag & 1) ? 0 : cnt); g0 += 4) {           // wave-uniform
-      const bool live = g0 + k4 < cnt;
-      const int r = live ? list[g0 + k4] : 0;
-      double zc[NB16];
+    if (diag & 4) __builtin_amdgcn_s_sleep(32);  // timing diagnostics: a delay of ~2000 cycles instead of the matrix work
+    if (!(diag & 1)) {
+      // whole groups of four out of (waiting rows, then the tile's agreeing rows in index order); what is left over
+      // (< 4 rows) waits in `pend` for the next tile -- a tile holds 4.6 agreeing rows on average at 29 % inliers, and
+      // rounding every tile up to whole groups by itself cost 1.7 groups a tile instead of 1.16
+      unsigned long long rest = in;
+      auto next_row = [&]() -> const double * {  // (scalar unit)
+        const int b = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        return tile + (b >> 2) * nz;
+      };
+      int total = npend + cnt, used = 0;          // used = waiting rows consumed
+      while (total >= 4) {                        // wave-uniform
+        const double *p[4];
 #pragma unroll
-      for (int b = 0; b < NB16; b++) {
-        const double v = tile[r * nz + off[b]];
-        zc[b] = (live && colok[b]) ? v : 0.0;
+        for (int j = 0; j < 4; j++) p[j] = used < npend ? pend + (used++) * nz : next_row();
+        group(p, 4);
+        total -= 4;
       }
-      int t = 0;
-#pragma unroll
-      for (int bi = 0; bi < NB16; bi++)
-#pragma unroll
-        for (int bj = bi; bj < NB16; bj++, t++)
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[bi], zc[bj], acc[t], 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the waiting rows have been read)
+      // what remains: either the untouched waiting rows plus tile rows (no group ran) or tile rows only
+      int slot = used < npend ? npend : 0;
+      while (rest) {                              // <= 3 rows
+        const double *src = next_row();
+        double *dst = pend + slot * nz;
+        for (int i = lane; i < nz; i += 64) dst[i] = src[i];
+        slot++;
+      }
+      npend = total;
     }
     __builtin_amdgcn_wave_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (npend) {  // the last, partial group
+    const double *p[4] = {pend, pend + (npend > 1 ? nz : 0), pend + (npend > 2 ? 2 * nz : 0), pend};
+    group(p, npend);
+    npend = 0;
+  }
   __syncthreads();  // every wave is done with its tiles: the LDS becomes the fold area
-  double *fold = smd;
+  double *fold = smd, *fvb = smd + NT * 256;
   for (int w = 0; w < 4; w++) {
     if (wave == w) {
 #pragma unroll
@@ -1060,7 +1108,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
           const int pos = t * 256 + (k4 + 4 * rg) * 16 + c16;
           fold[pos] = (w == 0 ? 0.0 : fold[pos]) + acc[t][rg];
         }
-      if (lane == 0) s_rows[w] = rows_used;
+      fvb[lane] = (w == 0 ? 0.0 : fvb[lane]) + vb;
+      if (lane == 0) {
+        fvb[64] = (w == 0 ? 0.0 : fvb[64]) + bb;
+        s_rows[w] = rows_used;
+      }
     }
     __syncthreads();
   }
@@ -1069,14 +1121,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
   for (int pos = threadIdx.x; pos < NT * 256; pos += 256) {
     const int t = pos >> 8, r = (pos >> 4) & 15, cc = pos & 15;
     int bi = 0, rem = t;
-    while (rem >= NB16 - bi) {
-      rem -= NB16 - bi;
+    while (rem >= NA16 - bi) {
+      rem -= NA16 - bi;
       bi++;
     }
     const int bj = bi + rem;
     const int i = 16 * bi + r, j = 16 * bj + cc;
-    if (i <= j && j < nz) out[i * nz - i * (i - 1) / 2 + (j - i)] = fold[pos];
+    if (i <= j && j < n) out[i * nz - i * (i - 1) / 2 + (j - i)] = fold[pos];
   }
+  if ((int)threadIdx.x < n) out[threadIdx.x * nz - (int)threadIdx.x * ((int)threadIdx.x - 1) / 2 + (n - (int)threadIdx.x)] = fvb[threadIdx.x];
+  if (threadIdx.x == 64) out[ne - 1] = fvb[64];
   if (threadIdx.x == 0) {
     const unsigned tot = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
     out[ne] = (double)tot;

@@ -152,7 +152,7 @@ struct lsqr_ctx {
   bool origin_valid = false;
   int opt_ppl = 0, opt_filter = 1, opt_lm_host = 1, opt_syrk_diag = 0;
   int opt_fuse_mask = 1;  // winner's mask + moment block in one pass (0: two kernels, for A/B runs)
-  int opt_mask_ring = 2;  // k_mask_syrk_dense: tile buffers per wave (2: two workgroups per CU; 4: one, three tiles in flight)
+  int opt_mask_ring = 4;  // k_mask_syrk_dense: tile buffers per wave (2: two workgroups per CU; 4: one, three tiles in flight)
   int opt_mask_diag = 0;  // timing diagnostics of k_mask_syrk_dense: 1 = no matrix instructions, 2 = no row evaluation
   int opt_mask_band = 0;  // tests: scale factor of the dense fused mask's band (forces its serial re-evaluation path)
   long long opt_max_iter = 0;  // 0 = the reference's bound (numTries <= C(N,k))
@@ -1927,8 +1927,10 @@ int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *
     size_t chunk = (cnt + nb - 1) / nb;
     chunk = (chunk + 63) / 64 * 64;                 // whole rounds of the four waves' 16-row tiles
     nb = (int)((cnt + chunk - 1) / chunk);
-    const int ps = dense_pstride(n), nb16 = (nz + 15) / 16;
-    const size_t lds = std::max<size_t>(sizeof(double) * (4 * nbuf * 16 * nz + 64) + 128, sizeof(double) * 15 * 256);
+    const int ps = dense_pstride(n), na16 = (n + 15) / 16;
+    // ring + model + waiting rows while streaming; the fold area afterwards
+    const size_t lds = std::max<size_t>(sizeof(double) * (4 * nbuf * 16 * nz + 64 + 4 * 3 * nz),
+                                        sizeof(double) * (10 * 256 + 80));
     if ((size_t)nb * ps > (size_t)2 * kDenseBlocks * 2160) return LSQR_OK;  // (partials area: 512 x 2160 doubles)
     *nmom = dense_ne(n) + 1;
     {
@@ -1940,14 +1942,13 @@ int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *
                            c->opt_mask_band > 0 ? (double)c->opt_mask_band : 1.0, c->opt_mask_diag);
       };
       if (nbuf == 4) {
-        launch(k_mask_syrk_dense<5, 4>);   // (A/B arrangement, n = 64 only)
+        launch(k_mask_syrk_dense<4, 4>);   // n = 64: one workgroup per CU, three tiles in flight per wave
       } else
-      switch (nb16) {
+      switch (na16) {
         case 1: launch(k_mask_syrk_dense<1, 2>); break;
         case 2: launch(k_mask_syrk_dense<2, 2>); break;
         case 3: launch(k_mask_syrk_dense<3, 2>); break;
-        case 4: launch(k_mask_syrk_dense<4, 2>); break;
-        default: launch(k_mask_syrk_dense<5, 2>); break;
+        default: launch(k_mask_syrk_dense<4, 2>); break;
       }
       HIPCHK(c, hipGetLastError());
     }
