@@ -961,6 +961,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ?
     const size_t rows = hi - base < (size_t)TR ? hi - base : (size_t)TR;
     const size_t bytes = rows * (size_t)nz * 8;
     const char *g = (const char *)(data + base * (size_t)nz);
+    if (NA16 == 4 && n == 64 && rows == (size_t)TR) {
+      // a whole tile of 65-double rows: 8320 bytes = eight full pieces and 128 bytes; one per-lane address and
+      // immediate offsets instead of nine 64-bit address computations and compares (one wave per SIMD: every
+      // instruction of the wave is on the tile's critical path)
+      typedef __attribute__((address_space(3))) void *lds_t;
+      const char *g0 = g + (size_t)lane * 16, *g1 = g0 + 4096;
+      char *d = (char *)dst;
+      // (the instruction's immediate offset moves the global AND the LDS address)
+      __builtin_amdgcn_global_load_lds((const void *)g0, (lds_t)(d), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g0, (lds_t)(d), 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g0, (lds_t)(d), 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g0, (lds_t)(d), 16, 3072, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g1, (lds_t)(d + 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g1, (lds_t)(d + 4096), 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g1, (lds_t)(d + 4096), 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((const void *)g1, (lds_t)(d + 4096), 16, 3072, 0);
+      if (lane < 8) __builtin_amdgcn_global_load_lds((const void *)(g1 + 4096), (lds_t)(d + 8192), 16, 0, 0);
+      return;
+    }
     for (size_t o = 0; o < bytes; o += 1024) {      // wave-uniform trip count
       const size_t mine = o + (size_t)lane * 16;
       if (mine + 16 <= bytes)
