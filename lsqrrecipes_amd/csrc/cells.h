@@ -727,9 +727,12 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
     // unit measured SLOWER in r02: the scalar unit is nearly as busy as the vector unit in this loop.)
     unsigned long long in[2 * PP];
     uint32_t dmin = 0xFFFFFFFFu;
+    v2f sv[PP];  // (all values first: PP independent chains for the scheduler to interleave)
+#pragma unroll
+    for (int p = 0; p < PP; p++) sv[p] = CM::value(xs[p], fp);
 #pragma unroll
     for (int p = 0; p < PP; p++) {
-      const v2f s = CM::value(xs[p], fp);
+      const v2f s = sv[p];
       const v2f d = __builtin_elementwise_fma(s, s, na);
       in[2 * p] = __ballot(d.x < 0.0f);
       in[2 * p + 1] = __ballot(d.y < 0.0f);
