@@ -1830,6 +1830,61 @@ def context_replay(n, k, p, subs, valid, votes):
     return (r["used"], r["i"], r["num_tries"], r["best_votes"], r["best_index"], r["has_best"], r["done"])
 
 
+@pytest.mark.parametrize("case", ["dense_inliers", "small_box", "offset_1e6", "thin_threshold", "two_planes", "axis_off"])
+def test_rank_bounds_of_the_plane_are_exact(ctx, case):
+    """axis.h (vote bounds by rank in axis-sorted cells): uploads whose cells along the model ARE flat, so that the
+    rank bounds -- not the pilots -- do the pruning, in situations that stress their fp32 margins: a box a tenth of the
+    size (cells a tenth of the size against the same threshold), a translation by 1e6 (cell-relative arithmetic), a
+    threshold of the noise level (many observations at the boundary), two parallel planes 1.5 thresholds apart (lower
+    bounds of one model compete with upper bounds of the other).  scan_bound 1 against counting everything: winner,
+    consensus, parameters, replay identical; every counted hypothesis has its exact votes; every other one reports 0
+    and could not have become the running maximum."""
+    n, H = 2_000_000, 2048
+    kw = dict(seed=77)
+    delta = 0.5
+    if case == "small_box":
+        kw.update(box=100.0, sigma=0.2)
+    if case == "thin_threshold":
+        delta = 0.4                                   # = sigma of the inlier noise
+    data = synth.plane(n, 0.3, **kw)[0]
+    if case == "offset_1e6":
+        data = data + np.array([1.0e6, -2.0e6, 3.0e6])
+    if case == "two_planes":
+        second, truth, _ = synth.plane(n // 2, 0.0, seed=77)
+        data[: n // 2] = second + 0.75 * truth[:3]    # same plane, shifted by 1.5 delta along its normal
+    ctx.set_option("scan_axis", 0 if case == "axis_off" else 1)
+    ctx.set_model(L.PLANE, 3, delta).upload(data)
+    ctx.set_option("scan_index", 2)
+    res = {}
+    for bound in (0, 1):
+        ctx.set_option("scan_bound", bound)
+        steps = []
+        for s in range(3):                            # three consecutive batches: best_before carried as in lsqr_ransac
+            r = ctx.batch_fit(91, s * H, H, want_consensus=True)
+            _, valid, votes = ctx.hypotheses(params=False)
+            steps.append((r, votes.copy(), valid.copy(), ctx.scan_workload() if bound else None,
+                          ctx.scan_work() if bound else None))
+        res[bound] = steps
+    ctx.set_option("scan_bound", 1)
+    ctx.set_option("scan_index", 1)
+    ctx.set_option("scan_axis", 1)
+    for s in range(3):
+        (r0, v0, ok0, _, _), (r1, v1, ok1, wl, wk) = res[0][s], res[1][s]
+        assert np.array_equal(ok0, ok1)
+        assert (r0["info"].best_index, r0["info"].best_votes) == (r1["info"].best_index, r1["info"].best_votes)
+        assert np.array_equal(r0["consensus"], r1["consensus"]) and np.array_equal(r0["params"], r1["params"])
+        skipped = v1 != v0
+        assert np.all(v1[skipped] == 0)
+        runmax = np.maximum.accumulate(np.where(ok0 > 0, v0, 0))
+        idx = np.flatnonzero(skipped)
+        assert np.all(v0[idx[idx > 0]] <= runmax[idx[idx > 0] - 1]) and (not skipped[0] or v0[0] == 0)
+        if case != "axis_off":
+            assert wk["candidates"] > 0, (wk, wl)      # the rank bounds ran
+        # (two_planes: 85 % of the records lie on one of the two planes, most samples are all-inlier ones and have to
+        #  be counted -- the selection still may not count everything)
+        assert wl["second_pass"] + wl["pilots"] < (0.8 if case == "two_planes" else 0.5) * H, wl
+
+
 def test_bounded_scan_inside_adaptive_ransac(ctx):
     """lsqr_ransac with batches large enough for the bounded scan (80 % outliers: thousands of iterations), the
     best votes of earlier batches carried as the lower bound: same iterations, winner and consensus as counting all"""
