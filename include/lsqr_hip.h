@@ -378,7 +378,16 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                identical (the band is decided exactly);
  * "dense_fast_solve": 1 (default) = the n x n minimal solves of the dense system use elimination with
  *                partial pivoting and only fall back to the SVD pseudo-inverse near the rank decision,
- *                0 = always the SVD pseudo-inverse. */
+ *                0 = always the SVD pseudo-inverse;
+ * "scan_axis":   plane in 3-D over an indexed upload: 1 (default) = every cell also gets the direction of least spread
+ *                of its observations, which are re-sorted inside the cell along it, and the bounded scan ("scan_bound")
+ *                takes upper AND lower vote bounds of its candidates by rank from that order (csrc/axis.h: no
+ *                observation is evaluated; what is counted exactly shrinks from ~500 to ~170 of 4096 hypotheses at
+ *                10 M points); 0 = box-population bounds and pilots only.  Results are identical either way;
+ * "dense_mask_ring": LDS tile buffers per wave of the dense final fit's fused mask + normal-equations pass: 4 (default at
+ *                n = 64) = one workgroup per CU with three tiles in flight, 2 = two workgroups per CU (A/B knob);
+ * "mom_chunk":   records per workgroup of the mask / moment passes in units of 256 (0 = default: 4, wide US / phantom
+ *                records 16; A/B knob -- the fixed-order sums, and with them the last bits of a fit, depend on it). */
 LSQR_API int lsqr_set_option(lsqr_ctx *ctx, const char *name, int value);
 
 /* State of the spatial index of the current upload ("scan_index"): out = {built (0/1), indexed

@@ -277,16 +277,26 @@ __global__ __launch_bounds__(512) void k_bound_axis(const CellBox *__restrict__ 
     }
     __syncthreads();
     if (!active) continue;
-    for (uint32_t i = 0; i < n; i++) {
+    // Per cell: level 1 and the four boundaries (prep), then the searches.  The searches are a chain of 11 dependent
+    // LDS reads; TWO cells are searched together (eight independent reads per round) -- with one the kernel ran at
+    // the latency of that chain (93 us per batch of ~500 candidates; r03).
+    struct Prep {
+      bool s, pre;
+      float ol, oh, il, ih;
+      uint32_t pop;
+      const float *T;
+    };
+    auto prep = [&](uint32_t i, Prep &p) -> bool {  // false: no lane of the wave survives in the cell
       const CellBox bx = s_box[i];
       const CellAxis ax = s_ax[i];
       const double ctr[3] = {(double)bx.c[0], (double)bx.c[1], (double)bx.c[2]};
       float bc[CM::NB];
-      const bool s = CM::level1(hy, bx, ctr, cc, bc);
-      if (!__ballot(s)) continue;  // wave-uniform
-      const uint32_t c = cb + i;
-      const size_t first = (size_t)c * CP;
-      const uint32_t pop = first + CP <= ns ? CP : (uint32_t)(ns - first);
+      p.s = CM::level1(hy, bx, ctr, cc, bc);
+      p.pre = false;
+      if (!__ballot(p.s)) return false;  // wave-uniform
+      const size_t first = (size_t)(cb + i) * CP;
+      p.pop = first + CP <= ns ? CP : (uint32_t)(ns - first);
+      p.T = (const float *)s_T + i * CP;
       const float iee = __builtin_amdgcn_rcpf(ax.e[0] * ax.e[0] + ax.e[1] * ax.e[1] + ax.e[2] * ax.e[2]);
       const float al = (bc[0] * ax.e[0] + bc[1] * ax.e[1] + bc[2] * ax.e[2]) * iee;  // bc[0..2] = n32
       const float m0 = bc[0] - al * ax.e[0], m1 = bc[1] - al * ax.e[1], m2 = bc[2] - al * ax.e[2];
@@ -294,46 +304,81 @@ __global__ __launch_bounds__(512) void k_bound_axis(const CellBox *__restrict__ 
       const float d0 = bc[3];
       const float E = (1.001f * (rho + 1.9e-7f * (bx.h[0] + bx.h[1] + bx.h[2])) + __builtin_fabsf(al) * 1.2e-7f * ax.tmax +
                        6.1e-8f * __builtin_fabsf(d0) + 4e-12f * xabs) * 1.00001f + 1e-30f;
-      const bool pre = s && __builtin_fabsf(al) >= 0.25f && E < 0.5f * thr_dn && bc[5] < __builtin_inff();
-      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-      if (pre) {
-        const float ia = __builtin_amdgcn_rcpf(al);
-        const float b_ol = (-thr_up - E - d0) * ia, b_oh = (thr_up + E - d0) * ia;
-        const float b_il = (-thr_dn + E - d0) * ia, b_ih = (thr_dn - E - d0) * ia;
-        float ol = fminf(b_ol, b_oh), oh = fmaxf(b_ol, b_oh), il = fminf(b_il, b_ih), ih = fmaxf(b_il, b_ih);
-        // fp32 evaluation of a boundary: the numerator (three terms of magnitude <= |d0| + thr + E) is off by at most
-        // 3u of that magnitude, the reciprocal and the product by 3u relative: move every boundary outwards by
-        // mar = 4e-7 (|d0| + thr + E) |1 / alpha| + 2e-6 |b| (certain sets shrink)
-        const float mag = 4e-7f * (__builtin_fabsf(d0) + thr_up + E) * __builtin_fabsf(ia);
-        ol -= mag + 2e-6f * __builtin_fabsf(ol);
-        oh += mag + 2e-6f * __builtin_fabsf(oh);
-        il += mag + 2e-6f * __builtin_fabsf(il);
-        ih -= mag + 2e-6f * __builtin_fabsf(ih);
-        const float *T = (const float *)s_T + i * CP;
-        // r0 = #{T < ol}, r3 = #{T <= oh}, r1 = #{T <= il}, r2 = #{T < ih}: the four searches step together
+      p.pre = p.s && __builtin_fabsf(al) >= 0.25f && E < 0.5f * thr_dn && bc[5] < __builtin_inff();
+      const float ia = __builtin_amdgcn_rcpf(al);
+      const float b_ol = (-thr_up - E - d0) * ia, b_oh = (thr_up + E - d0) * ia;
+      const float b_il = (-thr_dn + E - d0) * ia, b_ih = (thr_dn - E - d0) * ia;
+      float ol = fminf(b_ol, b_oh), oh = fmaxf(b_ol, b_oh), il = fminf(b_il, b_ih), ih = fmaxf(b_il, b_ih);
+      // fp32 evaluation of a boundary: the numerator (three terms of magnitude <= |d0| + thr + E) is off by at most
+      // 3u of that magnitude, the reciprocal and the product by 3u relative: move every boundary outwards by
+      // mar = 4e-7 (|d0| + thr + E) |1 / alpha| + 2e-6 |b| (certain sets shrink)
+      const float mag = 4e-7f * (__builtin_fabsf(d0) + thr_up + E) * __builtin_fabsf(ia);
+      p.ol = ol - (mag + 2e-6f * __builtin_fabsf(ol));
+      p.oh = oh + (mag + 2e-6f * __builtin_fabsf(oh));
+      p.il = il + (mag + 2e-6f * __builtin_fabsf(il));
+      p.ih = ih - (mag + 2e-6f * __builtin_fabsf(ih));
+      return true;
+    };
+    // r0 = #{T < ol}, r3 = #{T <= oh}, r1 = #{T <= il}, r2 = #{T < ih} for the lanes with `pre`, both cells' four
+    // searches stepping together; then the cell's contribution to the two bounds
+    auto search2 = [&](const Prep &A, const Prep &B, bool haveB) {
+      uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      const bool pb = haveB && B.pre;
+      if (A.pre || pb) {
+        const float *TA = A.T, *TB = haveB ? B.T : A.T;
+        // (a lane without `pre` in one of the cells searches with boundaries that keep its ranks at 0)
+        const float ninf = -__builtin_inff();
+        const float aol = A.pre ? A.ol : ninf, aoh = A.pre ? A.oh : ninf, ail = A.pre ? A.il : ninf,
+                    aih = A.pre ? A.ih : ninf;
+        const float bol = pb ? B.ol : ninf, boh = pb ? B.oh : ninf, bil = pb ? B.il : ninf, bih = pb ? B.ih : ninf;
 #pragma unroll
         for (uint32_t step = CP / 2; step > 0; step >>= 1) {
-          const float t0 = T[r0 + step - 1], t3 = T[r3 + step - 1], t1 = T[r1 + step - 1], t2 = T[r2 + step - 1];
-          r0 += t0 < ol ? step : 0u;
-          r3 += t3 <= oh ? step : 0u;
-          r1 += t1 <= il ? step : 0u;
-          r2 += t2 < ih ? step : 0u;
+          const float ta0 = TA[a0 + step - 1], ta3 = TA[a3 + step - 1], ta1 = TA[a1 + step - 1], ta2 = TA[a2 + step - 1];
+          const float tb0 = TB[b0 + step - 1], tb3 = TB[b3 + step - 1], tb1 = TB[b1 + step - 1], tb2 = TB[b2 + step - 1];
+          a0 += ta0 < aol ? step : 0u;
+          a3 += ta3 <= aoh ? step : 0u;
+          a1 += ta1 <= ail ? step : 0u;
+          a2 += ta2 < aih ? step : 0u;
+          b0 += tb0 < bol ? step : 0u;
+          b3 += tb3 <= boh ? step : 0u;
+          b1 += tb1 <= bil ? step : 0u;
+          b2 += tb2 < bih ? step : 0u;
         }
         {  // (the branchless search stops one short of CP)
-          const float t0 = T[r0], t3 = T[r3], t1 = T[r1], t2 = T[r2];
-          r0 += t0 < ol ? 1u : 0u;
-          r3 += t3 <= oh ? 1u : 0u;
-          r1 += t1 <= il ? 1u : 0u;
-          r2 += t2 < ih ? 1u : 0u;
+          const float ta0 = TA[a0], ta3 = TA[a3], ta1 = TA[a1], ta2 = TA[a2];
+          const float tb0 = TB[b0], tb3 = TB[b3], tb1 = TB[b1], tb2 = TB[b2];
+          a0 += ta0 < aol ? 1u : 0u;
+          a3 += ta3 <= aoh ? 1u : 0u;
+          a1 += ta1 <= ail ? 1u : 0u;
+          a2 += ta2 < aih ? 1u : 0u;
+          b0 += tb0 < bol ? 1u : 0u;
+          b3 += tb3 <= boh ? 1u : 0u;
+          b1 += tb1 <= bil ? 1u : 0u;
+          b2 += tb2 < bih ? 1u : 0u;
         }
-        r3 = r3 < pop ? r3 : pop;  // padding carries T = +inf and never counts
+      }
+      auto fold = [&](const Prep &P, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+        r3 = r3 < P.pop ? r3 : P.pop;  // padding carries T = +inf and never counts
         r0 = r0 < r3 ? r0 : r3;
         r1 = r1 < r0 ? r0 : (r1 > r3 ? r3 : r1);
         r2 = r2 < r1 ? r1 : (r2 > r3 ? r3 : r2);
+        u_acc += P.s ? (P.pre ? r3 - r0 : P.pop) : 0u;
+        l_acc += P.pre ? r2 - r1 : 0u;
+      };
+      fold(A, a0, a1, a2, a3);
+      if (haveB) fold(B, b0, b1, b2, b3);
+    };
+    Prep pa, pb;
+    bool havea = false;
+    for (uint32_t i = 0; i < n; i++) {  // (wave-uniform control flow throughout)
+      if (!havea) {
+        havea = prep(i, pa);
+      } else if (prep(i, pb)) {
+        search2(pa, pb, true);
+        havea = false;
       }
-      u_acc += s ? (pre ? r3 - r0 : pop) : 0u;
-      l_acc += pre ? r2 - r1 : 0u;
     }
+    if (havea) search2(pa, pa, false);
   }
   if (h < H) {
     if (u_acc) atomicAdd(&ub[h], u_acc);
@@ -383,6 +428,7 @@ __global__ __launch_bounds__(1024) void k_pick_cands(const uint32_t *__restrict_
     st->n_cand = s_scan[1023];
     st->n_pilot = 0;
     st->n_rest = 0;
+    st->known = 0;
   }
 }
 

@@ -956,8 +956,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? (
 constexpr int kPilots = 64;
 struct BoundSel {            // device-side state of one bounded scan
   uint32_t n_pilot, n_rest;  // number of selected hypotheses of the two passes
-  uint32_t n_cand;           // rank bounds (axis.h): hypotheses whose bounds were refined by rank (n_pilot is 0 then)
-  uint32_t pad;
+  uint32_t n_cand;           // rank bounds (axis.h): hypotheses whose bounds were refined by rank
+  uint32_t known;            // 1: a lower bound of the running maximum was known without pilots (k_pick_pilots)
 };
 
 // single block of 1024 threads, H <= 8192: pilots = the first kPilots valid hypotheses (index order) whose bound is
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict
                                                       const uint8_t *__restrict__ valid, uint32_t H,
                                                       uint32_t *__restrict__ sel, BoundSel *__restrict__ st,
                                                       uint32_t *__restrict__ votes, uint32_t best_before,
-                                                      const uint32_t *__restrict__ lo) {
+                                                      const uint32_t *__restrict__ lo, int no_pilots) {
   __shared__ uint32_t s_red[16], s_redl[16], s_scan[1024];
   const int t = threadIdx.x;
   for (uint32_t h = t; h < H; h += 1024) votes[h] = 0;  // a hypothesis that is not counted reports 0 votes
@@ -1012,8 +1012,11 @@ __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict
     // same RANSAC run already holds a maximum of at least half the largest bound (the pilots' own entry level), that
     // IS the bound: no pilots, the counting launches of the first pass find an empty cost table and return at once.
     // (The rank bounds' lower bounds count the same way.)
+    // no_pilots: the host did not launch a pilot pass for this batch (the last batch of the upload needed none:
+    // run_scan_bounded); `known` still says whether one would have been needed, which re-arms it for the next batch.
     const bool known = ml >= thr && ml > 0;
-    st->n_pilot = known ? 0u : (s_scan[1023] < kPilots ? s_scan[1023] : kPilots);
+    st->known = known ? 1u : 0u;
+    st->n_pilot = (known || no_pilots) ? 0u : (s_scan[1023] < kPilots ? s_scan[1023] : kPilots);
     st->n_rest = 0;
     if (!lo) st->n_cand = 0;
   }
@@ -1248,8 +1251,8 @@ __global__ __launch_bounds__(256) void k_cells_bounds(const CellBox *__restrict_
 //                        (two wave-wide prefix sums), walks cells and groups from there, repeats level 1 for the
 //                        groups it touches (bit-identical to the counting pass) and runs cells_survivors on its part
 //                        of the survivor mask.  No atomics except the vote flush, no waiting, every wave the same
-//                        number of pairs (a pair costs 27 - 55 vector instructions, a mix the 800+ pairs of a wave
-//                        average out).
+//                        number of pairs (a pair costs 31 vector instructions, an exact re-check a few hundred:
+//                        the 800+ pairs of a wave average out).
 constexpr uint32_t kChunkCells = 128;
 // A pair is the unit of cost; what a wave pays per group it evaluates (rows, level 1: ~2 pairs' worth of instructions
 // and a dependent load) and per cell it opens (box, 12 KB of observations) is charged as padding in front of the

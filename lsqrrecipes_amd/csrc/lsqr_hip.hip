@@ -931,7 +931,7 @@ int run_rank_bounds(lsqr_ctx *c, const uint32_t **lo_out) {
                      c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
   HIPCHK(c, hipGetLastError());
   const unsigned gy = (H + 511) / 512;  // (workgroups past the device-side candidate count return at once)
-  const uint32_t per = std::max<uint32_t>(8, ((c->n_cells + 767) / 768 + 7) / 8 * 8);
+  const uint32_t per = std::max<uint32_t>(8, ((c->n_cells + 3071) / 3072 + 7) / 8 * 8);
   const unsigned gx = (c->n_cells + per - 1) / per;
   float thr_up = (float)c->mc.thr, thr_dn = thr_up;
   if ((double)thr_up < c->mc.thr) thr_up = nextafterf(thr_up, INFINITY);
@@ -974,13 +974,21 @@ int run_scan_bounded(lsqr_ctx *c) {
     if (c->axis_valid && c->opt_axis && c->cell_pts == (uint32_t)(128 * PP))
       if ((st = run_rank_bounds<PP>(c, &lo)) != LSQR_OK) return st;
   }
+  // The pilot pass is five launches that find nothing to do when a lower bound of the running maximum is known
+  // without pilots (rank bounds, or the best of earlier batches).  Whether it was is reported back through pinned
+  // memory (h_bsel, possibly a batch late): after a batch of this upload that needed no pilots the pass is not
+  // launched -- k_pick_pilots then selects none; if that batch would have needed them after all, its second pass
+  // counts more hypotheses (never wrongly: L[h] is a lower bound either way) and the next batch gets its pilots back.
+  const bool no_pilots = c->h_bsel && c->h_bsel_H == H && c->h_bsel->known != 0;
   hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel,
-                     c->d_votes, c->best_before, lo);  // (also zeroes the batch's votes: skipped hypotheses report 0)
-  hipLaunchKernelGGL(k_gather_rows, dim3(kPilots / 4), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
-                     (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
-  HIPCHK(c, hipGetLastError());
-  const ScanBatch pa = {sp_a, spf_a, (size_t)kPilots, votes_a, &c->d_bsel->n_pilot};
-  if ((st = run_scan_pairs<CM, PP>(c, pa)) != LSQR_OK) return st;
+                     c->d_votes, c->best_before, lo, no_pilots ? 1 : 0);  // (also zeroes the batch's votes)
+  if (!no_pilots) {
+    hipLaunchKernelGGL(k_gather_rows, dim3(kPilots / 4), dim3(256), 0, c->stream, sel_a, &c->d_bsel->n_pilot,
+                       (uint32_t)kPilots, c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_a, spf_a);
+    HIPCHK(c, hipGetLastError());
+    const ScanBatch pa = {sp_a, spf_a, (size_t)kPilots, votes_a, &c->d_bsel->n_pilot};
+    if ((st = run_scan_pairs<CM, PP>(c, pa)) != LSQR_OK) return st;
+  }
 
   hipLaunchKernelGGL(k_pick_rest, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, votes_a,
                      c->best_before, sel_b, c->d_bsel, lo);
