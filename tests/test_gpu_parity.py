@@ -1830,7 +1830,8 @@ def context_replay(n, k, p, subs, valid, votes):
     return (r["used"], r["i"], r["num_tries"], r["best_votes"], r["best_index"], r["has_best"], r["done"])
 
 
-@pytest.mark.parametrize("case", ["dense_inliers", "small_box", "offset_1e6", "thin_threshold", "two_planes", "axis_off"])
+@pytest.mark.parametrize("case", ["dense_inliers", "small_box", "offset_1e6", "thin_threshold", "two_planes", "axis_off",
+                                  "cells_of_256", "batch_8192"])
 def test_rank_bounds_of_the_plane_are_exact(ctx, case):
     """axis.h (vote bounds by rank in axis-sorted cells): uploads whose cells along the model ARE flat, so that the
     rank bounds -- not the pilots -- do the pruning, in situations that stress their fp32 margins: a box a tenth of the
@@ -1839,7 +1840,7 @@ def test_rank_bounds_of_the_plane_are_exact(ctx, case):
     bounds of one model compete with upper bounds of the other).  scan_bound 1 against counting everything: winner,
     consensus, parameters, replay identical; every counted hypothesis has its exact votes; every other one reports 0
     and could not have become the running maximum."""
-    n, H = 2_000_000, 2048
+    n, H = 2_000_000, (8192 if case == "batch_8192" else 2048)
     kw = dict(seed=77)
     delta = 0.5
     if case == "small_box":
@@ -1853,6 +1854,7 @@ def test_rank_bounds_of_the_plane_are_exact(ctx, case):
         second, truth, _ = synth.plane(n // 2, 0.0, seed=77)
         data[: n // 2] = second + 0.75 * truth[:3]    # same plane, shifted by 1.5 delta along its normal
     ctx.set_option("scan_axis", 0 if case == "axis_off" else 1)
+    ctx.set_option("scan_cell", 256 if case == "cells_of_256" else 0)
     ctx.set_model(L.PLANE, 3, delta).upload(data)
     ctx.set_option("scan_index", 2)
     res = {}
@@ -1868,8 +1870,10 @@ def test_rank_bounds_of_the_plane_are_exact(ctx, case):
     ctx.set_option("scan_bound", 1)
     ctx.set_option("scan_index", 1)
     ctx.set_option("scan_axis", 1)
+    ctx.set_option("scan_cell", 0)
     for s in range(3):
         (r0, v0, ok0, _, _), (r1, v1, ok1, wl, wk) = res[0][s], res[1][s]
+        assert wl["cell_points"] == (256 if case == "cells_of_256" else 512)
         assert np.array_equal(ok0, ok1)
         assert (r0["info"].best_index, r0["info"].best_votes) == (r1["info"].best_index, r1["info"].best_votes)
         assert np.array_equal(r0["consensus"], r1["consensus"]) and np.array_equal(r0["params"], r1["params"])
