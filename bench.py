@@ -63,7 +63,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 # the packed square-minus-threshold) + 2 (combine + the band compare); everything else the kernel issues (the
 # per-observation compares behind the ballots, the band minimum, broadcasts, bookkeeping, exact re-checks) is overhead
 # against this roof.  (Same count as in r01 / r02, whose filter spent the threshold operation on a |.|-minimum.)
-SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 6}, "line": {"l1": 35, "pk": 12},
+SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 4}, "line": {"l1": 35, "pk": 12},
                "us": {"pk": 21}, "phantom": {"pk": 18}}
 
 DELTA = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}

@@ -467,14 +467,16 @@ inline CellConsts cell_consts(const PlaneCell<D> *, const ModelConsts &mc) {
 // with w = ctr - c (fp64, per hypothesis and cell)
 //   D* = |x - c|^2 = |w|^2 + 2 w.y + |y|^2,      T* = D* - mid = k0 + sum (2 w_i + y_i) y_i,   k0 = |w|^2 - mid,
 // so the fp32 arithmetic sees 2 r R-sized numbers instead of r^2-sized ones (r radius, R cell radius):
-//   t32 = fma chain  s = fl32(k0);  s = fma(fl32(x'_i + fl32(2 w_i)), x'_i, s)
-// Error of t32 against T* (u = 2^-24, Y_i = |y_i| <= h_i, W_i = |w_i|): x' rounding u Y_i (2W_i + 2Y_i), rounding
-// of 2w_i: 2u W_i Y_i, of the sum: u (2W_i + Y_i) Y_i, three fma results and fl32(k0): u (3S + |k0|) with
-// S <= |k0| + sum (2W_i + Y_i) Y_i, in total <= u (12 sum W_i Y_i + 6 sum Y_i^2 + 4 |k0|)
-//   <= u (12 |w| R + 6 R^2 + 4 |k0|).
+//   t32 = fma chain  s = fl32(fl32(k0) + q32);  s = fma(fl32(2 w_i), x'_i, s),   q32 = the fma chain of |x'|^2
+// -- q32 is a property of the observation alone and is formed once per cell (cells_load, xs[.][3]): 4 packed
+// instructions per pair of observations and hypothesis instead of 6 (r03; before: s = fma(x'_i + 2 w_i, x'_i, s)).
+// Error of t32 against T* (u = 2^-24, Y_i = |y_i| <= h_i, W_i = |w_i|): q32 against |y|^2: x' rounding 2u Y_i^2 per
+// term, three chain roundings 3u |y|^2: <= 5u sum Y_i^2;  2 w_i y_i: rounding of 2w_i 2u W_i Y_i, of x' 2u W_i Y_i;
+// fl32(k0) u |k0|, the sum k0 + q: u (|k0| + |y|^2); three fma results: 3u S with S <= |k0| + sum Y_i^2 + 2 sum W_i Y_i;
+// in total <= u (10 sum W_i Y_i + 9 sum Y_i^2 + 5 |k0|) <= u (10 |w| R + 9 R^2 + 5 |k0|).
 // A cell that can hold a candidate has |k0| <= K := half + 2|w|R + R^2 + slack (else level 1 drops it), and the
 // reference's fp64 D_ref, the fp64 evaluation of w and k0 are within eta = 1e-12 ((|w| + R)^2 + mid) of the
-// exact values.  With E = 1.01 u (12 |w| R + 6 R^2 + 4 K) + eta (evaluated in fp32 with |w| rounded up):
+// exact values.  With E = 1.01 u (12 |w| R + 9 R^2 + 5 K) + eta (evaluated in fp32 with |w| rounded up):
 //   |t32| < (half - E)(1 - 2^-21) => D_ref in [dlo, dhi] (agrees);   |t32| >= (half + E)(1 + 2^-21) => does not.
 // Level 1: T* over the box lies in [k0 - 2 rr, k0 + 2 rr + R^2], rr = sum W_i h_i; the cell is dropped when that
 // range (widened by E and 1e-5 relative for the fp32 evaluation of the bounds) misses [-tout, tout].
@@ -484,6 +486,7 @@ template <int D>
 struct SphereCell {
   typedef SphereModel<D> M;
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
+  enum { XQ = 1 };         // cells_load keeps q = |x'|^2 per observation in xs[.][3]
   enum { MIN_WAVES = 4 };  // 72 VGPRs = 7 waves per SIMD as compiled
   enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // measured (tools/ab_cells.py): 1.9 ms; 512 / v_readlane 2.1 ms
   enum { USE_BOUND = 1, BOUND_MERGE = 4 };  // the sphere's box test is 61 instructions: 0.29 -> 0.08 ms, 0.87 -> 0.70 ms / step
@@ -524,7 +527,7 @@ struct SphereCell {
     const float wr = wn * R, r2 = R * R;
     const float K = (h.half + 2.0f * wr + r2) * 1.0001f;
     // cc.f: 0 = 1.01 u, 1 = 1e-12 (both rounded up)
-    float E = cc.f[0] * (12.0f * wr + 6.0f * r2 + 4.0f * K) * 1.00001f +
+    float E = cc.f[0] * (12.0f * wr + 9.0f * r2 + 5.0f * K) * 1.00001f +
               cc.f[1] * ((wn + R) * (wn + R) + (float)h.mid) * 1.00001f;
     // K's 1e-4 head room has to cover E and the level-1 slack (see the bound on |k0| of a surviving cell)
     if (h.off || !(E <= 5e-5f * K)) E = __builtin_inff();
@@ -537,9 +540,9 @@ struct SphereCell {
     return !h.nan & (h.off | !miss);
   }
   static __device__ inline v2f value(const v2f *xs, const v2f *fp) {
-    v2f s = fp[3];
+    v2f s = fp[3] + xs[3];  // k0 + |x'|^2
 #pragma unroll
-    for (int i = D - 1; i >= 0; i--) s = __builtin_elementwise_fma(xs[i] + fp[i], xs[i], s);
+    for (int i = D - 1; i >= 0; i--) s = __builtin_elementwise_fma(fp[i], xs[i], s);
     return s;
   }
 };
@@ -678,7 +681,7 @@ __device__ __forceinline__ void cells_filter_squares(float (&bc)[NB]) {
 }
 
 template <class CM, int PP, bool LDSB>
-__device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const float (&bc)[CM::NB], float *s_bc,
+__device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const float (&bc)[CM::NB], float *s_bc,
                                                 unsigned long long surv, const int lane,
                                                 const double *__restrict__ sorted, const size_t ns, const size_t cell,
                                                 const double *__restrict__ spg, const ModelConsts &mc,
@@ -775,7 +778,7 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][3], const fl
 // the observations of cell `cell` as packed fp32 pairs, relative to the cell centre where the model asks for it
 template <class CM, int PP>
 __device__ __forceinline__ void cells_load(const double *__restrict__ sorted, const size_t ns, const size_t cell,
-                                           const int lane, const double (&ctr)[3], v2f (&xs)[PP][3]) {
+                                           const int lane, const double (&ctr)[3], v2f (&xs)[PP][4]) {
   constexpr int D = CM::M::ND, CP = 128 * PP;
 #pragma unroll
   for (int p = 0; p < PP; p++) {
@@ -790,6 +793,15 @@ __device__ __forceinline__ void cells_load(const double *__restrict__ sorted, co
       xs[p][d].x = (d < D && !(i0 < ns)) ? __builtin_nanf("") : a0;
       xs[p][d].y = (d < D && !(i1 < ns)) ? __builtin_nanf("") : a1;
     }
+    // xs[p][3]: a per-observation constant of the model's measure, formed once per cell instead of once per
+    // (hypothesis, cell) -- sphere: q = |x'|^2 (fma chain from the last coordinate down); unused otherwise
+    v2f q = {0.0f, 0.0f};
+    if constexpr (requires { CM::XQ; }) {
+      q = xs[p][D - 1] * xs[p][D - 1];
+#pragma unroll
+      for (int d = D - 2; d >= 0; d--) q = __builtin_elementwise_fma(xs[p][d], xs[p][d], q);
+    }
+    xs[p][3] = q;
   }
 }
 
@@ -865,7 +877,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? (
     const uint32_t wt = un / hsplit;
     const uint32_t hbeg = (un - wt * hsplit) * hseg, hend = hbeg + hseg < H ? hbeg + hseg : H;
     if (hbeg >= H) continue;
-    v2f xs[CPT][PP][3];
+    v2f xs[CPT][PP][4];
     CellBox bx[CPT];
     double ctr[CPT][3];
 #pragma unroll
@@ -1422,7 +1434,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
     double ctr[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) ctr[d] = (double)bx.c[d];
-    v2f xs[PP][3];
+    v2f xs[PP][4];
     cells_load<CM, PP>(sorted, ns, (size_t)cell, lane, ctr, xs);
     float4 nxt[NR4], nxt2[NR2 ? NR2 : 1];
     load_rows((uint32_t)__builtin_ctzll(gm), nxt, nxt2);
