@@ -19,7 +19,8 @@
 // where the bounded scan's box-population bound is 2.7 x the votes (every cell the structure passes through counts
 // whole) and cannot tell one near-model hypothesis from another.  k_bound_axis computes the two bounds for the bounded
 // scan's candidates; with them only the hypotheses whose upper bound exceeds the best LOWER bound before them are
-// counted exactly (plane, 10 M points, 50 % outliers: ~50 of 4096 instead of ~500, and no pilots).
+// counted exactly (plane, 10 M points, 50 % outliers: 169 of 4096 instead of 511, and no pilots; sparse uploads whose
+// cells are not flat keep the pilots: cells.h, k_pick_pilots).
 // (Tried first, r03: settling the pairs themselves by rank and evaluating only the shells, lane = hypothesis -- exact,
 // 3.5 M of 5.1 M near-model pairs settled, but the serial shell loops of 64 lanes run at the length of the longest and
 // at the latency of their LDS reads: 0.86 ms against the 0.31 ms of level-2 work they saved.  Removed.)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void k_cell_sort(double *__restrict__ sorted, 
 // population / zero elsewhere.  lane = hypothesis, blockIdx.y * 8 + wave = group of 64, blockIdx.x = a run of cells;
 // eight cells per round are staged in LDS (boxes, axes and their T[]: 2 KB a cell, read once per workgroup -- 40 MB per
 // 512 candidates at 10 M points) and the four searches of a pair step together over LDS (11 dependent rounds of four
-// reads; from global memory the same searches took 278 us per batch, 9x the LDS version).
+// reads; from global memory the same searches took 278 us per batch, from LDS 93 us, in 8-cell runs 71 us).
 // All per-pair quantities in fp32 here (a bound only has to be conservative): with u = 2^-24,
 //   alpha32 = fl(n32 . e) / fl(e . e):           |alpha32 - alpha| <= 8u (|n| <= 1.0000001, |e| ~ 1)
 //   m32 = n32 - alpha32 e,  rho32 = sum |m32_i| h_i:   the identity s = alpha32 t + d0 + m . (x - ctr) holds for
