@@ -1491,6 +1491,66 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
   for (uint32_t i = threadIdx.x; i < H; i += BS) vpart[(size_t)blockIdx.x * vstride + i] = s_cnt[i];
 }
 
+// ---- hypothesis order of a full count (plane) -------------------------------------------------------------------
+// k_scan_pairs evaluates level 1 for every (cell, 64-hypothesis group) in which the counting pass found a survivor.
+// With the hypotheses in sampling order a group is 64 unrelated planes and some of them cut almost every cell: 95 % of
+// the (cell, group) pairs have to be evaluated.  Sorted by a Morton key of (normal direction, offset) a group is 64
+// SIMILAR planes that miss the same cells: 52 % (10 M points, 4096 hypotheses) -- the scan walks the batch through a
+// permutation (rows gathered, votes scattered back: the count of a hypothesis does not depend on its position).
+// One workgroup of 1024 threads, H <= 4096: keys, bitonic sort of (key, index) in LDS; perm[j] = index of the j-th
+// hypothesis in key order, *count = H (the device-side count k_gather_rows takes).
+template <int SPD>
+__global__ __launch_bounds__(1024) void k_plane_order(const double *__restrict__ sp, uint32_t H, double xabs,
+                                                      uint32_t *__restrict__ perm, uint32_t *__restrict__ count) {
+  __shared__ unsigned long long s_k[4096];
+  const int t = threadIdx.x;
+  const double inv = 1.0 / (1.7320508075688774 * (xabs > 0.0 ? xabs : 1.0));
+  for (uint32_t h = t; h < 4096; h += 1024) {
+    unsigned long long key = ~0ull;  // past the batch: sorts to the end
+    if (h < H) {
+      const double *r = sp + (size_t)h * SPD;
+      const double n0 = r[0], n1 = r[1], n2 = r[2];
+      double c = n0 * r[3] + n1 * r[4] + n2 * r[5];
+      uint32_t m = 0x8000u;  // NaN models after all others
+      if (n0 == n0 && c == c) {
+        const double sg = (n2 != 0.0 ? n2 : n1 != 0.0 ? n1 : n0) < 0.0 ? -1.0 : 1.0;  // one of the two signs of a plane
+        auto q5 = [](double v) {  // [-1, 1] -> 0..31
+          const double w = (v + 1.0) * 16.0;
+          return (uint32_t)(w < 0.0 ? 0.0 : w > 31.0 ? 31.0 : w);
+        };
+        const uint32_t qa = q5(sg * n0), qb = q5(sg * n1), qd = q5(sg * c * inv);
+        m = 0;
+#pragma unroll
+        for (int b = 0; b < 5; b++)
+          m |= ((qa >> b) & 1u) << (3 * b) | ((qb >> b) & 1u) << (3 * b + 1) | ((qd >> b) & 1u) << (3 * b + 2);
+      }
+      key = ((unsigned long long)m << 32) | h;
+    }
+    s_k[h] = key;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= 4096; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = t; i < 4096; i += 1024) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = s_k[i], b = s_k[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) s_k[i] = b, s_k[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = t; i < H; i += 1024) perm[i] = (uint32_t)(s_k[i] & 0xFFFFFFFFull);
+  if (t == 0) *count = H;
+}
+// votes[perm[j]] = v[j]
+__global__ __launch_bounds__(256) void k_scatter_perm(const uint32_t *__restrict__ perm, uint32_t H,
+                                                      const uint32_t *__restrict__ v, uint32_t *__restrict__ votes) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < H) votes[perm[j]] = v[j];
+}
+
 // votes[h] += sum over the workgroups of k_scan_pairs of their partial counts; blockIdx.x = 64 hypotheses,
 // blockIdx.y = a slice of the workgroups
 __global__ __launch_bounds__(256) void k_votes_reduce(const uint32_t *__restrict__ vpart, uint32_t vstride,

@@ -90,6 +90,7 @@ struct lsqr_ctx {
   size_t axis_cap = 0, cellT_cap = 0;
   bool axis_valid = false;
   int opt_mom_chunk = 0;          // chunk of the mask / moment passes in units of kBlock records (0 = default; A/B)
+  int opt_hyp_order = 1;          // 1: a full count of the plane walks the batch in key order (k_plane_order)
   int opt_axis = 1;               // 1: the bounded scan of the plane takes its vote bounds by rank (k_bound_axis)
   uint32_t *d_ub2 = nullptr;  // rank bounds: [upper | lower] of the candidates (compact order) | lower per hypothesis
   uint8_t *d_paircnt = nullptr;   // k_scan_pairs: survivors per (cell, group of 64 hypotheses)
@@ -1398,6 +1399,29 @@ int run_scan(lsqr_ctx *c) {
             bool full_pairs = false;
             if constexpr (requires { CM::FULL_COUNT_PAIRS; }) full_pairs = c->opt_pairs == 0 && c->H >= 1024;
             if (c->opt_pairs == 1 || full_pairs) {
+              if constexpr (std::is_same<CM, PlaneCell<3>>::value) {
+                // the batch in key order (cells.h: k_plane_order): similar planes share a 64-group
+                if (c->opt_hyp_order && c->H >= 1024 && c->H <= 4096) {
+                  const uint32_t H = (uint32_t)c->H;
+                  uint32_t *perm = c->d_sel + kPilots, *cnt = (uint32_t *)(c->d_counter + 7);
+                  double *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
+                  float *spf_b = c->d_hparams2_f32 + (size_t)kPilots * M::SPF;
+                  uint32_t *votes_b = c->d_votes2 + kPilots;
+                  hipLaunchKernelGGL((k_plane_order<M::SP>), dim3(1), dim3(1024), 0, c->stream, c->d_hparams, H,
+                                     c->mc.absmax, perm, cnt);
+                  hipLaunchKernelGGL(k_gather_rows, dim3((H + 3) / 4), dim3(256), 0, c->stream, perm, cnt, H,
+                                     c->d_hparams, (int)M::SP, c->d_hparams_f32, (int)M::SPF, sp_b, spf_b);
+                  HIPCHK(c, hipGetLastError());
+                  const ScanBatch pb = {sp_b, spf_b, (size_t)H, votes_b, nullptr};
+                  int st2 = with_pp<CM>(cell_pts,
+                                        [&](auto pp) { return run_scan_pairs<CM, decltype(pp)::value>(c, pb); });
+                  if (st2 != LSQR_OK) return st2;
+                  hipLaunchKernelGGL(k_scatter_perm, dim3((H + 255) / 256), dim3(256), 0, c->stream, perm, H, votes_b,
+                                     c->d_votes);
+                  HIPCHK(c, hipGetLastError());
+                  return LSQR_OK;
+                }
+              }
               const ScanBatch b = {c->d_hparams, c->d_hparams_f32, c->H, c->d_votes, nullptr};
               return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_pairs<CM, decltype(pp)::value>(c, b); });
             }
@@ -4024,6 +4048,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "scan_axis")) {  // 1 (default): axis-sorted cells + vote bounds by rank (plane, 3-D); 0: off
     c->opt_axis = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_hyp_order")) {  // 1 (default): full counts of the plane in key order (similar planes share a group)
+    c->opt_hyp_order = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "mom_chunk")) {
