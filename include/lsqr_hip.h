@@ -384,6 +384,10 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                takes upper AND lower vote bounds of its candidates by rank from that order (csrc/axis.h: no
  *                observation is evaluated; what is counted exactly shrinks from ~500 to ~170 of 4096 hypotheses at
  *                10 M points); 0 = box-population bounds and pilots only.  Results are identical either way;
+ * "scan_hyp_order": plane in 3-D, full counts (scan_bound 0 / lsqr_scan) of 1024..4096 hypotheses over an indexed
+ *                upload: 1 (default) = the batch is walked in the order of a Morton key of (normal direction, offset)
+ *                so that the 64 hypotheses of a group miss the same cells (csrc/cells.h: k_plane_order); 0 = sampling
+ *                order.  Votes are identical;
  * "dense_mask_ring": LDS tile buffers per wave of the dense final fit's fused mask + normal-equations pass: 4 (default at
  *                n = 64) = one workgroup per CU with three tiles in flight, 2 = two workgroups per CU (A/B knob);
  * "mom_chunk":   records per workgroup of the mask / moment passes in units of 256 (0 = default: 4, wide US / phantom
