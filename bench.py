@@ -749,7 +749,9 @@ def report(R, rates, cpu_budget, headline=True):
                    "observations replicated" % a.gpus,
                    "world_size": comm.world,
                    "collectives": ("RCCL (torch.distributed nccl backend)" if R.dist is not None and comm.device != "cpu"
-                                   else ("gloo (rehearsal)" if R.dist is not None else "none (single GPU)")),
+                                   else ("gloo, host-side exchanges (FALLBACK -- RCCL did not come up: %s)"
+                                         % os.environ["LSQR_DIST_FALLBACK"] if os.environ.get("LSQR_DIST_FALLBACK")
+                                         else "gloo (rehearsal)") if R.dist is not None else "none (single GPU)"),
                    "streams": a.streams if R.multi_stream else 1,
                    "stream_priming_steps": 2 * a.streams if R.multi_stream else 0,
                    "repeats": max(1, a.repeats),
@@ -1014,7 +1016,30 @@ def main():
         if backend == "nccl":
             torch.cuda.set_device(local)
             device = "cuda:%d" % local
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            try:
+                # device_id makes the communicator come up here, and one small all-reduce proves it works, before
+                # any timing starts
+                dist.init_process_group("nccl", device_id=torch.device(device))
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != int(os.environ.get("WORLD_SIZE", "1")):
+                    raise RuntimeError("all_reduce probe returned %r" % probe.item())
+            except Exception as e:  # noqa: BLE001 -- whatever RCCL / the driver stack raises
+                # The exchanges of this path are 8 bytes and one moment block per step: they do not need RCCL to be
+                # fast.  If RCCL cannot come up on this node the run continues over gloo (host-side exchanges, one
+                # stream) and SAYS SO in config.collectives instead of producing no line at all.
+                sys.stderr.write("bench.py: RCCL unavailable on rank %d (%s: %s) -- continuing with gloo\n"
+                                 % (rank, type(e).__name__, e))
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                import datetime
+                backend = "gloo"
+                device = "cpu"
+                os.environ["LSQR_DIST_FALLBACK"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group(backend)
             if os.environ.get("LSQR_STEP") == "device":

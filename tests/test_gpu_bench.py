@@ -116,6 +116,15 @@ def test_bench_gpus_2_launches_its_own_ranks():
         assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
 
 
+def test_bench_falls_back_to_gloo_when_rccl_cannot_come_up():
+    """two ranks on ONE device with the default (nccl) backend: RCCL refuses the duplicate device on every rank, and
+    the run has to go on over gloo and say so in config.collectives -- a line, not a crash"""
+    j = _run(["--workload", "plane", "--gpus", "2", "--streams", "1"], env={"LSQR_SHARE_GPU": "1"})
+    _check(j, 1, n_gpus=2)
+    assert j["config"]["world_size"] == 2 and "FALLBACK" in j["config"]["collectives"], j["config"]["collectives"]
+    assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
+
+
 def test_bench_gpus_2_one_process_multi_transport():
     j = _run(["--workload", "plane", "--gpus", "2", "--transport", "multi"], env={"LSQR_SHARE_GPU": "1"})
     assert j["config"]["world_size"] == 2 and j["config"]["collectives"] == "peer copies (lsqr_multi)"
