@@ -66,6 +66,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 4}, "line": {"l1": 35, "pk": 12},
                "us": {"pk": 21}, "phantom": {"pk": 18}}
 
+COUNTER_ROUND = "r04"       # profiles/<round>_<workload>_<rate>_scan_counters.json (tools/collect_counters.py)
 DELTA = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}
 PROF_KEYS = ("scan", "mask", "moments", "estimate", "solve", "sample", "index")
 
@@ -112,6 +113,13 @@ def parse(argv=None):
                     "legs (tests; 1 = the BASELINE sizes)")
     ap.add_argument("--cpu-seconds", type=float, default=0.0, help="budget of the CPU full-count sample "
                     "(0 = 4 s for the headline, 3 s per leg)")
+    ap.add_argument("--detail", default="", help="file the FULL record of the run is written to (work models, per-kernel "
+                    "tables, notes, the legs of the other configs); default bench_detail.json next to bench.py.  The "
+                    "last stdout line is the compact headline only")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="--gpus N > 1: if RCCL cannot come up on ANY rank, continue over gloo (labelled in "
+                         "config.collectives) instead of exiting non-zero.  Never the default: a scaling line must not "
+                         "be a gloo line by accident")
     return ap.parse_args(argv)
 
 
@@ -237,10 +245,11 @@ def scan_roofline(R, mode, scan_ms, n_scan):
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_GBs": alg_bytes / t / 1e9 if t > 0 else 0.0,
             "algorithmic_note": "SURVEY 8(d) logical figure H*N*%d B / launch time: NOT a roofline fraction -- one pass "
-                                "over the observations serves all H hypotheses (and the two-level scan proves most "
-                                "(hypothesis, cell) pairs irrelevant from the cell boxes), so it exceeds the HBM peak by "
-                                "construction" % rec}
-    prof = profile_file("r03_%s_%s_scan_counters.json" % (w, mode))
+                                "over the observations serves all H hypotheses%s, so it exceeds the HBM peak by "
+                                "construction" % (rec, " (and the two-level scan proves most (hypothesis, cell) pairs "
+                                                  "irrelevant from the cell boxes)" if w in ("plane", "sphere", "line")
+                                                  else "")}
+    prof = profile_file("%s_%s_%s_scan_counters.json" % (COUNTER_ROUND, w, mode))
     traffic = prof.get("hbm_bytes_per_launch") if prof else None
     if prof:
         base["counters"] = {k: prof[k] for k in ("valu_issue_busy", "salu_issue_busy_per_cu", "lanes_active",
@@ -248,6 +257,12 @@ def scan_roofline(R, mode, scan_ms, n_scan):
                                                 "kernel_avg_ms", "collected_at", "source") if k in prof}
         if traffic and t > 0:
             base["hbm_frac_measured"] = traffic / t / 1e9 / HBM_PEAK_GBS
+        if prof.get("valu_wave_instructions") and t > 0:
+            # ISSUED vector wave-instructions of the launch (SQ_INSTS_VALU, counters) against both issue peaks: the
+            # 4-cycle one tools/microbench.hip measures for this instruction mix and MI355X_MICROARCH.md's 2-cycle one
+            issued = prof["valu_wave_instructions"] / t / 1e9
+            base["issued_valu_frac_4cyc"] = issued / VALU_ISSUE_PEAK_GWIPS
+            base["issued_valu_frac_2cyc"] = issued / (2 * VALU_ISSUE_PEAK_GWIPS)
     if w == "dense":
         wl = ctx.scan_work() if hasattr(ctx, "scan_work") else None
         rows_done = wl["row_hypothesis_pairs"] if wl else float(a.points) * H
@@ -256,6 +271,7 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         base.update({"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "frac_of_fp64_mfma_peak": ach / FP64_MFMA_PEAK_TFLOPS,
+                     "kernel_short": "k_scan_dense_mfma32r<64> fp32-MFMA filter + k_dense_recheck_seg (exact fp64)",
                      "kernel": "k_scan_dense_mfma32r<64> (fp32 MFMA filter, v_mfma_f32_16x16x4_f32, hypothesis fragments "
                                "through an LDS ring, next row tile in registers) + k_dense_recheck_seg (exact fp64 "
                                "decision of the ~1e-4 of the pairs inside the filter's band); launch_ms covers both "
@@ -307,6 +323,11 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         model = {"hypothesis_wave_pairs_evaluated": pairs, "hypothesis_wave_pairs_all": pairs_all,
                  "evaluated_fraction": pairs / pairs_all, "useful_instr_per_pair": v2_instr}
     ach = useful_instr / t / 1e9 if t > 0 else 0.0
+    base["kernel_short"] = (("k_scan_pairs<%s>" % w if (cells and (wl["bounded"] or R.full_pairs)) else
+                             "k_scan_cells<%s>" % w if cells else kname.split(" ")[0])
+                            + (" two-level scan, " + ("bounded" if wl["bounded"] else "every hypothesis counted")
+                               if cells else " packed fp32 filter + exact fp64 re-check"))
+    base["frac_of_2cycle_issue_peak"] = ach / (2 * VALU_ISSUE_PEAK_GWIPS)
     base.update({"bound": "valu", "achieved": ach, "peak": VALU_ISSUE_PEAK_GWIPS, "unit": "G wave-instr/s",
                  "frac": ach / VALU_ISSUE_PEAK_GWIPS, "traffic": traffic, "kernel": kname, "work_model": model,
                  "measured_cycles_per_instruction": measured_cycles(),
@@ -633,6 +654,7 @@ class Run:
         k_med = int(np.argsort(regions)[len(regions) // 2])
         per_rank = self.comm.allgather_f64(H * a.steps / own[k_med])   # each rank's own clock, median region
         prof = {k: ctx.profile_get(k) for k in PROF_KEYS}
+        prof_steps = a.steps * max(1, a.repeats)      # steps the profile above covers
         ctx.profile(False)
         single_stream = None
         if self.multi_stream:
@@ -655,6 +677,7 @@ class Run:
                                      "includes the time it shares the device)" % a.streams}
             prof1["index"] = prof["index"]
             prof = prof1
+            prof_steps = k1
         self.idx = ctx.index_info()
         vals = [H * a.gpus * a.steps / dt for dt in regions]
         med = float(np.median(vals))
@@ -668,6 +691,7 @@ class Run:
         out = {"mode": mode, "value": med, "values": vals, "ms_per_step": dt_med / a.steps * 1e3,
                "region_s": regions, "per_rank": per_rank, "last": last, "prof": prof, "idx_warm": idx_warm,
                "abs_warm": abs_warm, "single_stream": single_stream, "scan_ms": scan_ms, "lm_evaluations": nfev,
+               "prof_steps": prof_steps,
                "roofline": scan_roofline(self, mode, scan_ms, n_scan)}
         return out
 
@@ -784,8 +808,9 @@ def report(R, rates, cpu_budget, headline=True):
                          "scan": main_rate["scan_ms"],
                          "mask": prof["mask"][1] / max(prof["mask"][0], 1),
                          "moments": prof["moments"][1] / max(prof["moments"][0], 1),
-                         "moments_launches_per_step": prof["moments"][0] / max(min(a.steps, 20), 1),
-                         "reduce_and_solve_per_step": prof["solve"][1] / max(min(a.steps, 20), 1)}
+                         "moments_launches_per_step": prof["moments"][0] / max(main_rate["prof_steps"], 1),
+                         "reduce_and_solve_per_step": prof["solve"][1] / max(main_rate["prof_steps"], 1),
+                         "profiled_steps": main_rate["prof_steps"]}
     for r in rates[1:]:
         out["kernels_ms"]["scan_" + r["mode"]] = r["scan_ms"]
     out["index"] = {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
@@ -897,6 +922,145 @@ def run_legs(a0, local):
     return legs
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# What is printed.  The driver keeps an 8 KB tail of stdout and parses the LAST line: that line is the compact
+# headline (<= HEADLINE_LIMIT bytes, asserted); everything else -- work models, per-kernel tables, notes, the legs of
+# the other configs in full -- goes to the detail file (--detail, default bench_detail.json) and, per leg, to one short
+# line printed BEFORE the headline.
+HEADLINE_LIMIT = 4096
+
+
+def _sig(x, nd=6):
+    """floats to nd significant digits (the headline carries numbers, not 17-digit reprs)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, nd) for v in x]
+    return x
+
+
+def compact_roofline(r, one):
+    """the roofline block of the headline: the contract's keys, the measured HBM fraction, the issue fractions, and the
+    basis of launch_ms (the one-stream pass whose own rate stands beside it, so that launch_ms <= its ms_per_step)"""
+    if not r:
+        return None
+    c = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    for k in ("hbm_frac_measured", "launch_ms", "issued_valu_frac_4cyc", "issued_valu_frac_2cyc",
+              "frac_of_2cycle_issue_peak", "frac_of_fp64_mfma_peak"):
+        if r.get(k) is not None:
+            c[k] = r[k]
+    if r.get("counters"):
+        c["valu_issue_busy"] = r["counters"].get("valu_issue_busy")
+    c["kernel"] = str(r.get("kernel_short") or r.get("kernel") or "")[:80]
+    c["algorithmic_GBs"] = r.get("algorithmic_GBs")
+    if one:
+        c["basis"] = "one_stream pass: %.4g ms/step" % one["ms_per_step"]
+    return c
+
+
+def compact_cpu(cpu):
+    if not cpu:
+        return None
+    c = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind")}
+    c["sample"] = str(cpu.get("sample", ""))[:150]
+    if "full_count" in cpu:
+        f = cpu["full_count"]
+        c["full_count"] = {"value": f["value"], "kind": f["kind"], "cores": f["cores"], "sample": str(f["sample"])[:150]}
+    return c
+
+
+def leg_line(leg):
+    """one short stdout line per leg of the other configs (printed before the headline)"""
+    if "error" in leg:
+        return {"leg": leg["config"]["workload"][:60], "error": leg["error"][:200]}
+    ff = leg.get("final_fit", {})
+    r = leg.get("roofline") or {}
+    one = leg.get("single_stream")
+    o = {"leg": leg["config"]["workload"][:100], "points": leg["config"]["points"],
+         "hypotheses_per_step": leg["config"]["hypotheses_per_gpu_per_step"], "streams": leg["config"]["streams"],
+         "value": leg["value"], "unit": "hypotheses/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
+         "value_full_count": leg.get("value_full_count"), "value_early_exit": leg.get("value_early_exit"),
+         "one_stream": {"value": one["value"], "ms_per_step": one["ms_per_step"]} if one else None,
+         "roofline": compact_roofline(r, one),
+         "final_fit": {k: ff.get(k) for k in ("inliers", "winner_votes", "params_empty", "lm_info", "lm_nfev")},
+         "cpu_full_count_hyp_s": (leg.get("cpu_baseline") or {}).get("full_count", leg.get("cpu_baseline") or {}).get("value")}
+    if leg.get("lm"):
+        o["lm_evaluations_per_s"] = leg["lm"].get("evaluations_per_s")
+    return _sig(o, 5)
+
+
+def headline(out, detail_path):
+    """the LAST stdout line: the contract's keys + both rates + one-stream rate + roofline + cpu_baseline, <= 4 KB"""
+    cfg = out["config"]
+    one = out.get("single_stream")
+    ff = out.get("final_fit") or {}
+    h = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "n_gpus": out["n_gpus"],
+         "steps": out["steps"], "warmup": out["warmup"], "ms_per_step": out["ms_per_step"],
+         "higher_is_better": True, "scaling": out["scaling"], "vs_baseline": None, "dtype": out["dtype"],
+         "data": out["data"],
+         "config": {"workload": cfg["workload"][:140], "points": cfg["points"],
+                    "hypotheses_per_gpu_per_step": cfg["hypotheses_per_gpu_per_step"], "streams": cfg.get("streams"),
+                    "world_size": cfg.get("world_size"), "collectives": str(cfg.get("collectives"))[:120],
+                    "repeats": cfg.get("repeats")},
+         "value_is": out.get("value_is"),
+         "value_full_count": out.get("value_full_count"), "value_early_exit": out.get("value_early_exit"),
+         "ms_per_step_full_count": out.get("ms_per_step_full_count"),
+         "ms_per_step_early_exit": out.get("ms_per_step_early_exit"),
+         "one_stream": ({"value": one["value"], "ms_per_step": one["ms_per_step"], "steps": one["steps"]}
+                        if one else None),
+         "per_rank_hypotheses_per_s": out.get("per_rank_hypotheses_per_s"),
+         "roofline": compact_roofline(out.get("roofline"), one),
+         "cpu_baseline": compact_cpu(out.get("cpu_baseline")),
+         "speedup_vs_cpu_baseline": out.get("speedup_vs_cpu_baseline"),
+         "final_fit": {"inliers": ff.get("inliers"), "winner_votes": ff.get("winner_votes"),
+                       "params_empty": ff.get("params_empty"), "lm_info": ff.get("lm_info"),
+                       "lm_nfev": ff.get("lm_nfev"), "abs_dot_true_normal": ff.get("abs_dot_true_normal"),
+                       "residual_min_max_mean_sumsq": ff.get("residual_min_max_mean_sumsq")},
+         }
+    if out.get("roofline_early_exit"):
+        e = out["roofline_early_exit"]
+        h["roofline_early_exit"] = {k: e.get(k) for k in ("bound", "frac", "launch_ms", "hbm_frac_measured")}
+    if out.get("kernel_hbm"):
+        h["kernel_hbm"] = [{"kernel": str(k["kernel"]).split(" ")[0][:40], "ms": k["ms"],
+                            "frac_of_hbm_peak": k["frac_of_hbm_peak"]} for k in out["kernel_hbm"][:4]]
+    if out.get("lm"):
+        h["lm_evaluations_per_s"] = out["lm"].get("evaluations_per_s")
+    if out.get("other_configs"):
+        h["other_configs"] = [{"leg": (leg["config"]["workload"].split(",")[0])[:56],
+                               "value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"),
+                               "roofline_frac": (leg.get("roofline") or {}).get("frac"),
+                               "error": leg.get("error")} for leg in out["other_configs"]]
+    h["detail"] = detail_path
+    h = _sig(h, 6)
+    line = json.dumps(h, separators=(",", ":"))
+    if len(line) > HEADLINE_LIMIT:      # never hand the driver a line it will cut: drop the optional blocks
+        for k in ("other_configs", "kernel_hbm", "roofline_early_exit", "per_rank_hypotheses_per_s"):
+            h.pop(k, None)
+            line = json.dumps(h, separators=(",", ":"))
+            if len(line) <= HEADLINE_LIMIT:
+                break
+    assert len(line) <= HEADLINE_LIMIT, len(line)
+    return line
+
+
+def emit(out, a):
+    """detail file + one short line per leg + the headline as the LAST stdout line"""
+    path = a.detail or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        shown = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError as e:            # a read-only tree must not cost the headline
+        shown = "not written (%s)" % e
+    for leg in out.get("other_configs") or []:
+        print(json.dumps(leg_line(leg), separators=(",", ":")))
+    print(headline(out, shown))
+    sys.stdout.flush()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -919,6 +1083,8 @@ def launch_ranks(a):
     for ln in p.stdout:
         if ln.startswith('{"metric"'):
             line = ln.strip()
+        elif ln.startswith('{"leg"'):
+            sys.stdout.write(ln)
         else:
             sys.stderr.write(ln)
     rc = p.wait()
@@ -977,8 +1143,88 @@ def run_multi(a):
            "roofline": None, "cpu_baseline": None}
     for mode, vals in out_rates.items():
         out["value_" + mode] = float(np.median(vals))
-    print(json.dumps(out))
+    emit(out, a)
     return 0
+
+
+def bring_up_rccl(a, dist, torch, rank, world, device):
+    """RCCL communicator proven (one small all-reduce) before any timing, with a COLLECTIVE verdict: every rank posts
+    ok / fail to a side-channel TCPStore and all ranks act on the same tally.
+      all ok                    -> ("nccl", device)
+      all failed + --allow-gloo -> gloo over the host, labelled in config.collectives (LSQR_DIST_FALLBACK)
+      anything else             -> exit code 3 on every rank (a rank still inside RCCL 20 s after a peer reported a
+                                   failure is taken out by a watcher thread: no world split across two backends)"""
+    import datetime
+    import threading
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ["MASTER_PORT"])
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() in ("1", "true")
+    store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store),
+                          timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    side = dist.PrefixStore("lsqr_bench_rccl", store)
+    done = threading.Event()
+
+    def watch():
+        seen = None
+        while not done.is_set():
+            try:
+                failed = side.add("fail", 0)
+            except Exception:  # noqa: BLE001 -- the store went away: the main thread will notice
+                return
+            if failed > 0:
+                seen = seen or time.time()
+                if time.time() - seen > 20.0 and not done.is_set():
+                    sys.stderr.write("bench.py: rank %d still inside RCCL bring-up 20 s after a peer reported a "
+                                     "failure -- exiting (3)\n" % rank)
+                    sys.stderr.flush()
+                    os._exit(3)
+            time.sleep(0.25)
+    threading.Thread(target=watch, daemon=True).start()
+    err = None
+    try:
+        torch.cuda.set_device(torch.device(device))
+        dist.init_process_group("nccl", store=dist.PrefixStore("nccl", store), rank=rank, world_size=world,
+                                device_id=torch.device(device))
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError("all_reduce probe returned %r" % probe.item())
+    except Exception as e:  # noqa: BLE001 -- whatever RCCL / the driver stack raises
+        err = "%s: %s" % (type(e).__name__, str(e)[:160])
+        sys.stderr.write("bench.py: RCCL unavailable on rank %d (%s)\n" % (rank, err))
+    side.add("fail" if err else "ok", 1)
+    done.set()
+    t0 = time.time()
+    try:
+        while side.add("ok", 0) + side.add("fail", 0) < world:
+            if time.time() - t0 > 120.0:
+                raise TimeoutError("not every rank reported its RCCL status")
+            time.sleep(0.05)
+        failed = side.add("fail", 0)
+    except Exception as e:  # noqa: BLE001 -- the store's host (rank 0) left, or a rank never reported
+        sys.stderr.write("bench.py: rank %d: RCCL verdict incomplete (%s) -- exiting (3)\n" % (rank, type(e).__name__))
+        sys.stderr.flush()
+        os._exit(3)
+    if failed == 0:
+        return "nccl", device
+    if failed == world and a.allow_gloo:
+        # The exchanges of this path are 8 bytes and one moment block per step: they do not need RCCL to be fast.
+        # Only on request, only when NO rank has RCCL, and labelled in config.collectives.
+        sys.stderr.write("bench.py: rank %d continues over gloo (--allow-gloo)\n" % rank)
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        os.environ["LSQR_DIST_FALLBACK"] = err
+        dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=180))
+        return "gloo", "cpu"
+    sys.stderr.write("bench.py: RCCL did not come up on %d of %d ranks%s -- no line is produced (exit 3)\n"
+                     % (failed, world, "" if a.allow_gloo else "; --allow-gloo would continue over gloo if it had "
+                        "failed on every rank"))
+    sys.stderr.flush()
+    os._exit(3)
 
 
 def main():
@@ -1014,32 +1260,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
-            torch.cuda.set_device(local)
             device = "cuda:%d" % local
-            try:
-                # device_id makes the communicator come up here, and one small all-reduce proves it works, before
-                # any timing starts
-                dist.init_process_group("nccl", device_id=torch.device(device))
-                probe = torch.ones(1, device=device)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != int(os.environ.get("WORLD_SIZE", "1")):
-                    raise RuntimeError("all_reduce probe returned %r" % probe.item())
-            except Exception as e:  # noqa: BLE001 -- whatever RCCL / the driver stack raises
-                # The exchanges of this path are 8 bytes and one moment block per step: they do not need RCCL to be
-                # fast.  If RCCL cannot come up on this node the run continues over gloo (host-side exchanges, one
-                # stream) and SAYS SO in config.collectives instead of producing no line at all.
-                sys.stderr.write("bench.py: RCCL unavailable on rank %d (%s: %s) -- continuing with gloo\n"
-                                 % (rank, type(e).__name__, e))
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                import datetime
-                backend = "gloo"
-                device = "cpu"
-                os.environ["LSQR_DIST_FALLBACK"] = "%s: %s" % (type(e).__name__, str(e)[:160])
-                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+            backend, device = bring_up_rccl(a, dist, torch, rank, world if world > 1 else 1, device)
         else:
             dist.init_process_group(backend)
             if os.environ.get("LSQR_STEP") == "device":
@@ -1050,7 +1272,7 @@ def main():
         single_plain = a.gpus == 1 and dist is None
         if single_plain and a.workload == "plane" and not a.no_other_configs and a.rates == "both":
             out["other_configs"] = run_legs(a, local)
-        print(json.dumps(out))
+        emit(out, a)
     if dist is not None:
         dist.destroy_process_group()
 

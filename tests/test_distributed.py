@@ -144,3 +144,65 @@ def test_comm_world1_is_identity():
     c = Comm(None)
     assert c.allreduce_max_i64(7) == 7 and c.world == 1
     assert np.array_equal(c.allreduce_sum_f64([1.0, 2.0]), [1.0, 2.0])
+
+
+def _bringup(world, allow, mode):
+    """`world` ranks of tests/dist_bringup.py (bench.bring_up_rccl with no GPU: RCCL cannot come up) -> [(rc, stdout)]"""
+    import subprocess
+    port = str(_free_port())
+    ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_bringup.py"), str(r), str(world), port,
+                            "1" if allow else "0", mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+          for r in range(world)]
+    return [(p.wait(timeout=180), p.communicate()[0]) for p in ps]
+
+
+def test_rccl_verdict_is_collective_and_gloo_is_opt_in():
+    """bench.py --gpus N: a SCALE line can never be a gloo line by accident.  RCCL failing on every rank exits 3 on every
+    rank by default; with --allow-gloo all ranks move to gloo together and say so."""
+    res = _bringup(2, allow=False, mode="all")
+    assert [rc for rc, _ in res] == [3, 3], res
+    res = _bringup(2, allow=True, mode="all")
+    assert [rc for rc, _ in res] == [0, 0], res
+    for _, out in res:
+        assert "RESULT gloo cpu 2" in out and "No HIP GPUs" in out, out
+
+
+def test_rccl_partial_failure_never_splits_the_world():
+    """one rank stuck inside RCCL bring-up while its peer failed: nobody falls back alone -- every rank exits non-zero
+    within the watcher's 20 s, --allow-gloo or not"""
+    import time
+    t0 = time.time()
+    res = _bringup(2, allow=True, mode="some")
+    assert all(rc != 0 for rc, _ in res), res
+    assert not any("RESULT" in out for _, out in res)
+    assert time.time() - t0 < 90
+
+
+def test_bench_headline_fits_the_drivers_tail():
+    """the LAST stdout line of bench.py must stay under 4 KB whatever the run produced (BENCH_r03 was unparsable: one
+    42 KB line); checked here on the committed full record of a real default run"""
+    import json
+    import bench
+    rec = os.path.join(ROOT, "profiles", "r03_bench_plane.json")
+    d = json.load(open(rec))
+    line = bench.headline(d, "bench_detail.json")
+    assert len(line) <= bench.HEADLINE_LIMIT and "\n" not in line
+    h = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_full_count",
+              "value_early_exit"):
+        assert k in h, k
+    assert abs(h["value"] - d["value"]) < 1e-5 * d["value"] and h["config"]["points"] == 10_000_000
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "kernel"):
+        assert k in h["roofline"], k
+    assert len(h["roofline"]["kernel"]) <= 80
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in h["cpu_baseline"], k
+    legs = [json.dumps(bench.leg_line(leg), separators=(",", ":")) for leg in d["other_configs"]]
+    assert all(len(x) < 1200 for x in legs)
+    assert len(line) + sum(len(x) + 1 for x in legs) < 8000      # the whole stdout fits the driver's 8 KB tail
+    # a pathological record (huge strings everywhere) still yields a line under the limit
+    d["config"]["workload"] = "x" * 5000
+    d["cpu_baseline"]["sample"] = "y" * 5000
+    d["roofline"]["kernel"] = "z" * 5000
+    assert len(bench.headline(d, "bench_detail.json")) <= bench.HEADLINE_LIMIT

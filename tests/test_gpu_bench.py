@@ -7,6 +7,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -16,17 +17,48 @@ LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"
                 "TORCHELASTIC_RUN_ID")
 
 
-def _run(args, env=None, extra=("--no-cpu-baseline", "--no-end-to-end", "--no-other-configs")):
+def _run(args, env=None, extra=("--no-cpu-baseline", "--no-end-to-end", "--no-other-configs"), rc=0, points="200000"):
+    """-> the FULL record (the --detail file), after checking the stdout contract: the LAST line is the compact
+    headline (< 4 KB, the driver parses it), any earlier JSON lines are the short per-leg lines, the whole stdout fits
+    the driver's 8 KB tail, and the headline's numbers are the detail's"""
     e = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
     if env:
         e.update(env)
-    r = subprocess.run([sys.executable, "bench.py", "--points", "200000", "--steps", "6", "--warmup", "2",
-                        "--repeats", "2"] + list(extra) + args, cwd=ROOT, env=e, capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable, "bench.py", "--points", points, "--steps", "6", "--warmup", "2",
+                            "--repeats", "2", "--detail", detail] + list(extra) + args, cwd=ROOT, env=e,
+                           capture_output=True, text=True, timeout=900)
+        if rc:
+            assert r.returncode != 0, (r.returncode, r.stderr[-3000:])     # (torchrun maps a rank's exit 3 to 1)
+            assert "RCCL did not come up" in r.stderr, r.stderr[-3000:]
+            assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+            return r
+        assert r.returncode == 0, r.stderr[-3000:]
+        j = json.load(open(detail))
+    lines = r.stdout.strip().splitlines()
+    assert all(ln.startswith("{") for ln in lines), r.stdout[-2000:]
+    assert len(r.stdout) < 8000                                    # the driver keeps an 8 KB tail
+    assert len(lines[-1]) < 4096 and lines[-1].startswith('{"metric"')
+    assert all(ln.startswith('{"leg"') for ln in lines[:-1])
+    h = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in h, k
+    for k in ("value", "ms_per_step", "value_full_count", "value_early_exit"):
+        if j.get(k) is not None:
+            assert abs(h[k] - j[k]) <= 1e-5 * abs(j[k]), k
+    assert h["n_gpus"] == j["n_gpus"] and h["steps"] == j["steps"] and h["config"]["points"] == j["config"]["points"]
+    if j.get("roofline"):
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "kernel"):
+            assert k in h["roofline"], k
+        assert len(h["roofline"]["kernel"]) <= 80 and abs(h["roofline"]["frac"] - j["roofline"]["frac"]) < 1e-5
+        if j.get("single_stream"):
+            # the per-kernel figures come from the one-stream pass, whose own rate is in the line beside them: the
+            # dominant kernel's duration cannot exceed that pass's time per step
+            assert h["roofline"]["launch_ms"] <= h["one_stream"]["ms_per_step"] * 1.001
+    j["_headline"], j["_legs"] = h, [json.loads(ln) for ln in lines[:-1]]
+    return j
 
 
 def _check(j, streams, n_gpus=1):
@@ -116,12 +148,15 @@ def test_bench_gpus_2_launches_its_own_ranks():
         assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
 
 
-def test_bench_falls_back_to_gloo_when_rccl_cannot_come_up():
-    """two ranks on ONE device with the default (nccl) backend: RCCL refuses the duplicate device on every rank, and
-    the run has to go on over gloo and say so in config.collectives -- a line, not a crash"""
-    j = _run(["--workload", "plane", "--gpus", "2", "--streams", "1"], env={"LSQR_SHARE_GPU": "1"})
+def test_bench_gloo_fallback_is_opt_in():
+    """two ranks on ONE device with the default (nccl) backend: RCCL refuses the duplicate device on every rank.
+    Default: NO line, exit non-zero (a scaling record can never be a gloo line by accident).  --allow-gloo: every rank
+    moves to gloo together and the line says so in config.collectives."""
+    _run(["--workload", "plane", "--gpus", "2", "--streams", "1"], env={"LSQR_SHARE_GPU": "1"}, rc=3)
+    j = _run(["--workload", "plane", "--gpus", "2", "--streams", "1", "--allow-gloo"], env={"LSQR_SHARE_GPU": "1"})
     _check(j, 1, n_gpus=2)
     assert j["config"]["world_size"] == 2 and "FALLBACK" in j["config"]["collectives"], j["config"]["collectives"]
+    assert "FALLBACK" in j["_headline"]["config"]["collectives"]
     assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
 
 
@@ -145,6 +180,10 @@ def test_bench_default_run_carries_the_other_configs():
         for k in ("lm_info", "lm_nfev", "params_empty"):
             assert k in leg["final_fit"]
     assert legs[2]["final_fit"]["lm_nfev"] > 0 and legs[2]["lm"]["evaluations_per_s"] > 0
+    assert len(j["_legs"]) == 4 and [leg["value"] > 0 for leg in j["_legs"]]
+    assert len(j["_headline"]["other_configs"]) == 4
+    hb = j["_headline"]["cpu_baseline"]
+    assert hb["cores"] == 1 and hb["kind"] in ("reference", "port") and hb["full_count"]["value"] > 0
     cb = j["cpu_baseline"]
     assert cb["full_count"]["value"] > 0 and "full agree" in cb["unit_note"]
     assert abs(j["speedup_vs_cpu_baseline"] - j["value_full_count"] / cb["full_count"]["value"]) < 1e-6 * j["speedup_vs_cpu_baseline"]
