@@ -396,6 +396,7 @@ __global__ __launch_bounds__(1024) void k_pick_cands(const uint32_t *__restrict_
                                                      uint32_t *__restrict__ lo) {
   __shared__ uint32_t s_red[16], s_scan[1024];
   const int t = threadIdx.x;
+  if (H > kSelCap) return;  // 1024 threads x 8 hypotheses (models.h)
   for (uint32_t h = t; h < H; h += 1024) votes[h] = 0, ub2[h] = 0, lb2[h] = 0, lo[h] = 0;  // (uncounted hypotheses report 0)
   uint32_t mx = 0;
   for (uint32_t h = t; h < H; h += 1024) mx = valid[h] && ub[h] > mx ? ub[h] : mx;

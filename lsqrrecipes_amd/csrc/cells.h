@@ -982,6 +982,7 @@ __global__ __launch_bounds__(1024) void k_pick_pilots(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ lo, int no_pilots) {
   __shared__ uint32_t s_red[16], s_redl[16], s_scan[1024];
   const int t = threadIdx.x;
+  if (H > kSelCap) return;  // 1024 threads x 8 hypotheses (models.h)
   for (uint32_t h = t; h < H; h += 1024) votes[h] = 0;  // a hypothesis that is not counted reports 0 votes
   uint32_t mx = 0, ml = 0;
   for (uint32_t h = t; h < H; h += 1024) {
@@ -1043,6 +1044,7 @@ __global__ __launch_bounds__(1024) void k_pick_rest(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ lo) {
   __shared__ uint32_t s_pi[kPilots], s_pm[kPilots], s_scan[1024];
   const int t = threadIdx.x;
+  if (H > kSelCap) return;
   const uint32_t np = st->n_pilot;
   // lo (nullable): lower vote bounds per hypothesis; lob[k] = max of lo over the hypotheses before t * 8 + k
   uint32_t lob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1502,8 +1504,10 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(PP >= 8 ? 4 
 template <int SPD>
 __global__ __launch_bounds__(1024) void k_plane_order(const double *__restrict__ sp, uint32_t H, double xabs,
                                                       uint32_t *__restrict__ perm, uint32_t *__restrict__ count) {
-  __shared__ unsigned long long s_k[4096];
+  __shared__ unsigned long long s_k[kOrderCap];
+  static_assert(kOrderCap == 4096, "the key loop and the bitonic network below are written for 4096 slots");
   const int t = threadIdx.x;
+  if (H > kOrderCap) return;
   const double inv = 1.0 / (1.7320508075688774 * (xabs > 0.0 ? xabs : 1.0));
   for (uint32_t h = t; h < 4096; h += 1024) {
     unsigned long long key = ~0ull;  // past the batch: sorts to the end

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(1024) void k_ee_split(const uint32_t *__restrict__ 
                                                    EeState *__restrict__ st, uint32_t b1, uint32_t n) {
   __shared__ uint32_t s_red[16], s_scan[1024];
   const int t = threadIdx.x;
+  if (H > kSelCap) return;  // 1024 threads x 8 hypotheses (models.h)
   uint32_t mx = 0;
   for (uint32_t h = t; h < H; h += 1024) mx = valid[h] && votes[h] > mx ? votes[h] : mx;
   for (int o = 32; o > 0; o >>= 1) {
@@ -169,11 +170,12 @@ __global__ __launch_bounds__(1024) void k_ee_select(const uint32_t *__restrict__
                                                     uint32_t H, uint32_t n, int k, uint32_t best_before,
                                                     const uint32_t *__restrict__ sel_in, uint32_t *__restrict__ sel_out,
                                                     EeState *__restrict__ st) {
-  __shared__ uint32_t s_scan[1024], s_alive[256];  // alive bitmap of up to 8192 hypotheses
+  __shared__ uint32_t s_scan[1024], s_alive[kSelCap / 32];  // alive bitmap of up to kSelCap hypotheses
   const int t = threadIdx.x;
+  if (H > kSelCap) return;
   const uint32_t n_in = st->n_alive;
   const uint32_t R = n - st->rng[k][1];
-  if (t < 256) s_alive[t] = 0;
+  if (t < (int)(kSelCap / 32)) s_alive[t] = 0;
   __syncthreads();
   for (uint32_t j = t; j < n_in; j += 1024) {
     const uint32_t h = sel_in[j];

@@ -60,8 +60,25 @@ struct lsqr_ctx {
   CellBox *d_boxes = nullptr;   // [n_cells cell boxes | merged boxes of the bounds pass (k_super_boxes)]
   size_t sorted_cap = 0, boxes_cap = 0;  // doubles / boxes allocated
   uint32_t super_merge = 0;     // cells per merged box the second part currently holds (0: not built)
-  BoundSel *h_bsel = nullptr;   // pinned: selection counts of the last bounded scans (read without synchronising)
-  uint32_t h_bsel_H = 0;        // batch size those counts belong to
+  // Selection counts of the bounded scans come back through pinned memory and steer the NEXT batches' launch sequence
+  // (merged boxes or cells; pilot pass or not).  Two records, written alternately; a record is folded into
+  // `bsel_known` only at a point where the host HAS synchronised with the batch that wrote it -- a ..._wait of its
+  // slot, the end of a blocking entry point, or right before the record is reused (two bounded scans later) -- so the
+  // launch sequence of a batch follows from the call sequence, never from host / device timing.
+  BoundSel *h_bsel = nullptr;   // pinned [2], 64 B apart
+  hipEvent_t bsel_ev[2] = {nullptr, nullptr};
+  bool bsel_pending[2] = {false, false};
+  uint64_t bsel_seq_of[2] = {0, 0};
+  uint32_t bsel_H_of[2] = {0, 0};
+  uint64_t bsel_seq = 0;        // bounded scans issued on this context
+  int bsel_last_rec = -1;       // record the last bounded scan writes
+  BoundSel bsel_known{};        // counts of the latest bounded scan the host has synchronised with ...
+  uint32_t bsel_known_H = 0;    // ... its batch size (0: nothing known on this upload / model) ...
+  uint64_t bsel_known_seq = 0;  // ... and its sequence number
+  int slot_bsel_rec[2] = {-1, -1};   // lsqr_batch_fit_enqueue: the record of the slot's scan
+  uint64_t slot_bsel_seq[2] = {0, 0};
+  int step_bsel_rec[2] = {-1, -1};   // lsqr_step_finish_enqueue: the record of the step's scan (lsqr_step_scan)
+  uint64_t step_bsel_seq[2] = {0, 0};
   bool merge_off = false;       // this upload: merged boxes let too many hypotheses through, bounds stay on the cells
   int opt_bound_merge = 0;      // 0: the cell model's default, 1: bounds on the cells themselves, 2 / 4 / 8
   size_t n_sorted = 0;      // finite records (non-finite ones never agree and are left out)
@@ -109,7 +126,7 @@ struct lsqr_ctx {
   uint64_t last_bound[4] = {0, 0, 0, 0};  // diagnostics of the last bounded scan: {used, pilots, rest, H}
   // chunked early exit of the dense / US scans (earlyexit.h)
   void *d_ee = nullptr;             // [EeState | sel_c | sel_o x 2 | compact thresholds | compact fp32 rows]
-  EeState *h_ee = nullptr;          // pinned copy of the last early-exit scan's state (read without synchronising)
+  EeState *h_ee = nullptr;          // pinned copy of the last early-exit scan's state (diagnostics: read after a synchronisation, lsqr_scan_work)
   bool ee_last = false;             // the last scan of this context took the early-exit path
   uint64_t ee_H = 0, ee_n = 0;      // its batch size and observation count
   bool scanned = false;
@@ -407,6 +424,45 @@ int grid_for(size_t items, int per_block, int max_blocks) {
 template <int D>
 int run_bounds(lsqr_ctx *c);
 
+// ---- selection feedback of the bounded scan (see lsqr_ctx::h_bsel) ----------------------------------------------
+static BoundSel *bsel_rec(lsqr_ctx *c, int r) { return (BoundSel *)((char *)c->h_bsel + 64 * r); }
+// the host has synchronised with the batch that wrote record r
+static void bsel_fold(lsqr_ctx *c, int r) {
+  if (r < 0 || !c->h_bsel || !c->bsel_pending[r]) return;
+  c->bsel_pending[r] = false;
+  if (c->bsel_known_H && c->bsel_seq_of[r] < c->bsel_known_seq) return;  // an older batch than the one known
+  c->bsel_known = *bsel_rec(c, r);
+  c->bsel_known_H = c->bsel_H_of[r];
+  c->bsel_known_seq = c->bsel_seq_of[r];
+}
+// the host has synchronised with everything enqueued on the context's stream
+static void bsel_host_synced(lsqr_ctx *c) {
+  if (!c->h_bsel) return;
+  const int first = c->bsel_seq_of[0] <= c->bsel_seq_of[1] ? 0 : 1;
+  bsel_fold(c, first);
+  bsel_fold(c, first ^ 1);
+}
+// new records / new model: nothing is known; copies still in flight are waited for, not abandoned
+static void bsel_reset(lsqr_ctx *c) {
+  for (int r = 0; r < 2; r++)
+    if (c->bsel_pending[r] && c->bsel_ev[r]) {
+      (void)hipEventSynchronize(c->bsel_ev[r]);
+      c->bsel_pending[r] = false;
+    }
+  c->bsel_known = BoundSel{};
+  c->bsel_known_H = 0;
+  c->slot_bsel_rec[0] = c->slot_bsel_rec[1] = -1;
+  c->step_bsel_rec[0] = c->step_bsel_rec[1] = -1;
+  c->bsel_last_rec = -1;
+}
+
+// the host waits for everything enqueued on the context's stream: also the point where the selection feedback folds
+static hipError_t sync_stream(lsqr_ctx *c) {
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) bsel_host_synced(c);
+  return e;
+}
+
 int ensure_absmax(lsqr_ctx *c) {
   if (c->absmax_valid) return LSQR_OK;
   const int m = c->cfg.model;
@@ -437,7 +493,7 @@ int ensure_absmax(lsqr_ctx *c) {
   }
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 5, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   memcpy(&c->mc.absmax, c->h_pin, sizeof(double));
   memcpy(&c->mc.absmax_rot, (char *)c->h_pin + 8, sizeof(double));
   c->absmax_valid = true;
@@ -595,7 +651,7 @@ int run_bounds(lsqr_ctx *c) {
   hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, c->stream, rows, nb, rows + 1024);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_pin, rows + 1024, sizeof(BoundsRow), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   memcpy(&c->h_bounds, c->h_pin, sizeof(BoundsRow));
   c->bounds_valid = true;
   return LSQR_OK;
@@ -802,13 +858,13 @@ int run_cells_bounds(lsqr_ctx *c, uint32_t *d_ub, uint32_t *d_nc = nullptr) {
   // points in 147 boxes: 261 of 2048 hypotheses skipped instead of 1800)
   // ... and as long as the looser bound still prunes: a random plane cuts ~13 % of the cells but ~25 % of the merged
   // boxes, and with few inliers (80 % outliers and up) that population exceeds the best model's votes -- every
-  // hypothesis would be counted.  The selection counts of earlier batches come back through pinned memory (no
-  // synchronisation; a stale value only delays the switch): once a second pass held more than a third of its batch,
-  // the bounds of this upload stay on the cells.
+  // hypothesis would be counted.  The selection counts of earlier batches come back through pinned memory
+  // (bsel_known: the latest batch the host has synchronised with; an older value only delays the switch): once a
+  // second pass held more than a third of its batch, the bounds of this upload stay on the cells.
   uint32_t merge = c->opt_bound_merge ? (uint32_t)c->opt_bound_merge : (uint32_t)CM::BOUND_MERGE;
   if (!c->opt_bound_merge) {
     while (merge > 1 && c->n_cells / merge < 4096) merge /= 2;
-    if (c->h_bsel && c->h_bsel_H && (uint64_t)c->h_bsel->n_rest * 3 > c->h_bsel_H) c->merge_off = true;
+    if (c->bsel_known_H && (uint64_t)c->bsel_known.n_rest * 3 > c->bsel_known_H) c->merge_off = true;
     if (c->merge_off) merge = 1;
   }
   if (d_nc || merge < 2 || c->n_cells < 4 * merge) merge = 1;
@@ -963,6 +1019,18 @@ int run_scan_bounded(lsqr_ctx *c) {
     ~Mute() { c->prof = was; }
   } mute{c, c->prof};
   c->prof = false;
+  // the record this scan will write: whatever it still holds (the scan two back) has to have landed before it is
+  // reused, and is folded here at the latest
+  if (!c->h_bsel) {
+    HIPCHK(c, hipHostMalloc((void **)&c->h_bsel, 128));
+    memset(c->h_bsel, 0, 128);
+    for (int r = 0; r < 2; r++) HIPCHK(c, hipEventCreateWithFlags(&c->bsel_ev[r], hipEventDisableTiming));
+  }
+  const int rec = (int)(c->bsel_seq & 1);
+  if (c->bsel_pending[rec]) {
+    HIPCHK(c, hipEventSynchronize(c->bsel_ev[rec]));
+    bsel_fold(c, rec);
+  }
   int st = run_cells_bounds<CM, PP>(c, c->d_ub);
   if (st != LSQR_OK) return st;
   const uint32_t H = (uint32_t)c->H;
@@ -977,10 +1045,11 @@ int run_scan_bounded(lsqr_ctx *c) {
   }
   // The pilot pass is five launches that find nothing to do when a lower bound of the running maximum is known
   // without pilots (rank bounds, or the best of earlier batches).  Whether it was is reported back through pinned
-  // memory (h_bsel, possibly a batch late): after a batch of this upload that needed no pilots the pass is not
-  // launched -- k_pick_pilots then selects none; if that batch would have needed them after all, its second pass
-  // counts more hypotheses (never wrongly: L[h] is a lower bound either way) and the next batch gets its pilots back.
-  const bool no_pilots = c->h_bsel && c->h_bsel_H == H && c->h_bsel->known != 0;
+  // memory (bsel_known: the latest batch the host has synchronised with -- one or two batches back): after a batch of
+  // this upload and model that needed no pilots the pass is not launched -- k_pick_pilots then selects none; if that
+  // batch would have needed them after all, its second pass counts more hypotheses (never wrongly: L[h] is a lower
+  // bound either way) and a later batch gets its pilots back.
+  const bool no_pilots = c->bsel_known_H == H && c->bsel_known.known != 0;
   hipLaunchKernelGGL(k_pick_pilots, dim3(1), dim3(1024), 0, c->stream, c->d_ub, c->d_valid, H, sel_a, c->d_bsel,
                      c->d_votes, c->best_before, lo, no_pilots ? 1 : 0);  // (also zeroes the batch's votes)
   if (!no_pilots) {
@@ -1004,17 +1073,18 @@ int run_scan_bounded(lsqr_ctx *c) {
   HIPCHK(c, hipGetLastError());
   c->last_bound[0] = 1;
   c->last_bound[3] = H;
-  if (!c->h_bsel) {
-    HIPCHK(c, hipHostMalloc((void **)&c->h_bsel, 64));
-    memset(c->h_bsel, 0, 64);
-  }
-  HIPCHK(c, hipMemcpyAsync(c->h_bsel, c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
-  c->h_bsel_H = H;
+  HIPCHK(c, hipMemcpyAsync(bsel_rec(c, rec), c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->bsel_ev[rec], c->stream));
+  c->bsel_pending[rec] = true;
+  c->bsel_seq_of[rec] = ++c->bsel_seq;
+  c->bsel_H_of[rec] = H;
+  c->bsel_last_rec = rec;
   return LSQR_OK;
 }
 
 // ---- chunked early exit (earlyexit.h) ---------------------------------------------------------------------
-constexpr size_t kEeCap = 8192;  // hypotheses per batch the selection kernels handle
+constexpr size_t kEeCap = kSelCap;  // hypotheses per batch the selection kernels handle (models.h)
+static_assert(kEeCap <= kSelCap && kScanChunk <= kSelCap, "selection kernels: 1024 threads x 8 hypotheses");
 struct EeBuf {
   EeState *st;
   uint32_t *sel_c, *sel_o[2];
@@ -1136,7 +1206,7 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
   };
   if ((st = run_early_exit(c, 64, b, scan, gather)) != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   c->dense_amb_max = *(unsigned int *)c->h_pin;
   if (c->dense_amb_max <= seg_cap) {
     *done = true;
@@ -1266,7 +1336,7 @@ int run_scan(lsqr_ctx *c) {
               }
               HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                        c->stream));
-              HIPCHK(c, hipStreamSynchronize(c->stream));
+              HIPCHK(c, sync_stream(c));
               c->dense_amb_max = *(unsigned int *)c->h_pin;
               if (c->dense_amb_max <= seg_cap) return LSQR_OK;
               (void)fail(c, LSQR_OK, "dense fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used",
@@ -1311,7 +1381,7 @@ int run_scan(lsqr_ctx *c) {
           // worklist overflow (never seen: ~1e-13 of the pairs are ambiguous) -> exact kernel
           HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
+          HIPCHK(c, sync_stream(c));
           if (*(unsigned int *)c->h_pin <= kAmbCap) return LSQR_OK;
         }
       }
@@ -1390,7 +1460,7 @@ int run_scan(lsqr_ctx *c) {
             c->last_bound[0] = 0;
             // batch entry points: hypotheses that cannot become the running maximum are not counted (the extra
             // launches only pay for batches of >= 1024; the selection kernels handle <= 8192)
-            if (CM::USE_BOUND && c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= 8192 && c->n_cells > 0) {
+            if (CM::USE_BOUND && c->allow_bound && c->opt_bound && c->H >= 1024 && c->H <= kSelCap && c->n_cells > 0) {
               return with_pp<CM>(cell_pts, [&](auto pp) { return run_scan_bounded<CM, decltype(pp)::value>(c); });
             }
             // plain scans of a large batch: the statically balanced kernel where it measured faster (plane, 10 M x
@@ -1401,7 +1471,7 @@ int run_scan(lsqr_ctx *c) {
             if (c->opt_pairs == 1 || full_pairs) {
               if constexpr (std::is_same<CM, PlaneCell<3>>::value) {
                 // the batch in key order (cells.h: k_plane_order): similar planes share a 64-group
-                if (c->opt_hyp_order && c->H >= 1024 && c->H <= 4096) {
+                if (c->opt_hyp_order && c->H >= 1024 && c->H <= kOrderCap) {
                   const uint32_t H = (uint32_t)c->H;
                   uint32_t *perm = c->d_sel + kPilots, *cnt = (uint32_t *)(c->d_counter + 7);
                   double *sp_b = c->d_hparams2 + (size_t)kPilots * M::SP;
@@ -1607,7 +1677,7 @@ int launch_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phas
 int read_out(lsqr_ctx *c, SolveOut *o) {
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_out, sizeof(SolveOut), hipMemcpyDeviceToHost,
                            c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   memcpy(o, c->h_pin, sizeof(SolveOut));
   return LSQR_OK;
 }
@@ -1686,7 +1756,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
       if ((st = launch_moments_phantom(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
       HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToHost,
                                c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, sync_stream(c));
       phantom_solve_block(c->cfg, (const double *)c->h_pin, out);
       return LSQR_OK;
     } else if constexpr (M::IS_DENSE) {
@@ -1751,7 +1821,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, d_cnt, cb, d_off);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(pin + 200, d_off + cb, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c));
             cnt = *(const uint32_t *)(pin + 200);
             int st2 = ensure(c, &c->d_lmrec, &c->lmrec_cap, std::max<size_t>(cnt, 1) * M::ND);
             if (st2 != LSQR_OK) return st2;
@@ -1841,7 +1911,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             }
             if (!lm_advance(s, blk)) break;
           }
-          HIPCHK(c, hipStreamSynchronize(c->stream));
+          HIPCHK(c, sync_stream(c));
         } else
         for (;;) {
           for (int j = 0; j < n; j++) pin[j] = s.xtrial[j];
@@ -1850,7 +1920,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           if ((st = launch_moments<M>(c, use_mask, 0, c->n, 1, &nmom)) != LSQR_OK) return st;
           HIPCHK(c, hipMemcpyAsync(pin + 64, c->d_mom, sizeof(double) * nmom,
                                    hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
+          HIPCHK(c, sync_stream(c));
           if (!lm_advance(s, pin + 64)) break;
         }
         bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
@@ -1931,7 +2001,7 @@ int run_mask(lsqr_ctx *c, size_t begin, size_t end, uint8_t *mask_out, uint64_t 
   if (mask_out)
     HIPCHK(c, hipMemcpyAsync(mask_out, c->d_mask + begin, end - begin, hipMemcpyDeviceToHost,
                              c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   if (count_out) *count_out = *(unsigned long long *)c->h_pin;
   return LSQR_OK;
 }
@@ -2236,6 +2306,8 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_bsel) (void)hipHostFree(c->h_bsel);
+  for (int r = 0; r < 2; r++)
+    if (c->bsel_ev[r]) (void)hipEventDestroy(c->bsel_ev[r]);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_lmres) (void)hipHostFree(c->h_lmres);
   if (c->h_batch) (void)hipHostFree(c->h_batch);
@@ -2260,7 +2332,7 @@ const char *lsqr_last_error(const lsqr_ctx *c) { return c ? c->err : "null conte
 
 int lsqr_synchronize(lsqr_ctx *c) {
   if (!c) return LSQR_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   for (int i = 1; i < lsqr_ctx::kMaxLanes; i++)
     if (c->lanes[i]) HIPCHK(c, hipStreamSynchronize(c->lanes[i]->stream));
   return LSQR_OK;
@@ -2354,6 +2426,8 @@ int lsqr_set_model(lsqr_ctx *c, const lsqr_model_cfg *cfg) {
   c->scanned = false;
   c->mask_valid = false;
   c->origin_valid = false;
+  c->merge_off = false;   // selection feedback belongs to one model (threshold included) on one upload
+  bsel_reset(c);
   return LSQR_OK;
 }
 
@@ -2366,7 +2440,7 @@ static int set_data_common(lsqr_ctx *c, size_t count, size_t stride_bytes) {
   lanes_quiesce(c);  // lanes read the records this call is about to replace
   c->data_epoch++;
   c->merge_off = false;
-  c->h_bsel_H = 0;
+  bsel_reset(c);
   c->n = count;
   c->absmax_valid = false;
   c->bounds_valid = false;
@@ -2458,7 +2532,7 @@ int lsqr_upload(lsqr_ctx *c, const void *host, size_t count, size_t stride_bytes
   } else if (count) {
     HIPCHK(c, hipMemcpyAsync(c->d_data_owned, host, bytes, hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   c->last_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   c->d_data = c->d_data_owned;
   return LSQR_OK;
@@ -2486,7 +2560,7 @@ int lsqr_hypotheses_from_subsets(lsqr_ctx *c, const uint32_t *subsets, size_t H)
   c->scanned = false;
   HIPCHK(c, hipMemcpyAsync(c->d_subsets, subsets, H * c->K * sizeof(uint32_t),
                            hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may free `subsets` on return
+  HIPCHK(c, sync_stream(c));  // caller may free `subsets` on return
   return run_estimate(c);
 }
 
@@ -2514,7 +2588,7 @@ int lsqr_hypotheses_sample(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
   if (subsets_out) {
     HIPCHK(c, hipMemcpyAsync(subsets_out, c->d_subsets, H * c->K * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c));
   }
   return LSQR_OK;
 }
@@ -2551,7 +2625,7 @@ int lsqr_get_hypotheses(lsqr_ctx *c, double *params, uint8_t *valid, uint32_t *v
   if (votes)
     HIPCHK(c, hipMemcpyAsync(votes, c->d_votes, c->H * sizeof(uint32_t), hipMemcpyDeviceToHost,
                              c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   return LSQR_OK;
 }
 
@@ -2563,7 +2637,7 @@ int lsqr_get_hypothesis(lsqr_ctx *c, size_t h, double *params, uint8_t *valid) {
   HIPCHK(c, hipMemcpyAsync(hp, c->d_hparams + h * c->HS, sizeof(double) * c->P,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(hp + 64, c->d_valid + h, 1, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   if (params) memcpy(params, hp, sizeof(double) * c->P);
   if (valid) *valid = *(uint8_t *)(hp + 64);
   return LSQR_OK;
@@ -2578,7 +2652,7 @@ int lsqr_best(lsqr_ctx *c, uint64_t *packed) {
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 1, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   *packed = *(unsigned long long *)c->h_pin;
   return LSQR_OK;
 }
@@ -2592,7 +2666,7 @@ int lsqr_mask(lsqr_ctx *c, const double *params, size_t begin, size_t end, uint8
   HIPCHK(c, hipMemsetAsync(c->d_par, 0, sizeof(double) * 128, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_par, params, sizeof(double) * c->P, hipMemcpyHostToDevice,
                            c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   return run_mask(c, begin, end, mask_out, count_out);
 }
 
@@ -2611,7 +2685,7 @@ int lsqr_set_mask(lsqr_ctx *c, const uint8_t *mask) {
   if (!mask) return fail(c, LSQR_ERR_INVALID, "null mask");
   if ((st = ensure(c, &c->d_mask, &c->mask_cap, c->n)) != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(c->d_mask, mask, c->n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   c->mask_valid = true;
   c->origin_valid = false;
   return LSQR_OK;
@@ -2678,7 +2752,7 @@ int lsqr_moments(lsqr_ctx *c, int use_mask, size_t begin, size_t end, int phase,
   if (st != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(block_out, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToHost,
                            c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   return LSQR_OK;
 }
 
@@ -2783,7 +2857,7 @@ int lsqr_lm_begin(lsqr_ctx *c, const double *x0, double *x_trial_out) {
   hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out, n, ftol, xtol,
                      gtol, maxfev, 100.0);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   if (x_trial_out)
     for (int j = 0; j < n; j++) x_trial_out[j] = x0[j];
   return LSQR_OK;
@@ -2863,7 +2937,7 @@ int lsqr_lm_step(lsqr_ctx *c, const double *block, double *x_trial_out, int *con
     if (x_trial_out) {
       HIPCHK(c, hipMemcpyAsync(c->h_pin, (const char *)c->d_lm + offsetof(LmState, xtrial),
                                sizeof(double) * LM_NMAX, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, sync_stream(c));
       memcpy(x_trial_out, c->h_pin, sizeof(double) * c->P);
     }
     return LSQR_OK;
@@ -2901,7 +2975,7 @@ int lsqr_stats(lsqr_ctx *c, const double *params, int use_mask, double out[4]) {
   std::vector<double> part((size_t)nb * 8);
   HIPCHK(c, hipMemcpyAsync(part.data(), c->d_partials, part.size() * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   double mn = INFINITY, mx = -INFINITY, sum = 0, sq = 0, cnt = 0;
   for (int b = 0; b < nb; b++) {  // fixed order
     mn = std::min(mn, part[b * 8 + 0]);
@@ -2939,7 +3013,7 @@ int lsqr_residuals(lsqr_ctx *c, const double *params, size_t begin, size_t end, 
   if (st != LSQR_OK) return st;
   HIPCHK(c, hipMemcpyAsync(out, c->d_rows, sizeof(double) * (end - begin), hipMemcpyDeviceToHost,
                            c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   return LSQR_OK;
 }
 
@@ -3279,7 +3353,7 @@ int lsqr_winner_moments(lsqr_ctx *c, uint64_t seed, uint64_t stream_index, size_
                            c->stream));
   HIPCHK(c, hipMemcpyAsync(block_out, c->d_mom, sizeof(double) * nmom, hipMemcpyDeviceToHost,
                            c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   if (*(const uint8_t *)pin == 0) return LSQR_EMPTY;  // degenerate subset: not a possible winner
   if (count_out) memcpy(count_out, pin + 1, sizeof(uint64_t));
   if (params_out) memcpy(params_out, pin + 2, sizeof(double) * c->P);
@@ -3315,7 +3389,7 @@ static int lane_get(lsqr_ctx *c, int li, lsqr_ctx **out) {
       st = lsqr_set_option(l, c->opt_log[k].first.c_str(), c->opt_log[k].second);
     if (st == LSQR_OK) st = lsqr_attach(l, c->d_data, c->n, c->stride * sizeof(double));
     if (st != LSQR_OK) return fail(c, st, "lane %d: %s", li, lsqr_last_error(l));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // an upload still in flight on the parent's stream
+    HIPCHK(c, sync_stream(c));  // an upload still in flight on the parent's stream
     l->lane_epoch = c->data_epoch;
   }
   *out = l;
@@ -3344,7 +3418,10 @@ int lsqr_batch_fit_enqueue(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
     return fail(c, LSQR_ERR_INVALID, "this model's fit needs the host between device passes");
   int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
   if (st != LSQR_OK) return st;
+  const uint64_t seq_before = c->bsel_seq;
   if ((st = run_scan_batch(c, 0)) != LSQR_OK) return st;
+  c->slot_bsel_rec[slot] = c->bsel_seq != seq_before ? c->bsel_last_rec : -1;  // this batch's selection record
+  c->slot_bsel_seq[slot] = c->bsel_seq;
   c->scanned = true;
   hipLaunchKernelGGL(k_best, dim3(1), dim3(kBlock), 0, c->stream, c->d_votes, c->d_valid,
                      (uint32_t)c->H, c->d_counter + 1, 0u);
@@ -3389,6 +3466,9 @@ int lsqr_batch_fit_wait(lsqr_ctx *c, int slot, double *params_out, lsqr_ransac_i
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventSynchronize(c->slot_ev[slot]));
   c->slot_busy[slot] = false;
+  if (c->slot_bsel_rec[slot] >= 0 && c->bsel_seq_of[c->slot_bsel_rec[slot]] == c->slot_bsel_seq[slot])
+    bsel_fold(c, c->slot_bsel_rec[slot]);  // the host has synchronised with this batch: its selection counts count
+  c->slot_bsel_rec[slot] = -1;
   const char *pin = slot_pin(c, slot);
   unsigned long long head[2];
   SolveOut out;
@@ -3417,7 +3497,7 @@ int lsqr_batch_fit_wait(lsqr_ctx *c, int slot, double *params_out, lsqr_ransac_i
 int lsqr_set_stream(lsqr_ctx *c, void *hip_stream, int external) {
   if (!c) return LSQR_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of ours may still be in flight on the old stream
+  HIPCHK(c, sync_stream(c));  // nothing of ours may still be in flight on the old stream
   // profiling events recorded on the old stream stay valid (events are not bound to a stream)
   // external: the caller's stream as given -- NULL is the (legacy) default stream, which torch uses unless
   // told otherwise
@@ -3516,6 +3596,8 @@ int lsqr_step_finish_enqueue(lsqr_ctx *c, const uint64_t *packed_dev, const doub
   }
   if (!c->step_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->step_ev[slot], hipEventDisableTiming));
   HIPCHK(c, hipEventRecord(c->step_ev[slot], c->stream));
+  c->step_bsel_rec[slot] = c->bsel_last_rec;   // the step's scan (lsqr_step_scan) came before on this stream
+  c->step_bsel_seq[slot] = c->bsel_last_rec >= 0 ? c->bsel_seq_of[c->bsel_last_rec] : 0;
   c->step_busy[slot] = true;
   return LSQR_OK;
 }
@@ -3527,6 +3609,9 @@ int lsqr_step_finish_wait(lsqr_ctx *c, int slot, double *winner_out, double *par
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventSynchronize(c->step_ev[slot]));  // the one synchronisation of the step
   c->step_busy[slot] = false;
+  if (c->step_bsel_rec[slot] >= 0 && c->bsel_seq_of[c->step_bsel_rec[slot]] == c->step_bsel_seq[slot])
+    bsel_fold(c, c->step_bsel_rec[slot]);
+  c->step_bsel_rec[slot] = -1;
   const char *pin = step_pin(c, slot);
   unsigned long long pk;
   double count;
@@ -4117,7 +4202,7 @@ int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[8]) {
   uint32_t h_sel[2] = {0, 0};
   if (bounded) {  // the selection of the bounded scan that just ran is still on the device
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_bsel, sizeof(BoundSel), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c));
     memcpy(h_sel, c->h_pin, sizeof h_sel);
   }
   st = dispatch(c->cfg, [&](auto tag) -> int {
@@ -4144,7 +4229,7 @@ int lsqr_scan_workload(lsqr_ctx *c, uint32_t *bound_out, uint64_t out[8]) {
   HIPCHK(c, hipMemcpyAsync(pin + 1, c->d_counter + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   if (bound_out)
     HIPCHK(c, hipMemcpyAsync(bound_out, c->d_ub, c->H * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, sync_stream(c));
   out[0] = pin[0];
   out[1] = (uint64_t)c->n_cells * ((c->H + 63) / 64);
   out[2] = c->n_cells;
@@ -4172,7 +4257,10 @@ int lsqr_agree_host(const lsqr_model_cfg *cfg, const double *params, const void 
     typedef typename decltype(tag)::type M;
     double sp[128];
     for (int j = 0; j < 128; j++) sp[j] = 0.0;
-    for (int j = 0; j < (int)M::P; j++) sp[j] = params[j];
+    // the caller's vector holds lsqr_num_params(cfg) doubles: for the dense model that is cfg.dim, NOT the padded
+    // width M::P of DenseModel<8/16/32/64> (the zero fill above is the padding)
+    const int np = lsqr_num_params(cfg) < (int)M::P ? lsqr_num_params(cfg) : (int)M::P;
+    for (int j = 0; j < np; j++) sp[j] = params[j];
     M::prepare(sp, mc);
     double x[M::REC > 0 ? M::REC : 1];
     M::load((const double *)record, mc, x);
@@ -4211,7 +4299,7 @@ int lsqr_scan_work(lsqr_ctx *c, uint64_t out[6]) {
   if (st != LSQR_OK) return st;
   if (!out) return fail(c, LSQR_ERR_INVALID, "null argument");
   if (c->H == 0 || !c->scanned) return fail(c, LSQR_ERR_STATE, "no scanned batch");
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // the state of the last early-exit scan has landed in h_ee
+  HIPCHK(c, sync_stream(c));  // the state of the last early-exit scan has landed in h_ee
   const uint64_t all = (uint64_t)c->H * (uint64_t)c->n;
   memset(out, 0, 6 * sizeof(uint64_t));
   out[2] = all;
@@ -4223,8 +4311,9 @@ int lsqr_scan_work(lsqr_ctx *c, uint64_t out[6]) {
     out[5] = c->h_ee->n_alive;
   } else {
     out[1] = all;
-    if (c->last_bound[0] && c->last_bound[3] == c->H && c->h_bsel && c->h_bsel_H == c->H)
-      out[3] = c->h_bsel->n_cand;  // bounded plane scan with rank bounds: the hypotheses whose bounds were refined
+    bsel_host_synced(c);
+    if (c->last_bound[0] && c->last_bound[3] == c->H && c->bsel_known_H == c->H)
+      out[3] = c->bsel_known.n_cand;  // bounded plane scan with rank bounds: the hypotheses whose bounds were refined
   }
   return LSQR_OK;
 }

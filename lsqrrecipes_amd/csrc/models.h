@@ -13,6 +13,14 @@
 #include "lm_core.h"
 #include "small_linalg.h"
 
+// The one-workgroup selection kernels (k_pick_* in cells.h / axis.h, k_ee_* in earlyexit.h) give each of their 1024
+// threads 8 consecutive hypotheses and keep an alive bitmap of 256 words: H <= kSelCap.  k_plane_order sorts the batch
+// in LDS: H <= kOrderCap.  The host only launches them inside these limits (static_asserts in lsqr_hip.hip tie
+// kEeCap / kScanChunk to them) and the kernels return at once beyond them, so that a change of one constant cannot
+// turn into an out-of-bounds write.
+constexpr uint32_t kSelCap = 1024 * 8;
+constexpr uint32_t kOrderCap = 4096;
+
 namespace lsqr {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // two observations per packed fp32 op

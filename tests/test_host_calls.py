@@ -84,3 +84,24 @@ def test_host_agree_for_records_with_wide_layouts():
         assert st == L.OK and a == int(O.agree(oc, par, rec[i]))
     st, _ = _estimate(cfg, rec[:4])
     assert st == L.ERR_INVALID
+
+
+@pytest.mark.parametrize("dim", [5, 6, 9, 17, 33, 63])
+def test_host_agree_dense_reads_only_dim_parameters(dim):
+    """the dense model is compiled for padded widths 8/16/32/64; the caller's parameter vector has exactly `dim`
+    entries.  Poison (NaN) right behind them must not be read: 0 * NaN in the padded dot product would turn every
+    agree() into false (heap over-read in lsqr_agree_host)."""
+    rows, x_true, _ = synth.dense(200, dim, 0.2, seed=dim)
+    cfg = L.ModelCfg(L.DENSE, dim, 0.1, 0, 0, 0.0)
+    oc = O.cfg(O.DENSE, dim, 0.1)
+    buf = np.full(dim + 64, np.nan)
+    buf[:dim] = x_true
+    lib = L.load()
+    got, want = [], []
+    for i in range(len(rows)):
+        a = C.c_int(-1)
+        r = np.ascontiguousarray(rows[i])
+        assert lib.lsqr_agree_host(C.byref(cfg), L.ptr(buf), L.ptr(r), C.byref(a)) == L.OK
+        got.append(a.value)
+        want.append(int(O.agree(oc, x_true, rows[i])))
+    assert got == want and 0 < sum(want) < len(want)
