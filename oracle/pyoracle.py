@@ -162,6 +162,28 @@ def scan(c, params, data):
     return int(cnt), mask
 
 
+def scan_many(c, params_rows, valid, data, threads=None):
+    """vote counts of MANY hypotheses over the same records: orc_scan per hypothesis (the serial agree() loop of
+    RANSAC.hxx:94-99 without the exit), dealt to host threads (ctypes releases the GIL; every call is independent).
+    params_rows: (H, >= n_params) array; valid: (H,) -- invalid hypotheses get 0.  -> uint32 (H,)"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    a = as_records(c, data)
+    P = np.ascontiguousarray(params_rows, dtype=np.float64)
+    H = P.shape[0]
+    out = np.zeros(H, dtype=np.uint32)
+    L = lib()
+    threads = threads or max(1, min(32, (os.cpu_count() or 2)))
+
+    def work(k):
+        for h in range(k, H, threads):
+            if valid[h]:
+                out[h] = L.orc_scan(C.byref(c), _d(P[h]), _d(a), a.shape[0], a.shape[1], None)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    return out
+
+
 def ls(c, data, mask=None):
     a = as_records(c, data)
     out = np.zeros(80)

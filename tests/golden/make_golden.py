@@ -9,6 +9,8 @@ Outputs (all data, no reference source text):
                              examples/Data/augmentedMatrixWithOutliers.txt)
   ransac_ref_vectors.npz    inputs + outputs of the REFERENCE RANSAC.hxx (oracle/_ref) on
                             seeded data and seeded rand() streams
+  config1_ref_vectors.npz   BASELINE configs[0] as written (plane, 10 k points, 30 % outliers, p = 0.999) run by the
+                            REFERENCE RANSAC.hxx: subsets drawn, fraction, consensus set, parameters, call counts
   numerics_vectors.npz      NumPy/SciPy results (eigh, svd, lstsq, MINPACK lmder through
                             scipy.optimize.leastsq) on seeded inputs
   us_lm_vectors.npz         SciPy MINPACK on the US calibration at the reference's 1e-15 tolerances, 1 k / 20 k /
@@ -69,6 +71,26 @@ def ransac_vectors():
     out["exh_consensus"] = r["consensus"]
     out["exh_subsets"] = r["subsets"]
     np.savez_compressed(os.path.join(HERE, "ransac_ref_vectors.npz"), **out)
+
+
+def config1_vectors():
+    """BASELINE.json configs[0] as written: PlaneParametersEstimator + RANSAC, 10 k points, 30 % outliers, p = 0.999,
+    run by the REFERENCE's RANSAC.hxx (oracle/_ref).  The records are synth.plane(10_000, 0.3) (seeded: not stored);
+    stored: the reference run's subsets (non-duplicate draws in order), fraction, consensus set (packed bits),
+    parameters and call counts, for three rand() seeds."""
+    c = O.cfg(O.PLANE, 3, 0.5)
+    data = synth.plane(10_000, 0.3)[0]
+    out = {"data_sha": np.frombuffer(__import__("hashlib").sha256(data.tobytes()).digest(), dtype=np.uint8)}
+    for seed in (21, 22, 23):
+        r = O.ref_ransac(c, data, 0.999, seed=seed, subsets_cap=4096)
+        key = "s%d_" % seed
+        out[key + "fraction"] = np.array([r["fraction"]])
+        out[key + "params"] = r["params"]
+        out[key + "consensus_bits"] = np.packbits(r["consensus"])
+        out[key + "subsets"] = r["subsets"]
+        out[key + "counts"] = np.array([r["estimate_calls"], r["agree_calls"], r["ls_calls"], r["rand_calls"]],
+                                       dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "config1_ref_vectors.npz"), **out)
 
 
 def numerics_vectors():
@@ -161,11 +183,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "us_lm":
         us_lm_vectors()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":
+        config1_vectors()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "us_lm_flags":
         us_lm_flag_table()
         sys.exit(0)
     copy_data()
     ransac_vectors()
+    config1_vectors()
     numerics_vectors()
     us_lm_vectors()
     us_lm_flag_table()

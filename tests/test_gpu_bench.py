@@ -36,8 +36,9 @@ def _run(args, env=None, extra=("--no-cpu-baseline", "--no-end-to-end", "--no-ot
             return r
         assert r.returncode == 0, r.stderr[-3000:]
         j = json.load(open(detail))
-    lines = r.stdout.strip().splitlines()
-    assert all(ln.startswith("{") for ln in lines), r.stdout[-2000:]
+    raw = r.stdout.strip().splitlines()
+    assert raw[-1].startswith('{"metric"'), r.stdout[-2000:]      # the driver parses the LAST line
+    lines = [ln for ln in raw if ln.startswith("{")]               # (RCCL prints its version banner to stdout)
     assert len(r.stdout) < 8000                                    # the driver keeps an 8 KB tail
     assert len(lines[-1]) < 4096 and lines[-1].startswith('{"metric"')
     assert all(ln.startswith('{"leg"') for ln in lines[:-1])
