@@ -378,7 +378,16 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                identical (the band is decided exactly);
  * "dense_fast_solve": 1 (default) = the n x n minimal solves of the dense system use elimination with
  *                partial pivoting and only fall back to the SVD pseudo-inverse near the rank decision,
- *                0 = always the SVD pseudo-inverse;
+ *                0 = always the SVD pseudo-inverse (and, for the dense least-squares fit, always the double-double
+ *                route below);
+ * "dense_dd":    dense least-squares fit (leastSquaresEstimate, DenseLinear...Estimator.hxx:64-96): 1 (default) = when
+ *                the elimination on the normal equations A^T A meets a pivot below 1e-6 max|A^T A| (cond(A) beyond
+ *                ~1e3) the system is solved again FROM THE ROWS: augmented Gram matrix in double-double, its Cholesky
+ *                factor (= R and Q^T b of A's QR decomposition) in double-double, x = pinv(R) z by a Jacobi SVD with
+ *                the reference's ABSOLUTE rank threshold 2.2e-16 -- the singular values, rank decision and solution
+ *                of the reference's SVD pseudo-inverse of A, to 1e-6 up to cond(A) ~ 1e10 (tests/test_gpu_dense_cond.py);
+ *                0 = the pseudo-inverse of the Gram block with a relative rank test 1e-13 (what entry points that only
+ *                hold the block -- lsqr_solve_moments, the multi-GPU sum -- always do);
  * "scan_axis":   plane in 3-D over an indexed upload: 1 (default) = every cell also gets the direction of least spread
  *                of its observations, which are re-sorted inside the cell along it, and the bounded scan ("scan_bound")
  *                takes upper AND lower vote bounds of its candidates by rank from that order (csrc/axis.h: no

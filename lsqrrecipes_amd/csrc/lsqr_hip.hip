@@ -97,6 +97,8 @@ struct lsqr_ctx {
   int opt_dense_f32 = 1;  // dense scan filter at n = 64: 1 = fp32 matrix cores (worklist of ~1e-4 of the pairs, hypothesis
                           // fragments through an LDS ring + next tile in registers), 0 = fp64 matrix cores
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_dense_dd = 1;    // dense fit: systems the elimination refuses are solved again from the rows in double-double
+  double *d_ddpart = nullptr;  // partial double-double Gram blocks of k_gram_dd_dense (allocated on first use)
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
@@ -1612,10 +1614,33 @@ void phantom_solve_block(const lsqr_model_cfg &cfg, const double *blk, SolveOut 
   phantom_to_out(f, out);
 }
 
-int launch_solve_dense(lsqr_ctx *c) {
+// rows: the records the block in d_mom was summed over are at hand -- rows [begin, end) of the upload, those of the
+// mask when use_mask -- so a system the elimination refuses is solved again from them in double-double (dense.h:
+// k_gram_dd_dense / k_dense_dd_solve: the reference's SVD pseudo-inverse of A with its absolute rank test).  Without
+// rows (lsqr_solve_moments, the multi-GPU sum of blocks) the pseudo-inverse of the Gram block decides.
+int launch_solve_dense(lsqr_ctx *c, bool rows = false, int use_mask = 0, size_t begin = 0, size_t end = 0) {
   ProfScope ps(c, KID_SOLVE);
-  hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(256), dense_lds_bytes(c->cfg.dim), c->stream,
-                     c->d_mom, (int)c->cfg.dim, c->opt_dense_fast, c->d_out);
+  const int n = (int)c->cfg.dim;
+  int *flag = (int *)(c->d_counter + 7);
+  rows = rows && c->opt_dense_dd && end > begin;
+  if (rows) HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(256), dense_lds_bytes(n), c->stream, c->d_mom, n,
+                     c->opt_dense_fast, c->d_out, rows ? flag : (int *)nullptr);
+  HIPCHK(c, hipGetLastError());
+  if (!rows) return LSQR_OK;
+  if (!c->d_ddpart) HIPCHK(c, hipMalloc((void **)&c->d_ddpart, sizeof(double) * 2 * kDdNe * kDdBlocks));
+  const int nb = (int)std::min<size_t>(kDdBlocks, (end - begin + 31) / 32);
+  hipLaunchKernelGGL((k_gram_dd_dense<32>), dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride, begin, end, n,
+                     use_mask ? c->d_mask : (const uint8_t *)nullptr, flag, c->d_ddpart);
+  HIPCHK(c, hipGetLastError());
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_dense_dd_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)dense_dd_lds(64));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_dense_dd_solve, dim3(1), dim3(256), dense_dd_lds(n), c->stream, c->d_ddpart, nb, n, c->d_mom,
+                     flag, c->d_out);
   HIPCHK(c, hipGetLastError());
   return LSQR_OK;
 }
@@ -1723,7 +1748,7 @@ int enqueue_fit(lsqr_ctx *c, int use_mask, bool have_moments = false) {
     int nmom = 0, st;
     if constexpr (M::IS_DENSE) {
       if (!have_moments && (st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
-      return launch_solve_dense(c);
+      return launch_solve_dense(c, true, use_mask, 0, c->n);
     } else {
       if (!have_moments) {
         bool first_datum = !c->origin_valid;
@@ -1761,7 +1786,7 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
       return LSQR_OK;
     } else if constexpr (M::IS_DENSE) {
       if (!have_moments && (st = launch_moments_dense(c, use_mask, 0, c->n, &nmom)) != LSQR_OK) return st;
-      if ((st = launch_solve_dense(c)) != LSQR_OK) return st;
+      if ((st = launch_solve_dense(c, true, use_mask, 0, c->n)) != LSQR_OK) return st;
       return read_out(c, out);
     } else {
     if (!have_moments) {
@@ -2301,7 +2326,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     }
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -4186,6 +4211,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
     c->opt_dense_fast = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_dd")) {  // 0: an ill-conditioned dense fit stays on the Gram block (r03 behaviour; A/B)
+    c->opt_dense_dd = value != 0;
     return LSQR_OK;
   }
   return fail(c, LSQR_ERR_INVALID, "unknown option %s", name);

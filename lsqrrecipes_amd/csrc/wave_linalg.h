@@ -300,7 +300,7 @@ __device__ inline void block_null_vector(int m, int n, double *A, int lda, doubl
 // 1e-8 * max(1, max|A|) -- far from the rank decision -- and reports false otherwise, in which case the
 // caller reloads the system and takes the SVD path, which makes the reference's rank decision.
 template <int T>
-__device__ inline bool block_gepp_solve(int n, double *A, int lda, double *b, double *x) {
+__device__ inline bool block_gepp_solve(int n, double *A, int lda, double *b, double *x, double piv_rel = 1e-8) {
   __shared__ int s_p, s_fail;
   __shared__ double s_piv, s_amax, s_red[T / 64];
   const int tid = threadIdx.x;
@@ -319,7 +319,7 @@ __device__ inline bool block_gepp_solve(int n, double *A, int lda, double *b, do
     s_amax = m;
   }
   __syncthreads();
-  const double tol = 1e-8 * (s_amax > 1.0 ? s_amax : 1.0);
+  const double tol = piv_rel * (s_amax > 1.0 ? s_amax : 1.0);
   if (!(s_amax <= 1e150)) return false;
   for (int k = 0; k < n; k++) {
     if (tid < 64) {  // pivot search in column k (n <= 64: one element per lane)
