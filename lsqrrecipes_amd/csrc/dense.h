@@ -1233,10 +1233,12 @@ __global__ __launch_bounds__(256) void k_solve_dense(const double *__restrict__ 
 //   k_dense_dd_solve  (one workgroup) fixed-order double-double sum of the blocks' partials, Cholesky factor
 //                     (R | z ; 0 rho) of the augmented Gram matrix in double-double -- R is the triangular factor of
 //                     A's QR decomposition (A = QR) and z = Q^T b, to eps_dd cond(A)^2 --, both rounded to double,
-//                     then x = pinv(R) z by the one-sided Jacobi SVD (wave_linalg.h) with the reference's ABSOLUTE
-//                     threshold: R has the singular values and right singular vectors of A, so the rank decision and
-//                     the pseudo-inverse are those of :85-92 (to the accuracy of a backward-stable SVD: eps cond(A)).
-// A Cholesky breakdown (pivot <= 0 in double-double: cond(A) beyond ~1e15) is reported as EMPTY.
+//                     the one-sided Jacobi SVD of R (wave_linalg.h) gives the singular values of A for the
+//                     reference's ABSOLUTE rank test (:88-91), and with full rank x = pinv(A) b = R^-1 z is taken by
+//                     back substitution in double-double: the exact least-squares solution to ~1e-12 at cond 1e10,
+//                     i.e. what remains between this result and an SVD route's is the SVD's own eps cond(A).
+// A Cholesky breakdown (a column in the span of the earlier ones to 14 digits: cond(A) beyond ~1e14, exact dependencies
+// included) is reported as EMPTY -- as the oracle's Jacobi SVD reports exactly dependent columns.
 // Both kernels return at once while `flag` is 0 (well-conditioned system: the elimination's result stands).
 struct dd_t {
   double hi, lo;
@@ -1396,11 +1398,14 @@ __global__ __launch_bounds__(256) void k_dense_dd_solve(const double *__restrict
     // diagonal: thread 0 (a chain of i terms); the others wait
     if (tid == 0) {
       dd_t d = {Ghi[dd_packed(i, i)], Glo[dd_packed(i, i)]};
+      const double g0 = d.hi;                               // |a_i|^2
       for (int k = 0; k < i; k++) {
         const dd_t r = {Ghi[dd_packed(k, i)], Glo[dd_packed(k, i)]};
         d = dd_sub(d, dd_mul(r, r));
       }
-      if (i < n && !(d.hi > 0.0)) s_bad = 1;               // breakdown: rank deficient beyond double-double
+      // breakdown: column i lies in the span of the columns before it to 14 digits (what is left of |a_i|^2 is below
+      // 1e-28 of it: cond(A) beyond ~1e14, where the double-double Gram matrix has no digits left either)
+      if (i < n && !(d.hi > 1e-28 * g0)) s_bad = 1;
       const dd_t rii = d.hi > 0.0 ? dd_sqrt(d) : dd_t{0.0, 0.0};  // (i == n: the residual norm; may round to <= 0)
       Ghi[dd_packed(i, i)] = rii.hi;
       Glo[dd_packed(i, i)] = rii.lo;
@@ -1421,8 +1426,10 @@ __global__ __launch_bounds__(256) void k_dense_dd_solve(const double *__restrict
     __syncthreads();
   }
   int rank = 0;
+  __shared__ double s_zh[64], s_zl[64], s_xh[64];
   if (!s_bad) {
-    // R (n x n, upper) and z = Q^T b rounded to double; x = pinv(R) z with the reference's absolute threshold
+    // The rank decision is the reference's: singular values of R (= those of A) against EPS, absolute (:88-91) --
+    // one-sided Jacobi SVD of R rounded to double.
     for (int idx = tid; idx < n * n; idx += 256) {
       const int i = idx % n, j = idx / n;                    // column-major
       R[j * lda + i] = i <= j ? Ghi[dd_packed(i, j)] + Glo[dd_packed(i, j)] : 0.0;
@@ -1431,6 +1438,31 @@ __global__ __launch_bounds__(256) void k_dense_dd_solve(const double *__restrict
     __syncthreads();
     rank = block_pinv_solve<256>(n, n, R, lda, V, lda, z, kEPS, 0.0, x, cw);
     __syncthreads();
+    // With full rank pinv(A) b is THE least-squares solution R^-1 z: taken by back substitution in double-double
+    // from the double-double factor, it carries none of an SVD's eps cond(A) rounding (measured against the exact
+    // solution of consistent systems at cond 1e10: 1e-12, where the Jacobi SVD of R gave 1e-6 and the oracle's /
+    // LAPACK's SVD of A 5e-8 / 1e-8 -- tests/test_gpu_dense_cond.py).
+    if (rank == n) {
+      if (tid < n) {
+        s_zh[tid] = Ghi[dd_packed(tid, n)];
+        s_zl[tid] = Glo[dd_packed(tid, n)];
+      }
+      __syncthreads();
+      for (int i = n - 1; i >= 0; i--) {
+        const dd_t xi = dd_div(dd_t{s_zh[i], s_zl[i]}, dd_t{Ghi[dd_packed(i, i)], Glo[dd_packed(i, i)]});
+        __syncthreads();                                     // (everyone has read z_i)
+        if (tid < i) {
+          const dd_t zj = dd_sub(dd_t{s_zh[tid], s_zl[tid]},
+                                 dd_mul(dd_t{Ghi[dd_packed(tid, i)], Glo[dd_packed(tid, i)]}, xi));
+          s_zh[tid] = zj.hi;
+          s_zl[tid] = zj.lo;
+        }
+        if (tid == 0) s_xh[i] = xi.hi + xi.lo;
+        __syncthreads();
+      }
+      for (int j = tid; j < n; j += 256) x[j] = s_xh[j];
+      __syncthreads();
+    }
   }
   const int ne = nz * (nz + 1) / 2;
   const bool ok = !s_bad && rank == n && mom[ne] >= (double)n;

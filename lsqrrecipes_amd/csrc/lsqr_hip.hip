@@ -2730,6 +2730,7 @@ int lsqr_ls_fit(lsqr_ctx *c, int use_mask, double *params_out, lsqr_fit_info *in
     info->n_params = out.n_params;
     info->lm_info = out.lm_info;
     info->lm_nfev = out.lm_nfev;
+    info->reserved = out.pad;  // LM: stall evaluation; dense: 1 = the double-double route produced the result
     info->cost = out.cost;
   }
   if (!out.ok) {
