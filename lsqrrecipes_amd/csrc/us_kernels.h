@@ -90,19 +90,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
   constexpr int NFLD = M::NFLD, NF = M::NF32;
   extern __shared__ uint32_t s_cnt[];
   if (h_dev) {
-    const uint32_t hd = *h_dev;
+    // (read through a vector load: made scalar again, or the per-hypothesis address arithmetic of the loop below
+    // runs on the vector unit -- 7 of its ~57 instructions)
+    const uint32_t hd = __builtin_amdgcn_readfirstlane(*h_dev);
     H = hd < H ? hd : H;
   }
   // blockIdx.y selects a segment of the hypothesis range: more resident waves when the observations
   // alone give fewer tiles than the chip has wave slots
+  // (everything the hypothesis loop addresses with is wave-uniform; said explicitly -- readfirstlane -- because values
+  // derived from the vector load of *h_dev otherwise stay in vector registers and drag the per-hypothesis address
+  // arithmetic onto the vector unit)
   uint32_t hb0;
   {
-    const uint32_t hseg = (H + gridDim.y - 1) / gridDim.y, hb = blockIdx.y * hseg;
+    const uint32_t hseg = (H + gridDim.y - 1) / gridDim.y;
+    const uint32_t hb = __builtin_amdgcn_readfirstlane(blockIdx.y * hseg);
     if (hb >= H) return;
     sp += (size_t)hb * M::SP;
     spf += (size_t)hb * M::SPF;
     hb0 = hb;
-    H = hb + hseg < H ? hseg : H - hb;
+    H = __builtin_amdgcn_readfirstlane(hb + hseg < H ? hseg : H - hb);
   }
   for (uint32_t h = threadIdx.x; h < H; h += kBlock) s_cnt[h] = 0;
   __syncthreads();
@@ -121,9 +127,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         xs[q][k].y = i1 < n ? (float)p1[slot] : __builtin_nanf("");
       }
     }
-    float nx[NF];  // the next hypothesis' block is fetched (scalar loads) while the current one is used
+    // The hypothesis' fp32 block arrives through the scalar cache.  The loads of hypothesis h + 1 are ISSUED at the top
+    // of iteration h -- the scheduling barrier pins them there; left alone the compiler sinks them to the end of the
+    // body and every iteration starts by waiting out a scalar-cache round trip (r03: vector issue 68 % busy) -- so
+    // that the arithmetic of h covers their latency.
+    float nx[NF];
 #pragma unroll
     for (int k = 0; k < NF; k++) nx[k] = spf[k];
+    // (the first block is waited for HERE: with loads still pending at the loop header the compiler's wait-count
+    // pass puts an s_waitcnt lgkmcnt(0) behind the loads at the top of every iteration -- scalar loads return out
+    // of order, so that waits for the block just requested as well)
+#pragma unroll
+    for (int k = 0; k < NF; k++) asm volatile("" ::"s"(nx[k]));
     for (uint32_t h = 0; h < H; h++) {
       float fl[NF];
 #pragma unroll
@@ -133,6 +148,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #pragma unroll
         for (int k = 0; k < NF; k++) nx[k] = f[k];
       }
+      __builtin_amdgcn_sched_barrier(0);
       const float tin = fl[M::TIN], tout = fl[M::TIN + 1];
       v2f v[NP];
       float m = __builtin_inff();
@@ -145,23 +161,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
       uint32_t c = 0;
 #pragma unroll
       for (int q = 0; q < NP; q++) {
-        unsigned long long in0 = __ballot(v[q].x < tin), in1 = __ballot(v[q].y < tin);
-        if ((in0 ^ __ballot(v[q].x < tout)) | (in1 ^ __ballot(v[q].y < tout))) {
-          // a frame of this pair sits in the band: exact fp64 predicate (records re-read; one half
-          // of the pair at a time so that the fp64 record does not double the register footprint)
+        bool a0 = v[q].x < tin, a1 = v[q].y < tin;
+        const bool b0 = (v[q].x < tout) != a0, b1 = (v[q].y < tout) != a1;  // inside the filter's band
+        if (__ballot(b0 || b1)) {
+          // exact fp64 predicate for THE LANES whose frame sits in the band, each on its own record.  (r03 had the
+          // whole wave re-read both 64-frame halves of the pair -- 15 KB per event, 13.6 GB of fabric reads per launch
+          // for a 120 MB upload: profiles/r03_us_full_count_scan_counters.json.)
           const double *hp = sp + (size_t)h * M::SP;
-          unsigned long long ex[2];
 #pragma nounroll
           for (int half = 0; half < 2; half++) {
-            const size_t i = base + (size_t)(2 * q + half) * kBlock + threadIdx.x;
-            double r[M::REC];
-            M::load(data + (i < n ? i : 0) * stride, mc, r);
-            ex[half] = __ballot(i < n && M::agree(hp, r, mc));
+            if (half ? b1 : b0) {
+              const size_t i = base + (size_t)(2 * q + half) * kBlock + threadIdx.x;
+              bool ex = false;
+              if (i < n) {
+                double r[M::REC];
+                M::load(data + i * stride, mc, r);
+                ex = M::agree(hp, r, mc);
+              }
+              if (half) a1 = ex;
+              else a0 = ex;
+            }
           }
-          in0 = ex[0];
-          in1 = ex[1];
         }
-        c += (uint32_t)__builtin_popcountll(in0) + (uint32_t)__builtin_popcountll(in1);
+        c += (uint32_t)__builtin_popcountll(__ballot(a0)) + (uint32_t)__builtin_popcountll(__ballot(a1));
       }
       if (leader && c) atomicAdd(&s_cnt[h], c);
     }

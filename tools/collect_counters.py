@@ -118,7 +118,7 @@ def main():
         out["hbm_write_bytes"] = wr
         out["hbm_bytes_per_launch"] = rd + wr
         out["hbm_note"] = "FETCH_SIZE_KB*1024*2 (gfx950 correction) + WRITE_SIZE_KB*1024, separate passes"
-    path = os.path.join(out_dir, "r03_%s_%s_scan_counters.json" % (w, mode))
+    path = os.path.join(out_dir, "%s_%s_%s_scan_counters.json" % (os.environ.get("LSQR_ROUND", "r04"), w, mode))
     json.dump(out, open(path, "w"), indent=1)
     print(path)
     subprocess.run(["rm", "-rf", scratch])
