@@ -211,7 +211,7 @@ __device__ inline uint32_t spread2(uint32_t v) {  // 16 bits -> every second bit
 template <int D>
 __global__ __launch_bounds__(256) void k_keys(const double *__restrict__ data, size_t stride,
                                               size_t n, IndexGrid g, uint32_t *__restrict__ keys,
-                                              uint32_t *__restrict__ vals) {
+                                              uint32_t *__restrict__ vals, int presorted) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t q[3] = {0, 0, 0};
@@ -226,10 +226,241 @@ __global__ __launch_bounds__(256) void k_keys(const double *__restrict__ data, s
   }
   uint32_t key;
   if (!fin) key = g.nbins;
+  else if (presorted) key = 0;  // "scan_presorted": the upload order IS the cell order (stable sort: finite records keep it)
   else if (D == 3) key = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
   else key = spread2(q[0]) | (spread2(q[1]) << 1);
   keys[i] = key;
   vals[i] = (uint32_t)i;
+}
+
+// ---- pass 2b (r04): local k-d refinement of the Morton order ----------------------------------------------------------
+// A cell is a run of 128 * PP consecutive records of the sorted copy, and a run of a Z-order curve straddles octant
+// boundaries at every level: its bounding box is 2 - 3 times the volume of a compact region holding as many records, and
+// the first level of the scan lets that many more (hypothesis, cell) pairs through to the second.  Measured on the
+// bench's uploads (tools/ab_order_kd.py, host-side k-d order against the library's): plane 10.3 M -> 8.8 M surviving
+// pairs per 4096 hypotheses (full count 0.96 -> 0.81 ms), sphere 22.5 M -> 11.7 M (1.73 -> 1.24 ms), line 20.2 M ->
+// 13.4 M (2.28 -> 1.66 ms).  A global k-d build is ~15 segmented sorts; what is built instead keeps the Morton radix
+// sort as the coarse order and re-partitions every SUPER-RUN of kRunPts = 8192 consecutive records (16 cells of 512, 32
+// of 256) as a k-d tree, one workgroup per run, entirely in LDS: per level every segment takes the axis of its widest
+// extent and is split at its median along it (radix select + stable partition, below).  Only the permutation changes: votes do not
+// depend on the order of the observations (every parity test runs on the refined order), the boxes are formed from
+// the gathered records as before.  Simulation at 2 M points: Morton 19.9 % of the (plane, cell) pairs survive, runs of
+// 8192 refined 16.2 %, a full k-d partition 15.0 %.
+constexpr uint32_t kRunPts = 8192;
+__device__ __forceinline__ uint32_t ord_u32(float v) {  // monotone map float -> uint32 (NaN above +inf)
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_u32_inv(uint32_t o) {
+  const uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __builtin_bit_cast(float, b);
+}
+constexpr uint32_t kRunMaxSeg = 16;  // segments of a level: runs of kRunPts are split down to 512-record segments
+__host__ __device__ inline size_t refine_lds_bytes(int D) {
+  return (size_t)kRunPts * (sizeof(float) * D + 2 * sizeof(uint16_t)) + kRunMaxSeg * 256 * sizeof(uint32_t) + 1024;
+}
+// Position p = 8 t + r belongs to thread t (r = 0..7): a wave covers 512 consecutive positions, a segment (>= 512 long,
+// a power of two) is a whole number of waves.  Per level and segment: widest axis -> 16-bit keys -> the key K of
+// rank segn/2 - 1 by radix select (two 8-bit passes over per-segment LDS histograms) -> stable partition into
+// {key < K, the first t_eq keys equal to K} | rest, each side keeping its order: exactly segn/2 records left, ties
+// split by position, so the result is deterministic.  O(n) per level (a sort per level, the first version of this
+// kernel, took 2.2 ms per 10 M records; this takes ~0.2).
+template <int D>
+__global__ __launch_bounds__(1024) void k_refine_runs(const double *__restrict__ data, size_t stride,
+                                                      uint32_t *__restrict__ perm, size_t ns, uint32_t cell_pts) {
+  extern __shared__ unsigned char refine_smem[];
+  float *cx = (float *)refine_smem;                          // [D][kRunPts], by position in the ORIGINAL run
+  uint16_t *idxa = (uint16_t *)(cx + (size_t)D * kRunPts);    // [2][kRunPts]: current / next order
+  uint32_t *hist = (uint32_t *)(idxa + 2 * kRunPts);          // [kRunMaxSeg][256]
+  uint32_t *sbox = hist + kRunMaxSeg * 256;                   // [kRunMaxSeg][3][2]
+  uint32_t *spref = sbox + kRunMaxSeg * 6;                    // [kRunMaxSeg] key prefix found so far
+  uint32_t *srk = spref + kRunMaxSeg;                         // [kRunMaxSeg] rank still to resolve inside the prefix
+  uint32_t *saxis = srk + kRunMaxSeg;                         // [kRunMaxSeg]
+  uint32_t *wtot = saxis + kRunMaxSeg;                        // [16 waves]
+  const size_t base = (size_t)blockIdx.x * kRunPts;
+  if (base >= ns) return;
+  const uint32_t m = (uint32_t)(ns - base < kRunPts ? ns - base : kRunPts);  // records of this run; the rest is padding
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint32_t mine[kRunPts / 1024];
+#pragma unroll
+  for (uint32_t k = 0; k < kRunPts / 1024; k++) {
+    const uint32_t j = k * 1024 + t;
+    uint32_t src = 0;
+    if (j < m) {
+      src = perm[base + j];
+      const double *r = data + (size_t)src * stride;
+#pragma unroll
+      for (int d = 0; d < D; d++) cx[(size_t)d * kRunPts + j] = (float)r[d];
+    } else {
+#pragma unroll
+      for (int d = 0; d < D; d++) cx[(size_t)d * kRunPts + j] = __builtin_inff();
+    }
+    mine[k] = src;
+    idxa[j] = (uint16_t)j;
+  }
+  __syncthreads();
+  uint32_t cur = 0;
+  const uint32_t stop = cell_pts < 256 ? 256u : cell_pts;  // a segment is >= one wave (512 positions) when it is split:
+                                                           // 128-record cells keep 256-record leaves
+  for (uint32_t segn = kRunPts; segn > stop; segn >>= 1) {
+    const uint16_t *idx = idxa + cur * kRunPts;
+    uint16_t *idn = idxa + (cur ^ 1) * kRunPts;
+    const uint32_t nseg = kRunPts / segn, wps = segn / 512;  // waves per segment
+    const uint32_t sg = wave / wps, p0 = t * 8;
+    uint32_t e[8];
+    {
+      const uint4 raw = *(const uint4 *)(idx + p0);             // 8 x u16
+      e[0] = raw.x & 0xFFFFu, e[1] = raw.x >> 16, e[2] = raw.y & 0xFFFFu, e[3] = raw.y >> 16;
+      e[4] = raw.z & 0xFFFFu, e[5] = raw.z >> 16, e[6] = raw.w & 0xFFFFu, e[7] = raw.w >> 16;
+    }
+    for (uint32_t k = t; k < nseg * 6; k += 1024) sbox[k] = (k & 1) ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- extent of every segment over its records (padding sits at the tail of its segment at every level)
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        if (e[r] < m) {
+          const uint32_t u = ord_u32(cx[(size_t)d * kRunPts + e[r]]);
+          lo = u < lo ? u : lo;
+          hi = u > hi ? u : hi;
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+      }
+      if (lane == 0 && hi >= lo) {
+        atomicMin(&sbox[(sg * 3 + d) * 2], lo);
+        atomicMax(&sbox[(sg * 3 + d) * 2 + 1], hi);
+      }
+    }
+    __syncthreads();
+    if (t < nseg) {
+      int ax = 0;
+      float best = -1.0f;
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const uint32_t lo = sbox[(t * 3 + d) * 2], hi = sbox[(t * 3 + d) * 2 + 1];
+        const float ext = hi >= lo ? ord_u32_inv(hi) - ord_u32_inv(lo) : -1.0f;  // (segment of padding only: -1)
+        if (ext > best) best = ext, ax = d;
+      }
+      saxis[t] = (uint32_t)ax;
+      spref[t] = 0;
+      srk[t] = segn / 2 - 1;
+    }
+    __syncthreads();
+    // keys: the coordinate along the segment's axis in 65535 steps of the segment's extent (padding: 65535, above every
+    // record).  A median found on these keys is off by at most extent / 65535 -- nothing for the shape of the cells --
+    // and two 8-bit passes select it where the 32-bit key took four (the kernel is bound by its barriers).
+    uint32_t key[8];
+    {
+      const uint32_t ax = saxis[sg];
+      const float *ca = cx + (size_t)ax * kRunPts;
+      const uint32_t ulo = sbox[(sg * 3 + ax) * 2], uhi = sbox[(sg * 3 + ax) * 2 + 1];
+      const float lo = uhi >= ulo ? ord_u32_inv(ulo) : 0.0f, ext = uhi >= ulo ? ord_u32_inv(uhi) - lo : 0.0f;
+      const float sc = ext > 0.0f && ext < 3.0e38f ? 65534.0f / ext : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const float q = (ca[e[r] < m ? e[r] : 0] - lo) * sc;
+        const uint32_t qi = q >= 65534.0f ? 65534u : (q > 0.0f ? (uint32_t)q : 0u);   // (NaN -> 0)
+        key[r] = e[r] < m ? qi : 65535u;
+      }
+    }
+    // ---- radix select: the key of rank segn/2 - 1 of every segment
+    for (int shift = 8; shift >= 0; shift -= 8) {
+      for (uint32_t k = t; k < nseg * 256; k += 1024) hist[k] = 0;
+      __syncthreads();
+      {
+        const uint32_t pref = spref[sg], himask = shift == 8 ? 0u : 0xFF00u;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          if ((key[r] & himask) == pref) atomicAdd(&hist[sg * 256 + ((key[r] >> shift) & 255u)], 1u);
+      }
+      __syncthreads();
+      if (wave < nseg) {  // wave s resolves segment s: lane l owns digits 4l .. 4l + 3
+        const uint32_t *h = hist + wave * 256 + 4 * lane;
+        const uint32_t c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t inc = tot;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t a = __shfl_up(inc, o);
+          inc += (int)lane >= o ? a : 0u;
+        }
+        const uint32_t before = inc - tot, rk = srk[wave];
+        const bool here = rk >= before && rk < inc;   // exactly one lane (the candidates number more than rk)
+        if (here) {
+          uint32_t b = 0, cb = before;
+          if (rk >= cb + c0) {
+            cb += c0, b = 1;
+            if (rk >= cb + c1) {
+              cb += c1, b = 2;
+              if (rk >= cb + c2) cb += c2, b = 3;
+            }
+          }
+          spref[wave] |= (4 * lane + b) << shift;
+          srk[wave] = rk - cb;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- stable partition: {key < K, the first srk + 1 keys equal to K} go left
+    const uint32_t K = spref[sg], teq = srk[sg] + 1;
+    uint32_t nl = 0, ne = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) ne += key[r] == K ? 1u : 0u;
+    // exclusive scan of the equal-key counts over the segment (position order)
+    uint32_t inc = ne;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t a = __shfl_up(inc, o);
+      inc += (int)lane >= o ? a : 0u;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t eqb = inc - ne;
+    for (uint32_t w = sg * wps; w < wave; w++) eqb += wtot[w];
+    __syncthreads();
+    bool left[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const bool eq = key[r] == K;
+      left[r] = key[r] < K || (eq && eqb < teq);
+      eqb += eq ? 1u : 0u;
+      nl += left[r] ? 1u : 0u;
+    }
+    inc = nl;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t a = __shfl_up(inc, o);
+      inc += (int)lane >= o ? a : 0u;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t lb = inc - nl;                                   // lefts before my first position, in the segment
+    for (uint32_t w = sg * wps; w < wave; w++) lb += wtot[w];
+    const uint32_t sbase = sg * segn;
+    uint32_t rb = (p0 - sbase) - lb;                          // rights before my first position
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint32_t dst = left[r] ? sbase + lb : sbase + segn / 2 + rb;
+      idn[dst] = (uint16_t)e[r];
+      lb += left[r] ? 1u : 0u;
+      rb += left[r] ? 0u : 1u;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // the refined order of the run: position j takes the record that sat at position idx[j] of the Morton run
+  const uint16_t *idx = idxa + cur * kRunPts;
+  uint32_t *srcs = (uint32_t *)cx;  // (the coordinates are not needed any more)
+#pragma unroll
+  for (uint32_t k = 0; k < kRunPts / 1024; k++) srcs[k * 1024 + t] = mine[k];
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < kRunPts / 1024; k++) {
+    const uint32_t j = k * 1024 + t;
+    if (j < m) perm[base + j] = srcs[idx[j]];
+  }
 }
 
 __device__ inline float f32_up(double v) {  // smallest float >= v (v finite, >= 0)
@@ -689,10 +920,15 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
   typedef typename CM::M M;
   constexpr int D = M::ND, NB = CM::NB, NV = CM::NV, SPD = M::SP, CP = 128 * PP;
   (void)D, (void)NV, (void)CP;
+  // (NV == 4 -- plane, sphere: the measure's ADDEND bc[3] is stored first, so that it lands in the low half of a
+  // register pair and the packed fma takes it by op_sel; in the high half the compiler copies it first: one of the
+  // pair's vector instructions)
+  constexpr bool ROT = NV == 4;
   if (LDSB && surv) {  // the lane's values -> LDS; survivors are fetched with uniform-address reads
     float4 w0, w1;
     w0.x = bc[0], w0.y = NB > 1 ? bc[1 < NB ? 1 : 0] : 0.0f, w0.z = NB > 2 ? bc[2 < NB ? 2 : 0] : 0.0f,
     w0.w = NB > 3 ? bc[3 < NB ? 3 : 0] : 0.0f;
+    if (ROT) w0 = (float4){w0.w, w0.x, w0.y, w0.z};
     w1.x = NB > 4 ? bc[4 < NB ? 4 : 0] : 0.0f, w1.y = NB > 5 ? bc[5 < NB ? 5 : 0] : 0.0f,
     w1.z = NB > 6 ? bc[6 < NB ? 6 : 0] : 0.0f, w1.w = NB > 7 ? bc[7 < NB ? 7 : 0] : 0.0f;
     ((float4 *)s_bc)[2 * lane] = w0;
@@ -706,7 +942,8 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
     if (LDSB) {
       static_assert(NB <= 8, "broadcast area holds 8 floats per lane");
       const float4 r0 = ((const float4 *)s_bc)[2 * b], r1 = ((const float4 *)s_bc)[2 * b + 1];
-      const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      const float rb[8] = {ROT ? r0.y : r0.x, ROT ? r0.z : r0.y, ROT ? r0.w : r0.z, ROT ? r0.x : r0.w,
+                           r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
       for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
       na.x = -rb[NB - 2], na.y = -rb[NB - 2];
@@ -729,7 +966,7 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
     // rest of the body is 13 instructions.  Two compares per value with the mask logic and the counts on the scalar
     // unit measured SLOWER in r02: the scalar unit is nearly as busy as the vector unit in this loop.)
     unsigned long long in[2 * PP];
-    uint32_t dmin = 0xFFFFFFFFu;
+    uint32_t dmin = 0;
     v2f sv[PP];  // (all values first: PP independent chains for the scheduler to interleave)
 #pragma unroll
     for (int p = 0; p < PP; p++) sv[p] = CM::value(xs[p], fp);
@@ -742,10 +979,12 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
       // (the two halves are compared with each other FIRST: written as two running minima -- dmin = min(dmin, dx),
       // dmin = min(dmin, dy) -- hipcc 7.2 drops the high half of a packed fma's result from the chain; seen in the
       // ISA, a standalone kernel reproduces it, 50 votes in 4 M were lost)
+      // r04: ONE three-way unsigned minimum (v_min3_u32) per packed pair, written as the instruction itself -- the
+      // compiler had to be steered around the fault above with two minima per pair (4 of the pair's 31 instructions)
       typedef uint32_t v2u __attribute__((ext_vector_type(2)));
       const v2u du = __builtin_bit_cast(v2u, d);
-      const uint32_t m = du.x < du.y ? du.x : du.y;
-      dmin = m < dmin ? m : dmin;
+      if (p == 0) asm("v_min_u32 %0, %1, %2" : "=v"(dmin) : "v"(du.x), "v"(du.y));
+      else asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(du.x), "v"(du.y));
     }
     const unsigned long long amb = __ballot(dmin <= band);
     if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell

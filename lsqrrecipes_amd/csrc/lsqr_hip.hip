@@ -97,6 +97,8 @@ struct lsqr_ctx {
   int opt_dense_f32 = 1;  // dense scan filter at n = 64: 1 = fp32 matrix cores (worklist of ~1e-4 of the pairs, hypothesis
                           // fragments through an LDS ring + next tile in registers), 0 = fp64 matrix cores
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
+  int opt_presorted = 0;   // index build: cells = runs of the UPLOAD order (experiments with other spatial orders)
   int opt_dense_dd = 1;    // dense fit: systems the elimination refuses are solved again from the rows in double-double
   double *d_ddpart = nullptr;  // partial double-double Gram blocks of k_gram_dd_dense (allocated on first use)
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
@@ -725,11 +727,26 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
            *v_out = k_out + words;
   void *tmp = (void *)(v_out + words);
   const unsigned gn = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((k_keys<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n, g, k_in, v_in);
+  hipLaunchKernelGGL((k_keys<D>), dim3(gn), dim3(256), 0, c->stream, c->d_data, c->stride, n, g, k_in, v_in,
+                     c->opt_presorted);
   IDXCHK(hipGetLastError());
   IDXCHK(sort_pairs_u32(tmp, &tmp_bytes, k_in, k_out, v_in, v_out, n, (unsigned)(bits * D + 1), c->stream));
   c->n_sorted = n_sorted;
   c->n_cells = n_cells;
+  // local k-d refinement of the Morton order (cells.h: k_refine_runs): compact cells, fewer surviving pairs
+  if (c->opt_refine && !c->opt_presorted && n_sorted > cell_pts && cell_pts >= 128 && cell_pts < kRunPts &&
+      (cell_pts & (cell_pts - 1)) == 0) {
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[D - 2]) {
+      (void)hipFuncSetAttribute((const void *)k_refine_runs<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)refine_lds_bytes(D));
+      attr_set[D - 2] = true;
+    }
+    const unsigned runs = (unsigned)((n_sorted + kRunPts - 1) / kRunPts);
+    hipLaunchKernelGGL((k_refine_runs<D>), dim3(runs), dim3(1024), refine_lds_bytes(D), c->stream, c->d_data, c->stride,
+                       v_out, n_sorted, cell_pts);
+    IDXCHK(hipGetLastError());
+  }
   if (c->n_cells) {
     hipLaunchKernelGGL((k_gather_boxes<D>), dim3((c->n_cells + 3) / 4), dim3(256), 0, c->stream, c->d_data,
                        c->stride, v_out, c->n_sorted, c->n_cells, cell_pts, c->d_sorted, c->d_boxes);
@@ -4212,6 +4229,16 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
     c->opt_dense_fast = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_refine")) {  // 0: cells are plain runs of the Morton order (r03; A/B knob)
+    c->opt_refine = value != 0;
+    drop_index(c);
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_presorted")) {  // cells are runs of the upload order (set before the index is built)
+    c->opt_presorted = value != 0;
+    drop_index(c);
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_dd")) {  // 0: an ill-conditioned dense fit stays on the Gram block (r03 behaviour; A/B)
