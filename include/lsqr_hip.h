@@ -352,10 +352,11 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the
  *                host, 0 = in a single-lane device kernel (same lm_core.h code either way);
  * "scan_index":  two-level scan of the point models over a spatial index of the observations
- *                (Morton-sorted copy + one fp32 bounding box per cell of 256 / 512 observations, built on the
- *                device once per upload): 1 (default) = built when it pays -- the upload holds >= 65536
- *                observations and >= 512 hypotheses have been scanned on it or are still announced by the
- *                adaptive bound (the build costs about as much as 450 exhaustive hypothesis scans) --,
+ *                (Morton-sorted copy, re-partitioned as a k-d tree inside runs of 8192 records, + one fp32 bounding
+ *                box per cell of 256 / 512 observations, built on the device once per upload): 1 (default) = built
+ *                when it pays -- the upload holds >= 65536 observations and >= 768 hypotheses have been scanned on
+ *                it or are still announced by the adaptive bound (the build costs about as much as 700 exhaustive
+ *                hypothesis scans) --,
  *                0 = never, 2 = always.  Votes are
  *                bit-identical either way;  "scan_cell": observations per cell (128, 256 or 512; 0 = the
  *                model's default), "scan_cpt": cells per wave tile (1, 2 or 4; 0 = default), "scan_block":
@@ -367,6 +368,11 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                exactly such hypotheses).  Dense system (n > 32) and US calibrations: the observations are scanned in
  *                chunks and a hypothesis stops being counted once it cannot win any more (lsqr_scan_work; it reports
  *                its partial count).  0 = every hypothesis is counted.  lsqr_scan always counts all;
+ * "scan_refine": 1 (default) = the index build re-partitions every run of 8192 Morton-ordered records as a k-d tree
+ *                (median splits along the widest extent; csrc/cells.h: k_refine_runs) so that cells are compact:
+ *                15 % (plane) to 40 % (sphere) fewer (hypothesis, cell) pairs reach the second level of the scan;
+ *                0 = plain Morton runs (A/B knob).  "scan_presorted": 1 = cells are runs of the UPLOAD order (experiments
+ *                with other spatial orders: tools/ab_order_kd.py).  Votes are identical whatever the order;
  * "batch_lanes": streams (1..4, default 4) the slots of lsqr_batch_fit_enqueue / _wait are spread over (see there);
  * "scan_pairs":  plain (unbounded) scans of an indexed upload: 0 (default) = the model's measured choice (plane, batches
  *                of >= 1024: the statically balanced kernel of the bounded scan, k_scan_pairs; else k_scan_cells),

@@ -719,7 +719,9 @@ struct SphereCell {
   enum { NB = 6, NV = 4, RELATIVE = 1, ROW = M::SPF, ROW_F32 = 1, ROW2 = 0, ROW2_OFF = 0 };
   enum { XQ = 1 };         // cells_load keeps q = |x'|^2 per observation in xs[.][3]
   enum { MIN_WAVES = 4 };  // 72 VGPRs = 7 waves per SIMD as compiled
-  enum { DEFAULT_CELL = 256, LDS_BROADCAST = 1 };  // measured (tools/ab_cells.py): 1.9 ms; 512 / v_readlane 2.1 ms
+  // r04, with the k-d refined index (tools/ab_cell_size.py, 4096 x 10 M): 512-record cells 1.30 ms full count / 0.37 ms
+  // bounded against 1.36 / 0.41 ms with 256 (r03, plain Morton runs: 256 was the faster one, 1.9 against 2.1 ms)
+  enum { DEFAULT_CELL = 512, LDS_BROADCAST = 1 };
   enum { USE_BOUND = 1, BOUND_MERGE = 4 };  // the sphere's box test is 61 instructions: 0.29 -> 0.08 ms, 0.87 -> 0.70 ms / step
   struct Hyp {
     double c[3], mid;

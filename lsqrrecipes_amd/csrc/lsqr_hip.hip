@@ -1449,12 +1449,13 @@ int run_scan(lsqr_ctx *c) {
         // hypotheses to pay for the build (a few HBM passes)
         const bool tuned_defaults = c->opt_filter == 1 && c->opt_ppl == 0;  // A/B knobs untouched
         // Cost model of the build (auto mode).  Per (hypothesis, observation) the exhaustive filter kernel costs
-        // ~1.9e-13 s and the two-level scan ~0.3e-13 s (10 M points x 4096 hypotheses: 7.6 ms against 1.3 ms);
-        // the build costs ~0.7e-10 s per observation (radix sort + gather).  It pays for itself once
-        //   hypotheses still to come  >  0.7e-10 / 1.6e-13  ~  450,
+        // ~1.9e-13 s and the two-level scan ~0.2e-13 s (10 M points x 4096 hypotheses: 7.6 ms against 0.8 ms);
+        // the build costs ~1.2e-10 s per observation (radix sort + k-d refinement + gather; r03 without the
+        // refinement: 0.7e-10).  It pays for itself once
+        //   hypotheses still to come  >  1.2e-10 / 1.7e-13  ~  700,
         // and "still to come" is estimated by the larger of what the caller announced (lsqr_ransac: the current
         // numTries bound) and what this upload has been asked to scan so far, this batch included.
-        constexpr uint64_t kIndexPaysAfter = 512;
+        constexpr uint64_t kIndexPaysAfter = 768;
         const uint64_t to_come = std::max<uint64_t>(c->hyp_expected, c->hyp_since_upload);
         const bool want = c->opt_filter && f32_ok && c->mc.absmax >= 1e-10 && !c->index_failed &&
                           (c->opt_index == 2 ||
@@ -1638,7 +1639,7 @@ void phantom_solve_block(const lsqr_model_cfg &cfg, const double *blk, SolveOut 
 int launch_solve_dense(lsqr_ctx *c, bool rows = false, int use_mask = 0, size_t begin = 0, size_t end = 0) {
   ProfScope ps(c, KID_SOLVE);
   const int n = (int)c->cfg.dim;
-  int *flag = (int *)(c->d_counter + 7);
+  int *flag = (int *)(c->d_counter + 7) + 1;  // (the low word of the slot is k_plane_order's count: another model's)
   rows = rows && c->opt_dense_dd && end > begin;
   if (rows) HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(256), dense_lds_bytes(n), c->stream, c->d_mom, n,

@@ -163,7 +163,7 @@ def test_config2_plane_10M_batch_on_bench_path(ctx):
 def test_config3_sphere_10M_geometric_on_bench_path(ctx):
     """BASELINE configs[2] (one GPU's share): sphere, 10 M points, geometric (Levenberg-Marquardt) fit."""
     r, want, truth, lab, wmask = _point_model_fullsize(ctx, L.SPHERE, O.SPHERE, synth.sphere,
-                                                       L.LS_GEOMETRIC, 256)
+                                                       L.LS_GEOMETRIC, 512)
     assert 1 <= r["info"].fit.lm_info <= 4
     assert np.allclose(r["params"], want, rtol=REL, atol=1e-6)
     assert np.allclose(r["params"], truth, rtol=1e-4, atol=1e-2)
