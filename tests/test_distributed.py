@@ -139,6 +139,37 @@ def test_sharded_ransac_world2_matches_single_process():
     assert b[0][0] == 0 and b[-1][1] == 1501 and all(b[i][1] == b[i + 1][0] for i in range(3))
 
 
+def test_sharded_ransac_world8_matches_single_process():
+    """the driver's N = 8 shape rehearsed on CPU: eight gloo ranks, hypothesis stream sharded eight ways, all-reduce MAX
+    of the packed winner, all-reduce SUM of the slices' moment blocks -- the winner is the one a single process finds
+    in the same 8 x H stream, the consensus count and the fit are the whole upload's"""
+    from lsqrrecipes_amd import synth
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+    from oracle import pyoracle as O
+    data = synth.plane(1200, 0.4, seed=654)[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, data, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    votes, gidx, par, fit, cnt, votes2, gidx2 = res
+    sr = ShardedRansac(OracleEngine(data), Comm(None))
+    v1, g1, p1 = sr.batch(seed=5, batch_index=0, H=8 * 24)
+    assert (votes, gidx) == (v1, g1) and np.array_equal(par, p1)
+    oc = O.cfg(O.PLANE, 3, 0.5)
+    wcnt, wmask = O.scan(oc, par, data)
+    assert cnt == wcnt == votes
+    want = O.ls(oc, data, wmask)
+    assert abs(abs(fit[:3] @ want[:3]) - 1) < 1e-9
+    v2, g2, _ = sr.batch(seed=5, batch_index=1, H=8 * 24)
+    assert (votes2, gidx2) == (v2, g2) and 8 * 24 <= gidx2 < 2 * 8 * 24
+
+
 def test_comm_world1_is_identity():
     from lsqrrecipes_amd.distributed import Comm
     c = Comm(None)

@@ -149,6 +149,24 @@ def test_bench_gpus_2_launches_its_own_ranks():
         assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
 
 
+def test_bench_five_ranks_equal_one_rank_on_the_same_stream():
+    """rehearsal of the driver's multi-GPU run with as many ranks as the box allows on one card (the guard admits 6
+    processes on the GPU, the test runner is one of them; the 8-rank shape runs on CPU in tests/test_distributed.py):
+    five ranks share device 0, exchanges over gloo on device buffers.  The last step's winner, consensus count and
+    fit are those of ONE rank scanning the same 5 x H hypotheses per step."""
+    env = {"LSQR_SHARE_GPU": "1", "LSQR_DIST_BACKEND": "gloo", "LSQR_STEP": "device"}
+    a = _run(["--workload", "plane", "--gpus", "5", "--streams", "1", "--batch", "512"], env=env)
+    _check(a, 1, n_gpus=5)
+    assert a["config"]["world_size"] == 5 and len(a["per_rank_hypotheses_per_s"]) == 5
+    assert min(a["per_rank_hypotheses_per_s"]) > 0
+    assert abs(sum(a["per_rank_hypotheses_per_s"]) - a["value"]) < 0.35 * a["value"]   # each rank's own clock
+    b = _run(["--workload", "plane", "--streams", "1", "--batch", "2560"])
+    fa, fb = a["final_fit"], b["final_fit"]
+    assert fa["winner_votes"] == fb["winner_votes"] and fa["inliers"] == fb["inliers"]
+    pa, pb = fa["params"], fb["params"]
+    assert len(pa) == len(pb) == 6 and max(abs(x - y) for x, y in zip(pa, pb)) < 1e-9 * max(1.0, max(map(abs, pb)))
+
+
 def test_bench_gloo_fallback_is_opt_in():
     """two ranks on ONE device with the default (nccl) backend: RCCL refuses the duplicate device on every rank.
     Default: NO line, exit non-zero (a scaling record can never be a gloo line by accident).  --allow-gloo: every rank
