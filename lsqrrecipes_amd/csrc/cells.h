@@ -922,15 +922,10 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
   typedef typename CM::M M;
   constexpr int D = M::ND, NB = CM::NB, NV = CM::NV, SPD = M::SP, CP = 128 * PP;
   (void)D, (void)NV, (void)CP;
-  // (NV == 4 -- plane, sphere: the measure's ADDEND bc[3] is stored first, so that it lands in the low half of a
-  // register pair and the packed fma takes it by op_sel; in the high half the compiler copies it first: one of the
-  // pair's vector instructions)
-  constexpr bool ROT = NV == 4;
   if (LDSB && surv) {  // the lane's values -> LDS; survivors are fetched with uniform-address reads
     float4 w0, w1;
     w0.x = bc[0], w0.y = NB > 1 ? bc[1 < NB ? 1 : 0] : 0.0f, w0.z = NB > 2 ? bc[2 < NB ? 2 : 0] : 0.0f,
     w0.w = NB > 3 ? bc[3 < NB ? 3 : 0] : 0.0f;
-    if (ROT) w0 = (float4){w0.w, w0.x, w0.y, w0.z};
     w1.x = NB > 4 ? bc[4 < NB ? 4 : 0] : 0.0f, w1.y = NB > 5 ? bc[5 < NB ? 5 : 0] : 0.0f,
     w1.z = NB > 6 ? bc[6 < NB ? 6 : 0] : 0.0f, w1.w = NB > 7 ? bc[7 < NB ? 7 : 0] : 0.0f;
     ((float4 *)s_bc)[2 * lane] = w0;
@@ -944,8 +939,7 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
     if (LDSB) {
       static_assert(NB <= 8, "broadcast area holds 8 floats per lane");
       const float4 r0 = ((const float4 *)s_bc)[2 * b], r1 = ((const float4 *)s_bc)[2 * b + 1];
-      const float rb[8] = {ROT ? r0.y : r0.x, ROT ? r0.z : r0.y, ROT ? r0.w : r0.z, ROT ? r0.x : r0.w,
-                           r1.x, r1.y, r1.z, r1.w};
+      const float rb[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
       for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
       na.x = -rb[NB - 2], na.y = -rb[NB - 2];
@@ -968,7 +962,7 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
     // rest of the body is 13 instructions.  Two compares per value with the mask logic and the counts on the scalar
     // unit measured SLOWER in r02: the scalar unit is nearly as busy as the vector unit in this loop.)
     unsigned long long in[2 * PP];
-    uint32_t dmin = 0;
+    uint32_t dmin = 0xFFFFFFFFu;
     v2f sv[PP];  // (all values first: PP independent chains for the scheduler to interleave)
 #pragma unroll
     for (int p = 0; p < PP; p++) sv[p] = CM::value(xs[p], fp);
@@ -981,13 +975,11 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
       // (the two halves are compared with each other FIRST: written as two running minima -- dmin = min(dmin, dx),
       // dmin = min(dmin, dy) -- hipcc 7.2 drops the high half of a packed fma's result from the chain; seen in the
       // ISA, a standalone kernel reproduces it, 50 votes in 4 M were lost)
-      // r04: ONE three-way unsigned minimum (v_min3_u32) per packed pair, written as the instruction itself -- the
-      // compiler had to be steered around the fault above with two minima per pair (4 of the pair's 31 instructions)
       typedef uint32_t v2u __attribute__((ext_vector_type(2)));
       const v2u du = __builtin_bit_cast(v2u, d);
-      if (p == 0) asm("v_min_u32 %0, %1, %2" : "=v"(dmin) : "v"(du.x), "v"(du.y));
-      else asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(du.x), "v"(du.y));
-    }
+      const uint32_t m = du.x < du.y ? du.x : du.y;
+      dmin = m < dmin ? m : dmin;   // (the backend fuses the two minima into one v_min3_u32; r04: writing the
+    }                               // instruction by hand changes nothing -- checked in the ISA and by SQ_INSTS_VALU)
     const unsigned long long amb = __ballot(dmin <= band);
     if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
       const double *hp = spg + (size_t)b * SPD;  // wave-uniform -> scalar loads

@@ -1,5 +1,5 @@
 # Collect the per-round evidence under gpurun_out/<tag>/ (then copy what is to be judged into profiles/):
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 # per workload and hypothesis rate (full_count = every hypothesis counted, scan_bound 0 -- bench.py's `value`;
 # early_exit = scan_bound 1): (1) the SQ / HBM counters of the scan kernels (tools/collect_counters.py: separate
 # rocprofv3 --pmc passes), copied into profiles/ so that the bench lines below quote them; (2) a rocprofv3
@@ -17,7 +17,7 @@ for w in ${WORKLOADS:-plane sphere line dense us}; do
     timeout -k 10 500 python3 tools/collect_counters.py $w gpurun_out/$tag $rate > gpurun_out/$tag/counters_${w}_$rate.log 2>&1 && cp gpurun_out/$tag/r04_${w}_${rate}_scan_counters.json profiles/
     echo "counters $w $rate done"
     extra=""; [ $w = us ] && extra="--us-fit analytic"
-    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof_${w}_$rate -- python3 bench.py --workload $w $extra --steps 5 --warmup 1 --repeats 1 --streams 1 --rates $short --no-cpu-baseline --no-end-to-end --no-other-configs > gpurun_out/$tag/${tag}_${w}_${rate}_bench_under_rocprof.json 2> gpurun_out/$tag/prof_${w}_$rate.err || exit 1
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof_${w}_$rate -- python3 bench.py --workload $w $extra --steps 5 --warmup 1 --repeats 1 --streams 1 --rates $short --no-cpu-baseline --no-end-to-end --no-other-configs --detail gpurun_out/$tag/${tag}_${w}_${rate}_bench_under_rocprof_detail.json > gpurun_out/$tag/${tag}_${w}_${rate}_bench_under_rocprof.json 2> gpurun_out/$tag/prof_${w}_$rate.err || exit 1
     f=$(find gpurun_out/$tag/prof_${w}_$rate -name '*kernel_stats.csv' | head -1)
     cp "$f" gpurun_out/$tag/${tag}_${w}_${rate}_kernel_stats.csv
     rm -rf gpurun_out/$tag/prof_${w}_$rate
@@ -25,9 +25,9 @@ for w in ${WORKLOADS:-plane sphere line dense us}; do
   done
   if [ -z "$SKIP_BENCH" ]; then
     if [ $w = plane ]; then
-      timeout -k 10 600 python3 bench.py > gpurun_out/$tag/${tag}_bench_plane.json 2> gpurun_out/$tag/bench_plane.err || exit 1
+      timeout -k 10 600 python3 bench.py --detail gpurun_out/$tag/${tag}_bench_plane_detail.json > gpurun_out/$tag/${tag}_bench_plane.json 2> gpurun_out/$tag/bench_plane.err || exit 1
     else
-      timeout -k 10 400 python3 bench.py --workload $w > gpurun_out/$tag/${tag}_bench_$w.json 2> gpurun_out/$tag/bench_$w.err || exit 1
+      timeout -k 10 400 python3 bench.py --workload $w --detail gpurun_out/$tag/${tag}_bench_${w}_detail.json > gpurun_out/$tag/${tag}_bench_$w.json 2> gpurun_out/$tag/bench_$w.err || exit 1
     fi
     echo "bench $w done"
   fi
