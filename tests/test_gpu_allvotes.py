@@ -131,3 +131,44 @@ def test_config1_plane_10k_30pct_as_written(ctx, golden_dir):
         if O.ref_available():                               # and live, when the compiled reference travelled
             live = O.ref_ransac(oc, data, 0.999, seed=seed, subsets_cap=4096)
             assert live["fraction"] == r["fraction"] and np.array_equal(live["consensus"], r["consensus"])
+
+
+# ---- the refined index (k_refine_runs) on awkward uploads ---------------------------------------------------------------
+@pytest.mark.parametrize("n", [300, 511, 8191, 8192, 8193, 12_289, 70_001, 131_072])
+@pytest.mark.parametrize("kind", ["plane", "duplicates", "one_point", "collinear"])
+def test_refined_index_gives_the_exhaustive_kernels_votes(ctx, n, kind):
+    """run boundaries (8192 records per refined run), partial runs, partial cells; many equal coordinates (the radix
+    select's ties are split by position), every record the same point, every record on one line: the two-level scan
+    over the refined order counts exactly what the exhaustive fp64 kernel counts"""
+    g = np.random.default_rng(n)
+    if kind == "plane":
+        data = synth.plane(n, 0.5, seed=n)[0]
+    elif kind == "duplicates":          # 37 distinct points, each repeated ~n / 37 times, plus a few outliers
+        base = g.uniform(-50, 50, (37, 3))
+        data = base[g.integers(0, 37, n)]
+        data[:: 97] = g.uniform(-500, 500, (len(data[:: 97]), 3))
+    elif kind == "one_point":
+        data = np.tile(np.array([[3.0, -7.0, 11.0]]), (n, 1))
+        data[: n // 3] += g.normal(0, 0.2, (n // 3, 3))
+    else:
+        t = g.uniform(-1000, 1000, n)
+        data = np.outer(t, [0.6, 0.0, 0.8]) + [1.0, 2.0, 3.0]
+        data[::5] += g.normal(0, 0.3, (len(data[::5]), 3))
+    data = np.ascontiguousarray(data)
+    Hn = 512
+    for model, ls in ((L.PLANE, 0), (L.SPHERE, L.LS_ALGEBRAIC), (L.LINE, 0)):
+        ctx.set_model(model, 3, 0.5, ls).upload(data)
+        ctx.hypotheses_sample(5, 0, Hn)
+        out = {}
+        for index, refine in ((0, 1), (2, 1), (2, 0)):
+            ctx.set_option("scan_refine", refine)
+            ctx.set_option("scan_index", index)
+            ctx.set_option("scan_filter", 1 if index else 0)
+            ctx.scan()
+            out[(index, refine)] = ctx.hypotheses(params=False)[2].copy()
+        ctx.set_option("scan_refine", 1)
+        ctx.set_option("scan_index", 1)
+        ctx.set_option("scan_filter", 1)
+        assert np.array_equal(out[(2, 1)], out[(0, 1)]), (model, n, kind)
+        assert np.array_equal(out[(2, 0)], out[(0, 1)]), (model, n, kind)
+        assert out[(0, 1)].max() > 0
