@@ -737,6 +737,121 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass_mfma(const double *__restric
   }
 }
 
+// K3 + K4 of the US calibrations on the matrix cores (r04).  k_mask_moments<US> kept the 91 sums of the analytic
+// system {N, A^T A, A^T b} (...Estimator.cxx:137-190: three rows [u R2_j, v R2_j, R2_j, -e_j | -t2_j] per frame) as
+// per-lane fp64 accumulators -- 182 VGPRs, one or two waves per SIMD, 16 dependent 120-byte records per lane: 48 us
+// for the 121 MB of 1 M frames (0.31 of the HBM peak).  Here, as in k_lm_pass_mfma: the wave's 64 records arrive as
+// one coalesced stream (the NEXT tile's loads are issued before the current one is used), every lane evaluates agree()
+// on its record (exact predicate, the reference's operation order: the mask keeps its bits), and the rows of the
+// AGREEING lanes -- compacted to the front of the wave's LDS tile by their rank in the ballot -- are fed four at a
+// time to v_mfma_f64_16x16x4 with the same register as A and B operand: C = Z^T Z, Z = (A | b), 13 (10) columns.  One
+// 16 x 16 accumulator (8 VGPRs) per wave, no cross-lane reduction; with half of the frames agreeing 3 x 8 matrix
+// instructions per 64 frames.  The sums differ from the per-lane version's in the last bits only (another order).
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_mask_moments_us_mfma(const double *__restrict__ data, size_t begin, size_t end,
+                                                                 const double *__restrict__ par, ModelConsts mc,
+                                                                 uint8_t *__restrict__ mask,
+                                                                 unsigned long long *__restrict__ counter,
+                                                                 double *__restrict__ partials) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int NC = M::NC, NZ = NC + 1, REC = M::REC, P = REC > 16 ? REC + 1 : 17;  // odd row pitch (doubles)
+  static_assert(NZ <= 16, "one 16 x 16 accumulator tile");
+  __shared__ double s_z[kBlock / 64][64 * P];
+  __shared__ uint32_t s_c[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, c16 = lane & 15;
+  double sp[M::SP];
+  for (int j = 0; j < M::SP; j++) sp[j] = par[j];  // prepared by k_prepare; wave-uniform
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  uint32_t local = 0;
+  double *tile = s_z[wave];
+  const size_t total = end - begin, ntiles = (total + 63) / 64;
+  const size_t W = (size_t)gridDim.x * (kBlock / 64), w0 = (size_t)blockIdx.x * (kBlock / 64) + wave;
+  double nx[REC];
+  auto fetch = [&](size_t t) {  // tile t of the range as a coalesced stream: lane l takes doubles l, l + 64, ...
+    const size_t b0 = begin + t * 64;
+    const double *src = data + b0 * REC;
+    const size_t avail = (end - b0) * REC;  // doubles of the range from this tile on
+#pragma unroll
+    for (int j = 0; j < REC; j++) {
+      const size_t e = (size_t)lane + 64 * (size_t)j;
+      nx[j] = e < avail ? src[e] : 0.0;
+    }
+  };
+  if (w0 < ntiles) fetch(w0);
+  for (size_t t = w0; t < ntiles; t += W) {
+#pragma unroll
+    for (int j = 0; j < REC; j++) {
+      const int e = lane + 64 * j;
+      tile[(e / REC) * P + (e % REC)] = nx[j];
+    }
+    if (t + W < ntiles) fetch(t + W);          // in flight while this tile is evaluated
+    __builtin_amdgcn_wave_barrier();
+    double x[REC];
+#pragma unroll
+    for (int j = 0; j < REC; j++) x[j] = (j == 12) ? 0.0 : tile[lane * P + j];  // (slot 12: the int outputFormat)
+    __builtin_amdgcn_wave_barrier();
+    const size_t i = begin + t * 64 + lane;
+    const bool a = i < end && M::agree(sp, x, mc);
+    if (i < end) mask[i] = a ? 1 : 0;
+    const unsigned long long bal = __ballot(a);
+    const int cnt = __builtin_popcountll(bal);
+    const int r = __builtin_popcountll(bal & ((1ULL << lane) - 1ULL));  // my rank among the agreeing lanes
+    if (lane == 0) local += (uint32_t)cnt;
+    const int groups = (cnt + 3) >> 2;                                    // wave-uniform
+    if (groups == 0) continue;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (a) {
+        double arow[NC];
+        const double bj = M::row(x, j, arow);
+#pragma unroll
+        for (int c = 0; c < NC; c++) tile[r * P + c] = arow[c];
+        tile[r * P + NC] = bj;
+#pragma unroll
+        for (int c = NZ; c < 16; c++) tile[r * P + c] = 0.0;
+      }
+      if (lane < 48) {  // the rows that complete the last group of four
+        const int q = cnt + (lane >> 4);
+        if (q < 4 * groups) tile[q * P + c16] = 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int s = 0; s < groups; s++) {
+        const double v = tile[(4 * s + k) * P + c16];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // fold the four waves in order; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double *fold = &s_z[0][0];
+  if (lane == 0) s_c[wave] = local;
+  __syncthreads();
+  for (int w = 0; w < kBlock / 64; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int pos = (k + 4 * rg) * 16 + c16;
+        fold[pos] = (w == 0 ? 0.0 : fold[pos]) + acc[rg];
+      }
+    }
+    __syncthreads();
+  }
+  // -> the moment block layout of USModel::accumulate: {N, A^T A upper (packed row-major), A^T b}
+  const int t = threadIdx.x;
+  unsigned long long tot = 0;
+  for (int w = 0; w < kBlock / 64; w++) tot += s_c[w];
+  {
+    const int rr = t >> 4, cc = t & 15;
+    double *out = partials + (size_t)blockIdx.x * MOM_MAX;
+    if (rr < NC && cc < NC && rr <= cc) out[1 + rr * NC - rr * (rr - 1) / 2 + (cc - rr)] = fold[t];
+    if (rr < NC && cc == NC) out[1 + NC * (NC + 1) / 2 + rr] = fold[t];
+    if (t == 0) {
+      out[0] = (double)tot;
+      if (tot) atomicAdd(counter, tot);
+    }
+  }
+}
+
 // grid = nmom blocks of one wave.  out: host-visible pinned memory, 2 * nmom 8-byte GRANULES: moment k is published
 // as {high word | seq} and {low word | seq}, each one aligned 8-byte store -- a granule is valid the moment its tag
 // equals the sequence number of the evaluation the host is waiting for, so no fence, no ticket and no flag ordering

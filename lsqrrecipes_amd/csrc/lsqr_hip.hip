@@ -97,6 +97,7 @@ struct lsqr_ctx {
   int opt_dense_f32 = 1;  // dense scan filter at n = 64: 1 = fp32 matrix cores (worklist of ~1e-4 of the pairs, hypothesis
                           // fragments through an LDS ring + next tile in registers), 0 = fp64 matrix cores
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
   int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
   int opt_presorted = 0;   // index build: cells = runs of the UPLOAD order (experiments with other spatial orders)
   int opt_dense_dd = 1;    // dense fit: systems the elimination refuses are solved again from the rows in double-double
@@ -2124,7 +2125,20 @@ int launch_mask_moments(lsqr_ctx *c, size_t begin, size_t end, int *nmom, bool *
       nb = (int)((cnt + chunk - 1) / chunk);
       if (nb < 1) nb = 1;
       *nmom = M::NMOM;
-      {
+      bool done = false;
+      if constexpr (M::IS_US) {
+        // US calibrations with tight records: rows of the agreeing frames to the fp64 matrix cores (kernels.h)
+        if (c->opt_us_mask_mfma && c->stride == (size_t)M::REC && cnt > 0) {
+          nb = (int)std::min<size_t>(1024, (cnt + 4 * 64 * 2 - 1) / (4 * 64 * 2));  // >= two tiles per wave: one in flight
+          if (nb < 1) nb = 1;
+          ProfScope ps(c, KID_MASK);
+          hipLaunchKernelGGL((k_mask_moments_us_mfma<M>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data, begin, end,
+                             c->d_par, c->mc, c->d_mask, c->d_counter, c->d_partials);
+          HIPCHK(c, hipGetLastError());
+          done = true;
+        }
+      }
+      if (!done) {
         ProfScope ps(c, KID_MASK);
         hipLaunchKernelGGL((k_mask_moments<M>), dim3(nb), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
                            begin, end, chunk, c->d_par, c->d_vec, c->mc, c->d_mask, c->d_counter,
@@ -4230,6 +4244,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
     c->opt_dense_fast = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "us_mask_mfma")) {  // 0: per-lane accumulators (k_mask_moments<US>; r03, A/B knob)
+    c->opt_us_mask_mfma = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_refine")) {  // 0: cells are plain runs of the Morton order (r03; A/B knob)

@@ -149,18 +149,19 @@ def test_bench_gpus_2_launches_its_own_ranks():
         assert len(j["per_rank_hypotheses_per_s"]) == 2 and min(j["per_rank_hypotheses_per_s"]) > 0
 
 
-def test_bench_five_ranks_equal_one_rank_on_the_same_stream():
-    """rehearsal of the driver's multi-GPU run with as many ranks as the box allows on one card (the guard admits 6
-    processes on the GPU, the test runner is one of them; the 8-rank shape runs on CPU in tests/test_distributed.py):
-    five ranks share device 0, exchanges over gloo on device buffers.  The last step's winner, consensus count and
-    fit are those of ONE rank scanning the same 5 x H hypotheses per step."""
+def test_bench_four_ranks_equal_one_rank_on_the_same_stream():
+    """rehearsal of the driver's multi-GPU run with several ranks on the box's one card (its guard admits 6 processes
+    on the GPU at once; the test runner and whatever an earlier test left exiting count too, so four ranks; the
+    8-rank shape runs on CPU in tests/test_distributed.py): the ranks share device 0, exchanges over gloo on device
+    buffers.  The last step's winner, consensus count and fit are those of ONE rank scanning the same 4 x H hypotheses
+    per step."""
     env = {"LSQR_SHARE_GPU": "1", "LSQR_DIST_BACKEND": "gloo", "LSQR_STEP": "device"}
-    a = _run(["--workload", "plane", "--gpus", "5", "--streams", "1", "--batch", "512"], env=env)
-    _check(a, 1, n_gpus=5)
-    assert a["config"]["world_size"] == 5 and len(a["per_rank_hypotheses_per_s"]) == 5
+    a = _run(["--workload", "plane", "--gpus", "4", "--streams", "1", "--batch", "512"], env=env)
+    _check(a, 1, n_gpus=4)
+    assert a["config"]["world_size"] == 4 and len(a["per_rank_hypotheses_per_s"]) == 4
     assert min(a["per_rank_hypotheses_per_s"]) > 0
     assert abs(sum(a["per_rank_hypotheses_per_s"]) - a["value"]) < 0.35 * a["value"]   # each rank's own clock
-    b = _run(["--workload", "plane", "--streams", "1", "--batch", "2560"])
+    b = _run(["--workload", "plane", "--streams", "1", "--batch", "2048"])
     fa, fb = a["final_fit"], b["final_fit"]
     assert fa["winner_votes"] == fb["winner_votes"] and fa["inliers"] == fb["inliers"]
     pa, pb = fa["params"], fb["params"]

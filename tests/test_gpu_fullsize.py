@@ -302,8 +302,15 @@ def test_config5_us_iterative_fit_1M(ctx):
     got, fi = ctx.ls_fit(use_mask=True)
     assert fi.lm_nfev >= 30 and fi.lm_info in (1, 2, 3, 4, 5)
     assert (len(got) > 0) == (1 <= fi.lm_info <= 4)
-    # the batch's own fit ran the same minimisation (fixed-order sums: deterministic)
-    assert (fi.lm_info, fi.lm_nfev) == (info.fit.lm_info, info.fit.lm_nfev) and fi.cost == info.fit.cost
+    # the batch's own fit ran the same minimisation from the same analytic start -- to rounding: since r04 the batch
+    # takes the start's moment block from the matrix-core pass (k_mask_moments_us_mfma: another summation order), and
+    # 5000 evaluations along the valley carry a last-bit difference of the start into the 9th digit of the cost
+    assert (fi.lm_info, fi.lm_nfev) == (info.fit.lm_info, info.fit.lm_nfev)
+    assert abs(fi.cost - info.fit.cost) <= 1e-7 * info.fit.cost
+    ctx.set_option("us_mask_mfma", 0)   # ... and with the per-lane pass, bit for bit (fixed-order sums: deterministic)
+    r_lane = ctx.batch_fit(SEED, 0, H, want_consensus=True)
+    ctx.set_option("us_mask_mfma", 1)
+    assert r_lane["info"].fit.cost == fi.cost and np.array_equal(r_lane["consensus"], r["consensus"])
     assert (r["status"] == L.OK) == (len(got) > 0)
     x = ctx.last_iterate[:11]
     nlm = 11

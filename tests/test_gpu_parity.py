@@ -1784,8 +1784,58 @@ def test_fused_mask_and_moments_equal_two_kernels(ctx, model, dim, ls):
     assert np.array_equal(one["consensus"], two["consensus"])
     assert (one["info"].best_votes, one["info"].best_index, one["info"].fit.n_used) == \
            (two["info"].best_votes, two["info"].best_index, two["info"].fit.n_used)
-    assert np.array_equal(one["params"], two["params"])
+    if model == L.US_SINGLE:
+        # r04: the fused pass of the US calibrations accumulates on the fp64 matrix cores (another summation order:
+        # the block agrees to rounding); with the per-lane accumulators ("us_mask_mfma" 0) it is bit-identical
+        assert np.allclose(one["params"], two["params"], rtol=1e-9, atol=1e-9)
+        ctx.set_option("us_mask_mfma", 0)
+        lane = ctx.batch_fit(31, 0, 700, want_consensus=True)
+        ctx.set_option("us_mask_mfma", 1)
+        assert np.array_equal(lane["params"], two["params"]) and np.array_equal(lane["consensus"], two["consensus"])
+    else:
+        assert np.array_equal(one["params"], two["params"])
     assert one["consensus"].sum() == one["info"].fit.n_used
+
+
+@pytest.mark.parametrize("model,gen,n", [(L.US_SINGLE, "single", 70_001), (L.US_SINGLE, "single", 63),
+                                         (L.US_SINGLE, "single", 1_000_003), (L.US_POINTER, "pointer", 50_017)])
+def test_us_mask_and_moments_on_the_matrix_cores(ctx, model, gen, n):
+    """k_mask_moments_us_mfma (the fused mask + analytic moment block of the batch entry points) against the per-lane
+    kernel and the oracle: consensus mask bit-identical, count equal, the block and the analytic fit equal to rounding
+    (another summation order); ragged sizes (partial last tile, fewer frames than one tile) and a slice [begin, end)
+    of the upload as the multi-GPU step uses it"""
+    data = (synth.us_single_fast if gen == "single" else synth.us_pointer)(n, 0.3, seed=9)[0]
+    omodel = O.US_SINGLE if gen == "single" else O.US_POINTER
+    oc = O.cfg(omodel, 0, 3.0, 0)
+    ctx.set_model(model, 0, 3.0, L.LS_ANALYTIC).upload(data)
+    H = 256 if n > 1000 else 64
+    res = {}
+    for mf in (1, 0):
+        ctx.set_option("us_mask_mfma", mf)
+        r = ctx.batch_fit(5, 0, H, want_consensus=True)
+        assert r["status"] == L.OK
+        bi = int(r["info"].best_index)
+        slices = []
+        if n > 1000:
+            for lo, hi in ((0, n), (n // 3 + 7, n - 11), (64, 64 + 129)):
+                par, origin, blk, cnt = ctx.winner_moments(5, bi, lo, hi)
+                slices.append((par.copy(), blk.copy(), cnt))
+        res[mf] = (r, bi, slices)
+    ctx.set_option("us_mask_mfma", 1)
+    (r1, b1, s1), (r0, b0, s0) = res[1], res[0]
+    assert b1 == b0 and np.array_equal(r1["consensus"], r0["consensus"])
+    assert r1["info"].fit.n_used == r0["info"].fit.n_used == int(r1["consensus"].sum())
+    assert np.allclose(r1["params"], r0["params"], rtol=1e-9, atol=1e-9)
+    wpar = ctx.hypothesis(b1)[0] if False else None
+    ctx.hypotheses_sample(5, b1, 1)
+    wpar, _ = ctx.hypothesis(0)
+    wcnt, wmask = O.scan(oc, wpar, data)
+    assert wcnt == r1["info"].fit.n_used and np.array_equal(r1["consensus"], wmask)
+    want = O.ls(oc, data, wmask)
+    assert len(want) and np.allclose(r1["params"], want, rtol=1e-6, atol=1e-6)
+    for (p1, k1, c1), (p0, k0, c0) in zip(s1, s0):
+        assert c1 == c0 and np.array_equal(p1, p0) and k1[0] == k0[0] == c1
+        assert np.allclose(k1, k0, rtol=1e-11, atol=1e-9 * max(1.0, np.abs(k0).max()))
 
 
 # ---- bounded scan (cells.h: hypotheses that cannot win are not counted) ------------------------------------------
