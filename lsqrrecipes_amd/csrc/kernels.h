@@ -576,6 +576,42 @@ __global__ __launch_bounds__(kBlock) void k_compact_write(const double *__restri
   }
 }
 
+// the same compaction into TILES of 64 records stored field-major -- field k of record q at
+// dst[((q >> 6) * ND + k) * 64 + (q & 63)] -- so that the matrix-core LM pass (k_lm_pass_mfma_t) reads a wave's 64
+// records with ND perfectly coalesced loads, lane = record, and needs no transposition through LDS
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_compact_write_tiles(const double *__restrict__ data, size_t stride,
+                                                                const uint8_t *__restrict__ mask, size_t n,
+                                                                size_t chunk, const uint32_t *__restrict__ offs,
+                                                                double *__restrict__ dst) {
+  __shared__ uint32_t s_w[kBlock / 64];
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  size_t base = offs[blockIdx.x];
+  for (size_t i0 = lo; i0 < hi; i0 += kBlock) {
+    const size_t i = i0 + threadIdx.x;
+    const bool m = i < hi && mask[i];
+    const unsigned long long b = __ballot(m);
+    const uint32_t before = (uint32_t)__builtin_popcountll(b & ((1ULL << lane) - 1ULL));
+    if (lane == 0) s_w[wave] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+      if (w < wave) woff += s_w[w];
+      tot += s_w[w];
+    }
+    if (m) {
+      const double *src = data + i * stride;
+      const size_t q = base + woff + before;
+      double *d = dst + (q >> 6) * (size_t)(ND * 64) + (q & 63);
+#pragma unroll
+      for (int k = 0; k < ND; k++) d[(size_t)k * 64] = src[k];
+    }
+    base += tot;
+    __syncthreads();
+  }
+}
+
 // One Levenberg-Marquardt evaluation without a host synchronisation: k_lm_pass is the (masked) reduction of
 // k_moments<M, AccLm<M>> at the trial point `xk` -- passed BY VALUE, so consecutive evaluations need no staging
 // copy -- and k_lm_publish, next on the stream, sums the block partials (one wave per moment, in parallel across
@@ -735,6 +771,69 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass_mfma(const double *__restric
     if (r < NL && cc == NL) out[1 + NL * (NL + 1) / 2 + r] = fold[t];
     if (r == NL && cc == NL) out[0] = fold[t];
   }
+}
+
+// The matrix-core LM pass over the TILE layout of k_compact_write_tiles (r04): lane = record, field j of the wave's
+// tile is one coalesced 512-byte load; the NEXT tile's loads are issued before the current rows are formed, so the
+// memory latency of a tile is covered by the arithmetic of the one before (k_lm_pass_mfma started every tile by
+// waiting for its own loads and moved every record through LDS twice).  Same rows, same accumulation, same block.
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_lm_pass_mfma_t(const double *__restrict__ tiles, size_t n,
+                                                           typename M::LmCoef coef, double *__restrict__ partials) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int NZ = M::NLM + 1, P = 17, REC = M::REC;
+  static_assert(NZ <= 16, "one 16 x 16 accumulator tile");
+  __shared__ double s_z[kBlock / 64][64 * P];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, c16 = lane & 15;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  double *tile = s_z[wave];
+  const size_t ntiles = (n + 63) / 64;
+  const size_t W = (size_t)gridDim.x * (kBlock / 64), w0 = (size_t)blockIdx.x * (kBlock / 64) + wave;
+  double nx[REC];
+  auto fetch = [&](size_t t) {
+    const double *src = tiles + t * (size_t)(REC * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < REC; j++) nx[j] = (j == 12 && M::IS_US) ? 0.0 : src[(size_t)j * 64];
+  };
+  if (w0 < ntiles) fetch(w0);
+  for (size_t t = w0; t < ntiles; t += W) {
+    double x[REC];
+#pragma unroll
+    for (int j = 0; j < REC; j++) x[j] = nx[j];
+    if (t + W < ntiles) fetch(t + W);
+    double z[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) z[j] = 0.0;
+    if (t * 64 + lane < n) M::lm_row(x, coef, z);   // (lanes past the end of the last tile: a zero row)
+#pragma unroll
+    for (int j = 0; j < 16; j++) tile[lane * P + j] = z[j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const double v = tile[(4 * s + k) * P + c16];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  double *fold = &s_z[0][0];
+  __syncthreads();
+  for (int w = 0; w < kBlock / 64; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int pos = (k + 4 * rg) * 16 + c16;
+        fold[pos] = (w == 0 ? 0.0 : fold[pos]) + acc[rg];
+      }
+    }
+    __syncthreads();
+  }
+  constexpr int NL = M::NLM;
+  const int t = threadIdx.x;
+  const int r = t >> 4, cc = t & 15;
+  double *out = partials + (size_t)blockIdx.x * MOM_MAX;
+  if (r < NL && cc < NL && r <= cc) out[1 + r * NL - r * (r - 1) / 2 + (cc - r)] = fold[t];
+  if (r < NL && cc == NL) out[1 + NL * (NL + 1) / 2 + r] = fold[t];
+  if (r == NL && cc == NL) out[0] = fold[t];
 }
 
 // K3 + K4 of the US calibrations on the matrix cores (r04).  k_mask_moments<US> kept the 91 sums of the analytic

@@ -97,6 +97,7 @@ struct lsqr_ctx {
   int opt_dense_f32 = 1;  // dense scan filter at n = 64: 1 = fp32 matrix cores (worklist of ~1e-4 of the pairs, hypothesis
                           // fragments through an LDS ring + next tile in registers), 0 = fp64 matrix cores
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_lm_tiles = 1;      // matrix-core LM pass: compacted consensus set in field-major tiles, next tile in flight
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
   int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
   int opt_presorted = 0;   // index build: cells = runs of the UPLOAD order (experiments with other spatial orders)
@@ -1852,6 +1853,8 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           // matrix-core pass (US: thousands of evaluations) reads compacted records only and compacts at once.
           constexpr int kCompactAfter = 8;
           const bool mfma_pass = c->opt_lm_mfma && M::NLM >= 8;
+          const bool tile_layout = mfma_pass && c->opt_lm_tiles;   // compacted set in tiles of 64 records, field-major
+          bool tiles = false;                                      // ... and it has been written that way
           const double *lm_data = c->d_data;
           size_t lm_stride = c->stride, cnt = c->n;
           bool through_mask = use_mask;
@@ -1867,19 +1870,29 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
             HIPCHK(c, hipMemcpyAsync(pin + 200, d_off + cb, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, sync_stream(c));
             cnt = *(const uint32_t *)(pin + 200);
-            int st2 = ensure(c, &c->d_lmrec, &c->lmrec_cap, std::max<size_t>(cnt, 1) * M::ND);
+            int st2 = ensure(c, &c->d_lmrec, &c->lmrec_cap, ((std::max<size_t>(cnt, 1) + 63) & ~(size_t)63) * M::ND);
             if (st2 != LSQR_OK) return st2;
-            hipLaunchKernelGGL((k_compact_write<M::ND>), dim3(cb), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
-                               c->d_mask, c->n, cchunk, d_off, c->d_lmrec);
+            if (tile_layout)  // the matrix-core pass reads tiles of 64 records stored field-major (kernels.h)
+              hipLaunchKernelGGL((k_compact_write_tiles<M::ND>), dim3(cb), dim3(kBlock), 0, c->stream, c->d_data,
+                                 c->stride, c->d_mask, c->n, cchunk, d_off, c->d_lmrec);
+            else
+              hipLaunchKernelGGL((k_compact_write<M::ND>), dim3(cb), dim3(kBlock), 0, c->stream, c->d_data, c->stride,
+                                 c->d_mask, c->n, cchunk, d_off, c->d_lmrec);
             HIPCHK(c, hipGetLastError());
             lm_data = c->d_lmrec;
             lm_stride = M::ND;
             through_mask = false;
+            tiles = tile_layout;
             return LSQR_OK;
           };
           int nb = 1;
           size_t chunk = 0;
           auto shape = [&]() {
+            if (tiles) {   // four tiles per wave and more: one in flight behind the one being evaluated
+              nb = (int)std::min<size_t>(512, std::max<size_t>(1, (cnt + 1023) / 1024));
+              chunk = 0;
+              return;
+            }
             nb = grid_for(cnt, kBlock * (mfma_pass ? 2 : 8), kMaxPartials);
             chunk = (cnt + nb - 1) / nb;
             chunk = (chunk + kBlock - 1) / kBlock * kBlock;
@@ -1909,7 +1922,12 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
                 // the matrix-core pass pays when the (J | f) rows are wide (US: 12 / 9 columns, 78 / 45 sums); for the
                 // sphere's 5 columns the 16 x 16 tile is mostly padding and the instruction time alone (25 us at 3.8 M
                 // points) exceeds the per-lane version's whole pass
-                if (mfma_pass) {
+                if (mfma_pass && tiles) {
+                  typename M::LmCoef coef;
+                  M::lm_coef(xk.x, coef);
+                  hipLaunchKernelGGL((k_lm_pass_mfma_t<M>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, cnt, coef,
+                                     c->d_partials);
+                } else if (mfma_pass) {
                   typename M::LmCoef coef;
                   M::lm_coef(xk.x, coef);
                   hipLaunchKernelGGL((k_lm_pass_mfma<M>), dim3(nb), dim3(kBlock), 0, c->stream, lm_data, lm_stride,
@@ -4244,6 +4262,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
     c->opt_dense_fast = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_tiles")) {  // 0: the r03 pass over the record-major compacted set (A/B knob)
+    c->opt_lm_tiles = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "us_mask_mfma")) {  // 0: per-lane accumulators (k_mask_moments<US>; r03, A/B knob)
