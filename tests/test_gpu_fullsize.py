@@ -112,6 +112,11 @@ def _point_model_fullsize(ctx, model, omodel, gen, ls_type, expect_cell):
     for h in checked:
         if valid[h]:
             assert votes0[h] == O.scan(oc, par[h], data)[0], "full count differs at h=%d" % h
+    # r04: not a sample -- EVERY one of the 4096 full counts at 10 M observations against the oracle (orc_scan on the
+    # host's threads: 4096 x 22 ms of one core)
+    all_want = O.scan_many(oc, par, valid, data)
+    bad = np.flatnonzero(np.where(valid0 > 0, votes0, 0) != all_want)
+    assert len(bad) == 0, "full count differs from the oracle at %d of %d hypotheses (first h=%d)" % (len(bad), H, bad[0])
     assert np.all(votes <= votes0) and np.all((votes == votes0) | (votes == 0))
     assert r0["info"].best_index == info.best_index and r0["info"].best_votes == info.best_votes
     assert np.array_equal(r0["consensus"], r["consensus"]) and np.array_equal(r0["params"], r["params"])
@@ -194,6 +199,8 @@ def test_config4_dense_2Mx64_on_bench_path(ctx):
     for h in checked:
         assert valid[h]
         assert votes[h] == O.scan(oc, par[h], rows)[0], "vote count differs at h=%d" % h
+    all_want = O.scan_many(oc, par, valid, rows)       # r04: all 1024 full counts over the 2 M rows, not a sample
+    assert np.array_equal(np.where(valid > 0, votes, 0), all_want)
     for h in checked[:3]:   # the 64 x 64 minimal solve against the oracle's SVD pseudo-inverse
         want = O.estimate(oc, rows[subs[h]])
         assert len(want) == ncol
@@ -240,6 +247,8 @@ def test_config5_us_1M_frames_on_bench_path(ctx):
             continue
         assert np.allclose(par[h], want, rtol=REL, atol=REL * np.abs(want).max())
         assert votes[h] == O.scan(oc, par[h], rec)[0], "vote count differs at h=%d" % h
+    all_want = O.scan_many(oc, par, valid, rec)        # r04: all 4096 full counts over the 1 M frames, not a sample
+    assert np.array_equal(np.where(valid > 0, votes, 0), all_want)
     wcnt, wmask = O.scan(oc, par[bi], rec)
     assert wcnt == info.best_votes == info.fit.n_used
     assert np.array_equal(r["consensus"], wmask)
