@@ -71,6 +71,10 @@ inline double ord_u64_inv(unsigned long long o) {
 // bands (k_absmax's result: +inf as soon as one record is not finite, which switches the filters off).
 // Two stages: one row of 8 values per block, then a single-block reduction (same-address atomics cost
 // ~14 ns each: a few thousand of them on one cache line would take longer than the pass itself).
+// 46 us for 240 MB at 10 M points = 0.65 of the 8 TB/s peak (r04, HIP events around the kernel: tools/bounds_time.py;
+// r03 quoted 67 us / 0.44 because its profile scope included the final reduction, the copy back and the host
+// synchronisation).  A flat variant -- the array as one run of 16-byte pieces, fully coalesced, two (min, max) pairs per
+// lane -- was built and measured no faster (49 - 52 us): the record-per-lane reads are not what limits the pass.
 struct BoundsRow {
   unsigned long long mn[3], mx[3], amax, nonfinite;
 };
