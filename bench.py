@@ -113,6 +113,8 @@ def parse(argv=None):
                     "legs (tests; 1 = the BASELINE sizes)")
     ap.add_argument("--cpu-seconds", type=float, default=0.0, help="budget of the CPU full-count sample "
                     "(0 = 4 s for the headline, 3 s per leg)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="lsqr_set_option on every context of the run (A/B runs: scan_refine=0, scan_pairs=2, ...)")
     ap.add_argument("--detail", default="", help="file the FULL record of the run is written to (work models, per-kernel "
                     "tables, notes, the legs of the other configs); default bench_detail.json next to bench.py.  The "
                     "last stdout line is the compact headline only")
@@ -485,7 +487,7 @@ class Run:
         self.next_step = 0
         self.side_step = 1 << 20
         self.nfev_total = 0        # LM evaluations of the steps run so far (iterative fits)
-        self.full_pairs = w == "plane" and a.batch >= 1024   # cells.h: PlaneCell::FULL_COUNT_PAIRS
+        self.full_pairs = w in ("plane", "sphere") and a.batch >= 1024   # cells.h: <model>Cell::FULL_COUNT_PAIRS
         self.idx = None
 
     def _new_ctx(self):
@@ -496,6 +498,9 @@ class Run:
             c.set_option("scan_filter", 0)
         if a.no_index:
             c.set_option("scan_index", 0)
+        for kv in a.option:
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
         return c
 
     def all_ctx(self):

@@ -727,6 +727,12 @@ struct SphereCell {
   // bounded against 1.36 / 0.41 ms with 256 (r03, plain Morton runs: 256 was the faster one, 1.9 against 2.1 ms)
   enum { DEFAULT_CELL = 512, LDS_BROADCAST = 1 };
   enum { USE_BOUND = 1, BOUND_MERGE = 4 };  // the sphere's box test is 61 instructions: 0.29 -> 0.08 ms, 0.87 -> 0.70 ms / step
+  // r04, refined index: plain scans of >= 1024 hypotheses through the counted, statically balanced k_scan_pairs as
+  // well (tools/ab_pairs.py, 4096 x 10 M: 1.01 ms against 1.27 - 1.33 ms with k_scan_cells' dynamic tiles; on plain
+  // Morton runs, r03, the dynamic tiles were the faster ones).  bench.py --option scan_pairs=2 against the default on
+  // the same box: one stream 2.40 -> 2.63 M hypotheses/s; four streams 3.6 - 3.7 M either way (launches of the
+  // dynamic kernel share the chip more gracefully than four statically split ones)
+  enum { FULL_COUNT_PAIRS = 1 };
   struct Hyp {
     double c[3], mid;
     float half;
@@ -817,6 +823,9 @@ struct LineCell {
   // 50 % outliers) are 99 % of the work with or without the bound; with the statically balanced second level the
   // bounded path is the faster one all the same (2.17 against 2.34 ms per 4096 hypotheses)
   enum { USE_BOUND = 1, BOUND_MERGE = 4 };
+  // (r04, refined index: a plain scan through k_scan_pairs is 1.60 - 1.67 ms against 1.75 - 1.85 ms with k_scan_cells
+  // -- tools/ab_pairs.py -- but its counting pass costs the step what the scan gains: bench.py --option scan_pairs=1
+  // gives the same hypotheses/s on one stream and on four; the line keeps the dynamic tiles)
   struct Hyp {
     double n[3], a[3];
     float nf[3], rho, eh;
