@@ -101,6 +101,40 @@ __global__ __launch_bounds__(256) void k_mask_dense(const double *__restrict__ d
   if (lane == 0 && local) atomicAdd(counter, (unsigned long long)local);
 }
 
+// K1 dense, fast path (r04): FOUR hypotheses per workgroup, one wave each, the n x n system in the wave's own LDS
+// area, wave_gepp_solve (wave_linalg.h) -- bit-identical to block_gepp_solve, no workgroup barriers: 0.30 -> ~0.05 ms
+// per 1024 hypotheses at n = 64.  A system the elimination refuses (a pivot below 1e-8 max|A|: near the rank
+// decision) is marked valid[h] = 2 and k_estimate_dense, launched behind this kernel with `only_marked`, takes it
+// through the SVD pseudo-inverse exactly as before.
+__global__ __launch_bounds__(256) void k_estimate_dense_w4(const double *__restrict__ data, size_t stride, size_t nobs,
+                                                          const uint32_t *__restrict__ subsets, uint32_t H, int n,
+                                                          int sp_stride, double *__restrict__ hparams,
+                                                          uint8_t *__restrict__ valid) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t h = blockIdx.x * 4 + wave;
+  if (h >= H) return;                              // wave-uniform; no workgroup barrier below
+  const int lda = n | 1;
+  double *A = sm + (size_t)wave * (n * lda + 2 * n), *b = A + n * lda, *x = b + n;
+  bool in_range = true;
+  for (int l = 0; l < n; l++) {                    // lane = column: one coalesced read of a row's n doubles
+    size_t i = subsets[(size_t)h * n + l];
+    if (i >= nobs) {
+      in_range = false;
+      i = 0;
+    }
+    if (lane < n) A[lane * lda + l] = data[i * stride + lane];
+    if (lane == 0) b[l] = data[i * stride + n];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const bool solved = wave_gepp_solve(n, A, lda, b, x);
+  __builtin_amdgcn_wave_barrier();
+  const bool ok = solved && in_range;
+  const double qnan = __builtin_nan("");
+  for (int j = lane; j < sp_stride; j += 64) hparams[(size_t)h * sp_stride + j] = j < n ? (ok ? x[j] : qnan) : 0.0;
+  if (lane == 0) valid[h] = ok ? 1 : (in_range ? 2 : 0);   // 2: to the SVD path; out-of-range subset: invalid either way
+}
+
 // K1 dense: one wave per hypothesis; n x n system in LDS; x = pinv(A) b, singular if any
 // sigma <= EPS (DenseLinear...Estimator.hxx:17-49)
 __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict__ data,
@@ -108,11 +142,12 @@ __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict
                                                        const uint32_t *__restrict__ subsets,
                                                        uint32_t H, int n, int sp_stride, int fast,
                                                        double *__restrict__ hparams,
-                                                       uint8_t *__restrict__ valid) {
+                                                       uint8_t *__restrict__ valid, int only_marked) {
   extern __shared__ double sm[];
   __shared__ int s_bad;
   const int lane = threadIdx.x;
   const uint32_t h = blockIdx.x;
+  if (only_marked && valid[h] != 2) return;      // (behind k_estimate_dense_w4: the systems its elimination refused)
   const int lda = n | 1;
   double *A = sm, *V = A + n * lda, *b = V + n * lda, *cw = b + n, *x = cw + n;
   bool in_range = true;
@@ -1190,7 +1225,18 @@ __global__ __launch_bounds__(256) void k_solve_dense(const double *__restrict__ 
   int rank = n;
   // (with the rows at hand the elimination is only trusted while eps cond(G) stays far below the 1e-6 bar: pivots
   // above 1e-6 max|G|; without them, as for the minimal solves, above 1e-8)
-  if (!fast || !block_gepp_solve<256>(n, G, lda, rhs, x, flag ? 1e-6 : 1e-8)) {
+  // (r04: the elimination by ONE wave -- wave_linalg.h: wave_gepp_solve, bit-identical to block_gepp_solve<256> --
+  // while the other three wait: 0.14 -> ~0.05 ms for the 64 x 64 system, the workgroup version spends its time in
+  // barriers)
+  __shared__ int s_solved;
+  if (fast) {
+    if (tid < 64) {
+      const bool okw = wave_gepp_solve(n, G, lda, rhs, x, flag ? 1e-6 : 1e-8);
+      if (tid == 0) s_solved = okw ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (!fast || !s_solved) {
     if (flag) {              // the rows are at hand: the double-double route decides (workgroup-uniform branch)
       if (tid == 0) {
         *flag = 1;

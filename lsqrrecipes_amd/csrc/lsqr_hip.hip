@@ -101,6 +101,7 @@ struct lsqr_ctx {
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
   int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
   int opt_presorted = 0;   // index build: cells = runs of the UPLOAD order (experiments with other spatial orders)
+  int opt_dense_wave = 1;  // dense minimal solves: elimination by one wave per system, four per workgroup (dense.h)
   int opt_dense_dd = 1;    // dense fit: systems the elimination refuses are solved again from the rows in double-double
   double *d_ddpart = nullptr;  // partial double-double Gram blocks of k_gram_dd_dense (allocated on first use)
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
@@ -527,10 +528,26 @@ int run_estimate(lsqr_ctx *c) {
       hipLaunchKernelGGL((k_prepare_f32_us<M>), dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0,
                          c->stream, c->d_hparams, (uint32_t)c->H, c->mc, c->d_hparams_f32);
     } else if constexpr (M::IS_DENSE) {
-      hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256),
-                         dense_lds_bytes(c->cfg.dim), c->stream, c->d_data, c->stride, c->n,
-                         c->d_subsets, (uint32_t)c->H, (int)c->cfg.dim, (int)M::SP,
-                         c->opt_dense_fast, c->d_hparams, c->d_valid);
+      const int n = (int)c->cfg.dim;
+      if (c->opt_dense_fast && c->opt_dense_wave) {
+        // fast path: four hypotheses per workgroup, one wave each (dense.h: k_estimate_dense_w4); what its elimination
+        // refuses is marked and taken through the SVD pseudo-inverse by the workgroup kernel behind it
+        const size_t lds = sizeof(double) * 4 * ((size_t)n * (n | 1) + 2 * n);
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute((const void *)k_estimate_dense_w4, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(double) * 4 * (64 * 65 + 128)));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(k_estimate_dense_w4, dim3((unsigned)((c->H + 3) / 4)), dim3(256), lds, c->stream, c->d_data,
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, n, (int)M::SP, c->d_hparams, c->d_valid);
+        hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256), dense_lds_bytes(n), c->stream, c->d_data,
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, n, (int)M::SP, 0, c->d_hparams, c->d_valid, 1);
+      } else {
+        hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256), dense_lds_bytes(n), c->stream, c->d_data,
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, n, (int)M::SP, c->opt_dense_fast,
+                           c->d_hparams, c->d_valid, 0);
+      }
     } else if constexpr (M::IS_US) {
       hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
                          c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
@@ -4284,6 +4301,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   if (!strcmp(name, "scan_presorted")) {  // cells are runs of the upload order (set before the index is built)
     c->opt_presorted = value != 0;
     drop_index(c);
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "dense_wave_solve")) {  // 0: one workgroup per minimal solve (r03; bit-identical results, A/B)
+    c->opt_dense_wave = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_dd")) {  // 0: an ill-conditioned dense fit stays on the Gram block (r03 behaviour; A/B)

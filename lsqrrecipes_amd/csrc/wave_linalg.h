@@ -373,6 +373,87 @@ __device__ inline bool block_gepp_solve(int n, double *A, int lda, double *b, do
   return true;
 }
 
+// The same elimination by ONE wave (r04): the system in LDS is private to the wave, lane = row (n <= 64), no
+// workgroup barriers -- the LDS serves a wave's requests in order, a compiler barrier between dependent phases is all
+// it takes.  block_gepp_solve<256> spends its time in barriers (five per pivot step, 64 steps: 0.30 ms per 64 x 64
+// system whatever the chip is doing); here a pivot step is a butterfly over the column, a row swap, and n - k - 1
+// updates of one column each (one broadcast read of the pivot row's element, one read, one fma, one write per lane).
+// Same pivot rule, same multipliers, same fma updates, same back substitution: the result is BIT-IDENTICAL to
+// block_gepp_solve's (tests/test_gpu_dense_fused.py compares them).  Four systems per workgroup of 256 threads.
+__device__ inline bool wave_gepp_solve(int n, double *A, int lda, double *b, double *x, double piv_rel = 1e-8) {
+  const int lane = threadIdx.x & 63;
+  double am = 0.0;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const double v = fabs(A[(idx / n) * lda + idx % n]);
+    am = v > am ? v : (v == v ? am : INFINITY);  // NaN poisons the fast path
+  }
+  am = wave_max(am);
+  if (!(am <= 1e150)) return false;
+  const double tol = piv_rel * (am > 1.0 ? am : 1.0);
+  for (int k = 0; k < n; k++) {
+    // pivot search in column k: the butterfly of block_gepp_solve (largest |a|, ties to the lower row)
+    double v = (lane >= k && lane < n) ? fabs(A[k * lda + lane]) : -1.0;
+    int idx = lane;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o);
+      const int oi = __shfl_xor(idx, o);
+      if (ov > v || (ov == v && oi < idx)) v = ov, idx = oi;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(idx);
+    if (!(v > tol)) return false;               // (v is the same in every lane after the butterfly)
+    const double rpiv = 1.0 / A[k * lda + p];
+    if (p != k) {
+      if (lane >= k && lane < n) {
+        const double t = A[lane * lda + k];
+        A[lane * lda + k] = A[lane * lda + p];
+        A[lane * lda + p] = t;
+      }
+      if (lane == 0) {
+        const double t = b[k];
+        b[k] = b[p];
+        b[p] = t;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool below = lane > k && lane < n;
+    double mult = 0.0;
+    if (below) {
+      mult = A[k * lda + lane] * rpiv;
+      A[k * lda + lane] = mult;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double bk = b[k];
+    // eight columns per round: all their reads are issued before the first fma (a column at a time ran at the LDS
+    // latency: read, fma, write, read ...)
+    int j = k + 1;
+    for (; j + 8 <= n; j += 8) {
+      double akj[8], aij[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        akj[q] = A[(j + q) * lda + k];          // the pivot row's element: one address for the wave
+        aij[q] = A[(j + q) * lda + (below ? lane : k)];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (below) A[(j + q) * lda + lane] = fma(-mult, akj[q], aij[q]);
+    }
+    for (; j < n; j++) {
+      const double akj = A[j * lda + k];
+      if (below) A[j * lda + lane] = fma(-mult, akj, A[j * lda + lane]);
+    }
+    if (below) b[lane] = fma(-mult, bk, b[lane]);
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int k = n - 1; k >= 0; k--) {  // back substitution
+    const double xk = b[k] / A[k * lda + k];
+    if (lane == 0) x[k] = xk;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < k) b[lane] = fma(-A[k * lda + lane], xk, b[lane]);
+    __builtin_amdgcn_wave_barrier();
+  }
+  return true;
+}
+
 __device__ inline int wave_pinv_solve(int m, int n, double *A, int lda, double *V, int ldv,
                                       const double *b, double tol_abs, double tol_rel, double *x,
                                       double *cwork) {

@@ -75,3 +75,37 @@ def test_fused_mask_rows_on_the_threshold():
         c.set_model(L.DENSE, n, 0.1, 0).upload(rows)
         mask, cnt = c.mask(x)
         assert cnt == want_cnt and np.array_equal(mask, want_mask)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("ncol,m,H", [(5, 4000, 300), (8, 20_000, 512), (33, 30_000, 257), (64, 60_000, 1024)])
+def test_dense_minimal_solves_by_one_wave_are_bit_identical(ctx, ncol, m, H):
+    """r04: k_estimate_dense_w4 (four hypotheses per workgroup, elimination by one wave each: wave_gepp_solve) against
+    the workgroup kernel it replaces on the fast path -- every hypothesis bit for bit, validity included; subsets with
+    a repeated row (singular: the elimination refuses, the SVD pseudo-inverse decides) take the same path as before;
+    and the final fit's elimination (k_solve_dense) by one wave gives the same bits as well"""
+    rows = synth.dense(m, ncol, 0.2, seed=40 + ncol)[0]
+    ctx.set_model(L.DENSE, ncol, 0.1).upload(rows)
+    subs = O.ctr_subsets(77, 0, H, m, ncol)
+    subs[3, 1] = subs[3, 0]                       # a repeated row: rank deficient -> invalid
+    subs[H - 1, ncol - 1] = subs[H - 1, 0]
+    out = {}
+    for wave in (1, 0):
+        ctx.set_option("dense_wave_solve", wave)
+        ctx.hypotheses_from_subsets(subs)
+        par, valid, _ = ctx.hypotheses(votes=False)
+        ctx.scan()
+        votes = ctx.hypotheses(params=False)[2].copy()
+        r = ctx.batch_fit(5, 0, min(H, 256), want_consensus=True)
+        out[wave] = (par.copy(), valid.copy(), votes, r["params"].copy(), r["info"].best_index)
+    ctx.set_option("dense_wave_solve", 1)
+    (p1, v1, k1, f1, b1), (p0, v0, k0, f0, b0) = out[1], out[0]
+    assert np.array_equal(v1, v0) and not v1[3] and not v1[H - 1] and v1.sum() >= H - 4
+    assert np.array_equal(p1[v1 > 0], p0[v0 > 0])            # bit for bit
+    assert np.array_equal(k1, k0) and b1 == b0 and np.array_equal(f1, f0)
