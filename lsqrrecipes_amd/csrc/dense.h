@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_estimate_dense_w4(const double *__restr
                                                           uint8_t *__restrict__ valid) {
   extern __shared__ double sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t h = blockIdx.x * 4 + wave;
+  const uint32_t h = blockIdx.x * (blockDim.x >> 6) + wave;   // blockDim.x / 64 systems per workgroup
   if (h >= H) return;                              // wave-uniform; no workgroup barrier below
   const int lda = n | 1;
   double *A = sm + (size_t)wave * (n * lda + 2 * n), *b = A + n * lda, *x = b + n;

@@ -532,14 +532,15 @@ int run_estimate(lsqr_ctx *c) {
       if (c->opt_dense_fast && c->opt_dense_wave) {
         // fast path: four hypotheses per workgroup, one wave each (dense.h: k_estimate_dense_w4); what its elimination
         // refuses is marked and taken through the SVD pseudo-inverse by the workgroup kernel behind it
-        const size_t lds = sizeof(double) * 4 * ((size_t)n * (n | 1) + 2 * n);
+        const int wpb = c->opt_dense_wave == 2 ? 2 : 4;   // systems per workgroup (2: 68 KB of LDS at n = 64, A/B)
+        const size_t lds = sizeof(double) * wpb * ((size_t)n * (n | 1) + 2 * n);
         static bool attr_set = false;
         if (!attr_set) {
           (void)hipFuncSetAttribute((const void *)k_estimate_dense_w4, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(double) * 4 * (64 * 65 + 128)));
           attr_set = true;
         }
-        hipLaunchKernelGGL(k_estimate_dense_w4, dim3((unsigned)((c->H + 3) / 4)), dim3(256), lds, c->stream, c->d_data,
+        hipLaunchKernelGGL(k_estimate_dense_w4, dim3((unsigned)((c->H + wpb - 1) / wpb)), dim3(64 * wpb), lds, c->stream, c->d_data,
                            c->stride, c->n, c->d_subsets, (uint32_t)c->H, n, (int)M::SP, c->d_hparams, c->d_valid);
         hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256), dense_lds_bytes(n), c->stream, c->d_data,
                            c->stride, c->n, c->d_subsets, (uint32_t)c->H, n, (int)M::SP, 0, c->d_hparams, c->d_valid, 1);
@@ -4304,7 +4305,7 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_wave_solve")) {  // 0: one workgroup per minimal solve (r03; bit-identical results, A/B)
-    c->opt_dense_wave = value != 0;
+    c->opt_dense_wave = value;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_dd")) {  // 0: an ill-conditioned dense fit stays on the Gram block (r03 behaviour; A/B)
