@@ -956,8 +956,9 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
 #pragma unroll
       for (int k = 0; k < NV; k++) fp[k].x = rb[k], fp[k].y = rb[k];
       na.x = -rb[NB - 2], na.y = -rb[NB - 2];
-      // (the same value in every lane; said explicitly so that the compare below takes it from a scalar register)
-      band = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rb[NB - 1]));
+      // (the same value in every lane: compared vector against vector -- r04; moving it to a scalar register first was
+      // one of the pair's vector instructions)
+      band = __builtin_bit_cast(uint32_t, rb[NB - 1]);
     } else {
 #pragma unroll
       for (int k = 0; k < NV; k++) {
@@ -975,7 +976,7 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
     // rest of the body is 13 instructions.  Two compares per value with the mask logic and the counts on the scalar
     // unit measured SLOWER in r02: the scalar unit is nearly as busy as the vector unit in this loop.)
     unsigned long long in[2 * PP];
-    uint32_t dmin = 0xFFFFFFFFu;
+    uint32_t dmin = 0;
     v2f sv[PP];  // (all values first: PP independent chains for the scheduler to interleave)
 #pragma unroll
     for (int p = 0; p < PP; p++) sv[p] = CM::value(xs[p], fp);
@@ -991,8 +992,8 @@ __device__ __forceinline__ void cells_survivors(const v2f (&xs)[PP][4], const fl
       typedef uint32_t v2u __attribute__((ext_vector_type(2)));
       const v2u du = __builtin_bit_cast(v2u, d);
       const uint32_t m = du.x < du.y ? du.x : du.y;
-      dmin = m < dmin ? m : dmin;   // (the backend fuses the two minima into one v_min3_u32; r04: writing the
-    }                               // instruction by hand changes nothing -- checked in the ISA and by SQ_INSTS_VALU)
+      dmin = p == 0 ? m : (m < dmin ? m : dmin);   // (the backend fuses the two minima into one v_min3_u32; the first
+    }                                              // pair seeds the chain: no register to initialise)
     const unsigned long long amb = __ballot(dmin <= band);
     if (amb) {  // some observation sits in the band: exact fp64 predicate for the whole cell
       const double *hp = spg + (size_t)b * SPD;  // wave-uniform -> scalar loads
