@@ -114,8 +114,11 @@ struct PhantomModel {
     const double W = (fabs(R1[0]) + fabs(R1[1]) + fabs(R1[2])) * Q + fabs(sp[2]);
     const double E = 1.01 * ((20.0 * u32 + 72.0 * u64) * W);
     const double T = c.thr;
+    // (r04: no smallness condition on E -- |v - |err_ref|| <= E makes both implications above hold for ANY E; with E >=
+    // T there simply are no certain inliers.  r03 switched the filter off for E > T / 4, which sends every frame of a
+    // hypothesis with large scale factors to the exact predicate: the US scan lost a third of its time that way.)
     const bool ok = finite && X <= 1e15 && X >= 1e-10 && Rm <= 1e15 && W <= 1e30 && fabs(R1[a]) >= 0.5 &&
-                    dev <= 1e-11 * scale && E <= 0.25 * T && T > 1e-15 && T <= 1e15;
+                    dev <= 1e-11 * scale && T > 1e-15 && T <= 1e15;
     for (int j = 0; j < 3; j++) {
       f[j] = (float)c0[j];
       f[3 + j] = (float)c1[j];
@@ -124,7 +127,7 @@ struct PhantomModel {
     }
     f[12] = (float)sp[2];
     f[13] = 0.0f;
-    f[14] = ok ? PlaneModel<3>::round_down_f32(T - E) : -INFINITY;
+    f[14] = (ok && T - E > 0.0) ? PlaneModel<3>::round_down_f32(T - E) : -INFINITY;
     f[15] = ok ? PlaneModel<3>::round_up_f32(T + E) : INFINITY;
     if (!finite) f[14] = f[15] = __builtin_nanf("");  // NaN model: never agrees
   }
