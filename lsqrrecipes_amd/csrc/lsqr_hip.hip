@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "models_nd.h"
 #include "dense.h"
+#include "dense_h16.h"
 #include "us_kernels.h"
 #include "cells.h"
 #include "earlyexit.h"
@@ -94,8 +95,17 @@ struct lsqr_ctx {
   uint64_t hyp_since_upload = 0;  // hypotheses scanned on this upload (index build heuristic)
   uint64_t hyp_expected = 0;      // hypotheses the caller still expects to scan on this upload (lsqr_ransac: numTries)
   unsigned dense_amb_max = 0;  // fullest worklist segment of the last fp32 dense scan (diagnostics)
-  int opt_dense_f32 = 1;  // dense scan filter at n = 64: 1 = fp32 matrix cores (worklist of ~1e-4 of the pairs, hypothesis
-                          // fragments through an LDS ring + next tile in registers), 0 = fp64 matrix cores
+  int opt_dense_f32 = 2;  // dense scan filter at n = 64: 2 = fp16 matrix cores on two-way splits of the rows and the
+                          // unknowns (dense_h16.h; the rows' fragments are built once per upload), 1 = fp32 matrix
+                          // cores (hypothesis fragments through an LDS ring + next tile in registers), 0 = fp64 matrix
+                          // cores; every filter sends its band to the exact fp64 re-check
+  // dense_h16.h: the rows as fp16 fragment pairs (8 KiB per 32 rows) + the scaled right-hand sides, once per upload
+  uint4 *d_h16 = nullptr;
+  float *d_h16_bs = nullptr;
+  size_t h16_tiles_cap = 0;
+  bool h16_valid = false, h16_attr = false;
+  double h16_pa = 1.0;
+  float *d_h16_thr = nullptr;  // (-a, band, -ph, 0) per hypothesis of the batch
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_lm_tiles = 1;      // matrix-core LM pass: compacted consensus set in field-major tiles, next tile in flight
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
@@ -650,6 +660,7 @@ void lanes_quiesce(lsqr_ctx *c) {
 }
 
 void drop_index(lsqr_ctx *c) {
+  c->h16_valid = false;  // (derived from the records alone, like the index)
   c->n_sorted = 0;
   c->n_cells = 0;
   c->index_valid = false;
@@ -1134,7 +1145,7 @@ struct EeBuf {
   float *thr_c, *rows_c;
 };
 int ee_buffers(lsqr_ctx *c, EeBuf *b) {
-  const size_t bytes = 256 + 3 * kEeCap * sizeof(uint32_t) + (2 + 64) * (kEeCap + 64) * sizeof(float);
+  const size_t bytes = 256 + 3 * kEeCap * sizeof(uint32_t) + (4 + 64) * (kEeCap + 64) * sizeof(float);
   if (!c->d_ee) HIPCHK(c, hipMalloc(&c->d_ee, bytes));
   if (!c->h_ee) {
     HIPCHK(c, hipHostMalloc((void **)&c->h_ee, 64));
@@ -1146,7 +1157,7 @@ int ee_buffers(lsqr_ctx *c, EeBuf *b) {
   b->sel_o[0] = b->sel_c + kEeCap;
   b->sel_o[1] = b->sel_o[0] + kEeCap;
   b->thr_c = (float *)(b->sel_o[1] + kEeCap);
-  b->rows_c = b->thr_c + 2 * (kEeCap + 64);
+  b->rows_c = b->thr_c + 4 * (kEeCap + 64);  // (the fp16 filter keeps 4 floats per hypothesis, the fp32 filter 2)
   return LSQR_OK;
 }
 // scan(row_begin, row_end, range_dev, h_dev, sel): sel == null -> the context's whole batch over [row_begin, row_end),
@@ -1193,6 +1204,58 @@ int run_early_exit(lsqr_ctx *c, size_t align, const EeBuf &b, Scan &&scan, Gathe
   return LSQR_OK;
 }
 
+// dense system, n = 64: the rows as fp16 fragment pairs for dense_h16.h's filter, once per upload (2 M x 64: 0.5 GB,
+// ~1.9 ms).  *ok = false when the magnitudes do not fit the filter's scaling (the fp32 filter takes the scan).
+int ensure_dense_h16(lsqr_ctx *c, bool *ok) {
+  *ok = false;
+  const double amax = c->mc.absmax_rot, bmax = c->mc.absmax;
+  if (!(amax > 0.0) || !(amax < 1e15) || !(bmax < 1e15)) return LSQR_OK;
+  const double pa = 32768.0 / amax;
+  if (!(pa < 1e30) || !(bmax * pa < 1e18)) return LSQR_OK;
+  if (!c->h16_valid || c->h16_pa != pa) {
+    const size_t n_tiles = (c->n + 31) / 32 + 8;  // a workgroup pass reads up to 255 rows past its last one
+    if (n_tiles > c->h16_tiles_cap) {
+      if (c->d_h16) (void)hipFree(c->d_h16);
+      if (c->d_h16_bs) (void)hipFree(c->d_h16_bs);
+      c->d_h16 = nullptr, c->d_h16_bs = nullptr, c->h16_tiles_cap = 0;
+      HIPCHK(c, hipMalloc((void **)&c->d_h16, n_tiles * (size_t)kH16TileBytes));
+      HIPCHK(c, hipMalloc((void **)&c->d_h16_bs, n_tiles * 32 * sizeof(float)));
+      c->h16_tiles_cap = n_tiles;
+    }
+    hipLaunchKernelGGL(k_dense_rows_h16, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
+                       c->stride, c->n, (int)c->cfg.dim, pa, c->d_h16, c->d_h16_bs, n_tiles);
+    HIPCHK(c, hipGetLastError());
+    c->h16_valid = true;
+    c->h16_pa = pa;
+  }
+  if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
+  if (!c->h16_attr) {  // (per context: the attribute belongs to the device the context lives on)
+    c->h16_attr = true;
+    (void)hipFuncSetAttribute((const void *)k_scan_dense_h16<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)dense_h16_lds(1024));
+  }
+  *ok = true;
+  return LSQR_OK;
+}
+// rows [rb, re) against hypotheses of `xh` / `thr4` (the batch itself or a compact selection), in launches of 1024
+int launch_dense_h16(lsqr_ctx *c, size_t rb, size_t re, const _Float16 *xh, const float *thr4, uint32_t H,
+                     unsigned int *d_segcnt, uint32_t seg_cap, const uint32_t *h_dev, const uint32_t *sel,
+                     const uint32_t *range_dev, size_t *nblk_out) {
+  const size_t passes = (re - rb + kH16RowsPerWg - 1) / kH16RowsPerWg;
+  const size_t nb = std::min<size_t>(passes, 512);  // two workgroups per CU
+  const size_t rpb = (passes + nb - 1) / nb * kH16RowsPerWg;
+  const size_t nblk = (re - rb + rpb - 1) / rpb;
+  if (nblk_out) *nblk_out = nblk;
+  for (size_t h0 = 0; h0 < H; h0 += 1024) {
+    const uint32_t hc = (uint32_t)std::min<size_t>(1024, H - h0);
+    hipLaunchKernelGGL((k_scan_dense_h16<64>), dim3((unsigned)nblk), dim3(256), dense_h16_lds(hc), c->stream, c->d_h16,
+                       c->d_h16_bs, rb, re, rpb, xh + h0 * 128, thr4 + 4 * h0, hc, c->d_votes, c->d_amb, d_segcnt,
+                       seg_cap, (uint32_t)h0, h_dev, sel, range_dev);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LSQR_OK;
+}
+
 // dense system, n > 32: the fp32 matrix-core filter (dense.h: k_scan_dense_mfma32r) over row chunks and compacted
 // selections; the band of every chunk is decided exactly (k_dense_recheck_seg) before the next selection looks at the
 // votes.  Returns LSQR_OK with *done = false when a worklist segment overflowed (the caller counts everything with
@@ -1216,11 +1279,26 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
   c->prof = false;
   HIPCHK(c, hipMemsetAsync(d_segcnt, 0, 1024 * sizeof(unsigned int), c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_dense_thresholds32, dim3((H + 255) / 256), dim3(256), 0, c->stream, c->d_hparams, H,
-                     (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot, c->mc.absmax, d_thr32, d_sp32);
+  bool h16 = false;
+  if (c->opt_dense_f32 == 2 && (st = ensure_dense_h16(c, &h16)) != LSQR_OK) return st;
+  if (h16)  // the fp16 filter's rows live where the fp32 filter keeps its own (256 B per hypothesis either way)
+    hipLaunchKernelGGL(k_dense_prep_h16, dim3((H + 255) / 256), dim3(256), 0, c->stream, c->d_hparams, H, (int)c->cfg.dim,
+                       64, c->mc.delta, c->mc.absmax_rot, c->mc.absmax, c->h16_pa, (_Float16 *)d_sp32, c->d_h16_thr);
+  else
+    hipLaunchKernelGGL(k_dense_thresholds32, dim3((H + 255) / 256), dim3(256), 0, c->stream, c->d_hparams, H,
+                       (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot, c->mc.absmax, d_thr32, d_sp32);
   HIPCHK(c, hipGetLastError());
   auto scan = [&](size_t rb, size_t re, const uint32_t *range_dev, const uint32_t *h_dev, const uint32_t *sel) -> int {
     if (rb >= re) return LSQR_OK;
+    if (h16) {
+      int s2 = launch_dense_h16(c, rb, re, (const _Float16 *)(sel ? b.rows_c : d_sp32), sel ? b.thr_c : c->d_h16_thr, H,
+                                d_segcnt, seg_cap, h_dev, sel, range_dev, nullptr);
+      if (s2 != LSQR_OK) return s2;
+      hipLaunchKernelGGL((k_dense_recheck_seg<64>), dim3(512), dim3(256), 0, c->stream, c->d_data, c->stride,
+                         c->d_hparams, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes, (unsigned int *)(c->d_counter + 3));
+      HIPCHK(c, hipGetLastError());
+      return LSQR_OK;
+    }
     const size_t tiles = (re - rb + 63) / 64;
     const size_t nb2 = std::min<size_t>(tiles, 512);  // two workgroups per CU
     const size_t rpb = (tiles + nb2 - 1) / nb2 * 64;
@@ -1242,6 +1320,10 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
     return LSQR_OK;
   };
   auto gather = [&](const uint32_t *sel, const uint32_t *n_dev) -> int {
+    if (h16)  // (positions past the selection are never read: the scan takes its size from *n_dev)
+      hipLaunchKernelGGL(k_ee_gather_f32, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel, n_dev, H,
+                         (const float *)d_sp32, 64, b.rows_c, (const float *)c->d_h16_thr, 4, b.thr_c, 0.0f);
+    else
     hipLaunchKernelGGL(k_ee_gather_f32, dim3((H + 3) / 4), dim3(256), 0, c->stream, sel, n_dev, H,
                        (const float *)d_sp32, 64, b.rows_c, (const float *)d_thr32, 2, b.thr_c, -1.0f);
     HIPCHK(c, hipGetLastError());
@@ -1256,8 +1338,8 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
     return LSQR_OK;
   }
   c->ee_last = false;
-  (void)fail(c, LSQR_OK, "dense fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used", c->dense_amb_max,
-             seg_cap);
+  (void)fail(c, LSQR_OK, "dense fp16 / fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used",
+             c->dense_amb_max, seg_cap);
   return LSQR_OK;
 }
 
@@ -1353,7 +1435,23 @@ int run_scan(lsqr_ctx *c) {
               float *d_sp32 = (float *)c->d_partials + 2 * 8192;              // 64 floats per hypothesis (2 MB)
               unsigned int *d_segcnt = (unsigned int *)((float *)c->d_partials + 2 * 8192 + 64 * 8192);  // 1024 words
               HIPCHK(c, hipMemsetAsync(d_segcnt, 0, 1024 * sizeof(unsigned int), c->stream));
-              {
+              bool h16 = false;
+              if (c->opt_dense_f32 == 2 && (st = ensure_dense_h16(c, &h16)) != LSQR_OK) return st;
+              if (h16) {  // fp16 matrix cores on two-way splits (dense_h16.h)
+                ProfScope ps(c, KID_SCAN);
+                hipLaunchKernelGGL(k_dense_prep_h16, dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot,
+                                   c->mc.absmax, c->h16_pa, (_Float16 *)d_sp32, c->d_h16_thr);
+                HIPCHK(c, hipGetLastError());
+                size_t nb16 = 0;
+                if ((st = launch_dense_h16(c, 0, c->n, (const _Float16 *)d_sp32, c->d_h16_thr, (uint32_t)c->H, d_segcnt,
+                                           seg_cap, nullptr, nullptr, nullptr, &nb16)) != LSQR_OK)
+                  return st;
+                hipLaunchKernelGGL((k_dense_recheck_seg<64>), dim3((unsigned)nb16), dim3(256), 0, c->stream, c->d_data,
+                                   c->stride, c->d_hparams, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes,
+                                   (unsigned int *)(c->d_counter + 3));
+                HIPCHK(c, hipGetLastError());
+              } else {
                 ProfScope ps(c, KID_SCAN);
                 hipLaunchKernelGGL(k_dense_thresholds32, dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0, c->stream,
                                    c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot,
@@ -1382,7 +1480,7 @@ int run_scan(lsqr_ctx *c) {
               HIPCHK(c, sync_stream(c));
               c->dense_amb_max = *(unsigned int *)c->h_pin;
               if (c->dense_amb_max <= seg_cap) return LSQR_OK;
-              (void)fail(c, LSQR_OK, "dense fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used",
+              (void)fail(c, LSQR_OK, "dense fp16 / fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used",
                          c->dense_amb_max, seg_cap);
               HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));   // overflow: fp64 filter
               HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
@@ -2398,7 +2496,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     }
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_h16, c->d_h16_bs, c->d_h16_thr, c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -4278,8 +4376,8 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     c->opt_cell = value;
     return LSQR_OK;
   }
-  if (!strcmp(name, "dense_f32")) {  // 1 (default): dense scan filter on the fp32 matrix cores; 0: fp64 MFMA filter
-    c->opt_dense_f32 = value != 0;
+  if (!strcmp(name, "dense_f32")) {  // 2 (default): dense scan filter on the fp16 matrix cores (two-way splits);
+    c->opt_dense_f32 = value < 0 ? 0 : value > 2 ? 2 : value;  // 1: fp32 matrix cores; 0: fp64 matrix cores
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse
