@@ -56,6 +56,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_ISSUE_PEAK_GWIPS = 1024 * 2.4 / 4.0
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
+F16_MFMA_PEAK_TFLOPS = 2516.6   # 1024 SIMDs x 2.4 GHz x 32768 flop / 32 cycles (v_mfma_f32_32x32x16_f16; guide: ~2.5 PF dense)
 # USEFUL vector instructions of the scan kernels, counted from the source (csrc/cells.h, models.h, us.h; table in
 # DESIGN.md section 6): l1 = non-packed fp32 instructions of CM::level1 per (64-hypothesis group, cell); pk = packed-fp32
 # instructions of the filter measure per packed pair of observations per lane (128 observations per wave).
@@ -270,6 +271,31 @@ def scan_roofline(R, mode, scan_ms, n_scan):
         rows_done = wl["row_hypothesis_pairs"] if wl else float(a.points) * H
         flops = 2.0 * 64 * rows_done                 # the residual block rows x hypotheses as a GEMM
         ach = flops / t / 1e12 if t > 0 else 0.0
+        filt = 2
+        for kv in a.option:
+            if kv.split("=")[0] == "dense_f32":
+                filt = int(kv.split("=")[1])
+        wm = {"row_hypothesis_pairs_evaluated": rows_done, "row_hypothesis_pairs_all": float(a.points) * H,
+              "evaluated_fraction": rows_done / (float(a.points) * H)}
+        if filt >= 2:
+            # dense_h16.h: every fp32 product is three fp16 matrix products (a1 x2, a2 x1, a1 x1): `achieved` is the
+            # LOGICAL product (SURVEY 8(d)'s unit), `issued_*` what the matrix cores actually execute
+            base.update({"bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "issued_TFLOPs": 3.0 * ach, "frac_issued": 3.0 * ach / F16_MFMA_PEAK_TFLOPS,
+                         "x_fp32_matrix_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+                         "kernel_short": "k_scan_dense_h16<64> fp16-split MFMA filter + k_dense_recheck_seg (exact fp64)",
+                         "kernel": "k_scan_dense_h16<64> (rows and unknowns as two-way fp16 splits, three "
+                                   "v_mfma_f32_32x32x16_f16 per fp32 product, row fragments built once per upload and "
+                                   "resident in registers per pass, hypothesis tiles through an LDS ring, classification "
+                                   "on squares) + k_dense_recheck_seg (exact fp64 decision of the pairs inside the "
+                                   "filter's band); launch_ms covers both and the per-batch split of the unknowns",
+                         "work_model": wm,
+                         "note": "achieved = 2*n*(row, hypothesis) pairs evaluated / launch time (logical flops); peak = "
+                                 "the dense fp16 matrix rate; issued = 3 x logical (the three partial products); "
+                                 "x_fp32_matrix_peak = achieved / 157.3 TFLOP/s, the roof of the fp32 filter this "
+                                 "replaces (profiles/r04: 0.55 of it)"})
+            return base
         base.update({"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "frac_of_fp64_mfma_peak": ach / FP64_MFMA_PEAK_TFLOPS,
@@ -278,9 +304,7 @@ def scan_roofline(R, mode, scan_ms, n_scan):
                                "through an LDS ring, next row tile in registers) + k_dense_recheck_seg (exact fp64 "
                                "decision of the ~1e-4 of the pairs inside the filter's band); launch_ms covers both "
                                "and the thresholds",
-                     "work_model": {"row_hypothesis_pairs_evaluated": rows_done,
-                                    "row_hypothesis_pairs_all": float(a.points) * H,
-                                    "evaluated_fraction": rows_done / (float(a.points) * H)},
+                     "work_model": wm,
                      "note": "flops = 2*n*(row, hypothesis) pairs the filter GEMM actually evaluated; peak = the fp32 "
                              "dense matrix rate the filter runs at"})
         return base
@@ -954,7 +978,7 @@ def compact_roofline(r, one):
         return None
     c = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     for k in ("hbm_frac_measured", "launch_ms", "issued_valu_frac_4cyc", "issued_valu_frac_2cyc",
-              "frac_of_2cycle_issue_peak", "frac_of_fp64_mfma_peak"):
+              "frac_of_2cycle_issue_peak", "frac_of_fp64_mfma_peak", "frac_issued", "x_fp32_matrix_peak"):
         if r.get(k) is not None:
             c[k] = r[k]
     if r.get("counters"):

@@ -870,10 +870,10 @@ def test_dense_mfma_filter_is_exact(ctx):
     for delta in (rho, np.nextafter(rho, np.inf), np.nextafter(rho, 0.0), 0.1):
         oc = O.cfg(O.DENSE, ncol, delta)
         want = None
-        # fp32 (LDS ring: the default) and fp64 matrix-core filters, exact VALU kernel
-        for variant in ("mfma32r", "mfma64", "plain"):
+        # fp16-split (the default), fp32 (LDS ring) and fp64 matrix-core filters, exact VALU kernel
+        for variant in ("h16", "mfma32r", "mfma64", "plain"):
             ctx.set_option("scan_filter", 0 if variant == "plain" else 1)
-            ctx.set_option("dense_f32", 0 if variant == "mfma64" else 1)
+            ctx.set_option("dense_f32", {"h16": 2, "mfma64": 0}.get(variant, 1))
             ctx.set_model(L.DENSE, ncol, delta).upload(rows)
             ctx.hypotheses_from_subsets(subs)
             ctx.scan()
@@ -885,7 +885,7 @@ def test_dense_mfma_filter_is_exact(ctx):
         # the boundary row itself: strict '<'
         assert O.agree(oc, x, rows[777]) == (rho < delta)
     ctx.set_option("scan_filter", 1)
-    ctx.set_option("dense_f32", 1)
+    ctx.set_option("dense_f32", 2)
 
 
 # ---- two-level scan over the spatial index (csrc/cells.h) -------------------------------------------
@@ -1427,20 +1427,20 @@ def test_filters_and_cell_scan_across_scales(ctx, model):
 
 
 def test_dense_mfma_scan_arrangements_agree(ctx):
-    """the fp64 and the fp32 matrix-core filter scans and the exact VALU kernel count the same votes; ragged row and
+    """the fp64, the fp32 and the fp16-split matrix-core filter scans and the exact VALU kernel count the same votes; ragged row and
     hypothesis counts"""
     rows = synth.dense(70_013, 64, 0.05, seed=313)[0]
     ctx.set_model(L.DENSE, 64, 0.1).upload(rows)
     ctx.hypotheses_sample(17, 0, 333)
     res = []
-    for filt, f32 in ((1, 0), (0, 0), (1, 1)):
+    for filt, f32 in ((1, 0), (0, 0), (1, 1), (1, 2)):
         ctx.set_option("scan_filter", filt)
         ctx.set_option("dense_f32", f32)
         ctx.scan()
         res.append(ctx.hypotheses(params=False)[2].copy())
     ctx.set_option("scan_filter", 1)
-    ctx.set_option("dense_f32", 1)
-    assert np.array_equal(res[0], res[1]) and np.array_equal(res[2], res[1])
+    ctx.set_option("dense_f32", 2)
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[2], res[1]) and np.array_equal(res[3], res[1])
     assert res[0].max() > 1000
 
 
