@@ -1061,6 +1061,8 @@ def headline(out, detail_path):
         h["other_configs"] = [{"leg": (leg["config"]["workload"].split(",")[0])[:56],
                                "value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"),
                                "roofline_frac": (leg.get("roofline") or {}).get("frac"),
+                               **({"roofline_frac_issued": (leg.get("roofline") or {}).get("frac_issued")}
+                                  if (leg.get("roofline") or {}).get("frac_issued") is not None else {}),
                                "error": leg.get("error")} for leg in out["other_configs"]]
     h["detail"] = detail_path
     h = _sig(h, 6)

@@ -376,10 +376,29 @@ inline void phantom_e(const double *x, PhDual e[31]) {
   for (int a = 0; a < 3; a++) e[k++] = R1[a];
   e[k++] = p[2];
 }
-// LM block {sum f^2, J^T J (upper, row-major), J^T f} at x from the Gram matrix G (31 x 31, full)
-inline void phantom_lm_block(const double *G, const double *x, double *blk) {
+// LM block {sum f^2, J^T J (upper, row-major), J^T f} at x from the Gram matrix G (31 x 31, full).
+// The reference minimises WITHOUT a gradient (.cxx:552: vnl_levenberg_marquardt::minimize_without_gradient, i.e.
+// MINPACK lmdif): its Jacobian is the forward difference  J(:, j) = (f(x + h_j e_j) - f(x)) / h_j,
+// h_j = sqrt(eps) |x_j| (sqrt(eps) when x_j = 0; fdjac2 with vnl's epsfcn = xtol * 0.001 < eps).  Every residual is
+// a_i . e(x), so that Jacobian is  A dE  with  dE(:, j) = (e(x + h_j e_j) - e(x)) / h_j  -- the same forward
+// difference taken on the 31 coefficients instead of on the N residuals: same truncation error term by term, and the
+// iterates follow the reference's (fd = true, the default of the fit).  fd = false: exact derivatives (r01 - r04).
+inline void phantom_lm_block(const double *G, const double *x, double *blk, bool fd = true) {
   PhDual e[31];
   phantom_e(x, e);
+  if (fd) {
+    const double eps = 1.4901161193847656e-08;  // sqrt(2^-52)
+    for (int q = 0; q < 11; q++) {
+      double xx[11];
+      for (int i = 0; i < 11; i++) xx[i] = x[i];
+      double h = eps * fabs(x[q]);
+      if (h == 0.0) h = eps;
+      xx[q] = x[q] + h;
+      PhDual eh[31];
+      phantom_e(xx, eh);
+      for (int i = 0; i < 31; i++) e[i].d[q] = (eh[i].v - e[i].v) / h;
+    }
+  }
   double Ge[31], GE[31][11];
   for (int i = 0; i < 31; i++) {
     double t = 0;

@@ -1517,8 +1517,8 @@ def test_plane_phantom_device_path(ctx):
     ctx.set_model(L.PHANTOM, 0, 3.0, L.LS_ITERATIVE).upload(noisy)
     it, info = ctx.ls_fit(use_mask=False)
     want = O.ls(oc, noisy)
-    # the reference differentiates numerically (lmdif), the device path analytically: same minimum
-    _phantom_close(it, want, rtol=1e-5, atol=1e-5)
+    # the reference differentiates numerically (lmdif); so does the device path, on the 31 coefficients (phantom.h)
+    _phantom_close(it, want, rtol=1e-6, atol=1e-6)
     assert synth.phantom_check(it, truth)
     assert 1 <= info.lm_info <= 4
     st_it, st_an = ctx.stats(it), ctx.stats(an)
@@ -1541,7 +1541,7 @@ def test_plane_phantom_device_path(ctx):
     mask[5:70] = 1
     ctx.set_mask(mask)
     fit, _ = ctx.ls_fit(use_mask=True)
-    _phantom_close(fit, O.ls(oc, noisy, mask), rtol=1e-5, atol=1e-5)
+    _phantom_close(fit, O.ls(oc, noisy, mask), rtol=1e-6, atol=1e-6)
     # fewer than 31 frames: no estimate (.cxx:139-141)
     ctx.upload(noisy[:31])
     ctx.set_mask(np.r_[np.ones(30, np.uint8), np.zeros(1, np.uint8)])

@@ -337,7 +337,7 @@ def test_plane_phantom_host_math(hm):
         want = O.ls(O.cfg(O.PHANTOM, 0, 3.0, iterative), inl)
         assert n == 41 == len(want)
         s = 1.0 if np.dot(out[38:41], want[38:41]) >= 0 else -1.0     # singular-vector sign (phantom.h)
-        tol = 1e-5 if iterative else 1e-6
+        tol = 1e-6
         assert np.allclose(out[3:11], want[3:11], rtol=tol, atol=tol)
         assert np.allclose(s * out[11:41], want[11:41], rtol=tol, atol=tol)
         assert np.isclose(cost.value, O.stats(oc, want, inl)[3], rtol=1e-6)
