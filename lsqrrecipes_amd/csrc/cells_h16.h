@@ -34,7 +34,10 @@
 // the matrix instruction) at two waves per SIMD where k_scan_pairs runs six; the matrix unit aligns the products of one
 // instruction with two guard bits (tools/h16_bench.hip, "align probe": 15 small terms beside a large one lose 3.8 ulp
 // of it), so the band cannot be narrowed much below the 59 rr u taken here, and deferring the exact decisions to
-// per-lane queues (below) changed nothing -- the loop is issue bound, not waiting for them.
+// per-lane queues (below) changed nothing -- with the band switched off altogether (timing experiment, wrong votes) the
+// scan phase is the same 0.97 ms: the loop is issue bound.  40 issue slots per matrix instruction = 20 per (hypothesis,
+// cell) pair, plus ~7 per pair for level 1 and the split operands of a group, against k_scan_pairs' 37 -- a quarter
+// fewer, at a third of its occupancy.
 #pragma once
 #include <type_traits>
 #include <utility>
