@@ -24,7 +24,7 @@ from bench import kernel_source_hash  # noqa: E402
 # the kernels of the scan phase (bounded two-level scan: the level-1 passes and the balanced second level)
 CELLS = ("k_cells_bounds", "k_scan_pairs", "k_scan_cells", "k_bound_axis")
 KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32",),
-          "dense": ("k_scan_dense_mfma", "k_dense_recheck")}
+          "dense": ("k_scan_dense_mfma", "k_scan_dense_h16", "k_dense_prep_h16", "k_dense_recheck")}
 
 
 def is_scan(w, name):
@@ -36,7 +36,8 @@ SETS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM",
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY",
         "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU",
         "FETCH_SIZE", "WRITE_SIZE"]
-MFMA_SETS = ["SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES"]
+MFMA_SETS = ["SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES",
+             "SQ_INSTS_VALU_MFMA_MOPS_F16"]   # (a pass whose counter the tool does not know fails and is skipped)
 
 
 BOUND = "1"
