@@ -16,15 +16,16 @@
 //   representation      2 u (1 + 2^-11) S  +  2^-14 (sum|x''| + sum|a''|)  <=  2.01 u S + 4.1 u S   (sum|a''| <= 2^21,
 //                       sum|x''| >= 2^14, so 2^-14 2^21 <= 2^-22 S)
 //   dropped a2 x2       2^-24 S (1 + 2^-10)                                                  <=  1.01 u S
-//   accumulation        the matrix unit's fp32 accumulation is not specified bit by bit; ASSUMED: every one of the
-//                       16 products of an instruction and its addend enter the running sum with an error of at most
-//                       one ulp of the largest magnitude involved (2u relative: covers round-to-nearest, truncation,
-//                       and alignment to the largest exponent).  The eight instructions of the small terms come
-//                       first (partial sums <= 2^-10 S):  2u 136 2^-10 S <= 0.3 u S;  the four of a1 x1:
-//                       2u 68 (1 + 2^-9) S <= 136.3 u S.   (tests/test_gpu_dense_h16.py measures the unit: the largest
-//                       deviation seen is below 1.5 u S.)
+//   accumulation        the matrix unit's fp32 accumulation is not specified bit by bit.  MEASURED (tools/h16_bench.hip,
+//                       k_align_probe): the products of one instruction and its addend are aligned to the largest of
+//                       them with two guard bits and truncated -- fifteen terms just below an ulp of a 2^20 term lose
+//                       3.8 ulp of it, a quarter ulp = 0.5 u of the largest magnitude each.  ASSUMED: twice that, 1 u
+//                       of the largest magnitude involved per product and addend.  The eight instructions of the small
+//                       terms come first (partial sums <= 2^-10 S):  136 2^-10 u S <= 0.14 u S;  the four of a1 x1:
+//                       68 (1 + 2^-9) u S <= 68.2 u S.   (tests/test_gpu_dense_h16.py measures the whole chain on every
+//                       run: the largest deviation seen is below 1.5 u S.)
 //   b'' and the final fma   u B (fl32 of b pa) + u (S + B) (rounding of the result)
-//   in total  |r'' - res''| <= (145.8 S + 2 B) u;   k_dense_prep_h16 takes E'' = 1.01 (146 S + 2 B) u and, like
+//   in total  |r'' - res''| <= (77.5 S + 2 B) u;   k_dense_prep_h16 takes E'' = 1.01 (78 S + 2 B) u and, like
 //   dense.h's fp32 filter, the reference's fp64 running sum is within 1e-14 of that scale of res''.
 // Thresholds on SQUARES as in cells.h (cells_filter_squares): a = RD(t_in^2), band = RN(RU(t_out^2) - a),
 //   d = fma(r'', r'', -a):  d < 0 => certain inlier;  0 <= d <= band => ambiguous;  else certain outlier.
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void k_dense_prep_h16(const double *__restrict
   const double scale = pa * ph;
   // the bound of the header in the scaled domain; S = amax pa * l1 ph (amax pa = 2^15 up to rounding)
   const double S = amax * pa * l1 * ph, B = bmax * scale;
-  const double E = 1.01 * (146.0 * S + 2.0 * B) * u + 1e-14 * (S + B);
+  const double E = 1.01 * (78.0 * S + 2.0 * B) * u + 1e-14 * (S + B);
   const double tin = delta * scale - E, tout = delta * scale + E;
   const bool live = l1 == l1 && l1 < 1e15 && amax < 1e15 && bmax < 1e15 && xm > 0.0 && ph < 1e30 && ph > 1e-30 &&
                     scale < 1e30 && scale > 1e-30 && tout < 9.0e18 && tout == tout;
