@@ -17,7 +17,7 @@
 //                       sum|x''| >= 2^14, so 2^-14 2^21 <= 2^-22 S)
 //   dropped a2 x2       2^-24 S (1 + 2^-10)                                                  <=  1.01 u S
 //   accumulation        the matrix unit's fp32 accumulation is not specified bit by bit.  MEASURED (tools/h16_bench.hip,
-//                       k_align_probe): the products of one instruction and its addend are aligned to the largest of
+//                       k_dense_h16_probe below): the products of one instruction and its addend are aligned to the largest of
 //                       them with two guard bits and truncated -- fifteen terms just below an ulp of a 2^20 term lose
 //                       3.8 ulp of it, a quarter ulp = 0.5 u of the largest magnitude each.  ASSUMED: twice that, 1 u
 //                       of the largest magnitude involved per product and addend.  The eight instructions of the small
@@ -35,6 +35,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 namespace lsqr {
@@ -151,6 +152,55 @@ __device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t *p, uint32_t v) {
                : "memory");
   return r;
 }
+
+// How does THIS device's matrix unit align the 16 products of one instruction (and its addend) before it sums them?
+// The thresholds above assume at most 1 u of the largest magnitude per product; the probe hands the unit one large term
+// (2^20) and up to 15 terms just below fractions of its ulp -- a unit that truncated every aligned addend to the large
+// term's ulp would lose ~0.9 ulp per small term (1.8 u), gfx950 loses a quarter ulp (0.5 u: two guard bits).
+// out[v] = the result of variant v; dense_h16_probe_worst() compares with the exact sums.  Run once per context before the
+// filter is used: a unit that does not keep the assumption leaves the scan to the fp32 filter.
+constexpr int kH16ProbeVariants = 8;
+__device__ __host__ inline float dense_h16_probe_small(int v) {
+  const float smalls[kH16ProbeVariants] = {0.98975f, 0.98975f, -0.98975f, 0.0615f, 0.1245f, 0.49f, 0.98975f, 0.98975f};
+  return smalls[v];
+}
+__global__ __launch_bounds__(64) void k_dense_h16_probe(float *__restrict__ out) {
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+  for (int v = 0; v < kH16ProbeVariants; v++) {
+    h16x8 a, b;
+    for (int i = 0; i < 8; i++) a[i] = (_Float16)0.0f, b[i] = (_Float16)0.0f;
+    const int bigk[kH16ProbeVariants] = {0, 0, 0, 0, 0, 0, 15, 7};  // slot k = 8 half + i of row 0 / column 0
+    if (col == 0) {
+      for (int i = 0; i < 8; i++) {
+        const int k = 8 * half + i;
+        if (k == bigk[v]) {
+          a[i] = (_Float16)1024.0f, b[i] = (_Float16)1024.0f;
+        } else if (v != 1 || k < 13) {
+          a[i] = (_Float16)dense_h16_probe_small(v), b[i] = (_Float16)1.0f;
+        }
+      }
+    }
+    f32x16 acc;
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    if (v == 1 && lane == 0) acc[0] = dense_h16_probe_small(v);  // the addend as one more small term (12 products + C)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    if (lane == 0) out[v] = acc[0];
+  }
+}
+// worst deviation of the probe's results from the exact sums, in u of the sum of the magnitudes (gfx950: 7.6)
+inline double dense_h16_probe_worst(const float *res) {
+  double worst = 0.0;
+  for (int v = 0; v < kH16ProbeVariants; v++) {
+    const double sm = (double)(float)(_Float16)dense_h16_probe_small(v);
+    const int nsmall = v == 1 ? 13 : 15;
+    const double exact = 1048576.0 + nsmall * sm, mag = 1048576.0 + nsmall * fabs(sm);
+    const double dev = fabs((double)res[v] - exact) / (5.9604644775390625e-08 * mag);
+    if (!(dev <= worst)) worst = dev;  // (a NaN result is the worst)
+  }
+  return worst;
+}
+// the assumption is 1 u per product and addend of the largest magnitude: 17 u for a full instruction
+constexpr double kH16ProbeLimit = 12.0;
 
 // The scan.  One workgroup = four waves; a wave owns 64 rows (two 32-row tiles whose fragments stay in registers
 // for a whole pass over the batch), the workgroup 256.  The hypotheses come through a ring of 32-hypothesis tiles in

@@ -105,6 +105,8 @@ struct lsqr_ctx {
   float *d_h16_bs = nullptr;
   size_t h16_tiles_cap = 0;
   bool h16_valid = false, h16_attr = false;
+  int h16_unit = 0;       // 0: this device's matrix unit not probed yet, 1: keeps dense_h16.h's accumulation assumption, -1: not
+  double h16_unit_dev = 0.0;  // the probe's worst deviation (u of the sum of magnitudes)
   double h16_pa = 1.0;
   float *d_h16_thr = nullptr;  // (-a, band, -ph, 0) per hypothesis of the batch
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
@@ -1244,6 +1246,20 @@ int ensure_dense_h16(lsqr_ctx *c, bool *ok) {
   if (!(amax > 0.0) || !(amax < 1e15) || !(bmax < 1e15)) return LSQR_OK;
   const double pa = 32768.0 / amax;
   if (!(pa < 1e30) || !(bmax * pa < 1e18)) return LSQR_OK;
+  if (c->h16_unit == 0) {  // once per context: does this device's matrix unit align products as the thresholds assume?
+    if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
+    float *d_probe = c->d_h16_thr;  // (the batch's threshold block: not in use yet)
+    hipLaunchKernelGGL(k_dense_h16_probe, dim3(1), dim3(64), 0, c->stream, d_probe);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, d_probe, sizeof(float) * kH16ProbeVariants, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, sync_stream(c));
+    c->h16_unit_dev = dense_h16_probe_worst((const float *)c->h_pin);
+    c->h16_unit = c->h16_unit_dev <= kH16ProbeLimit ? 1 : -1;
+    if (c->h16_unit < 0)
+      (void)fail(c, LSQR_OK, "dense fp16 filter: this device's matrix unit loses %.1f u per instruction (limit %.1f): fp32 filter used",
+                 c->h16_unit_dev, kH16ProbeLimit);
+  }
+  if (c->h16_unit < 0) return LSQR_OK;
   if (!c->h16_valid || c->h16_pa != pa) {
     const size_t n_tiles = (c->n + 31) / 32 + 8;  // a workgroup pass reads up to 255 rows past its last one
     if (n_tiles > c->h16_tiles_cap) {

@@ -42,6 +42,8 @@ def test_h16_votes_equal_every_other_filter_and_the_oracle():
     subs[8, :32] = g.choice(np.arange(5000, 5200), 32, replace=False)
     with Context(0) as ctx:
         par, valid, votes16 = _votes(ctx, rows, ncol, 0.1, subs, 1, 2)
+        # the fp16 filter really ran: the library probes the device's matrix unit first and would say so otherwise
+        assert b"fp32 filter used" not in ctx._lib.lsqr_last_error(ctx._h)
         assert valid[3] == 0 or not np.all(np.isfinite(par[3]))
         for filt, f32, name in ((1, 1, "fp32 matrix cores"), (1, 0, "fp64 matrix cores"), (0, 2, "plain fp64 kernel")):
             p2, v2, votes = _votes(ctx, rows, ncol, 0.1, subs, filt, f32)

@@ -88,35 +88,6 @@ __global__ void k_probe(const uint4 *__restrict__ afrag, const float *__restrict
   }
 }
 
-// How does the matrix unit align the 16 products of one instruction (and its addend) before it sums them?  One large
-// term (2^20) and up to 15 terms just below / above fractions of its ulp (0.125): a unit that truncated every aligned
-// addend to the large term's ulp would lose ~0.9 ulp per small term.  out[v] = result of variant v, exact[v] by hand.
-__global__ void k_align_probe(float *__restrict__ out) {
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
-  for (int v = 0; v < 8; v++) {
-    h16x8 a, b;
-    for (int i = 0; i < 8; i++) a[i] = (_Float16)0.0f, b[i] = (_Float16)0.0f;
-    // row 0 / column 0 carry the test vector; slot k = 8 half + i
-    const float smalls[8] = {0.98975f, 0.98975f, -0.98975f, 0.0615f, 0.1245f, 0.49f, 0.98975f, 0.98975f};
-    const int bigk[8] = {0, 0, 0, 0, 0, 0, 15, 7};
-    if (col == 0) {
-      for (int i = 0; i < 8; i++) {
-        const int k = 8 * half + i;
-        if (k == bigk[v]) {
-          a[i] = (_Float16)1024.0f, b[i] = (_Float16)1024.0f;
-        } else if (v != 1 || k < 13) {
-          a[i] = (_Float16)smalls[v], b[i] = (_Float16)1.0f;
-        }
-      }
-    }
-    f32x16 acc;
-    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    if (v == 1 && lane == 0) acc[0] = 0.98975f;  // the addend as one more small term (13 products + C)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
-    if (lane == 0) out[v] = acc[0];
-  }
-}
-
 int main(int argc, char **argv) {
   const size_t N = argc > 1 ? strtoull(argv[1], nullptr, 10) : 524288;
   const uint32_t H = argc > 2 ? (uint32_t)atoi(argv[2]) : 1024;
@@ -320,19 +291,20 @@ int main(int argc, char **argv) {
   {
     float *d_al;
     CK(hipMalloc(&d_al, 64));
-    hipLaunchKernelGGL(k_align_probe, dim3(1), dim3(64), 0, 0, d_al);
+    hipLaunchKernelGGL(k_dense_h16_probe, dim3(1), dim3(64), 0, 0, d_al);
     CK(hipDeviceSynchronize());
     float al[8];
     CK(hipMemcpy(al, d_al, 32, hipMemcpyDeviceToHost));
-    const double smalls[8] = {0.98975, 0.98975, -0.98975, 0.0615, 0.1245, 0.49, 0.98975, 0.98975};
     for (int v = 0; v < 8; v++) {
-      const double sm = (double)(float)(_Float16)(float)smalls[v];
+      const double sm = (double)(float)(_Float16)dense_h16_probe_small(v);
       const int nsmall = v == 1 ? 12 + 1 : 15;
       const double exact = 1048576.0 + nsmall * sm;
       printf("align probe %d: %d terms of %+.5f beside 2^20 (ulp 0.125): result %.4f exact %.4f -> off by %+.3f ulp = %+.2f u of the sum of magnitudes\n",
              v, nsmall, sm, (double)al[v], exact, ((double)al[v] - exact) / 0.125,
              ((double)al[v] - exact) / (5.9604644775390625e-08 * (1048576.0 + nsmall * fabs(sm))));
     }
+    printf("align probe: worst %.2f u of the sum of magnitudes (the library refuses the fp16 filter beyond %.1f)\n",
+           dense_h16_probe_worst(al), kH16ProbeLimit);
   }
   return bad ? 1 : 0;
 }
