@@ -338,6 +338,31 @@ def scan_roofline(R, mode, scan_ms, n_scan):
                  "hypotheses_counted_exactly": (wl["pilots"] + wl["second_pass"]) if wl["bounded"] else H,
                  "surviving_fraction": wl["pairs"] / max(1.0, float(wl["cells"]) * H)}
     else:
+        us_mfma = 1
+        for kv in a.option:
+            if kv.split("=")[0] == "us_mfma":
+                us_mfma = int(kv.split("=")[1])
+        if w == "us" and us_mfma and not a.no_filter:
+            # us_h16.h: the three error components of (frame, hypothesis) as 13-term dot products on the fp16 matrix
+            # cores, two-way fp16 splits: nine v_mfma_f32_32x32x16_f16 per 32 frames x 32 hypotheses
+            wk = ctx.scan_work() if hasattr(ctx, "scan_work") else None
+            fh = float(wk["row_hypothesis_pairs"]) if wk else float(H) * a.points
+            ach = 78.0 * fh / t / 1e12 if t > 0 else 0.0          # 3 components x 13 terms x 2 flop, logical
+            issued = 9.0 * 32768.0 / 1024.0 * fh / t / 1e12 if t > 0 else 0.0
+            base.update({"bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F16_MFMA_PEAK_TFLOPS, "traffic": traffic, "issued_TFLOPs": issued,
+                         "frac_issued": issued / F16_MFMA_PEAK_TFLOPS,
+                         "kernel_short": "k_scan_us_h16<us> fp16-split MFMA filter + k_us_recheck_seg (exact fp64)",
+                         "kernel": "k_scan_us_h16 (frames and hypotheses as two-way fp16 splits, nine "
+                                   "v_mfma_f32_32x32x16_f16 per 32 x 32 (frame, hypothesis) pairs with the previous "
+                                   "step's classification issued between them, hypothesis fragments of a launch in LDS) "
+                                   "+ k_us_recheck_seg (exact fp64 decision of the band)",
+                         "work_model": {"frame_hypothesis_pairs_evaluated": fh,
+                                        "frame_hypothesis_pairs_all": float(H) * a.points},
+                         "note": "achieved = 78 flop x (frame, hypothesis) pairs / launch time (the logical 3 x 13-term "
+                                 "products); issued = nine 32x32x16 matrix instructions per 1024 pairs (three partial "
+                                 "products, K padded 13 -> 16); peak = the dense fp16 matrix rate"})
+            return base
         wk = ctx.scan_work() if hasattr(ctx, "scan_work") else None
         pairs_all = float(H) * a.points / 128.0      # every (hypothesis, packed pair of observations per wave)
         pairs = wk["row_hypothesis_pairs"] / 128.0 if wk else pairs_all

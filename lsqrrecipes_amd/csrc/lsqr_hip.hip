@@ -25,6 +25,7 @@
 #include "dense.h"
 #include "dense_h16.h"
 #include "us_kernels.h"
+#include "us_h16.h"
 #include "cells.h"
 #include "cells_h16.h"
 #include "earlyexit.h"
@@ -109,6 +110,12 @@ struct lsqr_ctx {
   double h16_unit_dev = 0.0;  // the probe's worst deviation (u of the sum of magnitudes)
   double h16_pa = 1.0;
   float *d_h16_thr = nullptr;  // (-a, band, -ph, 0) per hypothesis of the batch
+  // us_h16.h: the frames as fp16 fragment pairs (6 KiB per 32 frames), once per upload; the batch's hypothesis fragments
+  uint4 *d_us16 = nullptr, *d_us16_x = nullptr;
+  size_t us16_tiles_cap = 0;
+  bool us16_valid = false, us16_attr = false;
+  Us16Scales us16_sc{};
+  int opt_us_h16 = 1;  // US calibrations: 1 = agree() scan on the fp16 matrix cores (us_h16.h), 0 = packed fp32 filter
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_lm_tiles = 1;      // matrix-core LM pass: compacted consensus set in field-major tiles, next tile in flight
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
@@ -666,6 +673,7 @@ void lanes_quiesce(lsqr_ctx *c) {
 
 void drop_index(lsqr_ctx *c) {
   c->h16_valid = false;  // (derived from the records alone, like the index)
+  c->us16_valid = false;
   c->n_sorted = 0;
   c->n_cells = 0;
   c->index_valid = false;
@@ -1238,6 +1246,85 @@ int run_early_exit(lsqr_ctx *c, size_t align, const EeBuf &b, Scan &&scan, Gathe
   return LSQR_OK;
 }
 
+// once per context: does this device's matrix unit align the products of one instruction as the fp16 filters'
+// thresholds assume (dense_h16.h: k_dense_h16_probe)?  c->h16_unit = 1 / -1.
+int h16_probe_unit(lsqr_ctx *c) {
+  if (c->h16_unit != 0) return LSQR_OK;
+  if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
+  float *d_probe = c->d_h16_thr;  // (the batch's threshold block: not in use yet)
+  hipLaunchKernelGGL(k_dense_h16_probe, dim3(1), dim3(64), 0, c->stream, d_probe);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, d_probe, sizeof(float) * kH16ProbeVariants, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, sync_stream(c));
+  c->h16_unit_dev = dense_h16_probe_worst((const float *)c->h_pin);
+  c->h16_unit = c->h16_unit_dev <= kH16ProbeLimit ? 1 : -1;
+  if (c->h16_unit < 0)
+    (void)fail(c, LSQR_OK, "fp16 matrix-core filters: this device's matrix unit loses %.1f u per instruction (limit %.1f): fp32 filter used",
+               c->h16_unit_dev, kH16ProbeLimit);
+  return LSQR_OK;
+}
+
+// US calibrations: the frames as fp16 fragment pairs for us_h16.h's filter, once per upload (1 M frames: 192 MB).
+// *ok = false when the filter cannot be used (magnitudes, the device's matrix unit): the packed fp32 filter scans.
+template <class M>
+int ensure_us_h16(lsqr_ctx *c, bool *ok) {
+  *ok = false;
+  constexpr bool SINGLE = M::K == 4;
+  const double X = c->mc.absmax, Rm = c->mc.absmax_rot;
+  if (!c->absmax_valid || !(X > 0.0) || !(X < 1e15) || !(Rm > 0.0) || !(Rm < 1e15)) return LSQR_OK;
+  int st = h16_probe_unit(c);
+  if (st != LSQR_OK) return st;
+  if (c->h16_unit < 0) return LSQR_OK;
+  const Us16Scales sc = us16_scales<SINGLE>(X, Rm);
+  if (!c->us16_valid || memcmp(&sc, &c->us16_sc, sizeof sc) != 0) {
+    const size_t n_tiles = (c->n + 31) / 32 + 2;
+    if (n_tiles > c->us16_tiles_cap) {
+      if (c->d_us16) (void)hipFree(c->d_us16);
+      c->d_us16 = nullptr, c->us16_tiles_cap = 0;
+      HIPCHK(c, hipMalloc((void **)&c->d_us16, n_tiles * (size_t)kUs16FrameTile));
+      c->us16_tiles_cap = n_tiles;
+    }
+    hipLaunchKernelGGL((k_us_rows_h16<SINGLE>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
+                       c->stride, c->n, sc, c->d_us16, n_tiles);
+    HIPCHK(c, hipGetLastError());
+    c->us16_valid = true;
+    c->us16_sc = sc;
+  }
+  if (!c->d_us16_x) HIPCHK(c, hipMalloc((void **)&c->d_us16_x, (size_t)(8192 / 32) * 2048));
+  if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
+  if (!c->d_amb) HIPCHK(c, hipMalloc((void **)&c->d_amb, sizeof(unsigned long long) * kAmbCap));
+  if (!c->us16_attr) {
+    c->us16_attr = true;
+    (void)hipFuncSetAttribute((const void *)k_scan_us_h16<SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)us_h16_lds(kUs16HypChunk));
+  }
+  *ok = true;
+  return LSQR_OK;
+}
+// frames [rb, re) against the H hypotheses whose scan parameters are `sp` (the batch or a compact selection): split of
+// the unknowns, the filter in launches of 1024 hypotheses, the exact decision of the band
+template <class M>
+int launch_us_h16(lsqr_ctx *c, size_t rb, size_t re, const double *sp, uint32_t H, unsigned int *d_segcnt, uint32_t seg_cap,
+                  const uint32_t *h_dev, const uint32_t *sel, const uint32_t *range_dev) {
+  constexpr bool SINGLE = M::K == 4;
+  hipLaunchKernelGGL((k_us_prep_h16<SINGLE>), dim3((H + 31 + 255) / 256), dim3(256), 0, c->stream, sp, (int)M::SP, H,
+                     c->mc.delta_sq, c->mc.absmax, c->mc.absmax_rot, c->us16_sc, c->d_us16_x, c->d_h16_thr);
+  HIPCHK(c, hipGetLastError());
+  const size_t passes = (re - rb + kUs16Wg - 1) / kUs16Wg;
+  const unsigned nblk = (unsigned)std::min<size_t>(passes, 256);  // one workgroup (eight waves) per CU
+  for (size_t h0 = 0; h0 < H; h0 += kUs16HypChunk) {
+    const uint32_t hc = (uint32_t)std::min<size_t>(kUs16HypChunk, H - h0);
+    hipLaunchKernelGGL((k_scan_us_h16<SINGLE>), dim3(nblk), dim3(kUs16Wg), us_h16_lds(hc), c->stream, c->d_us16, c->n, rb,
+                       re, c->d_us16_x + (h0 / 32) * 128, c->d_h16_thr + 4 * h0, hc, c->d_votes, c->d_amb, d_segcnt, seg_cap,
+                       (uint32_t)h0, h_dev, sel, range_dev);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL((k_us_recheck_seg<M>), dim3(256), dim3(256), 0, c->stream, c->d_data, c->stride, c->d_hparams,
+                     (int)M::SP, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes, (unsigned int *)(c->d_counter + 3));
+  HIPCHK(c, hipGetLastError());
+  return LSQR_OK;
+}
+
 // dense system, n = 64: the rows as fp16 fragment pairs for dense_h16.h's filter, once per upload (2 M x 64: 0.5 GB,
 // ~1.9 ms).  *ok = false when the magnitudes do not fit the filter's scaling (the fp32 filter takes the scan).
 int ensure_dense_h16(lsqr_ctx *c, bool *ok) {
@@ -1246,19 +1333,8 @@ int ensure_dense_h16(lsqr_ctx *c, bool *ok) {
   if (!(amax > 0.0) || !(amax < 1e15) || !(bmax < 1e15)) return LSQR_OK;
   const double pa = 32768.0 / amax;
   if (!(pa < 1e30) || !(bmax * pa < 1e18)) return LSQR_OK;
-  if (c->h16_unit == 0) {  // once per context: does this device's matrix unit align products as the thresholds assume?
-    if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
-    float *d_probe = c->d_h16_thr;  // (the batch's threshold block: not in use yet)
-    hipLaunchKernelGGL(k_dense_h16_probe, dim3(1), dim3(64), 0, c->stream, d_probe);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, d_probe, sizeof(float) * kH16ProbeVariants, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, sync_stream(c));
-    c->h16_unit_dev = dense_h16_probe_worst((const float *)c->h_pin);
-    c->h16_unit = c->h16_unit_dev <= kH16ProbeLimit ? 1 : -1;
-    if (c->h16_unit < 0)
-      (void)fail(c, LSQR_OK, "dense fp16 filter: this device's matrix unit loses %.1f u per instruction (limit %.1f): fp32 filter used",
-                 c->h16_unit_dev, kH16ProbeLimit);
-  }
+  int stp = h16_probe_unit(c);
+  if (stp != LSQR_OK) return stp;
   if (c->h16_unit < 0) return LSQR_OK;
   if (!c->h16_valid || c->h16_pa != pa) {
     const size_t n_tiles = (c->n + 31) / 32 + 8;  // a workgroup pass reads up to 255 rows past its last one
@@ -1407,8 +1483,24 @@ int run_scan_us_ee(lsqr_ctx *c) {
     ~Mute() { c->prof = was; }
   } mute{c, c->prof};
   c->prof = false;
+  bool h16 = false;
+  unsigned int *d_segcnt = (unsigned int *)((float *)c->d_partials + 2 * 8192 + 64 * 8192);
+  const uint32_t seg_cap = kAmbCap / 1024;
+  if constexpr (M::IS_US) {
+    if (c->opt_us_h16 && H <= 8192) {
+      if ((st = ensure_us_h16<M>(c, &h16)) != LSQR_OK) return st;
+      if (h16) {
+        HIPCHK(c, hipMemsetAsync(d_segcnt, 0, 1024 * sizeof(unsigned int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+      }
+    }
+  }
   auto scan = [&](size_t rb, size_t re, const uint32_t *range_dev, const uint32_t *h_dev, const uint32_t *sel) -> int {
     if (rb >= re) return LSQR_OK;
+    if constexpr (M::IS_US) {
+      if (h16)  // fp16 matrix cores (us_h16.h); the band of every chunk is decided exactly before the next selection
+        return launch_us_h16<M>(c, rb, re, sel ? c->d_hparams2 : c->d_hparams, H, d_segcnt, seg_cap, h_dev, sel, range_dev);
+    }
     const size_t tiles = (re - rb + tile - 1) / tile;
     const size_t lds = (size_t)H * sizeof(uint32_t);
     int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
@@ -1436,7 +1528,22 @@ int run_scan_us_ee(lsqr_ctx *c) {
     HIPCHK(c, hipGetLastError());
     return LSQR_OK;
   };
-  return run_early_exit(c, tile, b, scan, gather);
+  if ((st = run_early_exit(c, tile, b, scan, gather)) != LSQR_OK) return st;
+  if (h16) {  // a worklist segment that overflowed (not seen): everything again with the packed fp32 filter
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, sync_stream(c));
+    if (*(unsigned int *)c->h_pin > seg_cap) {
+      (void)fail(c, LSQR_OK, "US fp16 filter: worklist segment overflow (fill %u > %u), fp32 filter used",
+                 *(unsigned int *)c->h_pin, seg_cap);
+      const int keep = c->opt_us_h16;
+      c->opt_us_h16 = 0;
+      c->prof = mute.was;
+      st = run_scan_us_ee<M>(c);
+      c->opt_us_h16 = keep;
+      return st;
+    }
+  }
+  return LSQR_OK;
 }
 
 int run_scan(lsqr_ctx *c) {
@@ -1582,6 +1689,32 @@ int run_scan(lsqr_ctx *c) {
           return run_scan_us_ee<M>(c);  // batch entry points: chunked early exit (earlyexit.h)
         const int np = c->opt_ppl == 2 ? 1 : 2;  // pairs of frames per lane (scan_ppl 2 / 4)
         HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+        if constexpr (M::IS_US) {
+          if (c->opt_us_h16 && c->H >= 32 && c->H <= 8192 && c->n >= 4096) {  // fp16 matrix cores (us_h16.h)
+            bool h16 = false;
+            int st = ensure_us_h16<M>(c, &h16);
+            if (st != LSQR_OK) return st;
+            if (h16) {
+              unsigned int *d_segcnt = (unsigned int *)((float *)c->d_partials + 2 * 8192 + 64 * 8192);
+              const uint32_t seg_cap = kAmbCap / 1024;
+              HIPCHK(c, hipMemsetAsync(d_segcnt, 0, 1024 * sizeof(unsigned int), c->stream));
+              HIPCHK(c, hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+              {
+                ProfScope ps(c, KID_SCAN);
+                if ((st = launch_us_h16<M>(c, 0, c->n, c->d_hparams, (uint32_t)c->H, d_segcnt, seg_cap, nullptr, nullptr,
+                                           nullptr)) != LSQR_OK)
+                  return st;
+              }
+              HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                       c->stream));
+              HIPCHK(c, sync_stream(c));
+              if (*(unsigned int *)c->h_pin <= seg_cap) return LSQR_OK;
+              (void)fail(c, LSQR_OK, "US fp16 filter: worklist segment overflow (fill %u > %u), fp32 filter used",
+                         *(unsigned int *)c->h_pin, seg_cap);
+              HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
+            }
+          }
+        }
         size_t tiles = (c->n + (size_t)kBlock * 2 * np - 1) / ((size_t)kBlock * 2 * np);
         for (size_t h0 = 0; h0 < c->H; h0 += kScanChunk) {
           uint32_t hc = (uint32_t)std::min<size_t>(kScanChunk, c->H - h0);
@@ -2544,7 +2677,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     }
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_h16, c->d_h16_bs, c->d_h16_thr, c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_us16, c->d_us16_x, c->d_h16, c->d_h16_bs, c->d_h16_thr, c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -4385,6 +4518,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "mom_chunk")) {
     c->opt_mom_chunk = value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "us_mfma")) {  // 1 (default): US calibrations' scan on the fp16 matrix cores; 0: packed fp32 filter
+    c->opt_us_h16 = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_pairs_mfma")) {  // 0 (default) / 1 / 2: level 2 of the plane's counted scan on the fp16 matrix cores

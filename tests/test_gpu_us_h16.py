@@ -1,0 +1,67 @@
+"""The US calibrations' agree() scan on the fp16 matrix cores (lsqrrecipes_amd/csrc/us_h16.h; reference:
+SinglePointTargetUSCalibrationParametersEstimator.cxx:74-107 / :728-766).  A filter: whatever it cannot decide goes through
+the exact fp64 predicate, so every vote must equal the packed fp32 filter's, the exact kernel's and the oracle's."""
+import numpy as np
+import pytest
+
+from lsqrrecipes_amd import _lib as L, synth
+from lsqrrecipes_amd.context import Context
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _votes(ctx, model, data, delta, seed, H, mfma, filt=1):
+    ctx.set_option("us_mfma", mfma)
+    ctx.set_option("scan_filter", filt)
+    ctx.set_model(model, 0, delta, L.LS_ANALYTIC).upload(data)
+    ctx.hypotheses_sample(seed, 0, H)
+    ctx.scan()
+    return ctx.hypotheses()
+
+
+@pytest.mark.parametrize("kind", ["single", "pointer"])
+def test_us_h16_votes_equal_the_other_paths_and_the_oracle(kind):
+    """ragged sizes (frames not a multiple of 512, hypotheses not a multiple of 32), thresholds from far below the
+    noise to far above the data, minimal solves on subsets with outlier frames (scale factors in the thousands)"""
+    if kind == "single":
+        data = synth.us_single_fast(70_013, 0.3, seed=5)
+        model, omodel = L.US_SINGLE, O.US_SINGLE
+    else:
+        data = synth.us_pointer(20_013, 0.3, seed=6)[0]
+        model, omodel = L.US_POINTER, O.US_POINTER
+    if isinstance(data, tuple):
+        data = data[0]
+    H = 333
+    with Context(0) as ctx:
+        for delta in (3.0, 1e-3, 1e4):
+            par, valid, v16 = _votes(ctx, model, data, delta, 77, H, 1)
+            assert b"fp32 filter used" not in ctx._lib.lsqr_last_error(ctx._h)
+            _, v2, v32 = _votes(ctx, model, data, delta, 77, H, 0)
+            _, v3, vex = _votes(ctx, model, data, delta, 77, H, 0, filt=0)
+            assert np.array_equal(valid, v2) and np.array_equal(valid, v3)
+            assert np.array_equal(v16, v32), (kind, delta)
+            assert np.array_equal(v16, vex), (kind, delta)
+            oc = O.cfg(omodel, 0, delta, 0)
+            for h in (0, 1, 2, 100, 332):
+                if valid[h]:
+                    assert v16[h] == O.scan(oc, par[h], data)[0], (kind, delta, h)
+        ctx.set_option("us_mfma", 1)
+        ctx.set_option("scan_filter", 1)
+
+
+def test_us_h16_delta_on_a_frames_own_distance():
+    """delta^2 placed exactly on one (frame, hypothesis) pair's reference squared distance, and one ulp either side:
+    strict '<' through the worklist"""
+    data = synth.us_single(20_000, 0.2, seed=9)[0]
+    with Context(0) as ctx:
+        par, valid, votes = _votes(ctx, L.US_SINGLE, data, 3.0, 5, 64, 1)
+        h = int(np.argmax(votes))
+        res = float(ctx.residuals(par[h], 777, 778)[0])      # sqrt of the reference's squared distance of frame 777
+        assert res > 0
+        for delta in (res, np.nextafter(res, np.inf), np.nextafter(res, 0.0), res * (1 + 1e-7), res * (1 - 1e-7)):
+            _, _, a = _votes(ctx, L.US_SINGLE, data, float(delta), 5, 64, 1)
+            _, _, b = _votes(ctx, L.US_SINGLE, data, float(delta), 5, 64, 0, filt=0)
+            assert np.array_equal(a, b), delta
+        ctx.set_option("us_mfma", 1)
+        ctx.set_option("scan_filter", 1)

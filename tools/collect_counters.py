@@ -23,7 +23,7 @@ from bench import kernel_source_hash  # noqa: E402
 
 # the kernels of the scan phase (bounded two-level scan: the level-1 passes and the balanced second level)
 CELLS = ("k_cells_bounds", "k_scan_pairs", "k_scan_cells", "k_bound_axis")
-KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32",),
+KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32", "k_scan_us_h16", "k_us_prep_h16", "k_us_recheck"),
           "dense": ("k_scan_dense_mfma", "k_scan_dense_h16", "k_dense_prep_h16", "k_dense_recheck")}
 
 
