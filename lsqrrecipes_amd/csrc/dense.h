@@ -135,6 +135,30 @@ __global__ __launch_bounds__(256) void k_estimate_dense_w4(const double *__restr
   if (lane == 0) valid[h] = ok ? 1 : (in_range ? 2 : 0);   // 2: to the SVD path; out-of-range subset: invalid either way
 }
 
+// K1 dense at n = 64 (r04, default): one wave per hypothesis, the 64 x 64 system IN REGISTERS -- lane = row -- and
+// wave_gepp_solve_reg64 (wave_linalg.h): the pivot row travels by v_readlane, no LDS round trip per column.  Results
+// bit-identical to k_estimate_dense_w4 / block_gepp_solve; what the elimination refuses is marked valid[h] = 2 for the
+// SVD path exactly as there.
+__global__ __launch_bounds__(64) void k_estimate_dense_r64(const double *__restrict__ data, size_t stride, size_t nobs,
+                                                           const uint32_t *__restrict__ subsets, uint32_t H, int sp_stride,
+                                                           double *__restrict__ hparams, uint8_t *__restrict__ valid) {
+  const int lane = threadIdx.x;
+  const uint32_t h = blockIdx.x;
+  if (h >= H) return;
+  size_t i = subsets[(size_t)h * 64 + lane];
+  const bool in_range = __ballot(i >= nobs) == 0;
+  if (i >= nobs) i = 0;
+  double a[64], xv;
+  const double *row = data + i * stride;
+#pragma unroll
+  for (int c = 0; c < 64; c++) a[c] = row[c];
+  const bool solved = wave_gepp_solve_reg64(a, row[64], xv);
+  const bool ok = solved && in_range;
+  const double qnan = __builtin_nan("");
+  for (int j = lane; j < sp_stride; j += 64) hparams[(size_t)h * sp_stride + j] = j < 64 ? (ok ? xv : qnan) : 0.0;
+  if (lane == 0) valid[h] = ok ? 1 : (in_range ? 2 : 0);
+}
+
 // K1 dense: one wave per hypothesis; n x n system in LDS; x = pinv(A) b, singular if any
 // sigma <= EPS (DenseLinear...Estimator.hxx:17-49)
 __global__ __launch_bounds__(256) void k_estimate_dense(const double *__restrict__ data,
@@ -1231,7 +1255,16 @@ __global__ __launch_bounds__(256) void k_solve_dense(const double *__restrict__ 
   __shared__ int s_solved;
   if (fast) {
     if (tid < 64) {
-      const bool okw = wave_gepp_solve(n, G, lda, rhs, x, flag ? 1e-6 : 1e-8);
+      bool okw;
+      if (n == 64) {  // the system in registers (wave_linalg.h: wave_gepp_solve_reg64, bit-identical): lane = row
+        double a[64], xv;
+#pragma unroll
+        for (int c = 0; c < 64; c++) a[c] = G[c * lda + tid];
+        okw = wave_gepp_solve_reg64(a, rhs[tid], xv, flag ? 1e-6 : 1e-8);
+        x[tid] = xv;
+      } else {
+        okw = wave_gepp_solve(n, G, lda, rhs, x, flag ? 1e-6 : 1e-8);
+      }
       if (tid == 0) s_solved = okw ? 1 : 0;
     }
     __syncthreads();

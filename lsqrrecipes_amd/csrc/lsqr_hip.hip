@@ -121,7 +121,8 @@ struct lsqr_ctx {
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
   int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
   int opt_presorted = 0;   // index build: cells = runs of the UPLOAD order (experiments with other spatial orders)
-  int opt_dense_wave = 1;  // dense minimal solves: elimination by one wave per system, four per workgroup (dense.h)
+  int opt_dense_wave = 3;  // dense minimal solves: 3 = elimination by one wave per system IN REGISTERS (n = 64; else as 1),
+                           // 1 / 2 = in the wave's LDS area, four / two systems per workgroup, 0 = one workgroup per system
   int opt_dense_dd = 1;    // dense fit: systems the elimination refuses are solved again from the rows in double-double
   double *d_ddpart = nullptr;  // partial double-double Gram blocks of k_gram_dd_dense (allocated on first use)
   int opt_pairs_mfma = 0;  // plane, 3-D, 512-record cells: 1 / 2 = level 2 of k_scan_pairs on the fp16 matrix cores with two /
@@ -562,6 +563,10 @@ int run_estimate(lsqr_ctx *c) {
                                     (int)(sizeof(double) * 4 * (64 * 65 + 128)));
           attr_set = true;
         }
+        if (n == 64 && c->opt_dense_wave == 3)  // the system in registers, one wave per hypothesis (k_estimate_dense_r64)
+          hipLaunchKernelGGL(k_estimate_dense_r64, dim3((unsigned)c->H), dim3(64), 0, c->stream, c->d_data, c->stride, c->n,
+                             c->d_subsets, (uint32_t)c->H, (int)M::SP, c->d_hparams, c->d_valid);
+        else
         hipLaunchKernelGGL(k_estimate_dense_w4, dim3((unsigned)((c->H + wpb - 1) / wpb)), dim3(64 * wpb), lds, c->stream, c->d_data,
                            c->stride, c->n, c->d_subsets, (uint32_t)c->H, n, (int)M::SP, c->d_hparams, c->d_valid);
         hipLaunchKernelGGL(k_estimate_dense, dim3((unsigned)c->H), dim3(256), dense_lds_bytes(n), c->stream, c->d_data,

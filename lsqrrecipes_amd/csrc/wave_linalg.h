@@ -454,6 +454,77 @@ __device__ inline bool wave_gepp_solve(int n, double *A, int lda, double *b, dou
   return true;
 }
 
+
+// The same elimination for n = 64 with the system IN REGISTERS: lane = row (its 64 coefficients and right-hand side in
+// 130 registers), the pivot row's elements broadcast with v_readlane as scalar operands of the update's fma -- no LDS
+// round trip per column, 64 steps of ~(64 - k) fmas and as many pairs of v_readlane instead of 64 steps of dependent LDS
+// reads and writes (~2 us each).  Rows are never moved: a row keeps its lane and a POSITION that the pivot steps
+// exchange, which is all wave_gepp_solve's swap does to the arithmetic -- same pivot rule (largest |a|, ties to the
+// lower position), same multipliers, same fma updates, same back substitution: BIT-IDENTICAL results
+// (tests/test_gpu_dense_fused.py).  x[k] is returned in lane k.
+__device__ __forceinline__ double wave_readlane_f64(double v, int l) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline bool wave_gepp_solve_reg64(double (&a)[64], double bv, double &xv, double piv_rel = 1e-8) {
+  const int lane = threadIdx.x & 63;
+  double am = 0.0;
+#pragma unroll
+  for (int c = 0; c < 64; c++) {
+    const double v = fabs(a[c]);
+    am = v > am ? v : (v == v ? am : INFINITY);  // NaN poisons the fast path
+  }
+  am = wave_max(am);
+  if (!(am <= 1e150)) return false;
+  const double tol = piv_rel * (am > 1.0 ? am : 1.0);
+  int pos = lane;  // the position of my row (wave_gepp_solve's row index after its swaps)
+  bool solved = true;
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    double v = pos >= k ? fabs(a[k]) : -1.0;
+    int idx = pos;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o);
+      const int oi = __shfl_xor(idx, o);
+      if (ov > v || (ov == v && oi < idx)) v = ov, idx = oi;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(idx);
+    // (v is the same in every lane after the butterfly.  A refused pivot ends wave_gepp_solve there; here the steps
+    // run on -- the loop has to be free of exits for the compiler to unroll it and keep the rows in registers -- and
+    // the result is discarded)
+    solved = solved && v > tol;
+    const int lp = __builtin_ctzll(__ballot(pos == p) | (1ull << 63));  // the lane that holds the pivot row
+    const double rpiv = 1.0 / wave_readlane_f64(a[k], lp);
+    if (p != k) pos = pos == p ? k : pos == k ? p : pos;
+    const bool below = pos > k;
+    double mult = 0.0;
+    if (below) {
+      mult = a[k] * rpiv;
+      a[k] = mult;
+    }
+    const double bk = wave_readlane_f64(bv, lp);
+#pragma unroll
+    for (int j = k + 1; j < 64; j++) {
+      const double akj = wave_readlane_f64(a[j], lp);
+      if (below) a[j] = fma(-mult, akj, a[j]);
+      // (the scheduler would fetch a whole step's pivot row first: 126 scalar registers, 394 spilled)
+      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (below) bv = fma(-mult, bk, bv);
+  }
+  xv = 0.0;
+#pragma unroll
+  for (int k = 63; k >= 0; k--) {  // back substitution
+    const int lk = __builtin_ctzll(__ballot(pos == k) | (1ull << 63));
+    const double xk = wave_readlane_f64(bv, lk) / wave_readlane_f64(a[k], lk);
+    if (lane == k) xv = xk;
+    if (pos < k) bv = fma(-a[k], xk, bv);
+  }
+  return solved;
+}
+
 __device__ inline int wave_pinv_solve(int m, int n, double *A, int lda, double *V, int ldv,
                                       const double *b, double tol_abs, double tol_rel, double *x,
                                       double *cwork) {

@@ -96,7 +96,7 @@ def test_dense_minimal_solves_by_one_wave_are_bit_identical(ctx, ncol, m, H):
     subs[3, 1] = subs[3, 0]                       # a repeated row: rank deficient -> invalid
     subs[H - 1, ncol - 1] = subs[H - 1, 0]
     out = {}
-    for wave in (1, 0):
+    for wave in (3, 1, 0):   # 3: the 64 x 64 system in registers (k_estimate_dense_r64; else as 1), 1: in LDS, 0: workgroup
         ctx.set_option("dense_wave_solve", wave)
         ctx.hypotheses_from_subsets(subs)
         par, valid, _ = ctx.hypotheses(votes=False)
@@ -104,8 +104,11 @@ def test_dense_minimal_solves_by_one_wave_are_bit_identical(ctx, ncol, m, H):
         votes = ctx.hypotheses(params=False)[2].copy()
         r = ctx.batch_fit(5, 0, min(H, 256), want_consensus=True)
         out[wave] = (par.copy(), valid.copy(), votes, r["params"].copy(), r["info"].best_index)
-    ctx.set_option("dense_wave_solve", 1)
+    ctx.set_option("dense_wave_solve", 3)
+    (p3, v3, k3, f3, b3) = out[3]
     (p1, v1, k1, f1, b1), (p0, v0, k0, f0, b0) = out[1], out[0]
+    assert np.array_equal(v3, v0) and np.array_equal(p3[v3 > 0], p0[v0 > 0])  # the register elimination: bit for bit
+    assert np.array_equal(k3, k0) and b3 == b0 and np.array_equal(f3, f0)
     assert np.array_equal(v1, v0) and not v1[3] and not v1[H - 1] and v1.sum() >= H - 4
     assert np.array_equal(p1[v1 > 0], p0[v0 > 0])            # bit for bit
     assert np.array_equal(k1, k0) and b1 == b0 and np.array_equal(f1, f0)
