@@ -105,7 +105,7 @@ struct lsqr_ctx {
   uint4 *d_h16 = nullptr;
   float *d_h16_bs = nullptr;
   size_t h16_tiles_cap = 0;
-  bool h16_valid = false, h16_attr = false;
+  bool h16_valid = false, h16_attr = false, h16_nomem = false;  // nomem: no room for the fragments on this upload
   int h16_unit = 0;       // 0: this device's matrix unit not probed yet, 1: keeps dense_h16.h's accumulation assumption, -1: not
   double h16_unit_dev = 0.0;  // the probe's worst deviation (u of the sum of magnitudes)
   double h16_pa = 1.0;
@@ -113,7 +113,7 @@ struct lsqr_ctx {
   // us_h16.h: the frames as fp16 fragment pairs (6 KiB per 32 frames), once per upload; the batch's hypothesis fragments
   uint4 *d_us16 = nullptr, *d_us16_x = nullptr;
   size_t us16_tiles_cap = 0;
-  bool us16_valid = false, us16_attr = false;
+  bool us16_valid = false, us16_attr = false, us16_nomem = false;
   Us16Scales us16_sc{};
   int opt_us_h16 = 1;  // US calibrations: 1 = agree() scan on the fp16 matrix cores (us_h16.h), 0 = packed fp32 filter
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
@@ -679,6 +679,7 @@ void lanes_quiesce(lsqr_ctx *c) {
 void drop_index(lsqr_ctx *c) {
   c->h16_valid = false;  // (derived from the records alone, like the index)
   c->us16_valid = false;
+  c->h16_nomem = c->us16_nomem = false;
   c->n_sorted = 0;
   c->n_cells = 0;
   c->index_valid = false;
@@ -1276,7 +1277,7 @@ int ensure_us_h16(lsqr_ctx *c, bool *ok) {
   *ok = false;
   constexpr bool SINGLE = M::K == 4;
   const double X = c->mc.absmax, Rm = c->mc.absmax_rot;
-  if (!c->absmax_valid || !(X > 0.0) || !(X < 1e15) || !(Rm > 0.0) || !(Rm < 1e15)) return LSQR_OK;
+  if (!c->absmax_valid || !(X > 0.0) || !(X < 1e15) || !(Rm > 0.0) || !(Rm < 1e15) || c->us16_nomem) return LSQR_OK;
   int st = h16_probe_unit(c);
   if (st != LSQR_OK) return st;
   if (c->h16_unit < 0) return LSQR_OK;
@@ -1286,7 +1287,12 @@ int ensure_us_h16(lsqr_ctx *c, bool *ok) {
     if (n_tiles > c->us16_tiles_cap) {
       if (c->d_us16) (void)hipFree(c->d_us16);
       c->d_us16 = nullptr, c->us16_tiles_cap = 0;
-      HIPCHK(c, hipMalloc((void **)&c->d_us16, n_tiles * (size_t)kUs16FrameTile));
+      if (hipMalloc((void **)&c->d_us16, n_tiles * (size_t)kUs16FrameTile) != hipSuccess) {
+        (void)hipGetLastError();  // (no room for the fragments: not an error -- the packed fp32 filter scans the records)
+        c->d_us16 = nullptr;
+        c->us16_nomem = true;
+        return LSQR_OK;
+      }
       c->us16_tiles_cap = n_tiles;
     }
     hipLaunchKernelGGL((k_us_rows_h16<SINGLE>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
@@ -1337,7 +1343,7 @@ int ensure_dense_h16(lsqr_ctx *c, bool *ok) {
   const double amax = c->mc.absmax_rot, bmax = c->mc.absmax;
   if (!(amax > 0.0) || !(amax < 1e15) || !(bmax < 1e15)) return LSQR_OK;
   const double pa = 32768.0 / amax;
-  if (!(pa < 1e30) || !(bmax * pa < 1e18)) return LSQR_OK;
+  if (!(pa < 1e30) || !(bmax * pa < 1e18) || c->h16_nomem) return LSQR_OK;
   int stp = h16_probe_unit(c);
   if (stp != LSQR_OK) return stp;
   if (c->h16_unit < 0) return LSQR_OK;
@@ -1347,8 +1353,15 @@ int ensure_dense_h16(lsqr_ctx *c, bool *ok) {
       if (c->d_h16) (void)hipFree(c->d_h16);
       if (c->d_h16_bs) (void)hipFree(c->d_h16_bs);
       c->d_h16 = nullptr, c->d_h16_bs = nullptr, c->h16_tiles_cap = 0;
-      HIPCHK(c, hipMalloc((void **)&c->d_h16, n_tiles * (size_t)kH16TileBytes));
-      HIPCHK(c, hipMalloc((void **)&c->d_h16_bs, n_tiles * 32 * sizeof(float)));
+      // (no room for the second copy of the rows: not an error -- the fp32 filter scans the fp64 rows)
+      if (hipMalloc((void **)&c->d_h16, n_tiles * (size_t)kH16TileBytes) != hipSuccess ||
+          hipMalloc((void **)&c->d_h16_bs, n_tiles * 32 * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->d_h16) (void)hipFree(c->d_h16);
+        c->d_h16 = nullptr, c->d_h16_bs = nullptr;
+        c->h16_nomem = true;
+        return LSQR_OK;
+      }
       c->h16_tiles_cap = n_tiles;
     }
     hipLaunchKernelGGL(k_dense_rows_h16, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
