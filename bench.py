@@ -363,6 +363,28 @@ def scan_roofline(R, mode, scan_ms, n_scan):
                                  "products); issued = nine 32x32x16 matrix instructions per 1024 pairs (three partial "
                                  "products, K padded 13 -> 16); peak = the dense fp16 matrix rate"})
             return base
+        if w == "phantom" and us_mfma and not a.no_filter:
+            # phantom_h16.h: the 31-term error of (frame, hypothesis) as one dot product on the fp16 matrix cores, two-way
+            # fp16 splits, two 16-slot blocks: six v_mfma_f32_32x32x16_f16 per 32 frames x 32 hypotheses
+            wk = ctx.scan_work() if hasattr(ctx, "scan_work") else None
+            fh = float(wk["row_hypothesis_pairs"]) if wk else float(H) * a.points
+            ach = 62.0 * fh / t / 1e12 if t > 0 else 0.0          # 31 terms x 2 flop, logical
+            issued = 6.0 * 32768.0 / 1024.0 * fh / t / 1e12 if t > 0 else 0.0
+            base.update({"bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F16_MFMA_PEAK_TFLOPS, "traffic": traffic, "issued_TFLOPs": issued,
+                         "frac_issued": issued / F16_MFMA_PEAK_TFLOPS,
+                         "kernel_short": "k_scan_phantom_h16 fp16-split MFMA filter + k_us_recheck_seg (exact fp64)",
+                         "kernel": "k_scan_phantom_h16 (frames and hypotheses as two-way fp16 splits, twelve "
+                                   "v_mfma_f32_32x32x16_f16 per 64 x 32 (frame, hypothesis) pairs with the previous "
+                                   "tile's classification issued between them, hypothesis fragments of a launch in LDS) "
+                                   "+ k_us_recheck_seg (exact fp64 decision of the band, after every launch)",
+                         "work_model": {"frame_hypothesis_pairs_evaluated": fh,
+                                        "frame_hypothesis_pairs_all": float(H) * a.points},
+                         "note": "achieved = 62 flop x (frame, hypothesis) pairs / launch time (the logical 31-term "
+                                 "product); issued = six 32x32x16 matrix instructions per 1024 pairs (three partial "
+                                 "products, K padded 31 -> 32); peak = the dense fp16 matrix rate; the time includes the "
+                                 "split of the unknowns and the exact re-checks"})
+            return base
         wk = ctx.scan_work() if hasattr(ctx, "scan_work") else None
         pairs_all = float(H) * a.points / 128.0      # every (hypothesis, packed pair of observations per wave)
         pairs = wk["row_hypothesis_pairs"] / 128.0 if wk else pairs_all

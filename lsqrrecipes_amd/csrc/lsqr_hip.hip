@@ -26,6 +26,7 @@
 #include "dense_h16.h"
 #include "us_kernels.h"
 #include "us_h16.h"
+#include "phantom_h16.h"
 #include "cells.h"
 #include "cells_h16.h"
 #include "earlyexit.h"
@@ -1273,9 +1274,12 @@ int h16_probe_unit(lsqr_ctx *c) {
 // US calibrations: the frames as fp16 fragment pairs for us_h16.h's filter, once per upload (1 M frames: 192 MB).
 // *ok = false when the filter cannot be used (magnitudes, the device's matrix unit): the packed fp32 filter scans.
 template <class M>
+constexpr bool kHasUsH16 = M::IS_US || requires { M::IS_PHANTOM; };
+template <class M>
 int ensure_us_h16(lsqr_ctx *c, bool *ok) {
   *ok = false;
-  constexpr bool SINGLE = M::K == 4;
+  constexpr bool PH = requires { M::IS_PHANTOM; };
+  constexpr bool SINGLE = PH || M::K == 4;
   const double X = c->mc.absmax, Rm = c->mc.absmax_rot;
   if (!c->absmax_valid || !(X > 0.0) || !(X < 1e15) || !(Rm > 0.0) || !(Rm < 1e15) || c->us16_nomem) return LSQR_OK;
   int st = h16_probe_unit(c);
@@ -1295,19 +1299,27 @@ int ensure_us_h16(lsqr_ctx *c, bool *ok) {
       }
       c->us16_tiles_cap = n_tiles;
     }
-    hipLaunchKernelGGL((k_us_rows_h16<SINGLE>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
-                       c->stride, c->n, sc, c->d_us16, n_tiles);
+    if constexpr (PH)  // (4 KiB per 32 frames of the 6 KiB the allocation holds)
+      hipLaunchKernelGGL(k_phantom_rows_h16, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data, c->stride,
+                         c->n, sc, c->d_us16, n_tiles);
+    else
+      hipLaunchKernelGGL((k_us_rows_h16<SINGLE>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
+                         c->stride, c->n, sc, c->d_us16, n_tiles);
     HIPCHK(c, hipGetLastError());
     c->us16_valid = true;
     c->us16_sc = sc;
   }
-  if (!c->d_us16_x) HIPCHK(c, hipMalloc((void **)&c->d_us16_x, (size_t)(8192 / 32) * 2048));
+  if (!c->d_us16_x) HIPCHK(c, hipMalloc((void **)&c->d_us16_x, (size_t)(8192 / 32) * 4096));
   if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
   if (!c->d_amb) HIPCHK(c, hipMalloc((void **)&c->d_amb, sizeof(unsigned long long) * kAmbCap));
   if (!c->us16_attr) {
     c->us16_attr = true;
-    (void)hipFuncSetAttribute((const void *)k_scan_us_h16<SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)us_h16_lds(kUs16HypChunk));
+    if constexpr (PH)
+      (void)hipFuncSetAttribute((const void *)k_scan_phantom_h16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)phantom_h16_lds(kPh16HypChunk));
+    else
+      (void)hipFuncSetAttribute((const void *)k_scan_us_h16<SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)us_h16_lds(kUs16HypChunk));
   }
   *ok = true;
   return LSQR_OK;
@@ -1317,22 +1329,36 @@ int ensure_us_h16(lsqr_ctx *c, bool *ok) {
 template <class M>
 int launch_us_h16(lsqr_ctx *c, size_t rb, size_t re, const double *sp, uint32_t H, unsigned int *d_segcnt, uint32_t seg_cap,
                   const uint32_t *h_dev, const uint32_t *sel, const uint32_t *range_dev) {
-  constexpr bool SINGLE = M::K == 4;
-  hipLaunchKernelGGL((k_us_prep_h16<SINGLE>), dim3((H + 31 + 255) / 256), dim3(256), 0, c->stream, sp, (int)M::SP, H,
-                     c->mc.delta_sq, c->mc.absmax, c->mc.absmax_rot, c->us16_sc, c->d_us16_x, c->d_h16_thr);
+  constexpr bool PH = requires { M::IS_PHANTOM; };
+  constexpr bool SINGLE = PH || M::K == 4;
+  if constexpr (PH)
+    hipLaunchKernelGGL(k_phantom_prep_h16, dim3((H + 31 + 255) / 256), dim3(256), 0, c->stream, sp, (int)M::SP, H,
+                       sqrt(c->mc.delta_sq), c->mc.absmax, c->mc.absmax_rot, c->us16_sc, c->d_us16_x, c->d_h16_thr);
+  else
+    hipLaunchKernelGGL((k_us_prep_h16<SINGLE>), dim3((H + 31 + 255) / 256), dim3(256), 0, c->stream, sp, (int)M::SP, H,
+                       c->mc.delta_sq, c->mc.absmax, c->mc.absmax_rot, c->us16_sc, c->d_us16_x, c->d_h16_thr);
   HIPCHK(c, hipGetLastError());
   const size_t passes = (re - rb + kUs16Wg - 1) / kUs16Wg;
   const unsigned nblk = (unsigned)std::min<size_t>(passes, 256);  // one workgroup (eight waves) per CU
   for (size_t h0 = 0; h0 < H; h0 += kUs16HypChunk) {
     const uint32_t hc = (uint32_t)std::min<size_t>(kUs16HypChunk, H - h0);
-    hipLaunchKernelGGL((k_scan_us_h16<SINGLE>), dim3(nblk), dim3(kUs16Wg), us_h16_lds(hc), c->stream, c->d_us16, c->n, rb,
-                       re, c->d_us16_x + (h0 / 32) * 128, c->d_h16_thr + 4 * h0, hc, c->d_votes, c->d_amb, d_segcnt, seg_cap,
-                       (uint32_t)h0, h_dev, sel, range_dev);
+    if constexpr (PH)
+      hipLaunchKernelGGL(k_scan_phantom_h16, dim3(nblk), dim3(kPh16Wg), phantom_h16_lds(hc), c->stream, c->d_us16, c->n, rb, re,
+                         c->d_us16_x + (h0 / 32) * 256, c->d_h16_thr + 4 * h0, hc, c->d_votes, c->d_amb, d_segcnt, seg_cap,
+                         (uint32_t)h0, h_dev, sel, range_dev);
+    else
+      hipLaunchKernelGGL((k_scan_us_h16<SINGLE>), dim3(nblk), dim3(kUs16Wg), us_h16_lds(hc), c->stream, c->d_us16, c->n, rb,
+                         re, c->d_us16_x + (h0 / 32) * 128, c->d_h16_thr + 4 * h0, hc, c->d_votes, c->d_amb, d_segcnt, seg_cap,
+                         (uint32_t)h0, h_dev, sel, range_dev);
     HIPCHK(c, hipGetLastError());
+    // the exact decision of the band: the phantom after every launch (its 31-term sums leave ~3e-4 of the pairs there,
+    // a workgroup's segment holds one launch's share, not four), the calibrations once
+    if (PH || h0 + kUs16HypChunk >= H) {
+      hipLaunchKernelGGL((k_us_recheck_seg<M>), dim3(256), dim3(1024), 0, c->stream, c->d_data, c->stride, c->d_hparams,
+                         (int)M::SP, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes, (unsigned int *)(c->d_counter + 3));
+      HIPCHK(c, hipGetLastError());
+    }
   }
-  hipLaunchKernelGGL((k_us_recheck_seg<M>), dim3(256), dim3(256), 0, c->stream, c->d_data, c->stride, c->d_hparams,
-                     (int)M::SP, c->mc, c->d_amb, d_segcnt, seg_cap, c->d_votes, (unsigned int *)(c->d_counter + 3));
-  HIPCHK(c, hipGetLastError());
   return LSQR_OK;
 }
 
@@ -1504,7 +1530,7 @@ int run_scan_us_ee(lsqr_ctx *c) {
   bool h16 = false;
   unsigned int *d_segcnt = (unsigned int *)((float *)c->d_partials + 2 * 8192 + 64 * 8192);
   const uint32_t seg_cap = kAmbCap / 1024;
-  if constexpr (M::IS_US) {
+  if constexpr (kHasUsH16<M>) {
     if (c->opt_us_h16 && H <= 8192) {
       if ((st = ensure_us_h16<M>(c, &h16)) != LSQR_OK) return st;
       if (h16) {
@@ -1515,7 +1541,7 @@ int run_scan_us_ee(lsqr_ctx *c) {
   }
   auto scan = [&](size_t rb, size_t re, const uint32_t *range_dev, const uint32_t *h_dev, const uint32_t *sel) -> int {
     if (rb >= re) return LSQR_OK;
-    if constexpr (M::IS_US) {
+    if constexpr (kHasUsH16<M>) {
       if (h16)  // fp16 matrix cores (us_h16.h); the band of every chunk is decided exactly before the next selection
         return launch_us_h16<M>(c, rb, re, sel ? c->d_hparams2 : c->d_hparams, H, d_segcnt, seg_cap, h_dev, sel, range_dev);
     }
@@ -1707,7 +1733,7 @@ int run_scan(lsqr_ctx *c) {
           return run_scan_us_ee<M>(c);  // batch entry points: chunked early exit (earlyexit.h)
         const int np = c->opt_ppl == 2 ? 1 : 2;  // pairs of frames per lane (scan_ppl 2 / 4)
         HIPCHK(c, hipMemsetAsync(c->d_votes, 0, c->H * sizeof(uint32_t), c->stream));
-        if constexpr (M::IS_US) {
+        if constexpr (kHasUsH16<M>) {
           if (c->opt_us_h16 && c->H >= 32 && c->H <= 8192 && c->n >= 4096) {  // fp16 matrix cores (us_h16.h)
             bool h16 = false;
             int st = ensure_us_h16<M>(c, &h16);

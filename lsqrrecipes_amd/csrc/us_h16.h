@@ -351,7 +351,7 @@ inline size_t us_h16_lds(uint32_t H) {
 
 // exact decision of the segmented worklist (one block per segment); out_max[0] = largest segment fill
 template <class M>
-__global__ __launch_bounds__(256) void k_us_recheck_seg(const double *__restrict__ data, size_t stride,
+__global__ __launch_bounds__(1024) void k_us_recheck_seg(const double *__restrict__ data, size_t stride,
                                                         const double *__restrict__ sp, int sp_stride, ModelConsts mc,
                                                         const unsigned long long *__restrict__ amb_list,
                                                         unsigned int *__restrict__ amb_counts, uint32_t seg_cap,
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_us_recheck_seg(const double *__restrict
   if (filled == 0) return;
   if (threadIdx.x == 0) atomicMax(out_max, filled);
   const unsigned total = filled < seg_cap ? filled : seg_cap;
-  for (unsigned e = threadIdx.x; e < total; e += 256) {
+  for (unsigned e = threadIdx.x; e < total; e += blockDim.x) {  // (dependent loads: one entry per thread where it fits)
     const unsigned long long v = amb_list[(size_t)blockIdx.x * seg_cap + e];
     const size_t row = (size_t)(v >> 32);
     const uint32_t h = (uint32_t)(v & 0xffffffffu);

@@ -1,6 +1,10 @@
 """The US calibrations' agree() scan on the fp16 matrix cores (lsqrrecipes_amd/csrc/us_h16.h; reference:
 SinglePointTargetUSCalibrationParametersEstimator.cxx:74-107 / :728-766).  A filter: whatever it cannot decide goes through
 the exact fp64 predicate, so every vote must equal the packed fp32 filter's, the exact kernel's and the oracle's."""
+import os
+import re
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -65,3 +69,53 @@ def test_us_h16_delta_on_a_frames_own_distance():
             assert np.array_equal(a, b), delta
         ctx.set_option("us_mfma", 1)
         ctx.set_option("scan_filter", 1)
+
+
+def test_phantom_h16_votes_equal_the_other_paths_and_the_oracle():
+    """plane phantom (lsqrrecipes_amd/csrc/phantom_h16.h; reference: PlanePhantomUSCalibrationParametersEstimator.cxx:73-135):
+    the 31-term error as one matrix product; ragged sizes, thresholds from far below the noise to above every frame,
+    the early-exit driver (scan_bound) and the plain one"""
+    data = synth.plane_phantom_fast(70_013, 0.05, seed=15, pixel_sigma=0.05)[0]
+    H = 333
+    with Context(0) as ctx:
+        for delta in (2.0, 1e-3, 1e4):
+            par, valid, v16 = _votes(ctx, L.PHANTOM, data, delta, 78, H, 1)
+            assert b"fp32 filter used" not in ctx._lib.lsqr_last_error(ctx._h)
+            _, v2, v32 = _votes(ctx, L.PHANTOM, data, delta, 78, H, 0)
+            _, v3, vex = _votes(ctx, L.PHANTOM, data, delta, 78, H, 0, filt=0)
+            assert np.array_equal(valid, v2) and np.array_equal(valid, v3)
+            assert np.array_equal(v16, v32), delta
+            assert np.array_equal(v16, vex), delta
+            oc = O.cfg(O.PHANTOM, 0, delta, 0)
+            for h in (0, 1, 100, 332):
+                if valid[h]:
+                    assert v16[h] == O.scan(oc, par[h], data)[0], (delta, h)
+        ctx.set_option("us_mfma", 1)
+        ctx.set_option("scan_filter", 1)
+
+
+def test_phantom_h16_delta_on_a_frames_own_error():
+    """delta placed exactly on one (frame, hypothesis) pair's |err|, and one ulp either side"""
+    data = synth.plane_phantom_fast(20_000, 0.05, seed=19, pixel_sigma=0.05)[0]
+    with Context(0) as ctx:
+        par, valid, votes = _votes(ctx, L.PHANTOM, data, 2.0, 5, 64, 1)
+        h = int(np.argmax(votes))
+        res = float(ctx.residuals(par[h], 777, 778)[0])
+        assert res > 0
+        for delta in (res, np.nextafter(res, np.inf), np.nextafter(res, 0.0), res * (1 + 1e-7), res * (1 - 1e-7)):
+            _, _, a = _votes(ctx, L.PHANTOM, data, float(delta), 5, 64, 1)
+            _, _, b = _votes(ctx, L.PHANTOM, data, float(delta), 5, 64, 0, filt=0)
+            assert np.array_equal(a, b), delta
+        ctx.set_option("us_mfma", 1)
+        ctx.set_option("scan_filter", 1)
+
+
+def test_phantom_h16_standalone_check():
+    """tools/ph16_bench (built by __graft_entry__.build()): every vote of 1001 hypotheses x 99 937 synthetic frames (ragged:
+    the last pass, the last hypothesis tile) against a brute-force count with the reference's predicate"""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ph16_bench")
+    if not os.path.exists(exe):
+        pytest.skip("tools/ph16_bench not built")
+    out = subprocess.run([exe, "99937", "1001", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert re.search(r"votes: 0 of 1001 hypotheses differ", out.stdout), out.stdout
