@@ -15,14 +15,14 @@
 // Error of s'' = s 2^14 px against the exact n . (x - a) 2^14 px, u = 2^-24, rr = sum |n_i| h_i, R = the power of two
 // above max h_i:
 //   as in cells.h: x' = fl32(x - ctr), n -> fp32, d0 -> fp32                      u (2 rr + |d0|)
-//   remainders of the two-way splits of p, n'', d (relative 2^-24 each)            u (2 rr + |d0|)
+//   remainders of the two-way splits of p, n'', d (relative 2^-23 = 2 u each)      u (4 rr + 2 |d0|)
 //   operands below 2^-14 may be flushed by the matrix unit: <= 2^-14 per slot against the other operand's <= 2^14
 //   (seven slots), in units of s:  7 / (2^14 px) = 7 R 2^-28                       Eflush = 8 R 2^-28
-//   the dropped lo x lo products                                                    u rr
+//   the dropped lo x lo products (each lo <= 2^-11 of its value)                    4 u rr
 //   accumulation inside the instruction: not specified bit by bit; ASSUMED (as in dense_h16.h) at most one ulp of the
 //   largest magnitude involved per product, 13 terms:                               26 u (rr + |d0|)
-// |s16 - s*| <= u (31 rr + 28 |d0|) + Eflush, and a cell that passed level 1 has |d0| <= (rr + tout)(1 + 2^-18):
-//   E16 = 1.01 u (59.1 rr + 28.1 T) + 8 R 2^-28 + 3e-12 X.    (cells.h's fp32 chain: 1.01 u (9.4 rr + 4.3 T).)
+// |s16 - s*| <= u (36 rr + 29 |d0|) + Eflush, and a cell that passed level 1 has |d0| <= (rr + tout)(1 + 2^-18):
+//   E16 = 1.01 u (65.1 rr + 29.1 T) + 8 R 2^-28 + 3e-12 X.    (cells.h's fp32 chain: 1.01 u (9.4 rr + 4.3 T).)
 // The band is wider, the re-check is narrower: a lane whose hypothesis has a value in the band evaluates the exact fp64
 // predicate for THAT observation (k_scan_pairs re-evaluates all 512 of the cell).
 // Level 1, the counted shares and the output are k_scan_pairs' own: same survivor masks, same (cell, group, lane)
@@ -33,7 +33,7 @@
 // tile the compiler emits ~60 issue slots (the 36 of the classification, 16 moves around the accumulator, waits behind
 // the matrix instruction) at two waves per SIMD where k_scan_pairs runs six; the matrix unit aligns the products of one
 // instruction with two guard bits (tools/h16_bench.hip, "align probe": 15 small terms beside a large one lose 3.8 ulp
-// of it), so the band cannot be narrowed much below the 59 rr u taken here, and deferring the exact decisions to
+// of it), so the band cannot be narrowed much below the 65 rr u taken here, and deferring the exact decisions to
 // per-lane queues (below) changed nothing -- with the band switched off altogether (timing experiment, wrong votes) the
 // scan phase is the same 0.97 ms: the loop is issue bound.  40 issue slots per matrix instruction = 20 per (hypothesis,
 // cell) pair, plus ~7 per pair for level 1 and the split operands of a group, against k_scan_pairs' 37 -- a quarter
@@ -55,8 +55,8 @@ struct PairsH16Consts {
 inline PairsH16Consts pairs_h16_consts(const ModelConsts &mc) {
   const double u = 5.9604644775390625e-08;
   PairsH16Consts k;
-  k.e_rr = f32_up_host(1.01 * 59.1 * u * (1.0 + 1e-6));
-  k.e_t = f32_up_host((1.01 * 28.1 * u * mc.thr + 3e-12 * mc.absmax) * (1.0 + 1e-6));
+  k.e_rr = f32_up_host(1.01 * 65.1 * u * (1.0 + 1e-6));
+  k.e_t = f32_up_host((1.01 * 29.1 * u * mc.thr + 3e-12 * mc.absmax) * (1.0 + 1e-6));
   k.e_r = f32_up_host(8.0 / 268435456.0 * (1.0 + 1e-6));
   k.tdn = f32_down_host(mc.thr);
   k.tup = f32_up_host(mc.thr);

@@ -13,10 +13,11 @@
 // entry| of the upload), and the hypothesis side carries x''_k = x_k G / pa_k with ONE factor G per hypothesis chosen so
 // that max_k |x''_k| = 2^15:  e'' = e G.
 // Error of a component against the exact e'' (u = 2^-24, S'' = 2^15 sum_k |x''_k| >= sum |a''_k x''_k|):
-//   splits' remainders 2 u S'', flushed operands (< 2^-14) 0.8 u S'', dropped lo x lo u S'', accumulation -- measured two
+//   splits' remainders 4 u S'' (2^-23 per factor), flushed operands (< 2^-14) 0.8 u S'', dropped lo x lo 4 u S'' (2^-11 of
+//   either factor), accumulation -- measured two
 //   guard bits, assumed 1 u of the largest magnitude per product and addend (dense_h16.h) -- 14 u S'' for the hi x hi
-//   instruction, 0.03 u S'' for the two before it:  |e16 - e''| <= 18 u S'';  the reference's fp64 components are within
-//   1e-13 S'' of exact (us.h: Ee64).   E = 1.01 (18 u + 1e-13) S''.
+//   instruction, 0.03 u S'' for the two before it:  |e16 - e''| <= 23 u S'';  the reference's fp64 components are within
+//   1e-13 S'' of exact (us.h: Ee64).   E = 1.01 (23 u + 1e-13) S''.
 // | |e16| - |e_ref| | <= sqrt(3) E, so with D = delta G:   v = |e16|^2 <  (D - sqrt3 E)^2 (1 - 1e-6) => agrees,
 //   v >= (D + sqrt3 E)^2 (1 + 1e-6) => does not (1e-6: the three roundings of the fp32 sum of squares and of delta^2),
 //   in between the exact predicate decides (worklist, k_us_recheck_seg).  Thresholds on d = v - a as in dense_h16.h.
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_us_prep_h16(const double *__restrict__ 
     xs[k] = k < 13 ? x[k] * G / sc.pa[us16_group(k)] : 0.0;
     S += 32768.0 * fabs(xs[k]);
   }
-  const double E = 1.01 * (18.0 * u + 1e-13) * S;
+  const double E = 1.01 * (23.0 * u + 1e-13) * S;
   const double D = sqrt(delta_sq > 0.0 ? delta_sq : 0.0) * G;
   const double tin = D - 1.7320508075688774 * E, tout = D + 1.7320508075688774 * E;
   const bool live = finite && delta_sq > 0.0 && X < 1e15 && Rm < 1e15 && G < 1e30 && G > 1e-30 && tout < 9.0e18 &&

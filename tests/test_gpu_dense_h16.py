@@ -85,7 +85,7 @@ def test_h16_magnitudes_that_do_not_fit_fall_back():
 def test_h16_standalone_check_and_error_of_the_matrix_unit():
     """tools/h16_bench (built by __graft_entry__.build()): every vote of 1000 hypotheses x 100 000 rows against a
     brute-force fp64 count, incl. hypotheses the filter cannot take; and the deviation of the matrix unit's residual
-    from the exact one, which the thresholds ASSUME to be below 78 u S (dense_h16.h header)"""
+    from the exact one, which the thresholds ASSUME to be below 83 u S (dense_h16.h header)"""
     exe = os.path.join(ROOT, "tools", "h16_bench")
     if not os.path.exists(exe):
         pytest.skip("tools/h16_bench not built")
@@ -93,7 +93,7 @@ def test_h16_standalone_check_and_error_of_the_matrix_unit():
     assert out.returncode == 0, out.stdout + out.stderr
     assert re.search(r"votes: 0 of 1000 hypotheses differ", out.stdout), out.stdout
     dev = float(re.search(r"probe: largest \|r'' - res''\| = ([0-9.eE+-]+) u S", out.stdout).group(1))
-    assert dev < 20.0, dev   # measured 0.8 - 1.5; the bound in use is 78
+    assert dev < 20.0, dev   # measured 0.8 - 1.5; the bound in use is 83
     # the alignment of one instruction's products: the probe's worst case must stay below half of what is assumed
     offs = [abs(float(m)) for m in re.findall(r"= ([+-][0-9.]+) u of the sum of magnitudes", out.stdout)]
     assert len(offs) == 8 and max(offs) < 8.5, offs   # 17 terms x 0.5 u; measured 5.5 - 7.6

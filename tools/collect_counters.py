@@ -24,7 +24,8 @@ from bench import kernel_source_hash  # noqa: E402
 # the kernels of the scan phase (bounded two-level scan: the level-1 passes and the balanced second level)
 CELLS = ("k_cells_bounds", "k_scan_pairs", "k_scan_cells", "k_bound_axis")
 KERNEL = {"plane": CELLS, "sphere": CELLS, "line": CELLS, "us": ("k_scan_us_f32", "k_scan_us_h16", "k_us_prep_h16", "k_us_recheck"),
-          "dense": ("k_scan_dense_mfma", "k_scan_dense_h16", "k_dense_prep_h16", "k_dense_recheck")}
+          "dense": ("k_scan_dense_mfma", "k_scan_dense_h16", "k_dense_prep_h16", "k_dense_recheck"),
+          "phantom": ("k_scan_us_f32", "k_scan_phantom_h16", "k_phantom_prep_h16", "k_us_recheck")}
 
 
 def is_scan(w, name):
@@ -73,7 +74,7 @@ def main():
     os.environ.setdefault("TMPDIR", "/tmp")
     scratch = os.path.join(out_dir, "pmc_%s_%s" % (w, mode))
     c = {}
-    for i, s in enumerate(SETS + (MFMA_SETS if w == "dense" else [])):
+    for i, s in enumerate(SETS + (MFMA_SETS if w in ("dense", "us", "phantom") else [])):
         got = run_pass(w, s, os.path.join(scratch, "p%d" % i))
         if got is None:
             print("pass failed: " + s, file=sys.stderr)

@@ -1,6 +1,7 @@
 // tools/mfma_rate.hip -- what one SIMD sustains of v_mfma_f32_32x32x16_f16 when EVERY SIMD of the chip issues them back to
-// back: time per instruction, shader cycles per instruction (s_memtime), hence the clock under this load.
-//   hipcc --offload-arch=gfx950 -O3 -o tools/mfma_rate tools/mfma_rate.hip;  tools/mfma_rate [waves per SIMD] [chains]
+// back: time per instruction, shader cycles per instruction (s_memtime), hence the clock under this load; and with V
+// independent v_fma_f32 behind every matrix instruction (do they run in its shadow?).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/mfma_rate tools/mfma_rate.hip;  tools/mfma_rate [waves per SIMD] [chains] [V]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -9,29 +10,45 @@
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CH>
+template <int CH, int V>
 __global__ __launch_bounds__(256) void k_rate(float *out, unsigned long long *cyc, int iters, float seed) {
   h16x8 a, b;
   for (int i = 0; i < 8; i++) a[i] = (_Float16)(seed + threadIdx.x * 1e-3f + i), b[i] = (_Float16)(seed * 0.5f + i);
   f32x16 acc[CH];
   for (int c = 0; c < CH; c++)
     for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
+  float v[8];
+  for (int i = 0; i < 8; i++) v[i] = seed * (i + 1);
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int c = 0; c < CH; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+    for (int c = 0; c < CH; c++) {
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < V; j++) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[j & 7]) : "v"(seed));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = 0.0f;
   for (int c = 0; c < CH; c++)
     for (int i = 0; i < 16; i++) s += acc[c][i];
+  for (int i = 0; i < 8; i++) s += v[i];
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int V>
+static void launch(int ch, int blocks, float *out, unsigned long long *cyc, int iters) {
+  if (ch == 1) hipLaunchKernelGGL((k_rate<1, V>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters, 1.0f);
+  else if (ch == 2) hipLaunchKernelGGL((k_rate<2, V>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters, 1.0f);
+  else hipLaunchKernelGGL((k_rate<4, V>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters, 1.0f);
 }
 
 int main(int argc, char **argv) {
   const int wps = argc > 1 ? atoi(argv[1]) : 1;   // waves per SIMD
   const int ch = argc > 2 ? atoi(argv[2]) : 4;    // independent accumulator chains per wave
+  const int nv = argc > 3 ? atoi(argv[3]) : 0;     // v_fma_f32 behind every matrix instruction
   const int iters = 20000;
   const int blocks = 256 * wps;                   // 256 threads = 4 waves = one per SIMD of a CU
   float *out;
@@ -42,9 +59,12 @@ int main(int argc, char **argv) {
   hipEventCreate(&e0), hipEventCreate(&e1);
   for (int rep = 0; rep < 3; rep++) {
     hipEventRecord(e0);
-    if (ch == 1) hipLaunchKernelGGL(k_rate<1>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters, 1.0f);
-    else if (ch == 2) hipLaunchKernelGGL(k_rate<2>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters, 1.0f);
-    else hipLaunchKernelGGL(k_rate<4>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters, 1.0f);
+    if (nv == 0) launch<0>(ch, blocks, out, cyc, iters);
+    else if (nv <= 2) launch<2>(ch, blocks, out, cyc, iters);
+    else if (nv <= 4) launch<4>(ch, blocks, out, cyc, iters);
+    else if (nv <= 6) launch<6>(ch, blocks, out, cyc, iters);
+    else if (nv <= 8) launch<8>(ch, blocks, out, cyc, iters);
+    else launch<12>(ch, blocks, out, cyc, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -52,8 +72,8 @@ int main(int argc, char **argv) {
     unsigned long long c0;
     hipMemcpy(&c0, cyc, 8, hipMemcpyDeviceToHost);
     const double n_per_simd = (double)iters * (ch == 1 ? 1 : ch == 2 ? 2 : 4) * wps;
-    printf("waves/SIMD %d, chains %d: %.3f ms, %.2f ns per instruction and SIMD = %.1f TFLOP/s on 1024 SIMDs; counter ticks per "
-           "instruction of one wave %.1f\n", wps, ch, ms, ms * 1e6 / n_per_simd, 32768.0 * 1024 / (ms * 1e6 / n_per_simd) / 1e3,
+    printf("waves/SIMD %d, chains %d, %d v_fma behind each: %.3f ms, %.2f ns per instruction and SIMD = %.1f TFLOP/s on 1024 SIMDs; counter ticks per "
+           "instruction of one wave %.1f\n", wps, ch, nv, ms, ms * 1e6 / n_per_simd, 32768.0 * 1024 / (ms * 1e6 / n_per_simd) / 1e3,
            (double)c0 / (iters * (ch == 1 ? 1 : ch == 2 ? 2 : 4)));
   }
   return 0;

@@ -1,9 +1,10 @@
-# Differential soak of the fp16 matrix-core filters (dense_h16.h, us_h16.h) on random uploads:
+# Differential soak of the fp16 matrix-core filters (dense_h16.h, us_h16.h, phantom_h16.h) on random uploads:
 #   python3 tools/soak_h16.py [seconds] [seed]
 # Dense: rows / right-hand sides rescaled over twelve orders of magnitude, thresholds from far below the noise to far
 # above the data, ragged row and hypothesis counts; truth = the fp64 matrix-core filter + exact re-check (dense_f32 0),
 # checked: the fp16 filter (2), the fp32 filter (1).  US single / pointer: truth = the exact fp64 kernel (scan_filter 0),
-# checked: the fp16 filter and the packed fp32 filter.  For every configuration also the batch entry point with and
+# checked: the fp16 filter and the packed fp32 filter; the plane phantom likewise, translations and pixel coordinates
+# rescaled over six orders of magnitude.  For every configuration also the batch entry point with and
 # without the early exit (winner, consensus set, parameters).
 import sys, time, numpy as np
 sys.path.insert(0, '.')
@@ -16,7 +17,8 @@ t_end = time.time() + budget
 ctx = Context(0)
 done, bad, rich = 0, 0, 0   # rich: configurations whose best hypothesis agrees with > 10 % of the observations
 while time.time() < t_end:
-    kind = ["dense", "us", "pointer"][int(g.integers(3))]
+    kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["dense", "us", "pointer", "phantom"]
+    kind = kinds[int(g.integers(len(kinds)))]
     seed = int(g.integers(1 << 30))
     H = int(g.choice([97, 333, 1024, 2048]))
     ok = True
@@ -55,11 +57,22 @@ while time.time() < t_end:
         if kind == "us":
             data = synth.us_single_fast(n, out, seed=seed, pixel_sigma=sig)
             model = L.US_SINGLE
+        elif kind == "phantom":
+            data = synth.plane_phantom_fast(n, min(out, 0.1), seed=seed, pixel_sigma=sig * 0.05)[0].copy()
+            st, sp_ = 10.0 ** float(g.integers(-3, 4)), 10.0 ** float(g.integers(-3, 4))
+            if g.random() < 0.5:                    # (rescaled frames no longer lie on a plane: every other upload as built)
+                st = sp_ = 1.0
+            data[:, 9:12] *= st                     # translations (and with them the plane's offset)
+            data[:, 13:15] *= sp_                   # pixel coordinates (the scale factors shrink by as much)
+            model = L.PHANTOM
+            H = min(H, 1024)
         else:
             data = synth.us_pointer(min(n, 70_013), out, seed=seed, pixel_sigma=sig)
             model = L.US_POINTER
         data = data[0] if isinstance(data, tuple) else data
         delta = float(g.choice([0.01, 1.0, 3.0, 50.0, 1e4]))
+        if kind == "phantom":
+            delta *= st
         cfg = dict(kind=kind, n=len(data), out=out, sig=sig, delta=delta, H=H, seed=seed)
         ls = L.LS_ANALYTIC
         dim = 0
