@@ -30,8 +30,9 @@
 //   dense.h's fp32 filter, the reference's fp64 running sum is within 1e-14 of that scale of res''.
 // Thresholds on SQUARES as in cells.h (cells_filter_squares): a = RD(t_in^2), band = RN(RU(t_out^2) - a),
 //   d = fma(r'', r'', -a):  d < 0 => certain inlier;  0 <= d <= band => ambiguous;  else certain outlier.
-// A hypothesis whose numbers do not fit (non-finite, thresholds beyond 2^63) gets x = 0, a = 0, band = the largest
-// finite float: every real row is ambiguous and decided exactly.  Rows past the end / outside the launch's range carry
+// A hypothesis whose numbers do not fit (infinite, thresholds beyond 2^63) gets x = 0, a = 0, band = the largest
+// finite float: every real row is ambiguous and decided exactly; one with a NaN among its unknowns -a = +inf, band = 0:
+// never counted, as the reference's comparison with a NaN.  Rows past the end / outside the launch's range carry
 // b'' = +inf: r'' = -inf, d = +inf, never counted, never ambiguous.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -123,6 +124,10 @@ __global__ __launch_bounds__(256) void k_dense_prep_h16(const double *__restrict
     band = c - a;
     nph = -phf;
   }
+  // an unknown that is NaN (a minimal system that was refused): the reference's |residual| < delta is false for every
+  // row, so the hypothesis is never counted and nothing of it is ambiguous (d = r''^2 + inf) -- not a row per
+  // observation in the worklist
+  if (!(l1 == l1)) a = -INFINITY, band = 0.0f;
   thr4[4 * (size_t)h] = -a;
   thr4[4 * (size_t)h + 1] = band;
   thr4[4 * (size_t)h + 2] = nph;

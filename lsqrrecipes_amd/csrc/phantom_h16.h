@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void k_phantom_prep_h16(const double *__restri
     c *= 1.0000002f;
     band = c - a;
   }
+  // a NaN among the coefficients (k_estimate_phantom refused the subset): err is NaN for every frame and the reference's
+  // '<' false -- never counted, nothing ambiguous (d = e^2 + inf), instead of a worklist entry per frame
+  bool has_nan = false;
+  for (int k = 0; k < 31; k++) has_nan = has_nan || x[k] != x[k];
+  if (has_nan) a = -INFINITY, band = 0.0f;
   if (h < H) {
     thr4[4 * (size_t)h] = -a;
     thr4[4 * (size_t)h + 1] = band;

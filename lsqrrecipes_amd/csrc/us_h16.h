@@ -21,7 +21,8 @@
 // | |e16| - |e_ref| | <= sqrt(3) E, so with D = delta G:   v = |e16|^2 <  (D - sqrt3 E)^2 (1 - 1e-6) => agrees,
 //   v >= (D + sqrt3 E)^2 (1 + 1e-6) => does not (1e-6: the three roundings of the fp32 sum of squares and of delta^2),
 //   in between the exact predicate decides (worklist, k_us_recheck_seg).  Thresholds on d = v - a as in dense_h16.h.
-// A hypothesis whose numbers do not fit gets zero operands and a band that holds every finite value.
+// A hypothesis whose numbers do not fit gets zero operands and a band that holds every finite value; one with a NaN among
+// its parameters -a = +inf and band 0 (never counted: the reference compares a NaN).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(256) void k_us_prep_h16(const double *__restrict__ 
     float c = (float)(tout * tout * (1.0 + 1e-6)) * 1.0000002f;
     band = c - a;
   }
+  // a NaN among the parameters (a minimal solve that was refused): the reference's squared distance is NaN for every
+  // frame and '<' false -- never counted, nothing ambiguous (d = v + inf), instead of a worklist entry per frame
+  bool has_nan = false;
+  for (int k = 0; k < 13; k++) has_nan = has_nan || x[k] != x[k];
+  if (has_nan) a = -INFINITY, band = 0.0f;
   if (h < H) {
     thr4[4 * (size_t)h] = -a;
     thr4[4 * (size_t)h + 1] = band;

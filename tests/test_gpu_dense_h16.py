@@ -97,3 +97,20 @@ def test_h16_standalone_check_and_error_of_the_matrix_unit():
     # the alignment of one instruction's products: the probe's worst case must stay below half of what is assumed
     offs = [abs(float(m)) for m in re.findall(r"= ([+-][0-9.]+) u of the sum of magnitudes", out.stdout)]
     assert len(offs) == 8 and max(offs) < 8.5, offs   # 17 terms x 0.5 u; measured 5.5 - 7.6
+
+
+def test_refused_minimal_systems_are_never_counted_and_do_not_flood_the_worklist():
+    """60 of 301 minimal systems hold a row twice: refused, unknowns NaN, |residual| < delta false for every row.  The
+    fp16 filter marks them 'never counted' instead of sending 60 x 150 003 pairs to the exact path (the worklist holds 4 M)"""
+    ncol, m, H = 64, 150_003, 301
+    rows = synth.dense(m, ncol, 0.1, seed=322, noise=0.01)[0]
+    subs = O.ctr_subsets(12, 0, H, m, ncol).copy()
+    subs[:60, 1] = subs[:60, 0]
+    with Context(0) as ctx:
+        par, valid, v16 = _votes(ctx, rows, ncol, 0.1, subs, 1, 2)
+        msg = ctx._lib.lsqr_last_error(ctx._h)
+        assert b"overflow" not in msg and b"fp32 filter used" not in msg, msg
+        assert not valid[:60].any() and not v16[:60].any()
+        _, v2, vex = _votes(ctx, rows, ncol, 0.1, subs, 0, 2)
+        assert np.array_equal(valid, v2) and np.array_equal(v16, vex)
+        ctx.set_option("scan_filter", 1)

@@ -119,3 +119,37 @@ def test_phantom_h16_standalone_check():
     out = subprocess.run([exe, "99937", "1001", "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert re.search(r"votes: 0 of 1001 hypotheses differ", out.stdout), out.stdout
+
+
+@pytest.mark.parametrize("kind", ["single", "phantom"])
+def test_refused_subsets_are_never_counted_and_do_not_flood_the_worklist(kind):
+    """150 of 333 minimal subsets are one frame K times: the solve is refused, the parameters are NaN, the reference's
+    comparison with a NaN is false for every frame.  The fp16 filters mark such a hypothesis 'never counted' instead of
+    sending every one of its frames to the exact path (10 M worklist entries here: the segments hold 1 M)"""
+    if kind == "single":
+        data = synth.us_single_fast(70_013, 0.3, seed=25)
+        model, K, delta = L.US_SINGLE, 4, 3.0
+    else:
+        data = synth.plane_phantom_fast(70_013, 0.05, seed=26, pixel_sigma=0.05)[0]
+        model, K, delta = L.PHANTOM, 31, 2.0
+    data = data[0] if isinstance(data, tuple) else data
+    H = 333
+    subs = O.ctr_subsets(5, 0, H, len(data), K).copy()
+    subs[:150, 1:] = subs[:150, :1]      # one frame K times
+    with Context(0) as ctx:
+        def votes(mfma, filt):
+            ctx.set_option("us_mfma", mfma)
+            ctx.set_option("scan_filter", filt)
+            ctx.set_model(model, 0, delta, L.LS_ANALYTIC).upload(data)
+            ctx.hypotheses_from_subsets(subs)
+            ctx.scan()
+            return ctx.hypotheses()
+        par, valid, v16 = votes(1, 1)
+        msg = ctx._lib.lsqr_last_error(ctx._h)
+        assert b"overflow" not in msg and b"fp32 filter used" not in msg, msg
+        assert int((valid[:150] == 0).sum()) >= 100 and not np.isfinite(par[:150][valid[:150] == 0]).any()
+        assert not v16[:150][valid[:150] == 0].any()
+        _, v2, vex = votes(0, 0)
+        assert np.array_equal(valid, v2) and np.array_equal(v16, vex)
+        ctx.set_option("us_mfma", 1)
+        ctx.set_option("scan_filter", 1)
