@@ -397,3 +397,31 @@ def test_plane_phantom_fp32_filter_band_is_conservative(hm):
             # the band is narrow: a few parts in 1e3 of delta at these magnitudes
             assert (tout - tin) < max(0.02, 0.01 * delta) + 2e-2
     assert checked_band >= 3 * 6 * 250   # the pushed frames sit inside the band
+
+
+def test_fp16_two_way_split_terms_of_the_filters_error_bounds():
+    """The representation terms the fp16 matrix-core filters charge (csrc/dense_h16.h, us_h16.h, phantom_h16.h): with
+    a1 = fp16(a), a2 = fp16(a - a1) and u = 2^-24,  |a2| <= 2^-11 |a|,  |a - a1 - a2| <= 2^-23 |a| = 2 u |a|  (values whose
+    low part stays a normal fp16 number), hence per product  |a x - (a1 x1 + a1 x2 + a2 x1)| <= (2 u + 2 u + 4 u) |a x|:
+    the splits' 4 u and the dropped lo x lo 4 u.  Checked on 2 M random operand pairs in the filters' scaled range."""
+    g = np.random.default_rng(2026)
+    u = 2.0 ** -24
+
+    def split(v):
+        hi = v.astype(np.float16).astype(np.float64)
+        lo = (v - hi).astype(np.float16).astype(np.float64)
+        return hi, lo
+    n = 2_000_000
+    a = g.uniform(-1.0, 1.0, n) * 2.0 ** g.integers(0, 16, n)      # |a| up to 2^15, low parts normal (>= 2^-14)
+    x = g.uniform(-1.0, 1.0, n) * 2.0 ** g.integers(0, 16, n)
+    a = np.where(np.abs(a) < 1.0, np.sign(a) + a, a)                # keep |a| >= 1: a2 >= 2^-12 ... normal or exact
+    x = np.where(np.abs(x) < 1.0, np.sign(x) + x, x)
+    a1, a2 = split(a)
+    x1, x2 = split(x)
+    assert np.all(np.abs(a2) <= 2.0 ** -11 * np.abs(a))
+    rel = np.abs(a - a1 - a2) / np.abs(a)
+    assert rel.max() <= 2.0 * u and rel.max() > 1.0 * u             # 2 u is needed: 1 u (what r04 first charged) is not
+    kept = a1 * x1 + a1 * x2 + a2 * x1
+    err = np.abs(a * x - kept) / np.abs(a * x)
+    assert err.max() <= 8.0 * u * (1 + 2.0 ** -10)
+    assert (np.abs(a2 * x2) / np.abs(a * x)).max() <= 4.0 * u
