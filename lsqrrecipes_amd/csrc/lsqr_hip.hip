@@ -118,6 +118,7 @@ struct lsqr_ctx {
   Us16Scales us16_sc{};
   int opt_us_h16 = 1;  // US calibrations: 1 = agree() scan on the fp16 matrix cores (us_h16.h), 0 = packed fp32 filter
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
+  int opt_us_fast = 1;     // US calibrations' minimal solves likewise (k_estimate_us)
   int opt_lm_tiles = 1;      // matrix-core LM pass: compacted consensus set in field-major tiles, next tile in flight
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
   int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
@@ -580,7 +581,7 @@ int run_estimate(lsqr_ctx *c) {
     } else if constexpr (M::IS_US) {
       hipLaunchKernelGGL((k_estimate_us<(M::K == 4)>), dim3((unsigned)c->H), dim3(64), 0,
                          c->stream, c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H,
-                         c->mc, c->d_hparams, c->d_valid);
+                         c->mc, c->d_hparams, c->d_valid, c->opt_us_fast);
       hipLaunchKernelGGL((k_prepare_f32_us<M>), dim3((unsigned)((c->H + 255) / 256)),
                          dim3(256), 0, c->stream, c->d_hparams, (uint32_t)c->H, c->mc,
                          c->d_hparams_f32);
@@ -4611,6 +4612,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "dense_f32")) {  // 2 (default): dense scan filter on the fp16 matrix cores (two-way splits);
     c->opt_dense_f32 = value < 0 ? 0 : value > 2 ? 2 : value;  // 1: fp32 matrix cores; 0: fp64 matrix cores
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "us_fast_solve")) {  // 0: every minimal solve of the US calibrations through the SVD pseudo-inverse
+    c->opt_us_fast = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "dense_fast_solve")) {  // 0: every minimal solve through the SVD pseudo-inverse

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ d
                                                     const uint32_t *__restrict__ subsets,
                                                     uint32_t H, ModelConsts mc,
                                                     double *__restrict__ hparams,
-                                                    uint8_t *__restrict__ valid) {
+                                                    uint8_t *__restrict__ valid, int fast) {
   typedef USModel<SINGLE> M;
   constexpr int NC = M::NC, MR = 3 * M::K, LDA = 13;
   __shared__ double A[NC * LDA], V[NC * LDA], b[MR], cw[NC], x[NC], recs[M::K][M::ND];
@@ -40,7 +40,28 @@ __global__ __launch_bounds__(64) void k_estimate_us(const double *__restrict__ d
     for (int c = 0; c < NC; c++) A[c * LDA + lane] = a[c];
   }
   __syncthreads();
-  int rank = block_pinv_solve<64, MR, NC>(MR, NC, A, LDA, V, LDA, b, kUsSvEps, 0.0, x, cw);
+  // The minimal system is square (12 x 12 / 9 x 9).  Fast path (r04, `us_fast_solve` 1): elimination with partial
+  // pivoting by the wave (wave_linalg.h: wave_gepp_solve) -- for a well-conditioned system the reference's SVD
+  // pseudo-inverse (...Estimator.cxx:137-201) gives the same solution to cond * eps.  It only ACCEPTS when every pivot
+  // exceeds 1e-3 -- four orders above the reference's rank threshold on the singular values (FLT_EPSILON, absolute) --
+  // and otherwise the system is rebuilt and takes the SVD below, which makes the reference's rank decision.
+  bool solved = false;
+  if constexpr (MR == NC) {
+    if (fast) {
+      solved = wave_gepp_solve(NC, A, LDA, b, x, 1e-8, 1e-3);
+      __syncthreads();
+      if (!solved) {
+        if (lane < MR) {
+          double a[NC];
+          b[lane] = M::row(recs[lane / 3], lane % 3, a);
+          for (int c = 0; c < NC; c++) A[c * LDA + lane] = a[c];
+        }
+        __syncthreads();
+      }
+    }
+  }
+  int rank = NC;
+  if (!solved) rank = block_pinv_solve<64, MR, NC>(MR, NC, A, LDA, V, LDA, b, kUsSvEps, 0.0, x, cw);
   bool ok = (rank == NC) && !__any(!in_range);
   if (lane == 0) {
     double par[M::SP];

@@ -380,7 +380,8 @@ __device__ inline bool block_gepp_solve(int n, double *A, int lda, double *b, do
 // updates of one column each (one broadcast read of the pivot row's element, one read, one fma, one write per lane).
 // Same pivot rule, same multipliers, same fma updates, same back substitution: the result is BIT-IDENTICAL to
 // block_gepp_solve's (tests/test_gpu_dense_fused.py compares them).  Four systems per workgroup of 256 threads.
-__device__ inline bool wave_gepp_solve(int n, double *A, int lda, double *b, double *x, double piv_rel = 1e-8) {
+__device__ inline bool wave_gepp_solve(int n, double *A, int lda, double *b, double *x, double piv_rel = 1e-8,
+                                       double piv_abs = 0.0) {
   const int lane = threadIdx.x & 63;
   double am = 0.0;
   for (int idx = lane; idx < n * n; idx += 64) {
@@ -389,7 +390,8 @@ __device__ inline bool wave_gepp_solve(int n, double *A, int lda, double *b, dou
   }
   am = wave_max(am);
   if (!(am <= 1e150)) return false;
-  const double tol = piv_rel * (am > 1.0 ? am : 1.0);
+  double tol = piv_rel * (am > 1.0 ? am : 1.0);
+  tol = tol > piv_abs ? tol : piv_abs;  // (callers whose rank decision is an absolute threshold: k_estimate_us)
   for (int k = 0; k < n; k++) {
     // pivot search in column k: the butterfly of block_gepp_solve (largest |a|, ties to the lower row)
     double v = (lane >= k && lane < n) ? fabs(A[k * lda + lane]) : -1.0;

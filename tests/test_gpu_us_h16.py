@@ -153,3 +153,35 @@ def test_refused_subsets_are_never_counted_and_do_not_flood_the_worklist(kind):
         assert np.array_equal(valid, v2) and np.array_equal(v16, vex)
         ctx.set_option("us_mfma", 1)
         ctx.set_option("scan_filter", 1)
+
+
+@pytest.mark.parametrize("kind", ["single", "pointer"])
+def test_us_minimal_solves_elimination_against_svd(kind):
+    """k_estimate_us (reference: SinglePointTargetUSCalibrationParametersEstimator.cxx:137-201, SVD pseudo-inverse with
+    the rank threshold FLT_EPSILON): the elimination fast path (`us_fast_solve` 1, default) against the SVD path (0) --
+    same hypotheses accepted and refused (degenerate subsets included), parameters equal to 1e-9 relative"""
+    if kind == "single":
+        data = synth.us_single_fast(50_000, 0.3, seed=31)
+        model, K = L.US_SINGLE, 4
+    else:
+        data = synth.us_pointer(20_000, 0.3, seed=32)[0]
+        model, K = L.US_POINTER, 3
+    data = data[0] if isinstance(data, tuple) else data
+    H = 2048
+    subs = O.ctr_subsets(9, 0, H, len(data), K).copy()
+    subs[:40, 1] = subs[:40, 0]            # a frame twice: rank-deficient, refused by both
+    with Context(0) as ctx:
+        res = []
+        for fast in (1, 0):
+            ctx.set_option("us_fast_solve", fast)
+            ctx.set_model(model, 0, 3.0, L.LS_ANALYTIC).upload(data)
+            ctx.hypotheses_from_subsets(subs)
+            ctx.scan()
+            res.append(ctx.hypotheses())
+        ctx.set_option("us_fast_solve", 1)
+    (p1, v1, c1), (p0, v0, c0) = res
+    assert np.array_equal(v1, v0) and not v1[:40].any() and v1[40:].mean() > 0.9
+    ok = v1.astype(bool)
+    scale = np.maximum(np.abs(p0[ok]).max(axis=0), 1e-300)
+    assert (np.abs(p1[ok] - p0[ok]) / scale).max() < 1e-9
+    assert np.abs(c1.astype(np.int64) - c0.astype(np.int64)).max() <= 2   # (a frame within 1e-10 of delta may flip)
