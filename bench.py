@@ -16,7 +16,7 @@
            Each rate has its own roofline block (roofline / roofline_early_exit).
   repeats  every rate is timed over --repeats regions of exactly K steps (barrier + synchronise on both sides, max over
            ranks); `value` is the median region, all regions are listed.
-  legs     the default single-GPU run appends short legs (5 steps) of BASELINE configs 3-5 -- sphere + geometric fit,
+  legs     the default single-GPU run appends legs (20 steps after 5, one timed region) of BASELINE configs 3-5 -- sphere + geometric fit,
            dense 2 M x 64, US calibration with the iterative and the analytic fit -- as other_configs[].
   N > 1    one process per GPU (torch.distributed, RCCL): observations replicated, the hypothesis stream sharded;
            all-reduce(MAX) picks the winner, all-reduce(SUM) of the moment block of each rank's observation slice gives
@@ -970,7 +970,9 @@ LEGS = (("sphere", "iterative", "SphereParametersEstimator + RANSAC, 10 M points
 
 
 def run_legs(a0, local):
-    """short legs of BASELINE configs 3-5 on this GPU (5 steps each), so that the driver's own run observes them"""
+    """legs of BASELINE configs 3-5 on this GPU (the headline's 20 steps after 5 warm-up steps, one timed region each:
+    with 5 steps after 2 the legs read 5-8 % below the same workloads' own runs), so that the driver's own run
+    observes them"""
     legs = []
     for w, fit, title in LEGS:
         t0 = time.perf_counter()
@@ -978,7 +980,7 @@ def run_legs(a0, local):
         a.workload, a.us_fit = w, fit
         a.points = max(4096, int({"dense": 2_000_000, "us": 1_000_000}.get(w, 10_000_000) * a0.leg_scale))
         a.batch = 1024 if w == "dense" else 4096
-        a.steps, a.warmup, a.repeats = 5, 2, 1
+        a.steps, a.warmup, a.repeats = 20, 5, 1
         a.streams = a0.streams
         a.no_end_to_end = True
         a.no_cpu_baseline = a0.no_cpu_baseline
