@@ -966,11 +966,13 @@ LEGS = (("sphere", "iterative", "SphereParametersEstimator + RANSAC, 10 M points
         ("dense", "iterative", "DenseLinearEquationSystemParametersEstimator, m = 2 M, n = 64 (BASELINE.json configs[3])"),
         ("us", "iterative", "SinglePointTargetUSCalibrationParametersEstimator, 1 M frames, ITERATIVE (LM) final fit "
          "with the reference's tolerances (BASELINE.json configs[4] as written)"),
-        ("us", "analytic", "SinglePointTargetUSCalibrationParametersEstimator, 1 M frames, ANALYTIC final fit"))
+        ("us", "analytic", "SinglePointTargetUSCalibrationParametersEstimator, 1 M frames, ANALYTIC final fit"),
+        ("phantom", "iterative", "PlanePhantomUSCalibrationParametersEstimator, 1 M frames, k = 31 (SURVEY 8(f): not a "
+         "BASELINE config; the reference's examples/planeUSCalibration)"))
 
 
 def run_legs(a0, local):
-    """legs of BASELINE configs 3-5 on this GPU (the headline's 20 steps after 5 warm-up steps, one timed region each:
+    """legs of BASELINE configs 3-5 (+ the US analytic fit and the plane phantom) on this GPU (the headline's 20 steps after 5 warm-up steps, one timed region each:
     with 5 steps after 2 the legs read 5-8 % below the same workloads' own runs), so that the driver's own run
     observes them"""
     legs = []
@@ -978,7 +980,8 @@ def run_legs(a0, local):
         t0 = time.perf_counter()
         a = parse([])
         a.workload, a.us_fit = w, fit
-        a.points = max(4096, int({"dense": 2_000_000, "us": 1_000_000}.get(w, 10_000_000) * a0.leg_scale))
+        a.points = max(4096, int({"dense": 2_000_000, "us": 1_000_000, "phantom": 1_000_000}.get(w, 10_000_000)
+                                 * a0.leg_scale))
         a.batch = 1024 if w == "dense" else 4096
         a.steps, a.warmup, a.repeats = 20, 5, 1
         a.streams = a0.streams

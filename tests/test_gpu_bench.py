@@ -191,17 +191,18 @@ def test_bench_default_run_carries_the_other_configs():
     """the default plane run appends short legs of BASELINE configs 3-5 (scaled down here)"""
     j = _run(["--workload", "plane", "--leg-scale", "0.02", "--cpu-seconds", "0.3"], extra=("--no-end-to-end",))
     legs = j["other_configs"]
-    assert len(legs) == 4 and not any("error" in leg for leg in legs), legs
+    assert len(legs) == 5 and not any("error" in leg for leg in legs), legs
     names = [leg["config"]["workload"] for leg in legs]
     assert "Sphere" in names[0] and "Dense" in names[1] and "ITERATIVE" in names[2] and "ANALYTIC" in names[3]
+    assert "PlanePhantom" in names[4]
     for leg in legs:
         assert leg["value"] > 0 and leg["ms_per_step"] > 0 and 0 < leg["roofline"]["frac"] <= 1
         assert leg["cpu_baseline"]["value"] > 0 and leg["cpu_baseline"]["cores"] == 1
         for k in ("lm_info", "lm_nfev", "params_empty"):
             assert k in leg["final_fit"]
     assert legs[2]["final_fit"]["lm_nfev"] > 0 and legs[2]["lm"]["evaluations_per_s"] > 0
-    assert len(j["_legs"]) == 4 and [leg["value"] > 0 for leg in j["_legs"]]
-    assert len(j["_headline"]["other_configs"]) == 4
+    assert len(j["_legs"]) == 5 and [leg["value"] > 0 for leg in j["_legs"]]
+    assert len(j["_headline"]["other_configs"]) == 5
     hb = j["_headline"]["cpu_baseline"]
     assert hb["cores"] == 1 and hb["kind"] in ("reference", "port") and hb["full_count"]["value"] > 0
     cb = j["cpu_baseline"]
