@@ -16,8 +16,9 @@
            Each rate has its own roofline block (roofline / roofline_early_exit).
   repeats  every rate is timed over --repeats regions of exactly K steps (barrier + synchronise on both sides, max over
            ranks); `value` is the median region, all regions are listed.
-  legs     the default single-GPU run appends legs (20 steps after 5, one timed region) of BASELINE configs 3-5 -- sphere + geometric fit,
-           dense 2 M x 64, US calibration with the iterative and the analytic fit -- as other_configs[].
+  legs     the default single-GPU run appends legs (20 steps after 5, one timed region) of BASELINE configs 3-5 -- sphere +
+           geometric fit, dense 2 M x 64, US calibration with the iterative and the analytic fit -- and of the plane phantom
+            as other_configs[].
   N > 1    one process per GPU (torch.distributed, RCCL): observations replicated, the hypothesis stream sharded;
            all-reduce(MAX) picks the winner, all-reduce(SUM) of the moment block of each rank's observation slice gives
            the final fit.  scaling = "weak" (H per GPU fixed).  `python bench.py --gpus N` without a launcher
