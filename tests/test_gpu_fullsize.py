@@ -346,3 +346,32 @@ def test_config5_us_iterative_fit_1M(ctx):
     ana, _ = ctx.ls_fit(use_mask=True)
     cost_ana = ctx.stats(ana, use_mask=True)[3]
     assert fi.cost <= cost_ana * (1 + 1e-12)
+
+
+def test_plane_phantom_1M_frames_on_bench_path(ctx):
+    """PlanePhantomUSCalibration at the size `bench.py --workload phantom` (and the fifth leg of the default run)
+    times -- 1 M frames, 4096 hypotheses (31-frame null-vector solves), the agree() scan on the fp16 matrix cores
+    (csrc/phantom_h16.h; reference PlanePhantomUSCalibrationParametersEstimator.cxx:73-135): EVERY one of the 4096 full
+    counts against the oracle, the winner's consensus mask bit-exact, the early exit against the full count."""
+    n, H = 1_000_000, 4096
+    rec = synth.plane_phantom_fast(n, 0.05, pixel_sigma=0.05)[0]    # bench.py: make_data("phantom", 1 M, .)
+    oc = O.cfg(O.PHANTOM, 0, 2.0, 0)
+    ctx.set_model(L.PHANTOM, 0, 2.0, L.LS_ANALYTIC).upload(rec)
+    ctx.set_option("scan_bound", 0)
+    r = ctx.batch_fit(SEED, 0, H, want_consensus=True)
+    assert r["status"] == L.OK
+    assert b"fp32 filter used" not in ctx._lib.lsqr_last_error(ctx._h)   # the fp16 filter ran, no worklist overflow
+    info = r["info"]
+    par, valid, votes = ctx.hypotheses()
+    bi = int(info.best_index)
+    vv = np.where(valid > 0, votes, 0)
+    assert valid.mean() > 0.99 and info.best_votes == vv.max() and bi == int(np.argmax(vv))
+    all_want = O.scan_many(oc, par, valid, rec)
+    bad = np.flatnonzero(vv != all_want)
+    assert len(bad) == 0, "full count differs from the oracle at %d of %d hypotheses (first h=%d)" % (len(bad), H, bad[0])
+    wcnt, wmask = O.scan(oc, par[bi], rec)
+    assert wcnt == info.best_votes and np.array_equal(r["consensus"], wmask)
+    assert wcnt > 0.9 * n                                            # 5 % off-plane frames
+    w = _early_exit_equals_full(ctx, r, valid, votes, H, n)
+    assert w["row_hypothesis_pairs"] < H * n
+    ctx.set_option("scan_bound", 1)
