@@ -126,6 +126,7 @@ SIGNATURES = {
     "lsqr_index_info": (C.c_int, [_ctx, _u64p]),
     "lsqr_scan_workload": (C.c_int, [_ctx, C.c_void_p, _u64p]),
     "lsqr_scan_work": (C.c_int, [_ctx, _u64p]),
+    "lsqr_lm_persist_info": (C.c_int, [_ctx, _u64p, _u64p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "lsqr_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "lsqr_profile_get": (C.c_int, [_ctx, C.c_int, _u64p, _dp]),
     "lsqr_profile_reset": (C.c_int, [_ctx]),

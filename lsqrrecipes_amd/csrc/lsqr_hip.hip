@@ -34,6 +34,10 @@
 #include "sort.h"
 #include "rigid.h"
 #include "phantom.h"
+#include "lm_persist.h"
+
+#include <condition_variable>
+#include <mutex>
 
 using namespace lsqr;
 
@@ -213,6 +217,24 @@ struct lsqr_ctx {
   uint32_t lm_seq = 0;        // sequence number of the last evaluation (the tag the host polls for)
   int opt_lm_mfma = 1;        // 1: the LM pass accumulates (J | f)^T (J | f) on the matrix cores; 0: per-lane sums
   int opt_lm_fused = 1;       // 1: one launch per LM evaluation, result polled in pinned memory; 0: r01 path
+  // lm_persist.h: a whole matrix-core LM fit in one launch.  0: the launch path (two launches per evaluation);
+  // 1: persistent kernel, MINPACK's step on the host between tagged granules in pinned memory; 2: persistent kernel,
+  // the step on the device (workgroup 0).  Same iterates all three ways.
+  int opt_lm_persist = 1;
+  int opt_lm_persist_wgs = 0;          // resident workgroups G (0: 256 / 128 / 64 by the number of contexts on the device)
+  int opt_lm_persist_timeout_ms = 2000;  // bound of every wait inside the kernel
+  int opt_lm_persist_resident = 0;       // 1: a fit alone on the device keeps its tiles in registers (k_lm_persist<M, 4>).  Built,
+                                         // bit-identical, measured no faster (r05: 12.4 us against 11.1 us per pass + broadcast at 245
+                                         // workgroups -- with 1.9 waves per SIMD the pass is bound by its dependent chains, not by HBM)
+  int opt_lm_persist_test_abort = 0;     // tests: workgroup 0 gives up at this evaluation (the fallback path)
+  LmpCtl *d_lmp = nullptr;
+  unsigned long long *h_lmcmd = nullptr;  // pinned, device-visible: the host's reply (coefficient granules + command)
+  bool lmp_attr = false;
+  bool counted = false;  // this context counts among the device's root contexts (lmp_pool: the share of a persistent fit)
+  // diagnostics of the last persistent fit: {mode, G, evaluations, status, kernel us, fallbacks, host ns waiting, host ns stepping}
+  uint64_t lmp_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t lmp_trace[LMP_TRACE][4];
+  uint32_t lmp_trace_n = 0;
 
   // staged upload (lsqr_upload of large pageable buffers): ring of pinned chunks filled by a few host threads
   // while earlier chunks are in flight to the device
@@ -2137,6 +2159,199 @@ int enqueue_fit(lsqr_ctx *c, int use_mask, bool have_moments = false) {
   });
 }
 
+// ---- persistent LM fit (lm_persist.h) -------------------------------------------------------------------------------
+// Compute-unit tokens: the persistent kernels of this process never ask for more workgroups than the device holds
+// (one per compute unit: the kernel's LDS request), so none of them can wait for a workgroup that another one keeps
+// from becoming resident.  A fit draws G tokens before it launches and returns them when its kernel has ended.
+struct LmpPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  int cus[16] = {0}, free_[16] = {0}, live[16] = {0};  // per device: compute units, free tokens, root contexts alive
+};
+LmpPool &lmp_pool() {
+  static LmpPool p;
+  return p;
+}
+void lmp_ctx_count(int device, int d) {
+  if (device < 0 || device >= 16) return;
+  LmpPool &p = lmp_pool();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.live[device] += d;
+}
+int lmp_acquire(int device, int want_auto, int forced, int need_max) {
+  LmpPool &p = lmp_pool();
+  std::unique_lock<std::mutex> lk(p.mu);
+  if (device < 0 || device >= 16) return 0;
+  if (!p.cus[device]) {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cu <= 0) return 0;
+    p.cus[device] = p.free_[device] = cu;
+  }
+  int G = forced > 0 ? forced : want_auto;
+  if (!G) {  // the device shared evenly by the contexts that may run a fit at the same time (up to four)
+    const int share = std::max(1, std::min(4, p.live[device]));
+    G = p.cus[device] / share;
+    int pw = 1;
+    while (2 * pw <= G) pw *= 2;
+    G = pw;
+  }
+  G = std::max(1, std::min({G, p.cus[device], need_max}));
+  p.cv.wait(lk, [&] { return p.free_[device] >= G; });
+  p.free_[device] -= G;
+  return G;
+}
+void lmp_release(int device, int G) {
+  LmpPool &p = lmp_pool();
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.free_[device] += G;
+  }
+  p.cv.notify_all();
+}
+
+// *done = true: finished, `s` holds the final state; false: not run or given up (the caller takes the launch path)
+template <class M>
+int lm_persist_fit(lsqr_ctx *c, const double *tiles, size_t cnt, int nb, LmState &s, const double *x0, int n,
+                   double ftol, double xtol, double gtol, int maxfev, bool *done) {
+  *done = false;
+  static const bool shared_gpu = getenv("LSQR_SHARE_GPU") != nullptr;  // several processes on one device: no tokens across them
+  if (!c->opt_lm_persist || shared_gpu || c->is_lane) return LSQR_OK;
+  typedef typename M::LmCoef Coef;
+  constexpr int NCW = (int)(sizeof(Coef) / 8), NMOM = (int)M::NMOM_LM;
+  if (!c->d_lmp) {
+    if (hipMalloc((void **)&c->d_lmp, sizeof(LmpCtl)) != hipSuccess) return LSQR_OK;
+    if (hipHostMalloc((void **)&c->h_lmcmd, sizeof(unsigned long long) * 256, hipHostMallocCoherent) != hipSuccess) {
+      (void)hipFree(c->d_lmp);
+      c->d_lmp = nullptr;
+      return LSQR_OK;
+    }
+    memset(c->h_lmcmd, 0, sizeof(unsigned long long) * 256);
+  }
+  if (c->lm_seq > 0xF0000000u) {  // tags would wrap: start again from clean granules (nothing is in flight here)
+    HIPCHK(c, sync_stream(c));
+    memset(c->h_lmcmd, 0, sizeof(unsigned long long) * 256);
+    memset(c->h_lmres, 0, sizeof(unsigned long long) * 256);
+    c->lm_seq = 0;
+  }
+  const int host_step = c->opt_lm_persist == 1;
+  // one round of virtual blocks when the device is ours alone (512-thread workgroups: two blocks at a time each)
+  const int G = lmp_acquire(c->device, 0, c->opt_lm_persist_wgs, (nb + 1) / 2);  // tokens held
+  if (G <= 0) return LSQR_OK;
+  // workgroups of eight waves (two virtual blocks at a time) when the tokens cover all blocks in one round -- the pass
+  // then spreads over twice the compute units --, else sixteen waves (four blocks at a time)
+  const int threads = G * 2 >= nb ? 512 : 1024;
+  const int Gl = threads == 512 ? G : std::min(G, (nb + 3) / 4);  // workgroups launched
+  const size_t lds = std::max<size_t>((size_t)(threads / 64) * 64 * 17 * sizeof(double), (size_t)96 << 10);
+  // a fit that has the device to itself in one round keeps its tiles in registers (k_lm_persist<M, 4>: 512 threads)
+  const bool resident = host_step && threads == 512 && (size_t)Gl * 2 >= (size_t)nb && c->opt_lm_persist_resident;
+  if (!c->lmp_attr) {
+    if (hipFuncSetAttribute((const void *)k_lm_persist<M, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void *)k_lm_persist<M, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) !=
+            hipSuccess) {
+      lmp_release(c->device, G);
+      return LSQR_OK;
+    }
+    c->lmp_attr = true;
+  }
+  LmpInit init{};
+  init.n = n;
+  init.maxfev = maxfev;
+  init.ftol = ftol;
+  init.xtol = xtol;
+  init.gtol = gtol;
+  init.factor = 100.0;
+  for (int j = 0; j < LM_NMAX; j++) init.x0[j] = j < n ? x0[j] : 0.0;
+  const uint32_t seq0 = c->lm_seq;
+  c->lm_seq += (uint32_t)maxfev + 8;
+  const unsigned long long timeout = (unsigned long long)std::max(1, c->opt_lm_persist_timeout_ms) * 100000ULL;  // 100 MHz
+  auto give_up = [&](int rc) {
+    lmp_release(c->device, G);
+    return rc;
+  };
+  if (hipMemsetAsync(c->d_lmp, 0, sizeof(LmpCtl), c->stream) != hipSuccess) return give_up(LSQR_OK);
+  {
+    ProfScope ps(c, KID_MOMENTS);
+    if (resident)
+      hipLaunchKernelGGL((k_lm_persist<M, 4>), dim3(Gl), dim3(threads), lds, c->stream, tiles, cnt, nb, c->d_lmp,
+                         c->d_partials, c->h_lmres, c->h_lmcmd, c->d_lm, c->d_out, init, seq0, host_step, timeout,
+                         (uint32_t)c->opt_lm_persist_test_abort);
+    else
+      hipLaunchKernelGGL((k_lm_persist<M, 0>), dim3(Gl), dim3(threads), lds, c->stream, tiles, cnt, nb, c->d_lmp,
+                         c->d_partials, c->h_lmres, c->h_lmcmd, c->d_lm, c->d_out, init, seq0, host_step, timeout,
+                         (uint32_t)c->opt_lm_persist_test_abort);
+  }
+  if (hipGetLastError() != hipSuccess) return give_up(LSQR_OK);
+  bool gave_up = false;
+  uint64_t host_wait_ns = 0, host_step_ns = 0;
+  if (host_step) {
+    lm_init(s, n, x0, ftol, xtol, gtol, maxfev, 100.0);
+    volatile unsigned long long *res = c->h_lmres;
+    volatile unsigned long long *cmd = c->h_lmcmd;
+    for (uint32_t e = 1; !gave_up; e++) {
+      const uint32_t tag = seq0 + e;
+      unsigned long long spins = 0;
+      double blk[LM_MOM_MAX];
+      const auto tw0 = std::chrono::steady_clock::now();
+      for (int j = 0; j < NMOM && !gave_up; j++) {
+        unsigned long long g0, g1;
+        while ((uint32_t)(g0 = res[2 * j]) != tag || (uint32_t)(g1 = res[2 * j + 1]) != tag) {
+          if ((++spins & 0xFFFF) == 0) {  // every 65 k polls: is the kernel still there?
+            hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+              lmp_release(c->device, G);
+              return fail(c, LSQR_ERR_HIP, "persistent LM kernel failed: %s", hipGetErrorString(q));
+            }
+            if (q == hipSuccess && ((uint32_t)res[2 * j] != tag || (uint32_t)res[2 * j + 1] != tag)) {
+              gave_up = true;  // the kernel left (a bounded wait expired) without this evaluation
+              break;
+            }
+          }
+        }
+        if (gave_up) break;
+        const unsigned long long bits = (g0 & 0xFFFFFFFF00000000ULL) | (g1 >> 32);
+        memcpy(&blk[j], &bits, 8);
+      }
+      if (gave_up) break;
+      const auto tw1 = std::chrono::steady_clock::now();
+      const bool cont = lm_advance(s, blk);
+      uint32_t words[2 * LMP_MAXCOEF] = {0};
+      if (cont) {
+        Coef k;
+        M::lm_coef(s.xtrial, k);
+        memcpy(words, &k, sizeof(Coef));
+      }
+      for (int i = 0; i < 2 * NCW; i++) cmd[i] = ((unsigned long long)words[i ^ 1] << 32) | tag;
+      std::atomic_thread_fence(std::memory_order_release);  // the command granule is what the device polls: written last
+      cmd[2 * NCW] = ((unsigned long long)(cont ? LMP_EVAL : LMP_FIN) << 32) | tag;
+      host_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tw1 - tw0).count();
+      host_step_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw1).count();
+      if (!cont) break;
+    }
+  }
+  hipError_t se = sync_stream(c);
+  lmp_release(c->device, G);
+  if (se != hipSuccess) return fail(c, LSQR_ERR_HIP, "persistent LM kernel: %s", hipGetErrorString(se));
+  LmpCtl *hc = (LmpCtl *)((char *)c->h_pin + 8192);
+  HIPCHK(c, hipMemcpy(hc, c->d_lmp, sizeof(LmpCtl), hipMemcpyDeviceToHost));
+  c->lmp_last[0] = (uint64_t)c->opt_lm_persist;
+  c->lmp_last[1] = (uint64_t)Gl;
+  c->lmp_last[2] = hc->evals;
+  c->lmp_last[3] = hc->status;
+  c->lmp_last[4] = (hc->t_end - hc->t_begin) / 100;  // us
+  c->lmp_last[6] = host_wait_ns;
+  c->lmp_last[7] = host_step_ns;
+  c->lmp_trace_n = std::min<uint32_t>(hc->evals, LMP_TRACE);
+  memcpy(c->lmp_trace, hc->trace, sizeof(hc->trace));
+  if (gave_up || hc->status != LMP_FIN) {
+    c->lmp_last[5]++;
+    return LSQR_OK;
+  }
+  if (!host_step) HIPCHK(c, hipMemcpy(&s, c->d_lm, sizeof(LmState), hipMemcpyDeviceToHost));
+  *done = true;
+  return LSQR_OK;
+}
+
 // leastSquaresEstimate over [0,n) (single device).  Leaves the result in d_out.
 // have_moments: d_mom already holds the phase-0 block about d_vec (launch_mask_moments)
 int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false) {
@@ -2247,8 +2462,17 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           };
           if (use_mask && mfma_pass && (st = compact()) != LSQR_OK) return st;
           shape();
+          bool persist_done = false;
+          if constexpr (requires { typename M::LmCoef; }) {
+            if (mfma_pass && tiles) {  // the whole fit in one launch (lm_persist.h); falls through when it gives up
+              if ((st = lm_persist_fit<M>(c, lm_data, cnt, nb, s, out->params, n, ftol, xtol, gtol, maxfev,
+                                          &persist_done)) != LSQR_OK)
+                return st;
+              if (!persist_done) lm_init(s, n, out->params, ftol, xtol, gtol, maxfev, 100.0);
+            }
+          }
           volatile unsigned long long *res = c->h_lmres;
-          for (;;) {
+          while (!persist_done) {
             if (through_mask && s.nfev >= kCompactAfter) {
               if ((st = compact()) != LSQR_OK) return st;
               shape();
@@ -2709,12 +2933,15 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
     return LSQR_ERR_HIP;
   }
   *out = c;
+  lmp_ctx_count(device, +1);
+  c->counted = true;
   return LSQR_OK;
 }
 
 void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->counted) lmp_ctx_count(c->device, -1);
   for (int i = 1; i < lsqr_ctx::kMaxLanes; i++)
     if (c->lanes[i]) {
       lsqr_ctx_destroy(c->lanes[i]);
@@ -2731,6 +2958,8 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     if (c->bsel_ev[r]) (void)hipEventDestroy(c->bsel_ev[r]);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_lmres) (void)hipHostFree(c->h_lmres);
+  if (c->h_lmcmd) (void)hipHostFree(c->h_lmcmd);
+  if (c->d_lmp) (void)hipFree(c->d_lmp);
   if (c->h_batch) (void)hipHostFree(c->h_batch);
   for (int i = 0; i < lsqr_ctx::kUpSlots; i++) {
     if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
@@ -3801,6 +4030,10 @@ static int lane_get(lsqr_ctx *c, int li, lsqr_ctx **out) {
     int st = lsqr_ctx_create(c->device, &l);
     if (st != LSQR_OK) return fail(c, st, "cannot create lane %d", li);
     l->is_lane = true;
+    if (l->counted) {  // lanes never run a persistent fit: they do not take a share of the device
+      lmp_ctx_count(l->device, -1);
+      l->counted = false;
+    }
     l->prof = c->prof;
   }
   if (l->lane_epoch != c->data_epoch) {
@@ -4622,6 +4855,29 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     c->opt_dense_fast = value != 0;
     return LSQR_OK;
   }
+  if (!strcmp(name, "lm_persist")) {  // 0: two launches per LM evaluation; 1 / 2: one persistent launch per fit, step on the host / device
+    if (value < 0 || value > 2) return LSQR_ERR_INVALID;
+    c->opt_lm_persist = (int)value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_persist_wgs")) {  // resident workgroups of the persistent fit (0: by the contexts on the device)
+    if (value < 0 || value > 1024) return LSQR_ERR_INVALID;
+    c->opt_lm_persist_wgs = (int)value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_persist_resident")) {
+    c->opt_lm_persist_resident = value != 0;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_persist_test_abort")) {
+    c->opt_lm_persist_test_abort = (int)std::max<long long>(0, value);
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "lm_persist_timeout_ms")) {
+    if (value < 1 || value > 60000) return LSQR_ERR_INVALID;
+    c->opt_lm_persist_timeout_ms = (int)value;
+    return LSQR_OK;
+  }
   if (!strcmp(name, "lm_tiles")) {  // 0: the r03 pass over the record-major compacted set (A/B knob)
     c->opt_lm_tiles = value != 0;
     return LSQR_OK;
@@ -4752,6 +5008,18 @@ int lsqr_estimate_host(const lsqr_model_cfg *cfg, const void *records, size_t co
       return ok ? LSQR_OK : LSQR_EMPTY;
     }
   });
+}
+
+int lsqr_lm_persist_info(const lsqr_ctx *c, uint64_t out[8], uint64_t *trace, uint32_t trace_cap, uint32_t *trace_n) {
+  if (!c || !out) return LSQR_ERR_INVALID;
+  for (int i = 0; i < 8; i++) out[i] = c->lmp_last[i];
+  uint32_t nt = 0;
+  if (trace) {
+    nt = std::min(trace_cap, c->lmp_trace_n);
+    memcpy(trace, c->lmp_trace, sizeof(uint64_t) * 4 * nt);
+  }
+  if (trace_n) *trace_n = nt;
+  return LSQR_OK;
 }
 
 int lsqr_scan_work(lsqr_ctx *c, uint64_t out[6]) {

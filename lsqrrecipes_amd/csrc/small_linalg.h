@@ -15,6 +15,74 @@
 
 namespace lsqr {
 
+// sin and cos with the SAME BITS on the host and on the device.  The Levenberg-Marquardt fits of the US calibrations
+// form their per-evaluation coefficients from three Euler angles; the step runs on the host (lsqr_hip.hip) or inside
+// the persistent kernel (lm_persist.h), and libm's and the device library's sin / cos differ in the last bit for some
+// arguments -- enough to send two runs of an ill-conditioned minimisation down different iterates.  This is the
+// classical argument reduction by three-part pi/2 (Cody & Waite) and the minimax polynomials on [-pi/4, pi/4] (the
+// published fdlibm coefficients), written with plain IEEE multiplies, adds and rint only (the library is compiled
+// with -ffp-contract=off), so every operation rounds identically everywhere.  Error < 1 ulp for |x| < 2^19 pi/2;
+// beyond that (never an Euler angle of a minimisation) the platform's own functions answer.
+LSQR_HD double sc_kernel_sin(double x, double y, bool have_y) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double z = x * x, v = z * x;
+  const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  if (!have_y) return x + v * (S1 + z * r);
+  return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+LSQR_HD double sc_kernel_cos(double x, double y) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double z = x * x;
+  const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double ax = fabs(x);
+  if (ax < 0.3) return 1.0 - (0.5 * z - (z * r - x * y));
+  // qx ~ x^2 / 2 with few significant bits, so that 1 - qx and x^2 / 2 - qx are exact (fdlibm clears the low word of
+  // x / 4; rounding to single precision serves the same purpose and is an IEEE operation on both sides)
+  const double qx = ax > 0.78125 ? 0.28125 : (double)(float)(0.25 * ax);
+  const double hz = 0.5 * z - qx, a = 1.0 - qx;
+  return a - (hz - (z * r - x * y));
+}
+LSQR_HD void lsqr_sincos(double x, double *s, double *c) {
+  const double ax = fabs(x);
+  if (!(ax < 8.2e5)) {  // huge, infinite or NaN: the platform's functions
+    *s = sin(x);
+    *c = cos(x);
+    return;
+  }
+  if (ax <= 0.78539816339744830962) {
+    *s = sc_kernel_sin(x, 0.0, false);
+    *c = sc_kernel_cos(x, 0.0);
+    return;
+  }
+  const double invpio2 = 6.36619772367581382433e-01, p1 = 1.57079632673412561417e+00, p1t = 6.07710050650619224932e-11,
+               p2 = 6.07710050630396597660e-11, p2t = 2.02226624879595063154e-21, p3 = 2.02226624871116645580e-21,
+               p3t = 8.47842766036889956997e-32;
+  const double fn = rint(x * invpio2);
+  // three rounds of the reduction, unconditionally (fdlibm stops early when the first difference kept enough bits;
+  // running all three costs a dozen operations and removes a data-dependent branch): r - w stays exact to ~118 bits
+  double r = x - fn * p1, w = fn * p1t;
+  {
+    double t = r;
+    w = fn * p2;
+    r = t - w;
+    w = fn * p2t - ((t - r) - w);
+    t = r;
+    w = fn * p3;
+    r = t - w;
+    w = fn * p3t - ((t - r) - w);
+  }
+  const double y0 = r - w, y1 = (r - y0) - w;
+  const double ks = sc_kernel_sin(y0, y1, true), kc = sc_kernel_cos(y0, y1);
+  switch ((long long)fn & 3) {
+    case 0: *s = ks, *c = kc; break;
+    case 1: *s = kc, *c = -ks; break;
+    case 2: *s = -ks, *c = -kc; break;
+    default: *s = -kc, *c = ks; break;
+  }
+}
+
 // Symmetric eigen decomposition, N <= 64.  a: n*n row-major (destroyed), w ascending,
 // v: columns are unit eigenvectors.
 LSQR_HD void sym_eig(int n, double *a, double *w, double *v) {

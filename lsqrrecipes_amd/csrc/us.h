@@ -417,9 +417,11 @@ struct USModel {
   static LSQR_HD void lm_coef(const double *xk, LmCoef &k) {
     const int o = SINGLE ? 3 : 0;
     for (int i = 0; i < 3; i++) k.t1[i] = SINGLE ? xk[i] : 0.0, k.t3[i] = xk[o + i];
-    const double sz = sin(xk[o + 3]), cz = cos(xk[o + 3]);
-    const double sy = sin(xk[o + 4]), cy = cos(xk[o + 4]);
-    const double sx = sin(xk[o + 5]), cx = cos(xk[o + 5]);
+    // lsqr_sincos: the same bits on the host and in the persistent kernel (small_linalg.h)
+    double sz, cz, sy, cy, sx, cx;
+    lsqr_sincos(xk[o + 3], &sz, &cz);
+    lsqr_sincos(xk[o + 4], &sy, &cy);
+    lsqr_sincos(xk[o + 5], &sx, &cx);
     const double m_x = xk[o + 6], m_y = xk[o + 7];
     const double r1[3] = {cz * cy, sz * cy, -sy};                                       // R3(:,1)
     const double r2[3] = {cz * sy * sx - sz * cx, sz * sy * sx + cz * cx, cy * sx};     // R3(:,2)
@@ -499,9 +501,10 @@ struct USModel {
   static LSQR_HD int lm_finalize(const double *x, double *par) {
     const int o = SINGLE ? 3 : 0;
     for (int i = 0; i < NLM; i++) par[i] = x[i];
-    const double cz = cos(x[o + 3]), sz = sin(x[o + 3]);
-    const double cy = cos(x[o + 4]), sy = sin(x[o + 4]);
-    const double cx = cos(x[o + 5]), sx = sin(x[o + 5]);
+    double sz, cz, sy, cy, sx, cx;
+    lsqr_sincos(x[o + 3], &sz, &cz);
+    lsqr_sincos(x[o + 4], &sy, &cy);
+    lsqr_sincos(x[o + 5], &sx, &cx);
     const double mx = x[o + 6], my = x[o + 7];
     int k = NLM;
     par[k++] = mx * cz * cy;
