@@ -92,7 +92,13 @@ typedef struct {
   int32_t lm_info;      /* MINPACK info code of the LM run (0 when no LM) */
   int32_t lm_nfev;      /* LM function evaluations (= device passes) */
   int32_t reserved;     /* LM runs: the evaluation after which the cost never again fell by more than 1e-7
-                           relative (diagnostics: where a run that ends at the evaluation limit stopped gaining) */
+                           relative (diagnostics: where a run that ends at the evaluation limit stopped gaining).
+                           Dense system: 1 = the elimination on the normal equations was refused and the fit was taken
+                           from the rows in double-double (the reference's SVD route, csrc/dense.h); 2 = only the summed
+                           block was at hand (lsqr_solve_moments, lsqr_step_finish*) and a pivot fell below 1e-6 max|G|:
+                           the result carries eps cond(A)^2 -- a caller that holds the rows should fit again from them
+                           (lsqr_mask + lsqr_ls_fit; lsqr_multi_* and distributed.ShardedRansac do, so that an N-GPU
+                           fit equals the one-GPU fit on ill-conditioned systems too) */
   uint64_t n_used;      /* observations that entered the fit */
   double cost;          /* final sum of squared residuals where the model defines one, else 0 */
 } lsqr_fit_info;
@@ -280,6 +286,12 @@ LSQR_API int lsqr_batch_fit_wait(lsqr_ctx *ctx, int slot, double *params_out, ls
  *                     parameters; info->best_votes / best_index (in-batch index) from packed_dev,
  *                     info->evaluated = 1 when the batch had a valid hypothesis (else 0),
  *                     info->fit.n_used = the summed count.  LSQR_EMPTY: no valid hypothesis / fit failed.
+ * Host synchronisations of a step: lsqr_step_finish / _wait is the one every model has.  The dense system and the
+ * US / plane-phantom calibrations add ONE inside lsqr_step_scan: their matrix-core filters decide the band of every
+ * batch from per-workgroup worklists, and the host reads the fullest segment's fill right after the scan so that an
+ * overflow (never seen) re-runs it on the exact kernels before the winner is packed -- the packed winner feeds a
+ * collective and cannot be taken back afterwards.  lsqr_batch_fit_enqueue, whose results stay local until
+ * lsqr_batch_fit_wait, defers that check to the wait and never blocks (r05).
  * lsqr_set_stream(external = 1) makes the context enqueue on the caller's HIP stream (the stream the
  * collectives are ordered with, e.g. torch's current stream; NULL = the default stream); external = 0
  * restores the context's own (non-blocking) stream. */
@@ -311,6 +323,13 @@ LSQR_API int lsqr_step_finish_wait(lsqr_ctx *ctx, int slot, double *winner_out, 
 typedef struct lsqr_multi lsqr_multi;
 LSQR_API int lsqr_multi_create(const int *devices, int n, lsqr_multi **out);
 LSQR_API void lsqr_multi_destroy(lsqr_multi *m);
+/* The transport of the handle's two exchanges: "peer-copy" (default: hipMemcpyPeerAsync into the first device's gather
+ * area + a fixed-order reduction kernel there) or "rccl" (environment LSQR_MULTI_TRANSPORT=rccl at lsqr_multi_create:
+ * one RCCL communicator per device -- ncclCommInitAll; librccl is dlopen'ed --, the winner as ncclAllReduce MAX of the
+ * packed 64-bit word, the moment blocks as ncclAllReduce SUM on fixed buffers, each on its context's stream; needs
+ * DISTINCT devices, lsqr_multi_create fails with LSQR_ERR_INVALID otherwise).  *bringup_seconds (nullable): what
+ * creating and proving the communicators took. */
+LSQR_API const char *lsqr_multi_transport(const lsqr_multi *m, double *bringup_seconds);
 LSQR_API int lsqr_multi_size(const lsqr_multi *m);
 LSQR_API lsqr_ctx *lsqr_multi_ctx(lsqr_multi *m, int rank); /* per-device options / profiling */
 LSQR_API const char *lsqr_multi_last_error(const lsqr_multi *m);

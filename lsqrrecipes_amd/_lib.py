@@ -108,6 +108,7 @@ SIGNATURES = {
     "lsqr_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "lsqr_multi_destroy": (None, [C.c_void_p]),
     "lsqr_multi_size": (C.c_int, [C.c_void_p]),
+    "lsqr_multi_transport": (C.c_char_p, [C.c_void_p, C.POINTER(C.c_double)]),
     "lsqr_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lsqr_multi_last_error": (C.c_char_p, [C.c_void_p]),
     "lsqr_multi_set_model": (C.c_int, [C.c_void_p, C.POINTER(ModelCfg)]),

@@ -373,6 +373,12 @@ class MultiContext:
         raise L.LsqrError(st, "%s (%s)" % (self._lib.lsqr_status_string(st).decode(),
                                            self._lib.lsqr_multi_last_error(self._h).decode()))
 
+    def transport(self):
+        """-> ("peer-copy" | "rccl", seconds spent bringing the RCCL communicators up)"""
+        t = C.c_double(0.0)
+        name = self._lib.lsqr_multi_transport(self._h, C.byref(t))
+        return name.decode(), t.value
+
     def set_model(self, model, dim=3, delta=0.5, ls_type=L.LS_GEOMETRIC, aux=0.0):
         self.cfg = L.ModelCfg(int(model), int(dim), float(delta), int(ls_type), 0, float(aux))
         self._chk(self._lib.lsqr_multi_set_model(self._h, C.byref(self.cfg)))

@@ -40,6 +40,9 @@
 #include <condition_variable>
 #include <mutex>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed when LSQR_MULTI_TRANSPORT=rccl asks for it
+
 using namespace lsqr;
 
 // ------------------------------------------------------------------------------------------------
@@ -181,6 +184,17 @@ struct lsqr_ctx {
   uint64_t lane_epoch = 0;   // (lanes) the epoch of the parent this lane is attached to
   std::vector<std::pair<std::string, int>> opt_log;  // options set on this context, replayed on new lanes
   hipEvent_t slot_ev[2] = {nullptr, nullptr};  // lsqr_batch_fit_enqueue / _wait
+  // The matrix-core filters of the dense / US / phantom scans decide their band from per-workgroup worklists; a segment
+  // that overflowed (never seen) means "scan again without the filter".  The blocking entry points read the fill right
+  // after the scan (one host synchronisation); lsqr_batch_fit_enqueue must not wait, so there the scan only notes the
+  // segment size (ovf_cap), the fill travels with the slot's pinned record and lsqr_batch_fit_wait runs the batch
+  // again without the filter if it ever exceeds it.
+  bool defer_ovf = false;        // set around run_scan_batch by lsqr_batch_fit_enqueue
+  uint32_t ovf_cap = 0;          // segment size the deferred check compares against (0: this scan has no worklist)
+  uint32_t slot_ovf_cap[2] = {0, 0};
+  uint64_t slot_seed[2] = {0, 0};
+  int opt_test_overflow = 0;     // tests: lsqr_batch_fit_wait treats the slot's worklist as overflowed
+  uint64_t ovf_reruns = 0;       // batches run again because a worklist segment overflowed (diagnostics)
   uint64_t slot_first[2] = {0, 0}, slot_H[2] = {0, 0};
   bool slot_busy[2] = {false, false};
   hipEvent_t mdev_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // lsqr_moments_dev: staging slots of x
@@ -230,7 +244,6 @@ struct lsqr_ctx {
   int opt_lm_persist_test_abort = 0;     // tests: workgroup 0 gives up at this evaluation (the fallback path)
   LmpCtl *d_lmp = nullptr;
   unsigned long long *h_lmcmd = nullptr;  // pinned, device-visible: the host's reply (coefficient granules + command)
-  bool lmp_attr = false;
   bool counted = false;  // this context counts among the device's root contexts (lmp_pool: the share of a persistent fit)
   // diagnostics of the last persistent fit: {mode, G, evaluations, status, kernel us, fallbacks, host ns waiting, host ns stepping}
   uint64_t lmp_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -499,12 +512,10 @@ int run_estimate(lsqr_ctx *c) {
         // refuses is marked and taken through the SVD pseudo-inverse by the workgroup kernel behind it
         const int wpb = c->opt_dense_wave == 2 ? 2 : 4;   // systems per workgroup (2: 68 KB of LDS at n = 64, A/B)
         const size_t lds = sizeof(double) * wpb * ((size_t)n * (n | 1) + 2 * n);
-        static bool attr_set = false;
-        if (!attr_set) {
-          (void)hipFuncSetAttribute((const void *)k_estimate_dense_w4, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(double) * 4 * (64 * 65 + 128)));
-          attr_set = true;
-        }
+        // (unconditionally: the attribute belongs to the (kernel, device) pair, and a flag per process or per context
+        // misses the second device / the second kernel; the call is cheap)
+        (void)hipFuncSetAttribute((const void *)k_estimate_dense_w4, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * 4 * (64 * 65 + 128)));
         if (n == 64 && c->opt_dense_wave == 3)  // the system in registers, one wave per hypothesis (k_estimate_dense_r64)
           hipLaunchKernelGGL(k_estimate_dense_r64, dim3((unsigned)c->H), dim3(64), 0, c->stream, c->d_data, c->stride, c->n,
                              c->d_subsets, (uint32_t)c->H, (int)M::SP, c->d_hparams, c->d_valid);
@@ -732,12 +743,8 @@ int build_index(lsqr_ctx *c, uint32_t cell_pts) {
   // local k-d refinement of the Morton order (cells.h: k_refine_runs): compact cells, fewer surviving pairs
   if (c->opt_refine && !c->opt_presorted && n_sorted > cell_pts && cell_pts >= 128 && cell_pts < kRunPts &&
       (cell_pts & (cell_pts - 1)) == 0) {
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[D - 2]) {
-      (void)hipFuncSetAttribute((const void *)k_refine_runs<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)refine_lds_bytes(D));
-      attr_set[D - 2] = true;
-    }
+    (void)hipFuncSetAttribute((const void *)k_refine_runs<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)refine_lds_bytes(D));
     const unsigned runs = (unsigned)((n_sorted + kRunPts - 1) / kRunPts);
     hipLaunchKernelGGL((k_refine_runs<D>), dim3(runs), dim3(1024), refine_lds_bytes(D), c->stream, c->d_data, c->stride,
                        v_out, n_sorted, cell_pts);
@@ -1253,15 +1260,12 @@ int ensure_us_h16(lsqr_ctx *c, bool *ok) {
   if (!c->d_us16_x) HIPCHK(c, hipMalloc((void **)&c->d_us16_x, (size_t)(8192 / 32) * 4096));
   if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
   if (!c->d_amb) HIPCHK(c, hipMalloc((void **)&c->d_amb, sizeof(unsigned long long) * kAmbCap));
-  if (!c->us16_attr) {
-    c->us16_attr = true;
-    if constexpr (PH)
-      (void)hipFuncSetAttribute((const void *)k_scan_phantom_h16, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)phantom_h16_lds(kPh16HypChunk));
-    else
-      (void)hipFuncSetAttribute((const void *)k_scan_us_h16<SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)us_h16_lds(kUs16HypChunk));
-  }
+  if constexpr (PH)  // (every time: one flag per context served two kernels and missed the second)
+    (void)hipFuncSetAttribute((const void *)k_scan_phantom_h16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)phantom_h16_lds(kPh16HypChunk));
+  else
+    (void)hipFuncSetAttribute((const void *)k_scan_us_h16<SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)us_h16_lds(kUs16HypChunk));
   *ok = true;
   return LSQR_OK;
 }
@@ -1439,6 +1443,11 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
     return LSQR_OK;
   };
   if ((st = run_early_exit(c, 64, b, scan, gather)) != LSQR_OK) return st;
+  if (c->defer_ovf) {  // lsqr_batch_fit_enqueue: no host synchronisation here, lsqr_batch_fit_wait checks the fill
+    c->ovf_cap = seg_cap;
+    *done = true;
+    return LSQR_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, sync_stream(c));
   c->dense_amb_max = *(unsigned int *)c->h_pin;
@@ -1514,6 +1523,10 @@ int run_scan_us_ee(lsqr_ctx *c) {
     return LSQR_OK;
   };
   if ((st = run_early_exit(c, tile, b, scan, gather)) != LSQR_OK) return st;
+  if (h16 && c->defer_ovf) {  // lsqr_batch_fit_enqueue: lsqr_batch_fit_wait checks the fill (no synchronisation here)
+    c->ovf_cap = seg_cap;
+    return LSQR_OK;
+  }
   if (h16) {  // a worklist segment that overflowed (not seen): everything again with the packed fp32 filter
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, sync_stream(c));
@@ -1615,6 +1628,10 @@ int run_scan(lsqr_ctx *c) {
                                    (unsigned int *)(c->d_counter + 3));
                 HIPCHK(c, hipGetLastError());
               }
+              if (c->defer_ovf) {
+                c->ovf_cap = seg_cap;
+                return LSQR_OK;
+              }
               HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                        c->stream));
               HIPCHK(c, sync_stream(c));
@@ -1660,6 +1677,10 @@ int run_scan(lsqr_ctx *c) {
             HIPCHK(c, hipGetLastError());
           }
           // worklist overflow (never seen: ~1e-13 of the pairs are ambiguous) -> exact kernel
+          if (c->defer_ovf) {
+            c->ovf_cap = kAmbCap;
+            return LSQR_OK;
+          }
           HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, c->stream));
           HIPCHK(c, sync_stream(c));
@@ -1689,6 +1710,10 @@ int run_scan(lsqr_ctx *c) {
                 if ((st = launch_us_h16<M>(c, 0, c->n, c->d_hparams, (uint32_t)c->H, d_segcnt, seg_cap, nullptr, nullptr,
                                            nullptr)) != LSQR_OK)
                   return st;
+              }
+              if (c->defer_ovf) {
+                c->ovf_cap = seg_cap;
+                return LSQR_OK;
               }
               HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                        c->stream));
@@ -1939,12 +1964,8 @@ int launch_solve_dense(lsqr_ctx *c, bool rows = false, int use_mask = 0, size_t 
   hipLaunchKernelGGL((k_gram_dd_dense<32>), dim3(nb), dim3(256), 0, c->stream, c->d_data, c->stride, begin, end, n,
                      use_mask ? c->d_mask : (const uint8_t *)nullptr, flag, c->d_ddpart);
   HIPCHK(c, hipGetLastError());
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_dense_dd_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)dense_dd_lds(64));
-    attr_set = true;
-  }
+  (void)hipFuncSetAttribute((const void *)k_dense_dd_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)dense_dd_lds(64));
   hipLaunchKernelGGL(k_dense_dd_solve, dim3(1), dim3(256), dense_dd_lds(n), c->stream, c->d_ddpart, nb, n, c->d_mom,
                      flag, c->d_out);
   HIPCHK(c, hipGetLastError());
@@ -2162,15 +2183,12 @@ int lm_persist_fit(lsqr_ctx *c, const double *tiles, size_t cnt, int nb, LmState
   const size_t lds = std::max<size_t>((size_t)(threads / 64) * 64 * 17 * sizeof(double), (size_t)96 << 10);
   // a fit that has the device to itself in one round keeps its tiles in registers (k_lm_persist<M, 4>: 512 threads)
   const bool resident = host_step && threads == 512 && (size_t)Gl * 2 >= (size_t)nb && c->opt_lm_persist_resident;
-  if (!c->lmp_attr) {
-    if (hipFuncSetAttribute((const void *)k_lm_persist<M, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void *)k_lm_persist<M, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) !=
-            hipSuccess) {
-      lmp_release(c->device, G);
-      return LSQR_OK;
-    }
-    c->lmp_attr = true;
+  if (hipFuncSetAttribute((const void *)k_lm_persist<M, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) !=
+          hipSuccess ||
+      hipFuncSetAttribute((const void *)k_lm_persist<M, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) !=
+          hipSuccess) {
+    lmp_release(c->device, G);
+    return LSQR_OK;
   }
   LmpInit init{};
   init.n = n;
@@ -2250,7 +2268,7 @@ int lm_persist_fit(lsqr_ctx *c, const double *tiles, size_t cnt, int nb, LmState
   hipError_t se = sync_stream(c);
   lmp_release(c->device, G);
   if (se != hipSuccess) return fail(c, LSQR_ERR_HIP, "persistent LM kernel: %s", hipGetErrorString(se));
-  LmpCtl *hc = (LmpCtl *)((char *)c->h_pin + 8192);
+  LmpCtl *hc = (LmpCtl *)((char *)c->h_pin + 32768);  // (8192: the mask count finish_ransac reads after the fit; 16384, 49152+: other stagings)
   HIPCHK(c, hipMemcpy(hc, c->d_lmp, sizeof(LmpCtl), hipMemcpyDeviceToHost));
   c->lmp_last[0] = (uint64_t)c->opt_lm_persist;
   c->lmp_last[1] = (uint64_t)Gl;
@@ -3797,7 +3815,16 @@ int lsqr_batch_fit_enqueue(lsqr_ctx *c, uint64_t seed, uint64_t first, size_t H,
   int st = lsqr_hypotheses_sample(c, seed, first, H, nullptr);
   if (st != LSQR_OK) return st;
   const uint64_t seq_before = c->bsel_seq;
-  if ((st = run_scan_batch(c, 0)) != LSQR_OK) return st;
+  c->defer_ovf = true;  // no host synchronisation inside the scan: the worklist fill is checked by lsqr_batch_fit_wait
+  c->ovf_cap = 0;
+  st = run_scan_batch(c, 0);
+  c->defer_ovf = false;
+  if (st != LSQR_OK) return st;
+  c->slot_ovf_cap[slot] = c->ovf_cap;
+  c->slot_seed[slot] = seed;
+  if (c->ovf_cap)  // {fullest worklist segment of this batch's scan} beside the slot's results
+    HIPCHK(c, hipMemcpyAsync(slot_pin(c, slot) + 32, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                             c->stream));
   c->slot_bsel_rec[slot] = c->bsel_seq != seq_before ? c->bsel_last_rec : -1;  // this batch's selection record
   c->slot_bsel_seq[slot] = c->bsel_seq;
   c->scanned = true;
@@ -3848,6 +3875,23 @@ int lsqr_batch_fit_wait(lsqr_ctx *c, int slot, double *params_out, lsqr_ransac_i
     bsel_fold(c, c->slot_bsel_rec[slot]);  // the host has synchronised with this batch: its selection counts count
   c->slot_bsel_rec[slot] = -1;
   const char *pin = slot_pin(c, slot);
+  if (c->slot_ovf_cap[slot]) {
+    unsigned int fill = 0;
+    memcpy(&fill, pin + 32, sizeof fill);
+    if (fill > c->slot_ovf_cap[slot] || c->opt_test_overflow) {
+      // a worklist segment of the matrix-core filter overflowed (never seen outside the tests): the batch again, blocking,
+      // on the exact kernels
+      (void)fail(c, LSQR_OK, "worklist segment overflow in slot %d (fill %u > %u): batch run again without the filter",
+                 slot, fill, c->slot_ovf_cap[slot]);
+      c->ovf_reruns++;
+      const int keep = c->opt_filter;
+      c->opt_filter = 0;
+      const int st2 = lsqr_batch_fit(c, c->slot_seed[slot], c->slot_first[slot], (size_t)c->slot_H[slot], params_out,
+                                     nullptr, info);
+      c->opt_filter = keep;
+      return st2;
+    }
+  }
   unsigned long long head[2];
   SolveOut out;
   memcpy(head, pin, sizeof head);
@@ -4067,6 +4111,11 @@ struct lsqr_multi {
   double *g_block = nullptr;
   std::vector<hipEvent_t> ev;                // per rank: "my contribution has been sent"
   hipEvent_t ev_root = nullptr;              // rank 0: "the reduced value is on its way back"
+  // LSQR_MULTI_TRANSPORT=rccl: the two exchanges as RCCL all-reduces over xGMI (one communicator per device,
+  // ncclCommInitAll) instead of peer copies into rank 0 + a reduction kernel
+  bool rccl = false;
+  std::vector<ncclComm_t> comm;
+  double rccl_bringup_s = 0.0;
   char err[512] = {0};
 };
 
@@ -4084,6 +4133,68 @@ int mfail(lsqr_multi *m, int st, const char *what, lsqr_ctx *c = nullptr) {
       return LSQR_ERR_HIP;                                                                                \
     }                                                                                                     \
   } while (0)
+
+// librccl, loaded on first use and only when asked for (a process that also imports PyTorch carries PyTorch's own copy
+// of the library: RTLD_LOCAL keeps the two apart)
+struct RcclApi {
+  void *lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  bool ok = false;
+};
+RcclApi &rccl_api() {
+  static RcclApi a;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {getenv("LSQR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    for (const char *nm : names) {
+      if (!nm || !*nm) continue;
+      a.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) return;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.lib, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+    a.GetVersion = (decltype(a.GetVersion))dlsym(a.lib, "ncclGetVersion");
+    a.ok = a.CommInitAll && a.CommDestroy && a.AllReduce && a.GroupStart && a.GroupEnd && a.GetErrorString;
+  });
+  return a;
+}
+#define MNCCL(m, call)                                                                                       \
+  do {                                                                                                       \
+    ncclResult_t r_ = (call);                                                                                \
+    if (r_ != ncclSuccess) {                                                                                 \
+      snprintf((m)->err, sizeof(m)->err, "%s failed: %s (%s:%d)", #call, rccl_api().GetErrorString(r_), __FILE__, \
+               __LINE__);                                                                                    \
+      return LSQR_ERR_HIP;                                                                                   \
+    }                                                                                                        \
+  } while (0)
+
+// RCCL transport: buf[r] (count elements on rank r's device) <- op over all ranks, in place, each on its own stream
+int multi_allreduce(lsqr_multi *m, const std::vector<void *> &buf, size_t count, ncclDataType_t type, ncclRedOp_t op) {
+  RcclApi &a = rccl_api();
+  MNCCL(m, a.GroupStart());
+  for (int r = 0; r < m->n; r++) {
+    ncclResult_t e = a.AllReduce(buf[r], buf[r], count, type, op, m->comm[r], m->ctx[r]->stream);
+    if (e != ncclSuccess) {
+      (void)a.GroupEnd();
+      snprintf(m->err, sizeof m->err, "ncclAllReduce failed on rank %d: %s", r, a.GetErrorString(e));
+      return LSQR_ERR_HIP;
+    }
+  }
+  MNCCL(m, a.GroupEnd());
+  MHIP(m, hipSetDevice(m->ctx[0]->device));
+  return LSQR_OK;
+}
 
 // every rank's `src[r]` (bytes) -> rank 0's gather area at r * pitch; rank 0's stream waits for all of them
 int multi_gather(lsqr_multi *m, const std::vector<const void *> &src, void *gather, size_t bytes, size_t pitch) {
@@ -4140,11 +4251,17 @@ int multi_finish(lsqr_multi *m, uint64_t seed, uint64_t batch_first, double *par
       return mfail(m, st, "lsqr_step_winner", m->ctx[r]);
     src[r] = m->block[r];
   }
+  if (m->rccl) {  // one all-reduce SUM of [moment block, inlier count]: every rank ends up with the summed block
+    std::vector<void *> buf(n);
+    for (int r = 0; r < n; r++) buf[r] = m->block[r];
+    if ((st = multi_allreduce(m, buf, (size_t)len + 1, ncclDouble, ncclSum)) != LSQR_OK) return st;
+  } else {
   if ((st = multi_gather(m, src, m->g_block, sizeof(double) * (len + 1), sizeof(double) * kMultiBlk)) != LSQR_OK)
     return st;
   hipLaunchKernelGGL(k_multi_sum, dim3((len + 1 + 255) / 256), dim3(256), 0, c0->stream, m->g_block, n, len + 1,
                      kMultiBlk, m->block[0]);
   MHIP(m, hipGetLastError());
+  }
   double winner[64], fit[64];
   lsqr_ransac_info local;
   if (!info) info = &local;
@@ -4160,6 +4277,22 @@ int multi_finish(lsqr_multi *m, uint64_t seed, uint64_t batch_first, double *par
         MHIP(m, hipMemcpyAsync(consensus_out + lo[r], c->d_mask + lo[r], hi[r] - lo[r], hipMemcpyDeviceToHost,
                                c->stream));
     }
+  if (c0->cfg.model == LSQR_MODEL_DENSE && info->fit.reserved == 2 && c0->opt_dense_dd) {
+    // the summed Gram block is ill-conditioned (a pivot below 1e-6 max|G|): its solution carries eps cond(A)^2, and a
+    // one-device fit of the same rows would have taken the double-double route.  The records are replicated, so rank 0
+    // masks the whole upload with the winner and fits from the rows -- the N-device fit IS the one-device fit then.
+    MHIP(m, hipSetDevice(c0->device));
+    uint64_t cnt = 0;
+    int st2 = lsqr_mask(c0, winner, 0, c0->n, nullptr, &cnt);
+    lsqr_fit_info fi;
+    if (st2 == LSQR_OK) st2 = lsqr_ls_fit(c0, 1, fit, &fi);
+    if (st2 != LSQR_OK && st2 != LSQR_EMPTY) return mfail(m, st2, "refit of an ill-conditioned dense system from the rows", c0);
+    const uint64_t used = info->fit.n_used;
+    info->fit = fi;
+    info->fit.n_used = used;
+    info->n_params = st2 == LSQR_OK ? fi.n_params : 0;
+    st = st2;
+  }
   if (st == LSQR_OK && wants_lm(c0->cfg) && c0->cfg.model != LSQR_MODEL_PHANTOM) {
     // Levenberg-Marquardt over the sharded consensus set: per evaluation every rank reduces its slice at the trial
     // point, the blocks are summed on rank 0, MINPACK's control flow runs there (lsqr_lm_begin / lsqr_lm_step)
@@ -4173,11 +4306,17 @@ int multi_finish(lsqr_multi *m, uint64_t seed, uint64_t batch_first, double *par
           return mfail(m, st, "lsqr_moments_dev", m->ctx[r]);
         src[r] = m->block[r];
       }
+      if (m->rccl) {  // one all-reduce SUM of the {sum f^2, J^T J, J^T f} block per evaluation
+        std::vector<void *> buf(n);
+        for (int r = 0; r < n; r++) buf[r] = m->block[r];
+        if ((st = multi_allreduce(m, buf, (size_t)n1, ncclDouble, ncclSum)) != LSQR_OK) return st;
+      } else {
       if ((st = multi_gather(m, src, m->g_block, sizeof(double) * n1, sizeof(double) * kMultiBlk)) != LSQR_OK)
         return st;
       hipLaunchKernelGGL(k_multi_sum, dim3((n1 + 255) / 256), dim3(256), 0, c0->stream, m->g_block, n, n1,
                          kMultiBlk, m->block[0]);
       MHIP(m, hipGetLastError());
+      }
       MHIP(m, hipMemcpyAsync(c0->h_pin, m->block[0], sizeof(double) * n1, hipMemcpyDeviceToHost, c0->stream));
       for (int r = 0; r < n; r++) {  // every rank's x staging must be consumed before the next trial point
         MHIP(m, hipSetDevice(m->ctx[r]->device));
@@ -4251,6 +4390,42 @@ int lsqr_multi_create(const int *devices, int n, lsqr_multi **out) {
         hipEventCreateWithFlags(&m->ev_root, hipEventDisableTiming) != hipSuccess)
       st = LSQR_ERR_HIP;
   }
+  const char *tr = getenv("LSQR_MULTI_TRANSPORT");
+  if (st == LSQR_OK && tr && !strcmp(tr, "rccl")) {
+    // RCCL wants one communicator per DISTINCT device of the process; anything else keeps the peer copies
+    bool distinct = true;
+    for (int r = 0; r < n; r++)
+      for (int q = 0; q < r; q++) distinct = distinct && devices[q] != devices[r];
+    RcclApi &a = rccl_api();
+    if (!a.ok || !distinct) {
+      snprintf(m->err, sizeof m->err, "LSQR_MULTI_TRANSPORT=rccl: %s", !a.ok ? "librccl could not be loaded" : "the same device is listed twice");
+      lsqr_multi_destroy(m);
+      return LSQR_ERR_INVALID;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    m->comm.assign((size_t)n, nullptr);
+    ncclResult_t e = a.CommInitAll(m->comm.data(), n, devices);
+    if (e != ncclSuccess) {
+      m->comm.clear();
+      lsqr_multi_destroy(m);
+      return LSQR_ERR_HIP;
+    }
+    m->rccl = true;
+    // prove the communicators with one small all-reduce before anything is timed
+    std::vector<void *> buf((size_t)n);
+    for (int r = 0; r < n; r++) {
+      buf[(size_t)r] = m->packed[(size_t)r];
+      (void)hipSetDevice(devices[r]);
+      (void)hipMemsetAsync(m->packed[(size_t)r], 0, 8, m->ctx[(size_t)r]->stream);
+    }
+    st = multi_allreduce(m, buf, 1, ncclUint64, ncclMax);
+    for (int r = 0; r < n && st == LSQR_OK; r++) {
+      (void)hipSetDevice(devices[r]);
+      if (hipStreamSynchronize(m->ctx[(size_t)r]->stream) != hipSuccess) st = LSQR_ERR_HIP;
+    }
+    (void)hipSetDevice(devices[0]);
+    m->rccl_bringup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   if (st != LSQR_OK) {
     lsqr_multi_destroy(m);
     return st;
@@ -4259,8 +4434,16 @@ int lsqr_multi_create(const int *devices, int n, lsqr_multi **out) {
   return LSQR_OK;
 }
 
+const char *lsqr_multi_transport(const lsqr_multi *m, double *bringup_seconds) {
+  if (bringup_seconds) *bringup_seconds = m ? m->rccl_bringup_s : 0.0;
+  return !m ? "none" : m->rccl ? "rccl" : "peer-copy";
+}
+
 void lsqr_multi_destroy(lsqr_multi *m) {
   if (!m) return;
+  for (ncclComm_t cm : m->comm)
+    if (cm) (void)rccl_api().CommDestroy(cm);
+  m->comm.clear();
   for (size_t r = 0; r < m->ctx.size(); r++) {
     (void)hipSetDevice(m->ctx[r]->device);
     (void)hipStreamSynchronize(m->ctx[r]->stream);
@@ -4327,10 +4510,14 @@ int lsqr_multi_batch_fit(lsqr_multi *m, uint64_t seed, uint64_t first, size_t H,
     src[r] = m->packed[r];
     dst[r] = m->packed[r];
   }
+  if (m->rccl) {  // all-reduce MAX of the packed (votes << 32) | ~index: the earliest best hypothesis, on every rank
+    if ((st = multi_allreduce(m, dst, 1, ncclUint64, ncclMax)) != LSQR_OK) return st;
+  } else {
   if ((st = multi_gather(m, src, m->g_packed, 8, 8)) != LSQR_OK) return st;
   hipLaunchKernelGGL(k_multi_max, dim3(1), dim3(64), 0, c0->stream, m->g_packed, n, m->packed[0]);
   MHIP(m, hipGetLastError());
   if ((st = multi_bcast(m, m->packed[0], dst, 8)) != LSQR_OK) return st;
+  }
   lsqr_ransac_info local;
   if (!info) info = &local;
   st = multi_finish(m, seed, first, params_out, consensus_out, info);
@@ -4586,6 +4773,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   if (!strcmp(name, "lm_persist_wgs")) {  // resident workgroups of the persistent fit (0: by the contexts on the device)
     if (value < 0 || value > 1024) return LSQR_ERR_INVALID;
     c->opt_lm_persist_wgs = (int)value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "scan_test_overflow")) {  // tests: the deferred worklist check of lsqr_batch_fit_wait fires
+    c->opt_test_overflow = value != 0;
     return LSQR_OK;
   }
   if (!strcmp(name, "lm_persist_resident")) {

@@ -157,7 +157,7 @@ class ShardedRansac:
         par, origin, blk, cnt = e.winner_moments(seed, gidx, lo, hi)
         blk = c.allreduce_sum_f64(np.concatenate([blk, [float(cnt)]]))
         fit, info = e.solve_moments(blk[:-1], origin)
-        fit, info = self._refine(fit, info, lo, hi)
+        fit, info = self._refine(fit, info, lo, hi, par)
         return int(win >> 32), gidx, par, fit, int(round(blk[-1])), info
 
     def step_device(self, seed, batch_index, H, slot=None):
@@ -200,7 +200,7 @@ class ShardedRansac:
         if not info.evaluated:   # no valid hypothesis in the whole batch
             return None
         gidx = batch_index * self.c.world * H + int(info.best_index)
-        fit, finfo = self._refine(fit, info.fit, lo, hi)
+        fit, finfo = self._refine(fit, info.fit, lo, hi, par)
         return int(info.best_votes), gidx, par, fit, int(info.fit.n_used), finfo
 
     def step_device_wait(self, slot):
@@ -210,11 +210,22 @@ class ShardedRansac:
         st, par, fit, info = self.e.step_finish_wait(slot)
         return self._step_result(info, par, fit, batch_index, H, lo, hi)
 
-    def _refine(self, fit, info, lo, hi):
-        """LM refinement over the sharded observation range (sphere geometric / US iterative)."""
+    def _refine(self, fit, info, lo, hi, winner=None):
+        """LM refinement over the sharded observation range (sphere geometric / US iterative); dense system: a fit from
+        the rows when the summed Gram block alone cannot guarantee 1e-6."""
         e, c = self.e, self.c
         from . import _lib as L
         model = e.cfg.model
+        if model == L.DENSE and winner is not None and getattr(info, "reserved", 0) == 2 and hasattr(e, "ls_fit"):
+            # the summed block is ill-conditioned (a pivot below 1e-6 max|G|, lsqr_hip.h: lsqr_fit_info.reserved == 2):
+            # its solution carries eps cond(A)^2 where a one-GPU fit takes the double-double route over the rows.  The
+            # records are replicated: every rank masks the whole upload with the winner and fits from the rows --
+            # identical on every rank, no exchange, and equal to the one-GPU result
+            n_used = info.n_used
+            e.mask(winner, 0, e.n, want_mask=False)
+            fit, info = e.ls_fit(use_mask=True)
+            info.n_used = n_used
+            return fit, info
         iterative = (model == L.SPHERE and e.cfg.ls_type == L.LS_GEOMETRIC) or (
             model in (L.US_SINGLE, L.US_POINTER) and e.cfg.ls_type == L.LS_ITERATIVE)
         if len(fit) and iterative and self._stream is not None and hasattr(e, "moments_dev"):
@@ -258,5 +269,5 @@ class ShardedRansac:
         blk = c.allreduce_sum_f64(blk)  # one fused exchange: moment block + inlier count
         total = int(round(blk[-1]))
         fit, info = e.solve_moments(blk[:-1], origin)
-        fit, info = self._refine(fit, info, lo, hi)
+        fit, info = self._refine(fit, info, lo, hi, params)
         return fit, total, info

@@ -52,9 +52,10 @@ def test_dense_ls_cond_sweep_follows_the_reference_svd(ctx):
     for n in (8, 33, 64):
         for ci, cond in enumerate(CONDS):
             # consistent systems (residual at rounding level): the forward error of a backward-stable solve is
-            # ~eps * cond; with a residual rho it carries eps * cond^2 * rho on top -- for ANY two solvers, the oracle
-            # and LAPACK included -- so the noisy variant stops at cond 1e6
-            for resid in ((0.0, 1e-3) if cond <= 1e6 else (0.0,)):
+            # ~eps * cond; with a residual r it carries eps * cond^2 * rho on top, rho = |r| / (sigma_max |x|) -- for
+            # ANY two solvers, the oracle and LAPACK included.  The noisy variant runs to cond 1e8 (r04: 1e6) and is
+            # held to that bound where it exceeds the 1e-6 bar (r05)
+            for resid in ((0.0, 1e-3) if cond <= 1e8 else (0.0,)):
                 rows, x_true = system(4000, n, cond, 1000 * n + ci, resid)
                 oc = O.cfg(O.DENSE, n, 0.1)
                 want = O.ls(oc, rows)                                  # SVD pseudo-inverse of A, absolute threshold
@@ -64,7 +65,11 @@ def test_dense_ls_cond_sweep_follows_the_reference_svd(ctx):
                 ctx.set_option("dense_dd", 0)                          # r03's route, for the record
                 old, _ = ctx.ls_fit(use_mask=False)
                 ctx.set_option("dense_dd", 1)
-                row = {"n": n, "cond": cond, "resid": resid, "oracle_empty": len(want) == 0,
+                rvec = rows[:, n] - rows[:, :n] @ lap
+                rho = float(np.linalg.norm(rvec) / (10.0 * np.linalg.norm(lap)))   # sigma_max = 10 (system())
+                row = {"n": n, "cond": cond, "resid": resid, "rho": rho,
+                       "bound_eps_cond2_rho": float(10 * np.finfo(float).eps * (cond + cond * cond * rho)),
+                       "oracle_empty": len(want) == 0,
                        "device_empty": len(got) == 0, "gram_route_empty": len(old) == 0,
                        "dd_route_used": bool(info.reserved),
                        "device_vs_oracle": rel(got, want) if len(got) and len(want) else None,
@@ -80,8 +85,12 @@ def test_dense_ls_cond_sweep_follows_the_reference_svd(ctx):
         cond = row["cond"]
         assert row["device_empty"] == row["oracle_empty"], row    # EMPTY only where the oracle's is
         if cond <= 1e10 and not row["oracle_empty"]:
-            # the bar: 1e-6 relative against the oracle's SVD pseudo-inverse
-            assert row["device_vs_oracle"] < 1e-6, row
+            # the bar: 1e-6 relative against the oracle's SVD pseudo-inverse; a noisy right-hand side beyond cond 1e6
+            # is held to the perturbation bound 10 eps (cond + cond^2 rho) every pair of stable solvers shares
+            bar = 1e-6 if (row["resid"] == 0.0 or cond <= 1e6) else max(1e-6, row["bound_eps_cond2_rho"])
+            assert row["device_vs_oracle"] < bar, row
+            if row["resid"] > 0.0:   # and the oracle itself against LAPACK, so the bound is seen to be the problem's
+                assert row["oracle_vs_lapack"] < max(1e-6, row["bound_eps_cond2_rho"]), row
         if cond >= 1e5:
             assert row["dd_route_used"], row                      # the elimination was refused
     # what r03 did on the same systems: the Gram route alone loses the bar or the solution somewhere in the sweep

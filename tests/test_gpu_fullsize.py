@@ -174,6 +174,18 @@ def test_config3_sphere_10M_geometric_on_bench_path(ctx):
     assert np.allclose(r["params"], truth, rtol=1e-4, atol=1e-2)
 
 
+def test_line_10M_batch_on_bench_path(ctx):
+    """north_star's third point model at the BASELINE size (not a BASELINE config: r04 compared it at 1 M only):
+    line, 10 M points, 50 % outliers, 4096 hypotheses -- sampled minimal solves bit-exact, EVERY full count against
+    the oracle, winner's consensus set bit for bit, the fit (LineParametersEstimator.hxx:68-111) to 1e-6."""
+    r, want, truth, lab, wmask = _point_model_fullsize(ctx, L.LINE, O.LINE, synth.line, 0, 256)
+    got = r["params"]
+    assert abs(abs(got[:3] @ want[:3]) - 1.0) < REL                       # direction, modulo sign (eigenvector)
+    d = got[3:] - want[3:]                                                  # the two points lie on the same line
+    assert np.linalg.norm(d - (d @ want[:3]) * want[:3]) < REL * max(1.0, np.abs(want[3:]).max())
+    assert abs(abs(got[:3] @ truth[:3]) - 1) < 1e-7
+
+
 def test_config4_dense_2Mx64_on_bench_path(ctx):
     """BASELINE configs[3]: dense Ax ~ b, m = 2 M, n = 64, 1024 hypotheses (MFMA filter scan + worklist),
     consensus mask, MFMA SYRK + 64 x 64 solve.  Votes and mask bit-exact against the oracle evaluated on

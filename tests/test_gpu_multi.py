@@ -82,3 +82,75 @@ def test_multi_upload_replicates_device_to_device():
             c1.set_model(L.PLANE, 3, 0.5).upload(data[::-1].copy())
             w2 = c1.batch_fit(5, 0, 768, want_consensus=True)
         assert np.array_equal(r2["consensus"], w2["consensus"])
+
+
+@pytest.mark.parametrize("model,dim,ls,delta", [(L.PLANE, 3, 0, 0.5), (L.SPHERE, 3, L.LS_GEOMETRIC, 0.5),
+                                                (L.DENSE, 8, 0, 0.1), (L.US_POINTER, 0, L.LS_ITERATIVE, 3.0)])
+def test_rccl_transport_equals_the_peer_copies(model, dim, ls, delta, monkeypatch):
+    """LSQR_MULTI_TRANSPORT=rccl (one communicator per device: ncclCommInitAll; winner = ncclAllReduce MAX, moment
+    blocks = ncclAllReduce SUM) at the ONE device this box has: librccl loads, the communicator comes up, is proved by an
+    all-reduce, and every result equals the default transport's (a world of one leaves nothing to re-associate).
+    More than one device has never run this code: no hardware scaling curve exists."""
+    data = _data(model, dim)
+    H = 128 if model == L.DENSE else 512
+    res = {}
+    for tr in ("peer-copy", "rccl"):
+        if tr == "rccl":
+            monkeypatch.setenv("LSQR_MULTI_TRANSPORT", "rccl")
+        else:
+            monkeypatch.delenv("LSQR_MULTI_TRANSPORT", raising=False)
+        with MultiContext([0]) as m:
+            name, secs = m.transport()
+            assert name == tr and (secs > 0) == (tr == "rccl")
+            m.set_model(model, dim, delta, ls).upload(data)
+            b = m.batch_fit(0xBEEF, 1000, H, want_consensus=True)
+            r = m.ransac(0.999, seed=5)
+            res[tr] = (b, r, secs)
+    b0, r0, _ = res["peer-copy"]
+    b1, r1, secs = res["rccl"]
+    print("rccl bring-up at one device: %.3f s" % secs)
+    assert b0["info"].best_votes == b1["info"].best_votes and b0["info"].best_index == b1["info"].best_index
+    assert np.array_equal(b0["consensus"], b1["consensus"]) and np.array_equal(b0["params"], b1["params"])
+    assert r0["info"].iterations == r1["info"].iterations and np.array_equal(r0["consensus"], r1["consensus"])
+    assert np.array_equal(r0["params"], r1["params"])
+    assert b0["info"].fit.lm_nfev == b1["info"].fit.lm_nfev
+
+
+def test_rccl_transport_refuses_a_device_listed_twice(monkeypatch):
+    monkeypatch.setenv("LSQR_MULTI_TRANSPORT", "rccl")
+    with pytest.raises(L.LsqrError):
+        MultiContext([0, 0])
+
+
+def test_sharded_dense_fit_on_an_ill_conditioned_system_equals_the_single_device_fit():
+    """with the rows at hand a one-GPU fit of an ill-conditioned system takes the double-double route
+    (1e-6 against the reference's SVD to cond 1e10); the sharded paths only hold the summed Gram block.  They now see
+    the refused pivot (lsqr_fit_info.reserved == 2) and fit again from the replicated rows: cond(A) = 1e7, two and three
+    contexts against one -- parameters equal, and within 1e-6 of the oracle's SVD pseudo-inverse over the same set."""
+    from oracle import pyoracle as O
+    from tests.test_gpu_dense_cond import system, rel
+    rows, x_true = system(20_000, 16, 1e7, 77, 1e-4)
+    g = np.random.default_rng(9)
+    out = g.choice(len(rows), 4000, replace=False)
+    rows[out, 16] += g.uniform(1.0, 50.0, 4000) * g.choice([-1.0, 1.0], 4000)
+    with Context(0) as c1:
+        c1.set_model(L.DENSE, 16, 0.01).upload(rows)
+        r1 = c1.batch_fit(0xD15E, 0, 512, want_consensus=True)
+        assert r1["status"] == L.OK and r1["info"].fit.reserved == 1          # the double-double route ran
+        want = O.ls(O.cfg(O.DENSE, 16, 0.01), rows, r1["consensus"])
+        assert rel(r1["params"], want) < 1e-6
+        # the block alone: flagged, and visibly worse than the bar
+        win, _ = c1.hypothesis(int(r1["info"].best_index))
+        c1.mask(win, want_mask=False)
+        blk = c1.moments(np.zeros(3), phase=0, use_mask=True)
+        fit_blk, info_blk = c1.solve_moments(blk, np.zeros(3))
+        assert info_blk.reserved == 2
+    for world in (2, 3):
+        with MultiContext([0] * world) as m:
+            m.set_model(L.DENSE, 16, 0.01).upload(rows)
+            # (the batch is world x 512 hypotheses: not the single context's batch -- compare the fits through the
+            # oracle of each consensus set, and the flag)
+            rm = m.batch_fit(0xD15E, 0, 512, want_consensus=True)
+            assert rm["status"] == L.OK and rm["info"].fit.reserved == 1, rm["info"].fit.reserved
+            wantm = O.ls(O.cfg(O.DENSE, 16, 0.01), rows, rm["consensus"])
+            assert rel(rm["params"], wantm) < 1e-6
