@@ -68,7 +68,7 @@ F16_MFMA_PEAK_TFLOPS = 2516.6   # 1024 SIMDs x 2.4 GHz x 32768 flop / 32 cycles 
 SCAN_USEFUL = {"plane": {"l1": 15, "pk": 3}, "sphere": {"l1": 61, "pk": 4}, "line": {"l1": 35, "pk": 12},
                "us": {"pk": 21}, "phantom": {"pk": 18}}
 
-COUNTER_ROUND = "r04"       # profiles/<round>_<workload>_<rate>_scan_counters.json (tools/collect_counters.py)
+COUNTER_ROUND = "r05"       # profiles/<round>_<workload>_<rate>_scan_counters.json (tools/collect_counters.py)
 DELTA = {"plane": 0.5, "sphere": 0.5, "line": 0.5, "dense": 0.1, "us": 3.0, "phantom": 2.0}
 PROF_KEYS = ("scan", "mask", "moments", "estimate", "solve", "sample", "index")
 
@@ -94,9 +94,12 @@ def parse(argv=None):
                     help="final fit of the US workload: Levenberg-Marquardt with the reference's settings (BASELINE "
                          "config 5 as written: tolerances 1e-15, 5000 evaluations -- at 1 M frames MINPACK uses all "
                          "of them, see tests/golden/us_lm_vectors.npz) or the analytic estimate alone")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=0,
                     help="single GPU, pipelined steps: HIP streams (lanes of lsqr_batch_fit_enqueue) the batches "
-                         "alternate over; batches of different streams overlap on the device (1 = one stream)")
+                         "alternate over; batches of different streams overlap on the device (1 = one stream; 0 = the "
+                         "default: 4, and 8 host threads with a context each for the US workload's iterative fit, whose "
+                         "steps are thousands of HBM-bound LM evaluations that overlap each other's host round trips: "
+                         "r05, 70 k hypotheses/s on eight against 50 - 60 k on four)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single GPU: one blocking lsqr_batch_fit per step instead of pipelined batches")
     ap.add_argument("--no-end-to-end", action="store_true",
@@ -228,14 +231,25 @@ def profile_file(name):
 
 
 def measured_cycles():
-    """the microbenchmark's per-instruction cycles (profiles/r03_microbench.json), quoted beside the roof"""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_microbench.json")))
-        return {"v_fma_f32": d["cycles"]["v_fma_f32"], "v_pk_fma_f32": d["cycles"]["v_pk_fma_f32"],
-                "level2_mix": d["cycles"]["level2_mix"], "source": "profiles/r03_microbench.json (tools/microbench.hip, "
-                "8 waves per SIMD, nominal cycles at 2.4 GHz)"}
-    except Exception:
-        return None
+    """the microbenchmark's per-instruction cycles, quoted beside the roof: this round's run on this round's level-2 mix
+    (profiles/r05_microbench.json: tools/microbench.hip OP 21, the filter on squares), else the round-3 file"""
+    for name in ("r05_microbench.json", "r03_microbench.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return {"v_fma_f32": d["cycles"]["v_fma_f32"], "v_pk_fma_f32": d["cycles"]["v_pk_fma_f32"],
+                    "level2_mix": d["cycles"]["level2_mix"], "source": "profiles/%s (tools/microbench.hip, 8 waves per "
+                    "SIMD, nominal cycles at 2.4 GHz)" % name}
+        except Exception:
+            continue
+    return None
+
+
+def isa_counts(kernel_key):
+    """vector instructions per loop body counted from the ISA of this tree's kernels (tools/isa_counts.py ->
+    profiles/r05_isa_counts.json, stamped with the kernel source hash like the counter files), quoted beside the
+    source-derived `useful` counts"""
+    d = profile_file("r05_isa_counts.json")
+    return d["kernels"].get(kernel_key) if d else None
 
 
 def scan_roofline(R, mode, scan_ms, n_scan):
@@ -258,7 +272,11 @@ def scan_roofline(R, mode, scan_ms, n_scan):
     if prof:
         base["counters"] = {k: prof[k] for k in ("valu_issue_busy", "salu_issue_busy_per_cu", "lanes_active",
                                                 "valu_wave_instructions", "salu_wave_instructions",
-                                                "kernel_avg_ms", "collected_at", "source") if k in prof}
+                                                "mfma_wave_instructions", "mfma_pipe_busy", "mfma_pipe_busy_from_insts",
+                                                "shader_clock_ghz", "kernel_avg_ms", "collected_at", "source")
+                            if k in prof}
+        if prof.get("mfma_pipe_busy") is not None:
+            base["mfma_pipe_busy"] = prof["mfma_pipe_busy"]   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the launch
         if traffic and t > 0:
             base["hbm_frac_measured"] = traffic / t / 1e9 / HBM_PEAK_GBS
         if prof.get("valu_wave_instructions") and t > 0:
@@ -405,6 +423,7 @@ def scan_roofline(R, mode, scan_ms, n_scan):
     base.update({"bound": "valu", "achieved": ach, "peak": VALU_ISSUE_PEAK_GWIPS, "unit": "G wave-instr/s",
                  "frac": ach / VALU_ISSUE_PEAK_GWIPS, "traffic": traffic, "kernel": kname, "work_model": model,
                  "measured_cycles_per_instruction": measured_cycles(),
+                 "isa_counts": isa_counts("k_scan_pairs_%s" % w if cells else "k_scan_us_f32"),
                  "note": "achieved = USEFUL vector instructions of the launch (counted from the kernel source, work "
                          "counts measured live by lsqr_scan_workload / lsqr_scan_work) / launch time; peak = 1024 SIMDs "
                          "x 2.4 GHz / 4 cycles per wave64 instruction (measured: profiles/r03_microbench.json).  The "
@@ -550,10 +569,34 @@ class Run:
         self.lanes = []
         if self.pipelined_dist and a.streams > 1 and str(device) != "cpu":
             import torch
+            # One communicator per stream, each PROVEN by an all-reduce on its stream before anything is timed, and a
+            # budget for the lot (LSQR_RCCL_BUDGET_S, default 90 s): an 8-rank run must not spend the driver's window
+            # -- or die -- creating S x 8 communicators.  The decision is collective (MAX of the elapsed time over the
+            # ranks), so every rank keeps the same number of groups; with fewer groups than --streams the run continues
+            # on those, labelled in config.rccl.
+            budget = float(os.environ.get("LSQR_RCCL_BUDGET_S", "90"))
+            spent = 0.0
             for k in range(a.streams):
-                ck = self.ctx if k == 0 else self._new_ctx()
+                t0 = time.perf_counter()
                 gk = dist.new_group(backend="nccl")        # every rank, same order
-                self.lanes.append((ShardedRansac(ck, Comm(dist, device, group=gk)), torch.cuda.Stream()))
+                sk = torch.cuda.Stream()
+                with torch.cuda.stream(sk):
+                    probe = torch.ones(1, device=device)
+                    dist.all_reduce(probe, group=gk)
+                sk.synchronize()
+                el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)      # the world's default group: proven in bring_up_rccl
+                spent += float(el.item())
+                ck = self.ctx if k == 0 else self._new_ctx()
+                self.lanes.append((ShardedRansac(ck, Comm(dist, device, group=gk)), sk))
+                if spent > budget and k + 1 < a.streams:
+                    RCCL_INFO["fallback"] = ("%d of %d per-stream communicators after %.1f s (budget %.0f s): the run "
+                                             "continues on %d stream(s)" % (k + 1, a.streams, spent, budget, k + 1))
+                    a.streams = k + 1
+                    break
+            RCCL_INFO["stream_groups_s"] = spent
+            RCCL_INFO["communicators"] = 1 + len(self.lanes)
+            self.cur_streams = a.streams
         self.multi_stream = a.streams > 1 and (self.pipelined or self.threaded or
                                                (self.pipelined_dist and bool(self.lanes)))
         self.next_step = 0
@@ -854,6 +897,11 @@ def report(R, rates, cpu_budget, headline=True):
                                          % os.environ["LSQR_DIST_FALLBACK"] if os.environ.get("LSQR_DIST_FALLBACK")
                                          else "gloo (rehearsal)") if R.dist is not None else "none (single GPU)"),
                    "streams": a.streams if R.multi_stream else 1,
+                   # RCCL bring-up of THIS run (rank 0's clock; stream groups: MAX over the ranks): what an N-rank run pays
+                   # before its first timed step
+                   "rccl": ({"bringup_s": RCCL_INFO["bringup_s"], "stream_groups_s": RCCL_INFO["stream_groups_s"],
+                             "communicators": RCCL_INFO["communicators"], "fallback": RCCL_INFO["fallback"]}
+                            if RCCL_INFO["communicators"] else None),
                    "stream_priming_steps": 2 * a.streams if R.multi_stream else 0,
                    "repeats": max(1, a.repeats),
                    "step": step_text(R) + "; " + what_value},
@@ -890,6 +938,39 @@ def report(R, rates, cpu_budget, headline=True):
                          "profiled_steps": main_rate["prof_steps"]}
     for r in rates[1:]:
         out["kernels_ms"]["scan_" + r["mode"]] = r["scan_ms"]
+    # the kernel group a step spends most of its device time in: when that is NOT the scan (plane phantom: the 31-frame
+    # null-vector solves), the roofline block says so and names it -- `roofline.kernel` is the dominant kernel (r05)
+    km = out["kernels_ms"]
+    groups = {"estimate": km["estimate"], "scan": km["scan"], "mask": km["mask"],
+              "moments": km["moments"] * km["moments_launches_per_step"], "solve": km["reduce_and_solve_per_step"]}
+    dom = max(groups, key=groups.get)
+    out["dominant_kernel"] = {"group": dom, "ms_per_step": groups[dom], "by_group_ms": groups}
+    if dom != "scan" and out.get("roofline"):
+        rf = dict(out["roofline"])
+        out["roofline_scan"] = out["roofline"]          # the scan's own block stays in the detail file
+        names = {"estimate": {"phantom": "k_estimate_phantom<64> (31 x 31 one-sided Jacobi null vector, one wave per "
+                                         "hypothesis)", "dense": "k_estimate_dense_r64", "us": "k_estimate_us"}.get(
+                                             w, "k_estimate<%s>" % w),
+                 "moments": "LM passes (k_lm_pass* / k_lm_persist) x %d per step" % round(km["moments_launches_per_step"]),
+                 "mask": "k_mask_moments<%s>" % w, "solve": "k_reduce + k_solve<%s>" % w}
+        t = groups[dom] * 1e-3
+        if dom == "estimate" and w == "phantom":
+            # 9.5 sweeps x 15.5 rounds x 16 column pairs x (3 dot products + 2 column rotations of A and V: 31 x 14
+            # flop) per hypothesis -- a flop MODEL of the fixed-sweep Jacobi, fp64 vector arithmetic
+            flops = H * 9.5 * 15.5 * 16 * 31 * 14.0
+            ach = flops / t / 1e12
+            rf.update({"bound": "valu", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp64 vector)",
+                       "frac": ach / FP64_MFMA_PEAK_TFLOPS, "launch_ms": groups[dom], "traffic": None,
+                       "note": "the step's dominant kernel is the minimal solve, not the scan: one wave per hypothesis, "
+                               "every Jacobi round a dependent chain through LDS, two waves per SIMD (19 KB of LDS per "
+                               "hypothesis) -- latency-bound; achieved = a flop model of the sweeps / kernel time "
+                               "against the 78.6 TFLOP/s fp64 vector rate.  The scan's block: roofline_scan"})
+        else:
+            rf.update({"launch_ms": groups[dom], "note": "dominant kernel group of the step is `%s`, not the scan; the "
+                       "figures of this block are the SCAN's (see roofline_scan), launch_ms is the dominant group's" % dom})
+        rf["kernel"] = names.get(dom, dom)
+        rf["kernel_short"] = names.get(dom, dom)[:80]
+        out["roofline"] = rf
     out["index"] = {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
                     "build_ms": ms_idx / n_idx if n_idx else None,
                     "builds_in_warmup": int(main_rate["idx_warm"][0]),
@@ -986,6 +1067,8 @@ def run_legs(a0, local):
         a.batch = 1024 if w == "dense" else 4096
         a.steps, a.warmup, a.repeats = 20, 5, 1
         a.streams = a0.streams
+        if getattr(a0, "streams_auto", False) and w == "us" and fit == "iterative":
+            a.streams, a.steps, a.warmup = 8, 24, 8      # eight host threads with a context each (see --streams)
         a.no_end_to_end = True
         a.no_cpu_baseline = a0.no_cpu_baseline
         try:
@@ -1086,7 +1169,7 @@ def headline(out, detail_path):
          "config": {"workload": cfg["workload"][:140], "points": cfg["points"],
                     "hypotheses_per_gpu_per_step": cfg["hypotheses_per_gpu_per_step"], "streams": cfg.get("streams"),
                     "world_size": cfg.get("world_size"), "collectives": str(cfg.get("collectives"))[:120],
-                    "repeats": cfg.get("repeats")},
+                    "rccl": cfg.get("rccl"), "repeats": cfg.get("repeats")},
          "value_is": out.get("value_is"),
          "value_full_count": out.get("value_full_count"), "value_early_exit": out.get("value_early_exit"),
          "ms_per_step_full_count": out.get("ms_per_step_full_count"),
@@ -1231,6 +1314,9 @@ def run_multi(a):
     return 0
 
 
+RCCL_INFO = {"bringup_s": None, "communicators": 0, "stream_groups_s": None, "fallback": None}
+
+
 def bring_up_rccl(a, dist, torch, rank, world, device):
     """RCCL communicator proven (one small all-reduce) before any timing, with a COLLECTIVE verdict: every rank posts
     ok / fail to a side-channel TCPStore and all ranks act on the same tally.
@@ -1265,6 +1351,7 @@ def bring_up_rccl(a, dist, torch, rank, world, device):
             time.sleep(0.25)
     threading.Thread(target=watch, daemon=True).start()
     err = None
+    t_up = time.perf_counter()
     try:
         torch.cuda.set_device(torch.device(device))
         dist.init_process_group("nccl", store=dist.PrefixStore("nccl", store), rank=rank, world_size=world,
@@ -1291,6 +1378,8 @@ def bring_up_rccl(a, dist, torch, rank, world, device):
         sys.stderr.flush()
         os._exit(3)
     if failed == 0:
+        RCCL_INFO["bringup_s"] = time.perf_counter() - t_up    # init_process_group + the probing all-reduce, this rank
+        RCCL_INFO["communicators"] = 1
         return "nccl", device
     if failed == world and a.allow_gloo:
         # The exchanges of this path are 8 bytes and one moment block per step: they do not need RCCL to be fast.
@@ -1317,6 +1406,9 @@ def main():
         a.points = {"dense": 2_000_000, "us": 1_000_000, "phantom": 1_000_000}.get(a.workload, 10_000_000)
     if a.batch <= 0:
         a.batch = 1024 if a.workload == "dense" else 4096
+    a.streams_auto = a.streams <= 0
+    if a.streams_auto:
+        a.streams = 8 if (a.workload == "us" and a.us_fit == "iterative" and a.gpus == 1) else 4
     in_launcher_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not in_launcher_env:
         # nothing in this process has touched the GPU yet (numpy and the standard library only)

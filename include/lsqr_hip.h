@@ -368,12 +368,15 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                faster on the MI355X box -- 56 GB/s; -1 = LSQR_UPLOAD_THREADS or 0);
  * "max_iterations": stop lsqr_ransac after this many loop iterations even if the adaptive bound
  *                asks for more (0 = the reference's behaviour: up to C(N,k));
- * "lm_persist": 1 (default) = an iterative US fit (SinglePointTarget...Estimator.cxx:272-329, :926-971) is ONE launch:
- *               the workgroups stay resident, every evaluation's pass over the compacted consensus set, the sum of the
- *               block partials and the hand-over of the next trial point happen inside it (csrc/lm_persist.h), MINPACK's
- *               step runs on the host between tagged granules in pinned memory; 2 = the step runs on the device too
- *               (no host in the loop at all); 0 = two launches per evaluation (r02-r04).  Same iterates, lm_info and
- *               lm_nfev all three ways.  "lm_persist_wgs": resident workgroups (0 = the device's compute units divided
+ * "lm_persist": 1 (default) = an iterative US fit (SinglePointTarget...Estimator.cxx:272-329, :926-971) is ONE launch
+ *               when this context is the only one of the process that has been fitting on the device lately: the
+ *               workgroups stay resident, every evaluation's pass over the compacted consensus set, the sum of the block
+ *               partials and the hand-over of the next trial point happen inside it (csrc/lm_persist.h), MINPACK's step
+ *               runs on the host between tagged granules in pinned memory (measured r05: 26 against 30 us per
+ *               evaluation); with several contexts fitting at once the launch path is taken (their passes overlap each
+ *               other's host round trips: the better aggregate); 3 = the persistent kernel always; 2 = persistent with
+ *               the step on the device too (no host in the loop at all: 230 us per step on one lane -- measured, kept
+ *               for the record); 0 = two launches per evaluation (r02-r04).  Same iterates, lm_info and lm_nfev every way.  "lm_persist_wgs": resident workgroups (0 = the device's compute units divided
  *               by the contexts alive on it, at most four ways); "lm_persist_timeout_ms": bound of every wait inside
  *               the kernel (2000) -- when it expires the fit is run again on the launch path;
  * "lm_host": 1 (default) = the Levenberg-Marquardt control flow between device passes runs on the
@@ -460,7 +463,7 @@ LSQR_API int lsqr_scan_workload(lsqr_ctx *ctx, uint32_t *bound_out, uint64_t out
 LSQR_API int lsqr_scan_work(lsqr_ctx *ctx, uint64_t out[6]);
 
 /* The LAST persistent Levenberg-Marquardt fit of this context (option "lm_persist"; csrc/lm_persist.h):
- * out[0..7] = {mode (1: MINPACK's step on the host between granules in pinned memory, 2: on the device), resident
+ * out[0..7] = {mode (1 / 3: MINPACK's step on the host between granules in pinned memory, 2: on the device), resident
  * workgroups, evaluations, end state (2: finished, 3: a bounded wait expired and the launch path took over), kernel
  * time in microseconds by the device's 100 MHz clock, fits of this context that fell back to the launch path, host
  * nanoseconds spent waiting for moment blocks, host nanoseconds spent in MINPACK's step (mode 1)}.

@@ -233,8 +233,9 @@ struct lsqr_ctx {
   int opt_lm_mfma = 1;        // 1: the LM pass accumulates (J | f)^T (J | f) on the matrix cores; 0: per-lane sums
   int opt_lm_fused = 1;       // 1: one launch per LM evaluation, result polled in pinned memory; 0: r01 path
   // lm_persist.h: a whole matrix-core LM fit in one launch.  0: the launch path (two launches per evaluation);
-  // 1: persistent kernel, MINPACK's step on the host between tagged granules in pinned memory; 2: persistent kernel,
-  // the step on the device (workgroup 0).  Same iterates all three ways.
+  // 1: persistent kernel with MINPACK's step on the host between tagged granules in pinned memory WHEN this context is
+  // the only one of the process fitting on the device, the launch path otherwise; 3: the same kernel always; 2: persistent
+  // kernel with the step on the device (workgroup 0).  Same iterates every way.
   int opt_lm_persist = 1;
   int opt_lm_persist_wgs = 0;          // resident workgroups G (0: 256 / 128 / 64 by the number of contexts on the device)
   int opt_lm_persist_timeout_ms = 2000;  // bound of every wait inside the kernel
@@ -2106,6 +2107,9 @@ struct LmpPool {
   std::mutex mu;
   std::condition_variable cv;
   int cus[16] = {0}, free_[16] = {0}, live[16] = {0};  // per device: compute units, free tokens, root contexts alive
+  // contexts that started a persistent fit lately: how many ways the device is shared (a process with four contexts
+  // of which one is fitting gives that one the whole device)
+  std::vector<std::pair<const void *, double>> recent[16];
 };
 LmpPool &lmp_pool() {
   static LmpPool p;
@@ -2117,7 +2121,7 @@ void lmp_ctx_count(int device, int d) {
   std::lock_guard<std::mutex> lk(p.mu);
   p.live[device] += d;
 }
-int lmp_acquire(int device, int want_auto, int forced, int need_max) {
+int lmp_acquire(int device, const void *who, int forced, int need_max, bool only_if_alone) {
   LmpPool &p = lmp_pool();
   std::unique_lock<std::mutex> lk(p.mu);
   if (device < 0 || device >= 16) return 0;
@@ -2126,13 +2130,40 @@ int lmp_acquire(int device, int want_auto, int forced, int need_max) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cu <= 0) return 0;
     p.cus[device] = p.free_[device] = cu;
   }
-  int G = forced > 0 ? forced : want_auto;
-  if (!G) {  // the device shared evenly by the contexts that may run a fit at the same time (up to four)
-    const int share = std::max(1, std::min(4, p.live[device]));
-    G = p.cus[device] / share;
-    int pw = 1;
-    while (2 * pw <= G) pw *= 2;
-    G = pw;
+  int G = forced;
+  {  // the device shared evenly by the contexts that have been fitting in the last half second (up to eight)
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    auto &rec = p.recent[device];
+    bool mine = false;
+    int active = 0;
+    for (auto it = rec.begin(); it != rec.end();) {
+      if (it->first == who) {
+        it->second = now;
+        mine = true;
+      }
+      if (now - it->second > 0.5) {
+        it = rec.erase(it);
+        continue;
+      }
+      active++;
+      ++it;
+    }
+    if (!mine) {
+      rec.push_back({who, now});
+      active++;
+    }
+    // "lm_persist" 1 (the default): several fits in flight are served better by the launch path -- their passes overlap
+    // each other's host round trips and the aggregate is HBM-bound either way (r05: 70 k hypotheses/s on eight streams
+    // of launches against 36 - 60 k on four to eight persistent fits) --, a fit alone on the device by the persistent
+    // kernel (31 k against 26 - 27 k)
+    if (only_if_alone && active > 1) return 0;
+    if (G <= 0) {
+      const int share = std::max(1, std::min(8, active));
+      G = p.cus[device] / share;
+      int pw = 1;
+      while (2 * pw <= G) pw *= 2;
+      G = pw;
+    }
   }
   G = std::max(1, std::min({G, p.cus[device], need_max}));
   p.cv.wait(lk, [&] { return p.free_[device] >= G; });
@@ -2172,9 +2203,9 @@ int lm_persist_fit(lsqr_ctx *c, const double *tiles, size_t cnt, int nb, LmState
     memset(c->h_lmres, 0, sizeof(unsigned long long) * 256);
     c->lm_seq = 0;
   }
-  const int host_step = c->opt_lm_persist == 1;
+  const int host_step = c->opt_lm_persist != 2;
   // one round of virtual blocks when the device is ours alone (512-thread workgroups: two blocks at a time each)
-  const int G = lmp_acquire(c->device, 0, c->opt_lm_persist_wgs, (nb + 1) / 2);  // tokens held
+  const int G = lmp_acquire(c->device, c, c->opt_lm_persist_wgs, (nb + 1) / 2, c->opt_lm_persist == 1);  // tokens held
   if (G <= 0) return LSQR_OK;
   // workgroups of eight waves (two virtual blocks at a time) when the tokens cover all blocks in one round -- the pass
   // then spreads over twice the compute units --, else sixteen waves (four blocks at a time)
@@ -4765,8 +4796,8 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     c->opt_dense_fast = value != 0;
     return LSQR_OK;
   }
-  if (!strcmp(name, "lm_persist")) {  // 0: two launches per LM evaluation; 1 / 2: one persistent launch per fit, step on the host / device
-    if (value < 0 || value > 2) return LSQR_ERR_INVALID;
+  if (!strcmp(name, "lm_persist")) {  // 0: two launches per LM evaluation; 1 (alone on the device) / 3 (always): one persistent launch per fit, step on the host; 2: step on the device
+    if (value < 0 || value > 3) return LSQR_ERR_INVALID;
     c->opt_lm_persist = (int)value;
     return LSQR_OK;
   }

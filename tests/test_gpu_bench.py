@@ -135,6 +135,21 @@ def test_bench_rccl_path_with_one_engine_per_stream():
              env={"LSQR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     _check(j, 2)
     assert j["config"]["world_size"] == 1 and "RCCL" in j["config"]["collectives"]
+    # the line says what bringing RCCL up cost: the world's communicator + one per stream, each proven by an all-reduce
+    r = j["config"]["rccl"]
+    assert r["communicators"] == 3 and r["bringup_s"] > 0 and r["stream_groups_s"] > 0 and r["fallback"] is None
+    print("RCCL bring-up at world 1: world group %.2f s, two stream groups %.2f s" % (r["bringup_s"], r["stream_groups_s"]))
+
+
+def test_bench_rccl_stream_groups_stop_at_their_budget():
+    """a budget of zero seconds: the first per-stream communicator is kept, the others are not created, the run goes on
+    with one stream and says so -- what keeps an 8-rank run inside the driver's window if communicator creation is slow"""
+    j = _run(["--workload", "plane", "--streams", "4"],
+             env={"LSQR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                  "LSQR_RCCL_BUDGET_S": "0"})
+    r = j["config"]["rccl"]
+    assert r["communicators"] == 2 and "1 of 4" in r["fallback"] and j["config"]["streams"] == 1
+    assert j["value"] > 0
 
 
 def test_bench_gpus_2_launches_its_own_ranks():

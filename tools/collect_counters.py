@@ -113,6 +113,16 @@ def main():
             out["salu_issue_busy_per_cu"] = c["SQ_INSTS_SALU"] / 256.0 / cyc
         if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_INSTS_VALU"):
             out["lanes_active"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
+        # matrix pipe (r05): busy cycles the SQ counted / SIMD-cycles of the launch, and the same from the instruction
+        # count (32 cycles per v_mfma_f32_32x32x16_f16 / v_mfma_f64_16x16x4) -- both in shader-clock cycles, so neither
+        # depends on an assumed clock; the clock the launch ran at follows from cycles and the kernel's duration
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            out["mfma_pipe_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+        if c.get("SQ_INSTS_MFMA"):
+            out["mfma_wave_instructions"] = c["SQ_INSTS_MFMA"]
+            out["mfma_pipe_busy_from_insts"] = c["SQ_INSTS_MFMA"] * 32.0 / (cyc * 1024.0)
+        if avg_ns:
+            out["shader_clock_ghz"] = cyc / avg_ns
     if "FETCH_SIZE" in c:
         rd = c["FETCH_SIZE"] * 1024 * 2             # gfx950: FETCH_SIZE under-reports wide streaming reads by 2
         wr = c.get("WRITE_SIZE", 0.0) * 1024
@@ -120,7 +130,7 @@ def main():
         out["hbm_write_bytes"] = wr
         out["hbm_bytes_per_launch"] = rd + wr
         out["hbm_note"] = "FETCH_SIZE_KB*1024*2 (gfx950 correction) + WRITE_SIZE_KB*1024, separate passes"
-    path = os.path.join(out_dir, "%s_%s_%s_scan_counters.json" % (os.environ.get("LSQR_ROUND", "r04"), w, mode))
+    path = os.path.join(out_dir, "%s_%s_%s_scan_counters.json" % (os.environ.get("LSQR_ROUND", "r05"), w, mode))
     json.dump(out, open(path, "w"), indent=1)
     print(path)
     subprocess.run(["rm", "-rf", scratch])

@@ -9,12 +9,13 @@
 # own bench line (<tag>_<w>_<rate>_bench_under_rocprof.json); (3) the plain bench line of the workload (with the CPU
 # leg; the headline plane line is the default run, other_configs included).
 tag=${1:-rXX}
+export LSQR_ROUND=$tag
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
 for w in ${WORKLOADS:-plane sphere line dense us}; do
   for rate in ${RATES:-full_count early_exit}; do
     short=full; [ $rate = early_exit ] && short=early
-    timeout -k 10 500 python3 tools/collect_counters.py $w gpurun_out/$tag $rate > gpurun_out/$tag/counters_${w}_$rate.log 2>&1 && cp gpurun_out/$tag/r04_${w}_${rate}_scan_counters.json profiles/
+    timeout -k 10 500 python3 tools/collect_counters.py $w gpurun_out/$tag $rate > gpurun_out/$tag/counters_${w}_$rate.log 2>&1 && cp gpurun_out/$tag/${tag}_${w}_${rate}_scan_counters.json profiles/
     echo "counters $w $rate done"
     extra=""; [ $w = us ] && extra="--us-fit analytic"
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof_${w}_$rate -- python3 bench.py --workload $w $extra --steps 5 --warmup 1 --repeats 1 --streams 1 --rates $short --no-cpu-baseline --no-end-to-end --no-other-configs --detail gpurun_out/$tag/${tag}_${w}_${rate}_bench_under_rocprof_detail.json > gpurun_out/$tag/${tag}_${w}_${rate}_bench_under_rocprof.json 2> gpurun_out/$tag/prof_${w}_$rate.err || exit 1

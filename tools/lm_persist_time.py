@@ -65,7 +65,7 @@ def main():
             r["kernel"] = info(ctxs[0])
         res["runs"].append(r)
         print(json.dumps(r), file=sys.stderr, flush=True)
-    for nfl, mode, wgs in ((2, 0, 0), (4, 0, 0), (4, 1, 64), (4, 1, 256)):
+    for nfl, mode, wgs in ((2, 0, 0), (4, 0, 0), (4, 3, 64), (4, 3, 256)):
         out = [None] * nfl
 
         def work(k):

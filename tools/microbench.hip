@@ -72,6 +72,18 @@ __global__ __launch_bounds__(256) void bench(double *out, double a, double b, fl
                    : "=s"(b0), "=s"(b1), "=s"(b2), "=s"(b3), "=&v"(t0), "=&v"(t1), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(f0), "+v"(f1)
                    : "s"(b), "s"(fa), "v"(dm));
       cnt += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3) + (dm & 1); }
+    if (OP == 21) {  // r04 / r05 level-2 body (filter on squares, cells.h: cells_filter_squares) per TWO packed pairs of
+      // observations: 6 v_pk_fma_f32 (measure) + 2 v_pk_fma_f32 (d = v v - a), 4 v_cmp_lt_f32 of the halves into SGPR
+      // pairs (inlier ballots), 2 v_min3_u32 (band minimum over the bit patterns of d): 14 vector instructions
+      unsigned long long b0, b1, b2, b3; unsigned dm = 0xFFFFFFFFu;
+      asm volatile("v_pk_fma_f32 %4, %5, %10, %4\n v_pk_fma_f32 %4, %6, %10, %4\n v_pk_fma_f32 %4, %7, %10, %4\n"
+                   "v_pk_fma_f32 %5, %4, %10, %5\n v_pk_fma_f32 %5, %6, %10, %5\n v_pk_fma_f32 %5, %7, %10, %5\n"
+                   "v_pk_fma_f32 %6, %4, %4, %6\n v_pk_fma_f32 %7, %5, %5, %7\n"
+                   "v_cmp_lt_f32 %0, %8, %11\n v_cmp_lt_f32 %1, %9, %11\n v_cmp_gt_f32 %2, %8, %11\n v_cmp_gt_f32 %3, %9, %11\n"
+                   "v_min3_u32 %12, %12, %8, %9\n v_min3_u32 %12, %12, %9, %8"
+                   : "=s"(b0), "=s"(b1), "=s"(b2), "=s"(b3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(f0), "+v"(f1)
+                   : "s"(b), "s"(fa), "v"(dm));
+      cnt += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3) + (dm & 1); }
     if (OP == 20) { unsigned r0, r1, r2, r3;   // v_readlane_b32 x 4 + v_writelane_b32 x 4 (the hypothesis broadcast / vote scatter)
       asm volatile("v_readlane_b32 %0, %4, 3\n v_readlane_b32 %1, %5, 7\n v_readlane_b32 %2, %6, 11\n v_readlane_b32 %3, %7, 13\n s_nop 3\n"
                    "v_writelane_b32 %4, %0, 5\n v_writelane_b32 %5, %1, 9\n v_writelane_b32 %6, %2, 17\n v_writelane_b32 %7, %3, 21"
@@ -112,7 +124,7 @@ int main(int argc, char **argv) {
     run<7>("v_cmp_lt_f64", 64, d, b); run<8>("v_cmp_lt_f32", 64, d, b);
     run<10>("cmp64vcc+bcnt", 64, d, b); run<11>("cmp32vcc+bcnt", 64, d, b); run<12>("addco+addc x8", 128, d, b);
     run<13>("2cmp+8add f64", 80, d, b);
-    run<17>("v_min3_f32_abs", 64, d, b); run<18>("v_min_u32", 64, d, b); run<19>("level2_mix_20", 64, d, b, 20); run<20>("readlane4+writelane4", 64, d, b, 8);
+    run<17>("v_min3_f32_abs", 64, d, b); run<18>("v_min_u32", 64, d, b); run<19>("level2_mix_20", 64, d, b, 20); run<21>("level2_squares_14", 64, d, b, 14); run<20>("readlane4+writelane4", 64, d, b, 8);
     run<16>("mfma_f64_16x16x4", 64, d, b);
     run<14>("dep mul->add", 128, d, b); run<15>("2 chains", 128, d, b);
     printf("\n");
