@@ -127,6 +127,9 @@ struct lsqr_ctx {
   int opt_us_h16 = 1;  // US calibrations: 1 = agree() scan on the fp16 matrix cores (us_h16.h), 0 = packed fp32 filter
   int opt_dense_fast = 1;  // minimal solves: elimination first, SVD when near the rank decision
   int opt_us_fast = 1;     // US calibrations' minimal solves likewise (k_estimate_us)
+  uint8_t *d_refused = nullptr;  // k_estimate_phantom_lu: hypotheses left to the Jacobi kernel
+  size_t refused_cap = 0;
+  int opt_phantom_fast = 1;  // plane phantom's minimal solves: LU + inverse iteration first (> 1: its iteration limit), Jacobi SVD for what it refuses; 0: Jacobi only
   int opt_lm_tiles = 1;      // matrix-core LM pass: compacted consensus set in field-major tiles, next tile in flight
   int opt_us_mask_mfma = 1;  // US calibrations: mask + analytic moment block on the fp64 matrix cores (kernels.h)
   int opt_refine = 1;      // index build: k-d refinement of the Morton order inside runs of 8192 records (cells.h)
@@ -498,12 +501,41 @@ int run_estimate(lsqr_ctx *c) {
     if constexpr (requires { M::IS_PHANTOM; }) {
       // one wave per hypothesis (measured 1.76 ms per 4096 against 1.96 / 2.53 ms with 128 / 256 threads:
       // the sweeps are bound by instruction issue, and a single-wave workgroup lands on any SIMD)
-      if (c->opt_block == 256)
+      if (c->opt_phantom_fast) {
+        // r05: LU + inverse iteration (phantom.h: k_estimate_phantom_lu), the Jacobi SVD for what it refuses
+        int st = ensure(c, &c->d_refused, &c->refused_cap, std::max<size_t>(c->H, 1));
+        if (st != LSQR_OK) return st;
+        uint8_t *d_ref = c->d_refused;
+        static const bool dbg_on = getenv("LSQR_PHANTOM_DEBUG") != nullptr;
+        unsigned long long *d_dbg = nullptr;
+        if (dbg_on) (void)hipMalloc((void **)&d_dbg, sizeof(unsigned long long) * 4 * c->H);
+        hipLaunchKernelGGL(k_estimate_phantom_lu, dim3((unsigned)((c->H + 3) / 4)), dim3(256), 0, c->stream, c->d_data,
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, d_ref,
+                           c->opt_phantom_fast > 1 ? c->opt_phantom_fast : 96, d_dbg);
+        if (d_dbg) {  // diagnostics (LSQR_PHANTOM_DEBUG): iterations and 10-ns ticks per phase and hypothesis
+          std::vector<unsigned long long> hd(4 * c->H);
+          (void)hipStreamSynchronize(c->stream);
+          (void)hipMemcpy(hd.data(), d_dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+          (void)hipFree(d_dbg);
+          double sit = 0, slu = 0, sitr = 0, sfin = 0, mit = 0, mitr = 0;
+          size_t nref = 0, nconv = 0;
+          for (size_t h = 0; h < c->H; h++) {
+            const double it = (double)(hd[4 * h] & 0xFFFFFFFFu);
+            sit += it, slu += (double)hd[4 * h + 1], sitr += (double)hd[4 * h + 2], sfin += (double)hd[4 * h + 3];
+            mit = std::max(mit, it), mitr = std::max(mitr, (double)hd[4 * h + 2]);
+            nref += (hd[4 * h] >> 32) & 1, nconv += (hd[4 * h] >> 33) & 1;
+          }
+          fprintf(stderr, "phantom_lu: H %zu mean it %.1f max %.0f refused %zu converged %zu; mean us: setup+LU %.1f iter %.1f (max %.1f) finish %.1f\n",
+                  c->H, sit / c->H, mit, nref, nconv, slu / c->H / 100, sitr / c->H / 100, mitr / 100, sfin / c->H / 100);
+        }
+        hipLaunchKernelGGL(k_estimate_phantom<64>, dim3((unsigned)c->H), dim3(64), 0, c->stream, c->d_data,
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, (const uint8_t *)d_ref);
+      } else if (c->opt_block == 256)
         hipLaunchKernelGGL(k_estimate_phantom<256>, dim3((unsigned)c->H), dim3(256), 0, c->stream, c->d_data,
-                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid);
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, (const uint8_t *)nullptr);
       else
         hipLaunchKernelGGL(k_estimate_phantom<64>, dim3((unsigned)c->H), dim3(64), 0, c->stream, c->d_data,
-                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid);
+                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, (const uint8_t *)nullptr);
       hipLaunchKernelGGL((k_prepare_f32_us<M>), dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0,
                          c->stream, c->d_hparams, (uint32_t)c->H, c->mc, c->d_hparams_f32);
     } else if constexpr (M::IS_DENSE) {
@@ -2115,11 +2147,15 @@ LmpPool &lmp_pool() {
   static LmpPool p;
   return p;
 }
-void lmp_ctx_count(int device, int d) {
+void lmp_ctx_count(int device, int d, const void *who = nullptr) {
   if (device < 0 || device >= 16) return;
   LmpPool &p = lmp_pool();
   std::lock_guard<std::mutex> lk(p.mu);
   p.live[device] += d;
+  if (who) {  // a context that is gone is not fitting any more
+    auto &rec = p.recent[device];
+    for (auto it = rec.begin(); it != rec.end();) it = it->first == who ? rec.erase(it) : it + 1;
+  }
 }
 int lmp_acquire(int device, const void *who, int forced, int need_max, bool only_if_alone) {
   LmpPool &p = lmp_pool();
@@ -2822,7 +2858,7 @@ int lsqr_ctx_create(int device, lsqr_ctx **out) {
 void lsqr_ctx_destroy(lsqr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->counted) lmp_ctx_count(c->device, -1);
+  lmp_ctx_count(c->device, c->counted ? -1 : 0, c);
   for (int i = 1; i < lsqr_ctx::kMaxLanes; i++)
     if (c->lanes[i]) {
       lsqr_ctx_destroy(c->lanes[i]);
@@ -2830,7 +2866,7 @@ void lsqr_ctx_destroy(lsqr_ctx *c) {
     }
   (void)hipStreamSynchronize(c->stream);
   free_index(c);
-  void *bufs[] = {c->d_us16, c->d_us16_x, c->d_h16, c->d_h16_bs, c->d_h16_thr, c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
+  void *bufs[] = {c->d_refused, c->d_us16, c->d_us16_x, c->d_h16, c->d_h16_bs, c->d_h16_thr, c->d_ddpart, c->d_ub2, c->d_axis, c->d_cellT, c->d_vpart, c->d_paircnt, c->d_paircost, c->d_sel, c->d_bsel, c->d_hparams2, c->d_hparams2_f32, c->d_votes2, c->d_lmrec, c->d_idx_scratch, c->d_ub, c->d_queues, c->d_data_owned, c->d_subsets, c->d_hparams, c->d_hparams_f32, c->d_amb, c->d_valid, c->d_votes, c->d_mask, c->d_rows,
                   c->d_partials, c->d_mom, c->d_vec, c->d_par, c->d_best, c->d_lm, c->d_out, c->d_counter};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -4804,6 +4840,10 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
   if (!strcmp(name, "lm_persist_wgs")) {  // resident workgroups of the persistent fit (0: by the contexts on the device)
     if (value < 0 || value > 1024) return LSQR_ERR_INVALID;
     c->opt_lm_persist_wgs = (int)value;
+    return LSQR_OK;
+  }
+  if (!strcmp(name, "phantom_fast_solve")) {  // 1 (default): null vectors by LU + inverse iteration, Jacobi SVD as the fallback; 0: Jacobi only; n > 1: iteration limit
+    c->opt_phantom_fast = (int)std::max<long long>(0, value);
     return LSQR_OK;
   }
   if (!strcmp(name, "scan_test_overflow")) {  // tests: the deferred worklist check of lsqr_batch_fit_wait fires

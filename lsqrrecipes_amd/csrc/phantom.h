@@ -258,13 +258,15 @@ __global__ __launch_bounds__(T) void k_estimate_phantom(const double *__restrict
                                                           size_t nobs,
                                                           const uint32_t *__restrict__ subsets,
                                                           uint32_t H, double *__restrict__ hparams,
-                                                          uint8_t *__restrict__ valid) {
+                                                          uint8_t *__restrict__ valid,
+                                                          const uint8_t *__restrict__ only = nullptr) {
   typedef PhantomModel M;
   constexpr int N = 31, LDA = 31;
   __shared__ double A[N * LDA], V[N * LDA], recs[N][M::ND], x[N];
   __shared__ int s_bad, s_npos;
   const int tid = threadIdx.x;
   const uint32_t h = blockIdx.x;
+  if (only && !only[h]) return;  // (behind k_estimate_phantom_lu: only what the fast path refused)
   if (tid == 0) s_bad = 0;
   __syncthreads();
   for (int idx = tid; idx < N * M::ND; idx += T) {
@@ -292,6 +294,215 @@ __global__ __launch_bounds__(T) void k_estimate_phantom(const double *__restrict
     const double qnan = __builtin_nan("");
     for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = ok ? par[j] : qnan;
     valid[h] = ok ? 1 : 0;
+  }
+}
+
+// K1, fast path (r05): the null vector by LU + inverse iteration, one wave per hypothesis, four per workgroup.
+//
+// k_estimate_phantom above takes the right singular vector of the smallest singular value of the 31 x 31 system from a
+// one-sided Jacobi SVD: ~295 rounds of a dependent chain through LDS per hypothesis, 1.57 ms per 4096 -- half of a
+// plane-phantom step.  Only ONE singular vector is wanted, and on the bench's frames sigma_31 / sigma_30 is
+// 0.2 in the median, 0.6 at the 90th percentile (all-inlier subsets: 1e-5), so inverse iteration on A^T A converges
+// by (sigma_31 / sigma_30)^2 per step: 6 steps in the median, ~20 at the 90th percentile.  A^T A is never formed
+// (sigma_1 / sigma_30 reaches 6e5: its square would cost the vector ten digits): with P A = L U,
+//     (A^T A)^-1 v = U^-1 L^-1 L^-T U^-T v                 (the permutation cancels)
+// four triangular solves per step.  Lane k holds row k of the factors (pivot order) AND column k (a transposed copy,
+// through LDS once): every solve is 31 steps of {broadcast one lane's value with v_readlane, one fma on the lanes
+// behind it}, nothing but registers.  The elimination is wave_gepp_solve_reg64's (rows keep their lanes, positions are
+// exchanged).  A pivot below 1e-14 max|A| (an exactly dependent subset: the reference's "rank < 31"), a non-finite
+// entry or a system that has not converged to 1e-9 after `max_iter` steps is marked in `refused` and goes through the
+// Jacobi kernel behind this one, which then returns at once for everything else.  The vector is the same vector --
+// 1e-9 against the SVD's on the bench's subsets (tests/test_gpu_phantom_estimate.py: against the oracle's SVD at 1e-6,
+// and the Jacobi kernel's); votes are counted on the device's own models either way.
+__global__ __launch_bounds__(256) void k_estimate_phantom_lu(const double *__restrict__ data, size_t stride, size_t nobs,
+                                                             const uint32_t *__restrict__ subsets, uint32_t H,
+                                                             double *__restrict__ hparams, uint8_t *__restrict__ valid,
+                                                             uint8_t *__restrict__ refused, int max_iter,
+                                                             unsigned long long *__restrict__ dbg = nullptr) {
+  typedef PhantomModel M;
+  constexpr int N = 31, PT = 33;
+  const unsigned long long tdbg0 = wall_clock64();  // odd pitch: the transposition's column reads hit distinct banks
+  __shared__ double s_t[4][N * PT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t h = blockIdx.x * 4 + wave;
+  if (h >= H) return;  // (whole waves: no workgroup barrier below)
+  double *T = s_t[wave];
+  const bool row = lane < N;
+  bool bad = false;
+  double a[N];
+  {
+    size_t i = row ? subsets[(size_t)h * N + lane] : 0;
+    if (i >= nobs) {
+      bad = true;
+      i = 0;
+    }
+    double rec[M::ND];
+#pragma unroll
+    for (int c = 0; c < M::ND; c++) rec[c] = (c == 12) ? 0.0 : data[i * stride + c];
+#pragma unroll
+    for (int c = 0; c < N; c++) a[c] = row ? M::row_entry(rec, c) : 0.0;
+  }
+  bad = __ballot(bad && row) != 0;
+  double am = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c++) {
+    const double v = fabs(a[c]);
+    am = v > am ? v : (v == v ? am : INFINITY);
+  }
+  am = wave_max(am);
+  const double tiny = 1e-14 * am;
+  bool refuse = !(am <= 1e150) || !(am > 0.0);
+  // ---- P A = L U, rows on their lanes, positions exchanged (wave_linalg.h: wave_gepp_solve_reg64) --------------------
+  int pos = row ? lane : 64 + lane;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double v = (row && pos >= k) ? fabs(a[k]) : -1.0;
+    int idx = pos;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o);
+      const int oi = __shfl_xor(idx, o);
+      if (ov > v || (ov == v && oi < idx)) v = ov, idx = oi;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(idx);
+    refuse = refuse || !(v > tiny);
+    const int lp = __builtin_ctzll(__ballot(pos == p) | (1ull << 63));
+    const double rpiv = 1.0 / wave_readlane_f64(a[k], lp);
+    if (p != k) pos = pos == p ? k : pos == k ? p : pos;
+    const bool below = row && pos > k;
+    double mult = 0.0;
+    if (below) {
+      mult = a[k] * rpiv;
+      a[k] = mult;
+    }
+#pragma unroll
+    for (int j = k + 1; j < N; j++) {
+      const double akj = wave_readlane_f64(a[j], lp);
+      if (below) a[j] = fma(-mult, akj, a[j]);
+      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // rows into pivot order (lane k <- the row at position k), then the transposed copy through LDS
+  {
+    int src = lane;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const int lk = __builtin_ctzll(__ballot(pos == k) | (1ull << 63));
+      if (lane == k) src = lk;
+    }
+#pragma unroll
+    for (int c = 0; c < N; c++) a[c] = __shfl(a[c], src);
+  }
+  double t[N];
+  if (row) {
+#pragma unroll
+    for (int c = 0; c < N; c++) T[lane * PT + c] = a[c];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < N; c++) t[c] = row ? T[c * PT + lane] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  // 1 / U_kk on lane k
+  double dk = 1.0;
+#pragma unroll
+  for (int c = 0; c < N; c++)
+    if (lane == c) dk = a[c];
+  const double rd = 1.0 / dk;
+  // ---- inverse iteration --------------------------------------------------------------------------------------------
+  const unsigned long long tdbg1 = wall_clock64();
+  double r = row ? 1.0 / sqrt((double)N) * (1.0 + 0.01 * lane) : 0.0;  // start: no symmetry the null vector could be orthogonal to
+  bool conv = false;
+  int it = 0, since = 0;
+  double pp = r;
+  if (!refuse) {
+    for (; it < max_iter; it++) {
+      const double prev = r;
+      // U^T s = v      (forward; U_ji on lane i is t[j])
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        const double sj = wave_readlane_f64(r * rd, j);
+        r = lane == j ? sj : (lane > j ? fma(-t[j], sj, r) : r);
+      }
+      // L^T u = s      (backward, unit diagonal; L_ji on lane i is t[j])
+#pragma unroll
+      for (int j = N - 1; j > 0; j--) {
+        const double uj = wave_readlane_f64(r, j);
+        r = lane < j ? fma(-t[j], uj, r) : r;
+      }
+      // L c = u        (forward; L_ij on lane i is a[j])
+#pragma unroll
+      for (int j = 0; j < N - 1; j++) {
+        const double cj = wave_readlane_f64(r, j);
+        r = (row && lane > j) ? fma(-a[j], cj, r) : r;
+      }
+      // U v' = c       (backward; U_ij on lane i is a[j])
+#pragma unroll
+      for (int j = N - 1; j >= 0; j--) {
+        const double vj = wave_readlane_f64(r * rd, j);
+        r = lane == j ? vj : (lane < j ? fma(-a[j], vj, r) : r);
+      }
+      // unit length; (A^T A)^-1 is positive definite, so consecutive iterates do not flip their sign
+      double n2 = row ? r * r : 0.0;
+      for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+      r = row ? r / sqrt(n2) : 0.0;
+      double d = fabs(r - prev);
+      d = wave_max(d);
+      if (!(n2 > 0.0) || !(n2 < INFINITY)) break;  // overflow / breakdown: the Jacobi kernel decides
+      // the iterate settles at eps sigma_1 / sigma_30 (6e-11 on the bench's subsets: a tighter test never fires and the
+      // wave runs to the limit -- 0.7 ms, measured); 1e-9 here leaves r / (1 - r) 1e-9 < 1e-7 of the neighbour's direction
+      if (d < 1e-9 && it >= 1) {
+        conv = true;
+        break;
+      }
+      // Aitken's extrapolation of the vector sequence: with sigma_31 / sigma_30 near one the error is one mode decaying
+      // by rho = (sigma_31 / sigma_30)^2 per step; three clean iterates give rho and the limit x + rho / (1 - rho) dx.
+      // On the bench's subsets: plain iteration 99 % within 61 steps, 15 of 3000 beyond 80, the slowest beyond 300;
+      // with the extrapolation 99 % within 20, the slowest 79 (one wave at the limit used to BE the kernel's time).
+      if (++since >= 3) {
+        const double d1 = prev - pp, d2 = r - prev;
+        double den = row ? d1 * d1 : 0.0, num = row ? d2 * d1 : 0.0;
+        for (int o = 32; o > 0; o >>= 1) {
+          den += __shfl_xor(den, o);
+          num += __shfl_xor(num, o);
+        }
+        const double rho = num / den;
+        if (den > 0.0 && rho > 0.3 && rho < 0.999) {
+          r = fma(rho / (1.0 - rho), d2, r);
+          double m2 = row ? r * r : 0.0;
+          for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+          r = row ? r / sqrt(m2) : 0.0;
+          since = 0;
+        }
+      }
+      pp = prev;
+    }
+  }
+  const bool ok_vec = !refuse && conv;
+  const unsigned long long tdbg2 = wall_clock64();
+  if (dbg && lane == 0) {
+    dbg[(size_t)h * 4 + 0] = (unsigned long long)it | ((unsigned long long)(refuse ? 1 : 0) << 32) | ((unsigned long long)(conv ? 1 : 0) << 33);
+    dbg[(size_t)h * 4 + 1] = tdbg1 - tdbg0;
+    dbg[(size_t)h * 4 + 2] = tdbg2 - tdbg1;
+  }
+  if (!ok_vec) {  // the Jacobi kernel behind this one takes the hypothesis
+    if (lane == 0) refused[h] = bad ? 0 : 1;
+    if (bad && lane == 0) {
+      const double qnan = __builtin_nan("");
+      for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = qnan;
+      valid[h] = 0;
+    }
+    return;
+  }
+  if (row) T[lane] = r;
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    double x[N], par[M::P];
+    for (int j = 0; j < N; j++) x[j] = T[j];
+    const bool ok = !bad && M::finish(x, par);
+    const double qnan = __builtin_nan("");
+    for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = ok ? par[j] : qnan;
+    valid[h] = ok ? 1 : 0;
+    refused[h] = 0;
+    if (dbg) dbg[(size_t)h * 4 + 3] = wall_clock64() - tdbg2;
   }
 }
 

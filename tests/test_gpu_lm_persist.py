@@ -49,7 +49,7 @@ def test_three_drivers_one_minimisation(kind):
             model = L.US_POINTER
         with Context(0) as ctx:
             ref = _fit(ctx, model, data, 0)
-            for mode in (1, 2):
+            for mode in (3, 2):          # 3: the persistent kernel with the host's step, always; 2: with the device's step
                 for wgs in (0, 64, 7, 1):
                     got = _fit(ctx, model, data, mode, wgs)
                     inf = _info(ctx)
@@ -58,6 +58,10 @@ def test_three_drivers_one_minimisation(kind):
                     assert np.array_equal(got[1], ref[1]), (m, mode, wgs)
                     assert np.array_equal(got[0], ref[0]) and got[4] == ref[4], (m, mode, wgs)
             assert _info(ctx)["fallbacks"] == 0
+            # the default (1): this context is the only one fitting on the device -> the persistent kernel
+            got = _fit(ctx, model, data, 1)
+            assert np.array_equal(got[1], ref[1]) and got[2:4] == ref[2:4]
+            assert _info(ctx)["mode"] == 1 and _info(ctx)["status"] == 2
 
 
 def test_persistent_fit_through_the_mask():
@@ -68,7 +72,7 @@ def test_persistent_fit_through_the_mask():
     mask = lab.astype(np.uint8)
     with Context(0) as ctx:
         ref = _fit(ctx, L.US_SINGLE, data, 0, use_mask=mask)
-        for mode in (1, 2):
+        for mode in (3, 2):
             got = _fit(ctx, L.US_SINGLE, data, mode, use_mask=mask)
             assert got[2:4] == ref[2:4] and np.array_equal(got[1], ref[1])
     assert np.allclose(ref[1][:3], truth[:3], atol=0.5) and np.allclose(ref[1][9:11], truth[9:11], atol=2e-3)
@@ -78,14 +82,14 @@ def test_a_wait_that_expires_falls_back_to_the_launch_path():
     data = synth.us_single_fast(40_000, 0.0, seed=41)[0]
     with Context(0) as ctx:
         ref = _fit(ctx, L.US_SINGLE, data, 0)
-        for mode in (1, 2):
+        for mode in (3, 2):
             before = _info(ctx)["fallbacks"]
             got = _fit(ctx, L.US_SINGLE, data, mode, lm_persist_test_abort=17)
             inf = _info(ctx)
             assert inf["status"] == 3 and inf["fallbacks"] == before + 1 and inf["evals"] == 17
             assert got[2:4] == ref[2:4] and np.array_equal(got[1], ref[1])
         ctx.set_option("lm_persist_test_abort", 0)
-        got = _fit(ctx, L.US_SINGLE, data, 1)
+        got = _fit(ctx, L.US_SINGLE, data, 3)
         assert _info(ctx)["status"] == 2 and np.array_equal(got[1], ref[1])
 
 
@@ -130,7 +134,7 @@ def test_lsqr_sincos_is_the_hosts_on_the_device():
     host's to the bit -- the parameters 11..19 of the two persistent modes"""
     data = synth.us_single_fast(5_000, 0.0, seed=61)[0]
     with Context(0) as ctx:
-        a = _fit(ctx, L.US_SINGLE, data, 1)
+        a = _fit(ctx, L.US_SINGLE, data, 3)
         b = _fit(ctx, L.US_SINGLE, data, 2)
         assert np.array_equal(a[1], b[1])
         if len(a[0]):
