@@ -28,7 +28,6 @@
 #include "us_h16.h"
 #include "phantom_h16.h"
 #include "cells.h"
-#include "cells_h16.h"
 #include "earlyexit.h"
 #include "axis.h"
 #include "sort.h"
@@ -138,8 +137,6 @@ struct lsqr_ctx {
                            // 1 / 2 = in the wave's LDS area, four / two systems per workgroup, 0 = one workgroup per system
   int opt_dense_dd = 1;    // dense fit: systems the elimination refuses are solved again from the rows in double-double
   double *d_ddpart = nullptr;  // partial double-double Gram blocks of k_gram_dd_dense (allocated on first use)
-  int opt_pairs_mfma = 0;  // plane, 3-D, 512-record cells: 1 / 2 = level 2 of k_scan_pairs on the fp16 matrix cores with two /
-                           // three waves per SIMD (cells_h16.h: exact, measured 25 % SLOWER than the packed fp32 level 2 -- off)
   int opt_index = 1, opt_cpt = 0, opt_cell = 0, opt_block = 0, opt_hsplit = 0, opt_pairs = 0, opt_pairs_waves = 0;  // 0 off, 1 auto, 2 always; cells per wave tile, cell size
   uint8_t *d_valid = nullptr;
   uint32_t *d_votes = nullptr;
@@ -1018,35 +1015,6 @@ int run_scan_pairs(lsqr_ctx *c, const ScanBatch &b0) {
     HIPCHK(c, hipGetLastError());
     return LSQR_OK;
   };
-  if constexpr (std::is_same_v<CM, PlaneCell<3>> && PP == 4) {
-    if (c->opt_pairs_mfma) {  // survivors compacted into tiles of 32, one matrix instruction per 32 x 32 values
-      const PairsH16Consts kc = pairs_h16_consts(c->mc);
-      const size_t lds16 = (size_t)((Hc + 3) & ~3u) * sizeof(uint32_t) + (size_t)wpb * 88 * 16 + (size_t)BS * kPairsQueue * 8;
-      auto launch16 = [&](auto kern) -> int {
-        int per_cu = (int)std::min<size_t>(32 / wpb, (160 * 1024) / std::max<size_t>(lds16, 1)), occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, BS, lds16) == hipSuccess && occ >= 1)
-          per_cu = std::min(per_cu, occ);
-        else
-          (void)hipGetLastError();
-        if (per_cu < 1) per_cu = 1;
-        if (c->opt_pairs_waves > 0) per_cu = std::min(per_cu, c->opt_pairs_waves);
-        const unsigned blocks = (unsigned)std::min<size_t>(((size_t)c->n_cells + wpb - 1) / wpb, (size_t)256 * per_cu);
-        int st2 = ensure(c, &c->d_vpart, &c->vpart_cap, (size_t)blocks * Hc);
-        if (st2 != LSQR_OK) return st2;
-        ProfScope ps(c, KID_SCAN);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(BS), lds16, c->stream, c->d_sorted, c->n_sorted,
-                           c->d_boxes, c->n_cells, b.sp, rows, b.spf, Hc, c->mc, cc, kc, c->d_vpart, Hc, b.h_dev,
-                           (const uint8_t *)c->d_paircnt, gstride, (const uint32_t *)d_cost, (const uint32_t *)d_csum,
-                           nchunks, b.h_off);
-        HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(k_votes_reduce, dim3((Hc + 63) / 64, 48), dim3(256), 0, c->stream,
-                           (const uint32_t *)c->d_vpart, Hc, (uint32_t)blocks, Hc, b.h_dev, b.votes, b.h_off);
-        HIPCHK(c, hipGetLastError());
-        return LSQR_OK;
-      };
-      return c->opt_pairs_mfma == 2 ? launch16(k_scan_pairs_h16<BS, 3>) : launch16(k_scan_pairs_h16<BS, 2>);
-    }
-  }
   return ldsb ? launch(k_scan_pairs<CM, PP, BS, true>) : launch(k_scan_pairs<CM, PP, BS, false>);
 }
 
@@ -4779,9 +4747,9 @@ static int set_option_one(lsqr_ctx *c, const char *name, int value) {
     c->opt_us_h16 = value != 0;
     return LSQR_OK;
   }
-  if (!strcmp(name, "scan_pairs_mfma")) {  // 0 (default) / 1 / 2: level 2 of the plane's counted scan on the fp16 matrix cores
-    c->opt_pairs_mfma = value < 0 ? 0 : value > 2 ? 2 : value;  // (2: three waves per SIMD)
-    return LSQR_OK;
+  if (!strcmp(name, "scan_pairs_mfma")) {  // r04's level 2 of the plane on the fp16 matrix cores: exact, measured 25 % slower;
+    // out of the product since r05 (the kernel is kept under tools/attic/cells_h16.h)
+    return value == 0 ? LSQR_OK : fail(c, LSQR_ERR_INVALID, "scan_pairs_mfma: removed (measured slower; tools/attic/cells_h16.h)");
   }
   if (!strcmp(name, "scan_pairs_waves")) {  // workgroups per CU of k_scan_pairs (0 = what fits)
     c->opt_pairs_waves = value;

@@ -75,31 +75,6 @@ def test_all_4096_plane_votes_at_1M_equal_the_oracle(ctx):
     assert abs(abs(r["params"][:3] @ want[:3]) - 1) < 1e-6
 
 
-@pytest.mark.parametrize("waves", [1, 2])
-def test_plane_level2_on_the_matrix_cores(ctx, waves):
-    """cells_h16.h (scan_pairs_mfma 1 / 2: survivors compacted into tiles of 32, one fp16 matrix instruction per 32 x 32
-    values, exact predicate per value in the band through per-lane queues): every vote of the full count and of the
-    bounded scan equals the default level 2's, which the test above compares with the oracle; 1 M points + a ragged
-    upload whose last cell is partial, thresholds from far below to far above the cell size"""
-    for n, delta in ((N, 0.5), (300_007, 0.5), (300_007, 1e-4), (300_007, 40.0)):
-        data = synth.plane(n, 0.5, seed=43)[0]
-        got = []
-        for opt in (0, waves):
-            ctx.set_option("scan_pairs_mfma", opt)
-            ctx.set_model(L.PLANE, 3, delta, 0).upload(data)
-            ctx.set_option("scan_index", 2)
-            for bound in (0, 1):
-                ctx.set_option("scan_bound", bound)
-                r = ctx.batch_fit(SEED, 0, H, want_consensus=True)
-                got.append((ctx.hypotheses(params=False)[2].copy(), int(r["info"].best_index), r["consensus"].copy()))
-        ctx.set_option("scan_pairs_mfma", 0)
-        ctx.set_option("scan_index", 1)
-        ctx.set_option("scan_bound", 1)
-        for a, b in ((got[0], got[2]), (got[1], got[3])):
-            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]), (n, delta)
-        assert got[0][0].max() > 0
-
-
 def test_all_4096_sphere_votes_at_1M_equal_the_oracle(ctx):
     data = synth.sphere(N, 0.5, seed=42)[0]
     r, oc, wmask = _all_votes(ctx, L.SPHERE, O.SPHERE, data, 0.5, L.LS_ALGEBRAIC, True)
