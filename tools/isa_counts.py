@@ -74,10 +74,18 @@ def main():
         body = text[best[0]:best[2]].split("\n")
         loops = collections.OrderedDict()
         cur = ("entry", 0)
-        for line in body:
+        for li, line in enumerate(body):
             m = re.match(r"^(\.LBB\d+_\d+):\s*;?\s*(.*)$", line)
             if m:
                 lab, rest = m.group(1), m.group(2)
+                # a nested loop's header carries its parents on the label line and "This (Inner) Loop Header: Depth=n"
+                # on one of the comment lines that follow
+                k = li + 1
+                while "Parent Loop" in rest and k < len(body) and body[k].lstrip().startswith(";"):
+                    if "Loop Header" in body[k]:
+                        rest = body[k]
+                        break
+                    k += 1
                 d = re.search(r"Depth=(\d+)", rest)
                 h = re.search(r"Header=(BB\d+_\d+)", rest)
                 if "Loop Header" in rest and d:
