@@ -922,6 +922,15 @@ def report(R, rates, cpu_budget, headline=True):
                      "note": "one evaluation = one device pass (k_lm_pass*) over the winner's consensus set + the "
                              "MINPACK step; with --streams > 1 several fits are in flight"}
     out["roofline"] = main_rate["roofline"]
+    # the same work against the TIMED REGION's step time (several streams): `frac` above prices the dominant kernel by its
+    # own duration on one stream, and that duration can exceed ms_per_step of the multi-stream region (VERDICT r04, weak
+    # 11) -- this is the fraction of the roof the timed region itself sustains, all kernels of a step included
+    rf0 = out["roofline"]
+    if rf0 and rf0.get("achieved") and rf0.get("launch_ms") and rf0.get("peak"):
+        work = rf0["achieved"] * rf0["launch_ms"]          # (unit x ms): the launch's useful work
+        rf0["timed_region"] = {"ms_per_step": main_rate["ms_per_step"],
+                               "frac": work / main_rate["ms_per_step"] / rf0["peak"],
+                               "note": "useful work of one step's scan / ms_per_step of the timed region / peak"}
     for r in rates[1:]:
         out["roofline_" + r["mode"]] = r["roofline"]
         out["single_stream_" + r["mode"]] = r["single_stream"]
@@ -1119,6 +1128,10 @@ def compact_roofline(r, one):
             c[k] = r[k]
     if r.get("counters"):
         c["valu_issue_busy"] = r["counters"].get("valu_issue_busy")
+    if r.get("mfma_pipe_busy") is not None:
+        c["mfma_pipe_busy"] = r["mfma_pipe_busy"]
+    if r.get("timed_region"):
+        c["frac_timed_region"] = r["timed_region"]["frac"]
     c["kernel"] = str(r.get("kernel_short") or r.get("kernel") or "")[:80]
     c["algorithmic_GBs"] = r.get("algorithmic_GBs")
     if one:
