@@ -433,7 +433,7 @@ def scan_roofline(R, mode, scan_ms, n_scan):
     return base
 
 
-def hbm_table(R, prof, abs_prof, idx_prof, cnt, lm_nfev=0):
+def hbm_table(R, prof, abs_prof, idx_prof, cnt, lm_nfev=0, steps=0):
     """HBM-bound kernels of the step: algorithmic bytes / HIP-event time / 8 TB/s (live)"""
     a, rec = R.a, R.rec
     n = float(a.points)
@@ -460,7 +460,17 @@ def hbm_table(R, prof, abs_prof, idx_prof, cnt, lm_nfev=0):
             # the set is compacted before the first evaluation for the matrix-core pass (US) and otherwise after 8
             # evaluations through the mask (csrc/lsqr_hip.hip: kCompactAfter)
             tight = w in ("us", "phantom") or lm_nfev >= 8
-            add("k_lm_pass<%s> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f over the consensus set)" % w,
+            # (the launch path profiles every 16th evaluation: hundreds of launches per step; the persistent kernel is one)
+            if w == "us" and lm_nfev > 64 and steps and prof["moments"][0] <= 2 * steps:
+                # one launch for the whole fit (csrc/lm_persist.h: the one-stream pass runs alone on the device): the
+                # launch's bytes are the consensus set once per evaluation
+                nl_, ms_ = prof["moments"]
+                add("k_lm_persist<%s> (a whole Levenberg-Marquardt fit in one launch: %d evaluations, each a pass over the "
+                    "consensus set)" % (w, lm_nfev), cnt * rec * lm_nfev, nl_, ms_,
+                    note="bytes = %d consensus records x %d evaluations (read from HBM every evaluation unless "
+                         "lm_persist_resident keeps them in registers)" % (cnt, lm_nfev))
+            else:
+              add("k_lm_pass<%s> (one Levenberg-Marquardt evaluation: sum f^2, J^T J, J^T f over the consensus set)" % w,
                 cnt * rec if tight else n * rec + n, *prof["moments"],
                 note=("reads the %d consensus records (tight copy)" % cnt) if tight else
                 "fewer than 8 evaluations: every evaluation reads all records through the mask (no compaction pass)")
@@ -936,7 +946,7 @@ def report(R, rates, cpu_budget, headline=True):
         out["single_stream_" + r["mode"]] = r["single_stream"]
     cnt = int(last["cnt"]) if last else 0
     out["kernel_hbm"] = hbm_table(R, prof, main_rate["abs_warm"], (n_idx, ms_idx), cnt,
-                                  int(last["lm_nfev"]) if last else 0)
+                                  int(last["lm_nfev"]) if last else 0, main_rate["prof_steps"])
     out["kernels_ms"] = {"sample": prof["sample"][1] / max(prof["sample"][0], 1),
                          "estimate": prof["estimate"][1] / max(prof["estimate"][0], 1),
                          "scan": main_rate["scan_ms"],
@@ -974,11 +984,28 @@ def report(R, rates, cpu_budget, headline=True):
                                "every Jacobi round a dependent chain through LDS, two waves per SIMD (19 KB of LDS per "
                                "hypothesis) -- latency-bound; achieved = a flop model of the sweeps / kernel time "
                                "against the 78.6 TFLOP/s fp64 vector rate.  The scan's block: roofline_scan"})
+        elif dom == "moments" and any(r_["kernel"].startswith("k_lm_p") for r_ in out["kernel_hbm"]):
+            # iterative fit: the step is its Levenberg-Marquardt evaluations, each a pass over the consensus set -- HBM
+            row = [r_ for r_ in out["kernel_hbm"] if r_["kernel"].startswith("k_lm_p")][0]
+            rf.update({"bound": "hbm", "achieved": row["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": row["frac_of_hbm_peak"], "launch_ms": groups[dom], "traffic": None,
+                       "note": "the step's dominant kernel group is the %d LM evaluations of the final fit (BASELINE config "
+                               "5 as written ends at MINPACK's evaluation limit), each a pass over the compacted consensus "
+                               "set: achieved = consensus bytes x evaluations / their time on ONE stream (one fit alone: "
+                               "the synchronisation between evaluations is inside that time; several fits in flight "
+                               "overlap it -- lm.evaluations_per_s).  The scan's block: roofline_scan"
+                               % round(km["moments_launches_per_step"] if km["moments_launches_per_step"] > 2 else
+                                       (last["lm_nfev"] if last else 0))})
+            names["moments"] = row["kernel"][:80]
         else:
             rf.update({"launch_ms": groups[dom], "note": "dominant kernel group of the step is `%s`, not the scan; the "
                        "figures of this block are the SCAN's (see roofline_scan), launch_ms is the dominant group's" % dom})
         rf["kernel"] = names.get(dom, dom)
         rf["kernel_short"] = names.get(dom, dom)[:80]
+        rf.pop("timed_region", None)      # (that entry priced the scan's work; it stays in roofline_scan)
+        for k_ in ("issued_valu_frac_4cyc", "issued_valu_frac_2cyc", "frac_issued", "issued_TFLOPs", "mfma_pipe_busy",
+                   "hbm_frac_measured", "counters", "x_fp32_matrix_peak", "work_model"):
+            rf.pop(k_, None)              # the scan's counters do not describe this kernel
         out["roofline"] = rf
     out["index"] = {"built": idx["built"], "cells": idx["cells"], "cell_points": idx["cell_points"],
                     "build_ms": ms_idx / n_idx if n_idx else None,

@@ -237,3 +237,36 @@ def test_bench_headline_fits_the_drivers_tail():
     d["cpu_baseline"]["sample"] = "y" * 5000
     d["roofline"]["kernel"] = "z" * 5000
     assert len(bench.headline(d, "bench_detail.json")) <= bench.HEADLINE_LIMIT
+
+
+def test_sharded_dense_fit_is_taken_from_the_rows_when_the_block_is_ill_conditioned():
+    """ShardedRansac._refine (r05): a dense final fit that only had the summed Gram block and saw a pivot below 1e-6
+    max|G| (lsqr_fit_info.reserved == 2) is taken again from the replicated rows -- the winner masks the WHOLE upload,
+    lsqr_ls_fit runs the double-double route -- on every rank alike; any other fit is left alone"""
+    from types import SimpleNamespace
+    from lsqrrecipes_amd import _lib as L
+    from lsqrrecipes_amd.distributed import Comm, ShardedRansac
+
+    class Eng:
+        def __init__(self):
+            self.cfg = L.ModelCfg(L.DENSE, 8, 0.1, 0, 0)
+            self.n, self.P, self.calls = 1000, 8, []
+
+        def mask(self, params, begin, end, want_mask=False):
+            self.calls.append(("mask", begin, end, tuple(params)))
+            return None, 700
+
+        def ls_fit(self, use_mask=False):
+            self.calls.append(("ls_fit", use_mask))
+            return np.arange(8.0), SimpleNamespace(n_params=8, reserved=1, n_used=0, lm_info=0, lm_nfev=0)
+
+    e = Eng()
+    s = ShardedRansac(e, Comm(None, "cpu"))
+    winner = np.linspace(1, 2, 8)
+    block_fit = np.ones(8)
+    fit, info = s._refine(block_fit, SimpleNamespace(n_params=8, reserved=2, n_used=640), 0, 500, winner)
+    assert e.calls == [("mask", 0, 1000, tuple(winner)), ("ls_fit", True)]
+    assert np.array_equal(fit, np.arange(8.0)) and info.reserved == 1 and info.n_used == 640
+    e.calls.clear()
+    fit, info = s._refine(block_fit, SimpleNamespace(n_params=8, reserved=0, n_used=640), 0, 500, winner)
+    assert e.calls == [] and fit is block_fit and info.reserved == 0
