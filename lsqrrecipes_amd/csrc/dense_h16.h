@@ -212,6 +212,7 @@ constexpr double kH16ProbeLimit = 12.0;
 // for a whole pass over the batch), the workgroup 256.  The hypotheses come through a ring of 32-hypothesis tiles in
 // LDS, filled two tiles ahead by global_load_lds (no staging registers), one barrier per tile.
 template <int NR, bool SKIP_AMB = false, int DBG = 0>  // SKIP_AMB / DBG: tools/h16_bench.hip times parts of the loop
+                                                        // (1-3: parts alone; 7: s_memtime per phase; 8: packed classification)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_scan_dense_h16(
     const uint4 *__restrict__ afrag, const float *__restrict__ bs, size_t row_begin, size_t row_end,
     size_t rows_per_block, const _Float16 *__restrict__ xh, const float *__restrict__ thr4, uint32_t H,
@@ -274,6 +275,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds(g + 64, (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
   };
+  unsigned long long tphase[5] = {0, 0, 0, 0, 0};
+  const unsigned long long tstart = DBG == 7 ? __builtin_readcyclecounter() : 0;
   uint32_t q = 0;  // tiles started, over all passes: slot = q % 3, hypothesis tile = q % NT
   for (uint32_t k = 0; k + 1 < (uint32_t)kH16Slots; k++) issue(k % NT, k);
   uint32_t pass = 0;
@@ -298,15 +301,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     for (uint32_t T = 0; T < NT; T++, q++) {
       const uint32_t slot = q % kH16Slots;
+      unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+      if (DBG == 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        tq0 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // the two loads of tile q have landed (younger: the two of tile q + 1; at the top of a pass everything is
       // waited for -- the fragments are needed now)
       if (DBG != 3) {
-      if (T == 0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kH16Slots - 2)) : "memory");
-      __syncthreads();  // tile q is complete in LDS; everybody is done reading tile q - 1
-      issue((T + kH16Slots - 1) % NT, (q + kH16Slots - 1) % kH16Slots);
+        // (r05, measured and not kept: one barrier per TWO tiles -- the barrier phase of tools/h16_bench's s_memtime
+        // clocks falls from 470 to 310 cycles per tile, the launch takes 0.84 instead of 0.825 ms: the requests run one
+        // tile less ahead)
+        if (T == 0)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kH16Slots - 2)) : "memory");
+        __syncthreads();  // tile q is complete in LDS; everybody is done reading tile q - 1
+        issue((T + kH16Slots - 1) % NT, (q + kH16Slots - 1) % kH16Slots);
+      }
+      if (DBG == 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        tq1 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
       }
       h16x8 x[4][2];
       const unsigned char *sl = ring + slot * kH16TileBytes + lane * 16;
@@ -316,6 +333,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int part = 0; part < 2; part++) x[kb][part] = *(const h16x8 *)(sl + (kb * 2 + part) * 1024);
       const f32x2 na = *(const f32x2 *)(thl + 4 * (T * 32 + col)), nph = *(const f32x2 *)(thl + 4 * (T * 32 + col) + 2);
       const uint32_t band = s_band[T * 32 + col];
+      if (DBG == 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        tq2 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       f32x16 acc[2];
 #pragma unroll
       for (int m = 0; m < 2; m++)
@@ -345,8 +367,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (cc) lds_add_u32(&s_cnt[T * 32 + col], cc);
         continue;
       }
-      // classify: lane = hypothesis column T * 32 + col; register i of tile m = row 8 (i / 4) + 4 half + i % 4
-      uint32_t bits = 0, dmin = 0xFFFFFFFFu;
+      if (DBG == 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        tq3 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // classify: lane = hypothesis column T * 32 + col; register i of tile m = row 8 (i / 4) + 4 half + i % 4.
+      // The sign bits of d are shifted into `bits` value by value: value j = 16 m + 4 g + rr ends at bit 31 - j.
+      uint32_t bits = 0, dmin[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int m = 0; m < 2; m++) {
@@ -355,6 +383,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const f32x4 bq = *(const f32x4 *)(sb + 64 * wave + 32 * m + 8 * g + 4 * half);
 #pragma unroll
           for (int p = 0; p < 2; p++) {
+            if (DBG != 8) {
+              // plain v_fma_f32, not v_pk_fma_f32: a packed fp32 instruction takes two issue slots and does not run beside
+              // the other wave's matrix instructions (tools/mfma_rate), and with the worklist branch compiled in the
+              // packed form of this loop came with 16 s_nop per tile -- measured (tools/h16_bench, 2 M x 1024, r05): 0.82 ms
+              // against 0.90-0.95 ms at the bench's band, 0.73-0.75 against 0.80-0.88 ms with an empty band
+              const float r0 = __builtin_fmaf(p ? bq.z : bq.x, nph.x, acc[m][4 * g + 2 * p]);
+              const float r1 = __builtin_fmaf(p ? bq.w : bq.y, nph.x, acc[m][4 * g + 2 * p + 1]);
+              const uint32_t d0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(r0, r0, na.x));
+              const uint32_t d1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(r1, r1, na.x));
+              bits = __builtin_amdgcn_alignbit(bits, d0, 31);
+              bits = __builtin_amdgcn_alignbit(bits, d1, 31);
+              const uint32_t mn = d0 < d1 ? d0 : d1;
+              dmin[m] = mn < dmin[m] ? mn : dmin[m];
+              continue;
+            }
+            // DBG 8 (tools/h16_bench): the packed form, until r05 the product's
             const f32x2 ac = {acc[m][4 * g + 2 * p], acc[m][4 * g + 2 * p + 1]};
             const f32x2 bb = {p ? bq.z : bq.x, p ? bq.w : bq.y};
             const f32x2 r = __builtin_elementwise_fma(bb, nph, ac);
@@ -363,15 +407,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bits = __builtin_amdgcn_alignbit(bits, du.x, 31);
             bits = __builtin_amdgcn_alignbit(bits, du.y, 31);
             const uint32_t mn = du.x < du.y ? du.x : du.y;  // (halves first: cells.h on hipcc 7.2 and packed results)
-            dmin = mn < dmin ? mn : dmin;
+            dmin[m] = mn < dmin[m] ? mn : dmin[m];
           }
         }
       }
       const uint32_t c = (uint32_t)__builtin_popcount(bits);
-      if (!SKIP_AMB && dmin <= band) {  // rare: some pair of this lane sits in the band -> worklist (one counter update per lane)
-        uint32_t am = 0;
+      // Rare per lane (some pair of the lane's 32 sits in the band), not per wave: at the bench's band one wave-tile in
+      // five has such a lane, and a branch is taken by the wave.  So the branch is kept short: only the 32-row half whose
+      // minimum fell into the band is evaluated again, and the band's mask comes out of sign bits like the inliers' --
+      // z = band - d is negative exactly when d > band (a float difference has the sign of the exact one), `bits` already
+      // holds d < 0 in the same order: ambiguous = neither.  (Until r05: all 32 values again with a compare, a select and
+      // an or each -- 150 vector instructions per taken branch against 135 for the whole tile.)
+      if (!SKIP_AMB && (dmin[0] < dmin[1] ? dmin[0] : dmin[1]) <= band) {
+        const float bandf = __builtin_bit_cast(float, band);
+        uint32_t am = 0;  // bit 31 - j: value j = 16 m + 4 g + rr is in the band
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < 2; m++) {
+          if (dmin[m] > band) continue;  // (lanes of the branch whose other half was hit)
+          uint32_t zb = 0;
 #pragma unroll
           for (int g = 0; g < 4; g++) {
             const f32x4 bq = *(const f32x4 *)(sb + 64 * wave + 32 * m + 8 * g + 4 * half);
@@ -379,23 +432,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int rr = 0; rr < 4; rr++) {
               const float r = __builtin_fmaf(bq[rr], nph.x, acc[m][4 * g + rr]);
               const float d = __builtin_fmaf(r, r, na.x);
-              am |= __builtin_bit_cast(uint32_t, d) <= band ? 1u << (16 * m + 4 * g + rr) : 0u;
+              zb = __builtin_amdgcn_alignbit(zb, __builtin_bit_cast(uint32_t, bandf - d), 31);
             }
           }
+          const uint32_t neg = (bits >> (16 * (1 - m))) & 0xFFFFu;  // d < 0, value 4 g + rr of this half at bit 15 - (4 g + rr)
+          am |= (~zb & ~neg & 0xFFFFu) << (16 * (1 - m));
+        }
         unsigned slot_w = lds_add_rtn_u32(s_amb, (uint32_t)__builtin_popcount(am));
         const unsigned long long hid = (unsigned long long)s_hid[T * 32 + col];
         while (am) {
-          const int i = __builtin_ctz(am);  // bit 16 m + 4 g + rr -> row 32 m + 8 g + 4 half + rr
-          am &= am - 1;
+          const int j = __builtin_clz(am);  // value j = 16 m + 4 g + rr -> row 32 m + 8 g + 4 half + rr
+          am &= ~(0x80000000u >> j);
           if (slot_w < seg_cap)
             amb_list[(size_t)blockIdx.x * seg_cap + slot_w] =
-                ((unsigned long long)(base + 64 * wave + 32 * (i >> 4) + 8 * ((i >> 2) & 3) + 4 * half + (i & 3)) << 32) |
+                ((unsigned long long)(base + 64 * wave + 32 * (j >> 4) + 8 * ((j >> 2) & 3) + 4 * half + (j & 3)) << 32) |
                 hid;
           slot_w++;
         }
       }
       if (c) lds_add_u32(&s_cnt[T * 32 + col], c);
+      if (DBG == 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tq4 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        tphase[0] += tq1 - tq0, tphase[1] += tq2 - tq1, tphase[2] += tq3 - tq2, tphase[3] += tq4 - tq3;
+        tphase[4] += 1;
+      }
     }
+  }
+  if (DBG == 7 && lane == 0) {
+    for (int i = 0; i < 5; i++) amb_list[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tphase[i];
+    amb_list[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = __builtin_readcyclecounter() - tstart;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS write of mine may still be in flight when the LDS is freed
   __syncthreads();

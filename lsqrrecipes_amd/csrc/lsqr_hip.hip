@@ -514,16 +514,17 @@ int run_estimate(lsqr_ctx *c) {
           (void)hipStreamSynchronize(c->stream);
           (void)hipMemcpy(hd.data(), d_dbg, hd.size() * 8, hipMemcpyDeviceToHost);
           (void)hipFree(d_dbg);
-          double sit = 0, slu = 0, sitr = 0, sfin = 0, mit = 0, mitr = 0;
+          double sit = 0, slu = 0, sitr = 0, sfin = 0, mit = 0, mitr = 0, spcg = 0, mpcg = 0;
           size_t nref = 0, nconv = 0;
           for (size_t h = 0; h < c->H; h++) {
             const double it = (double)(hd[4 * h] & 0xFFFFFFFFu);
             sit += it, slu += (double)hd[4 * h + 1], sitr += (double)hd[4 * h + 2], sfin += (double)hd[4 * h + 3];
             mit = std::max(mit, it), mitr = std::max(mitr, (double)hd[4 * h + 2]);
+            spcg += (double)((hd[4 * h] >> 40) & 0xFF), mpcg = std::max(mpcg, (double)((hd[4 * h] >> 40) & 0xFF));
             nref += (hd[4 * h] >> 32) & 1, nconv += (hd[4 * h] >> 33) & 1;
           }
-          fprintf(stderr, "phantom_lu: H %zu mean it %.1f max %.0f refused %zu converged %zu; mean us: setup+LU %.1f iter %.1f (max %.1f) finish %.1f\n",
-                  c->H, sit / c->H, mit, nref, nconv, slu / c->H / 100, sitr / c->H / 100, mitr / 100, sfin / c->H / 100);
+          fprintf(stderr, "phantom_lu: H %zu mean it %.1f max %.0f, correction steps mean %.2f max %.0f, refused %zu converged %zu; mean us: setup+LU %.1f iter %.1f (max %.1f) finish %.1f\n",
+                  c->H, sit / c->H, mit, spcg / c->H, mpcg, nref, nconv, slu / c->H / 100, sitr / c->H / 100, mitr / 100, sfin / c->H / 100);
         }
         hipLaunchKernelGGL(k_estimate_phantom<64>, dim3((unsigned)c->H), dim3(64), 0, c->stream, c->d_data,
                            c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, (const uint8_t *)d_ref);
@@ -1370,6 +1371,18 @@ int launch_dense_h16(lsqr_ctx *c, size_t rb, size_t re, const _Float16 *xh, cons
   return LSQR_OK;
 }
 
+// diagnostics (LSQR_DENSE_DEBUG): how much of a dense scan went to the worklist
+static void dense_worklist_debug(lsqr_ctx *c, const unsigned int *d_segcnt, uint32_t seg_cap) {
+  static const bool dbg_on = getenv("LSQR_DENSE_DEBUG") != nullptr;
+  if (!dbg_on) return;
+  std::vector<unsigned int> seg(1024);
+  (void)hipMemcpy(seg.data(), d_segcnt, seg.size() * sizeof(unsigned int), hipMemcpyDeviceToHost);
+  unsigned long long tot = 0;
+  for (unsigned v : seg) tot += v;
+  fprintf(stderr, "dense scan: worklist %llu pairs of %.3g (%.3g), fullest segment %u of %u\n", tot,
+          (double)c->n * (double)c->H, (double)tot / ((double)c->n * (double)c->H), c->dense_amb_max, seg_cap);
+}
+
 // dense system, n > 32: the fp32 matrix-core filter (dense.h: k_scan_dense_mfma32r) over row chunks and compacted
 // selections; the band of every chunk is decided exactly (k_dense_recheck_seg) before the next selection looks at the
 // votes.  Returns LSQR_OK with *done = false when a worklist segment overflowed (the caller counts everything with
@@ -1452,6 +1465,7 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
   HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, sync_stream(c));
   c->dense_amb_max = *(unsigned int *)c->h_pin;
+  dense_worklist_debug(c, d_segcnt, seg_cap);
   if (c->dense_amb_max <= seg_cap) {
     *done = true;
     return LSQR_OK;
@@ -1637,6 +1651,7 @@ int run_scan(lsqr_ctx *c) {
                                        c->stream));
               HIPCHK(c, sync_stream(c));
               c->dense_amb_max = *(unsigned int *)c->h_pin;
+              dense_worklist_debug(c, d_segcnt, seg_cap);
               if (c->dense_amb_max <= seg_cap) return LSQR_OK;
               (void)fail(c, LSQR_OK, "dense fp16 / fp32 filter: worklist segment overflow (fill %u > %u), fp64 filter used",
                          c->dense_amb_max, seg_cap);

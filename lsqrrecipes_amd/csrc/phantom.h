@@ -409,77 +409,203 @@ __global__ __launch_bounds__(256) void k_estimate_phantom_lu(const double *__res
   const double rd = 1.0 / dk;
   // ---- inverse iteration --------------------------------------------------------------------------------------------
   const unsigned long long tdbg1 = wall_clock64();
+  // v -> (A^T A)^-1 v = U^-1 L^-1 L^-T U^-T v: four triangular solves, lane i = component i
+  auto inv_apply = [&](double r) -> double {
+    // U^T s = v      (forward; U_ji on lane i is t[j])
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double sj = wave_readlane_f64(r * rd, j);
+      r = lane == j ? sj : (lane > j ? fma(-t[j], sj, r) : r);
+    }
+    // L^T u = s      (backward, unit diagonal; L_ji on lane i is t[j])
+#pragma unroll
+    for (int j = N - 1; j > 0; j--) {
+      const double uj = wave_readlane_f64(r, j);
+      r = lane < j ? fma(-t[j], uj, r) : r;
+    }
+    // L c = u        (forward; L_ij on lane i is a[j])
+#pragma unroll
+    for (int j = 0; j < N - 1; j++) {
+      const double cj = wave_readlane_f64(r, j);
+      r = (row && lane > j) ? fma(-a[j], cj, r) : r;
+    }
+    // U v' = c       (backward; U_ij on lane i is a[j])
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) {
+      const double vj = wave_readlane_f64(r * rd, j);
+      r = lane == j ? vj : (lane < j ? fma(-a[j], vj, r) : r);
+    }
+    return row ? r : 0.0;
+  };
+  // v -> A^T A v = U^T L^T L U v through the same factors (the permutation cancels): four triangular PRODUCTS -- every
+  // step reads the same input vector, no dependent chain as in the solves
+  auto fwd_apply = [&](double x) -> double {
+    double y = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double xj = wave_readlane_f64(x, j);
+      y = lane <= j ? fma(a[j], xj, y) : y;  // U x
+    }
+    x = row ? y : 0.0;
+#pragma unroll
+    for (int j = 0; j < N - 1; j++) {
+      const double xj = wave_readlane_f64(x, j);
+      y = (row && lane > j) ? fma(a[j], xj, y) : y;  // L x (unit diagonal: y starts as x)
+    }
+    x = row ? y : 0.0;
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+      const double xj = wave_readlane_f64(x, j);
+      y = lane < j ? fma(t[j], xj, y) : y;  // L^T x
+    }
+    x = row ? y : 0.0;
+    y = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double xj = wave_readlane_f64(x, j);
+      y = lane >= j ? fma(t[j], xj, y) : y;  // U^T x
+    }
+    return row ? y : 0.0;
+  };
   double r = row ? 1.0 / sqrt((double)N) * (1.0 + 0.01 * lane) : 0.0;  // start: no symmetry the null vector could be orthogonal to
   bool conv = false;
-  int it = 0, since = 0;
-  double pp = r;
+  int it = 0, since = 0, pcg = 0;
+  double pp = r, dprev = 0.0;
   if (!refuse) {
     for (; it < max_iter; it++) {
       const double prev = r;
-      // U^T s = v      (forward; U_ji on lane i is t[j])
-#pragma unroll
-      for (int j = 0; j < N; j++) {
-        const double sj = wave_readlane_f64(r * rd, j);
-        r = lane == j ? sj : (lane > j ? fma(-t[j], sj, r) : r);
-      }
-      // L^T u = s      (backward, unit diagonal; L_ji on lane i is t[j])
-#pragma unroll
-      for (int j = N - 1; j > 0; j--) {
-        const double uj = wave_readlane_f64(r, j);
-        r = lane < j ? fma(-t[j], uj, r) : r;
-      }
-      // L c = u        (forward; L_ij on lane i is a[j])
-#pragma unroll
-      for (int j = 0; j < N - 1; j++) {
-        const double cj = wave_readlane_f64(r, j);
-        r = (row && lane > j) ? fma(-a[j], cj, r) : r;
-      }
-      // U v' = c       (backward; U_ij on lane i is a[j])
-#pragma unroll
-      for (int j = N - 1; j >= 0; j--) {
-        const double vj = wave_readlane_f64(r * rd, j);
-        r = lane == j ? vj : (lane < j ? fma(-a[j], vj, r) : r);
-      }
+      r = inv_apply(r);
       // unit length; (A^T A)^-1 is positive definite, so consecutive iterates do not flip their sign
-      double n2 = row ? r * r : 0.0;
-      for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+      const double n2 = wave_sum(row ? r * r : 0.0);
       r = row ? r / sqrt(n2) : 0.0;
       double d = fabs(r - prev);
       d = wave_max(d);
       if (!(n2 > 0.0) || !(n2 < INFINITY)) break;  // overflow / breakdown: the Jacobi kernel decides
-      // the iterate settles at eps sigma_1 / sigma_30 (6e-11 on the bench's subsets: a tighter test never fires and the
-      // wave runs to the limit -- 0.7 ms, measured); 1e-9 here leaves r / (1 - r) 1e-9 < 1e-7 of the neighbour's direction
-      if (d < 1e-9 && it >= 1) {
+      // PHASE 1 only has to bring the vector close enough for the correction below to be linear (its square below
+      // 1e-14): the distance to the limit is d rho / (1 - rho) with rho the decay per step, estimated from two steps
+      const double rho_hat = dprev > 0.0 ? fmin(d / dprev, 0.999) : 0.999;
+      if (it >= 1 && d < 1e-7 && d * rho_hat / (1.0 - rho_hat) < 1e-7) {
         conv = true;
         break;
       }
+      dprev = d;
       // Aitken's extrapolation of the vector sequence: with sigma_31 / sigma_30 near one the error is one mode decaying
       // by rho = (sigma_31 / sigma_30)^2 per step; three clean iterates give rho and the limit x + rho / (1 - rho) dx.
       // On the bench's subsets: plain iteration 99 % within 61 steps, 15 of 3000 beyond 80, the slowest beyond 300;
       // with the extrapolation 99 % within 20, the slowest 79 (one wave at the limit used to BE the kernel's time).
       if (++since >= 3) {
         const double d1 = prev - pp, d2 = r - prev;
-        double den = row ? d1 * d1 : 0.0, num = row ? d2 * d1 : 0.0;
-        for (int o = 32; o > 0; o >>= 1) {
-          den += __shfl_xor(den, o);
-          num += __shfl_xor(num, o);
-        }
+        const double den = wave_sum(row ? d1 * d1 : 0.0), num = wave_sum(row ? d2 * d1 : 0.0);
         const double rho = num / den;
         if (den > 0.0 && rho > 0.3 && rho < 0.999) {
           r = fma(rho / (1.0 - rho), d2, r);
-          double m2 = row ? r * r : 0.0;
-          for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+          const double m2 = wave_sum(row ? r * r : 0.0);
           r = row ? r / sqrt(m2) : 0.0;
           since = 0;
+          dprev = 0.0;
         }
       }
       pp = prev;
     }
   }
+  // ---- PHASE 2: one correction from an ACCURATE residual ------------------------------------------------------------
+  // The fixed point of the iteration above is the singular vector of a matrix eps ||A|| away from A: eps sigma_1 /
+  // sigma_30 from the wanted vector -- 1e-11 in the median and up to 6e-10 on rescaled uploads (sigma_1 / sigma_30 to
+  // 3e6), and M::finish divides by the vector's SMALL components (R1's entries are 1e-3 of its largest): 1e-9 in
+  // the vector was 1e-6 .. 1e-4 in the 41 parameters for one hypothesis in 800 (soak against the oracle, r05), where
+  // the Jacobi SVD -- accurate relative to each column's scale -- stays at 1e-11.  So: g = A^T (A v) from the ORIGINAL
+  // rows in double-double arithmetic (error-free products through fma, two-sum accumulation: A v must be good to
+  // 1e-13 sigma_30 beside terms of size sigma_1), the Rayleigh quotient lambda = v.g, and the correction equation
+  //     P (A^T A - lambda) P e = P (g - lambda v),      P = I - v v^T,          v <- (v - e) / |v - e|
+  // solved by conjugate gradients preconditioned with P (A^T A)^-1 P through the factors (the operator through them
+  // too: e is small, the factors' eps is relative to e).  The preconditioned spectrum is 1 - (sigma_31 / sigma_j)^2:
+  // one cluster at 1 and a few values below it -- 1 step for 45 % of the subsets, 2 for 47 %, never more than 4 in a
+  // numpy model of this loop (1200 subsets over random uploads), after which the vector is within 2e-13 and the
+  // parameters within 5e-10 of a long-double reference (LAPACK's own SVD: 9e-13 / 2e-9).
+  if (!refuse && conv) {
+    conv = false;
+    // the original rows again (the elimination overwrote them): lane i -> T[i][*]
+    {
+      size_t i = row ? subsets[(size_t)h * N + lane] : 0;
+      if (i >= nobs) i = 0;  // (such a subset is marked bad above and never reaches M::finish)
+      double rec[M::ND];
+#pragma unroll
+      for (int c = 0; c < M::ND; c++) rec[c] = (c == 12) ? 0.0 : data[i * stride + c];
+      if (row) {
+#pragma unroll
+        for (int c = 0; c < N; c++) T[lane * PT + c] = M::row_entry(rec, c);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // r1 = A v, lane = row, double-double
+    double r1h = 0.0, r1l = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+      const double ac = row ? T[lane * PT + c] : 0.0, vc = wave_readlane_f64(r, c);
+      const double p = ac * vc, e = fma(ac, vc, -p);
+      const double s = r1h + p, z = s - r1h;
+      r1l += ((r1h - (s - z)) + (p - z)) + e;
+      r1h = s;
+    }
+    {
+      const double s = r1h + r1l;
+      r1l = r1l - (s - r1h);
+      r1h = s;
+    }
+    // g = A^T r1, lane = column, double-double
+    double gh = 0.0, gl = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const double ac = row ? T[i * PT + lane] : 0.0;
+      const double bh = wave_readlane_f64(r1h, i), bl = wave_readlane_f64(r1l, i);
+      const double p = ac * bh, e = fma(ac, bh, -p) + ac * bl;
+      const double s = gh + p, z = s - gh;
+      gl += ((gh - (s - z)) + (p - z)) + e;
+      gh = s;
+    }
+    const double g = row ? gh + gl : 0.0;
+    const double lam = wave_sum(g * r);
+    auto proj = [&](double x) -> double { return fma(-wave_sum(x * r), r, x); };
+    double rr = proj(fma(-lam, r, g));
+    double z = proj(inv_apply(rr));
+    double pdir = z, e = 0.0;
+    double rz = wave_sum(rr * z);
+    const double rz0 = rz;
+    bool fine = rz0 == rz0 && rz0 < INFINITY;
+    if (fine && rz0 > 0.0) {
+      fine = false;
+      for (; pcg < 8; pcg++) {
+        const double ap = proj(fma(-lam, pdir, fwd_apply(pdir)));
+        const double pap = wave_sum(pdir * ap);
+        if (!(pap > 0.0)) break;  // not positive definite on v's complement: lambda is not the smallest -- Jacobi decides
+        const double alpha = rz / pap;
+        e = fma(alpha, pdir, e);
+        rr = fma(-alpha, ap, rr);
+        z = proj(inv_apply(rr));
+        const double rz2 = wave_sum(rr * z);
+        if (!(rz2 == rz2)) break;
+        if (rz2 <= 1e-10 * rz0) {  // the preconditioned residual 1e-5 of the start's
+          fine = true;
+          pcg++;
+          break;
+        }
+        pdir = fma(rz2 / rz, pdir, z);
+        rz = rz2;
+      }
+    }
+    if (fine) {
+      r = r - e;
+      const double m2 = wave_sum(row ? r * r : 0.0);
+      r = row ? r / sqrt(m2) : 0.0;
+      // e beyond what phase 1 left (1e-5 with the margin) means the linearisation does not hold
+      conv = wave_max(fabs(e)) < 1e-5 && m2 > 0.0 && m2 < INFINITY;
+    }
+  }
   const bool ok_vec = !refuse && conv;
   const unsigned long long tdbg2 = wall_clock64();
   if (dbg && lane == 0) {
-    dbg[(size_t)h * 4 + 0] = (unsigned long long)it | ((unsigned long long)(refuse ? 1 : 0) << 32) | ((unsigned long long)(conv ? 1 : 0) << 33);
+    dbg[(size_t)h * 4 + 0] = (unsigned long long)it | ((unsigned long long)(refuse ? 1 : 0) << 32) |
+                             ((unsigned long long)(conv ? 1 : 0) << 33) | ((unsigned long long)pcg << 40);
     dbg[(size_t)h * 4 + 1] = tdbg1 - tdbg0;
     dbg[(size_t)h * 4 + 2] = tdbg2 - tdbg1;
   }

@@ -240,6 +240,9 @@ __global__ __launch_bounds__(kUs16Wg) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const Meta &pm, uint32_t &bits, uint32_t &dmin) __attribute__((always_inline)) {
       bits = 0, dmin = 0xFFFFFFFFu;
       auto chunk = [&](int p) __attribute__((always_inline)) {
+        // (r05: plain v_fma_f32 instead of the packed form -- what the dense filter's classification gained 10 % from --
+        // costs THIS loop 17 %, 1.18 -> 1.38 ms per 4096 x 1 M, and the plane phantom's 5 %: here the chunks sit in
+        // source order between the matrix instructions and the packed form is the shorter stream; tools/scan_ab.py)
         const f32x2 e0 = {prv[0][2 * p], prv[0][2 * p + 1]}, e1 = {prv[1][2 * p], prv[1][2 * p + 1]},
                     e2 = {prv[2][2 * p], prv[2][2 * p + 1]};
         f32x2 d = __builtin_elementwise_fma(e0, e0, pm.na);

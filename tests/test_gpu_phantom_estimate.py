@@ -14,16 +14,26 @@ pytestmark = pytest.mark.gpu
 
 
 def _align(p, q):
-    """the null vector's sign is arbitrary: T1's entries (indices 0..2 hold omega / t1_z ... the products 11..40 and
-    par[2] flip together) -- compare after flipping q's sign-bearing block to p's"""
+    """the null vector's sign is arbitrary: the products 11..40 and par[2] flip together, the row R1 of the flipped
+    vector is -R1 and its two Euler angles (-omega_y, omega_x +- pi) -- unless omega_y is within the reference's
+    small angle of +-pi/2 (.cxx:240-260), where omega_x is SET to zero whatever the sign"""
     q = q.copy()
     blk = list(range(11, 41)) + [2]
     if np.dot(p[blk], q[blk]) < 0:
         q[blk] = -q[blk]
-        # the row R1 of the flipped vector is -R1: its two Euler angles are (-omega_y, omega_x +- pi)
+        if abs(abs(q[0]) - np.pi / 2) > 0.008726535498373935:
+            q[1] = q[1] - np.pi if abs(q[1] - np.pi - p[1]) < abs(q[1] + np.pi - p[1]) else q[1] + np.pi
         q[0] = -q[0]
-        q[1] = q[1] - np.pi if q[1] - np.pi > -np.pi - 1e-9 and abs(q[1] - np.pi - p[1]) < abs(q[1] + np.pi - p[1]) else q[1] + np.pi
     return q
+
+
+def _dist(p, q):
+    """largest difference of the 41 parameters relative to max(|p_i|, 1e-3 max |p|); the five angles modulo 2 pi"""
+    q = _align(p, q)
+    d = np.abs(q - p)
+    ang = [0, 1, 6, 7, 8]
+    d[ang] = np.minimum(d[ang], np.abs(2 * np.pi - d[ang]))
+    return float(np.max(d / np.maximum(np.abs(p), 1e-3 * np.abs(p).max())))
 
 
 def _estimate(ctx, data, H, fast, seed=0xC0FFEE):
@@ -45,19 +55,15 @@ def test_fast_null_vectors_equal_the_jacobi_svd_and_the_oracle():
     worst = 0.0
     for h in np.flatnonzero(vj):
         for other in (pf, pl):
-            q = _align(pj[h], other[h])
-            scale = np.maximum(np.abs(pj[h]), 1e-3 * np.abs(pj[h]).max())
-            worst = max(worst, float(np.max(np.abs(q - pj[h]) / scale)))
-    assert worst < 1e-6, worst
+            worst = max(worst, _dist(pj[h], other[h]))
+    assert worst < 1e-7, worst     # (r05: the fast path's vector is corrected from a double-double residual)
     # the oracle's SVD on a sample of the same subsets
     oc = O.cfg(O.PHANTOM, 0, 2.0, 0)
     subs = O.ctr_subsets(0xC0FFEE, 0, H, len(data), 31)
     for h in list(np.flatnonzero(vj)[:40]):
         want = O.estimate(oc, data[subs[h]])
         assert len(want) == 41
-        q = _align(want, pf[h])
-        scale = np.maximum(np.abs(want), 1e-3 * np.abs(want).max())
-        assert np.max(np.abs(q - want) / scale) < 1e-6, h
+        assert _dist(want, pf[h]) < 1e-7, h
 
 
 def test_fast_path_votes_and_step_equal_the_jacobi_path():
@@ -94,6 +100,4 @@ def test_degenerate_subsets_take_the_same_decision():
     for h in np.flatnonzero(vj):
         if h in (5, 9):
             continue   # whatever vector an (almost) rank-deficient system yields, both paths call it valid or not alike
-        q = _align(pj[h], pf[h])
-        scale = np.maximum(np.abs(pj[h]), 1e-3 * np.abs(pj[h]).max())
-        assert np.max(np.abs(q - pj[h]) / scale) < 1e-6, h
+        assert _dist(pj[h], pf[h]) < 1e-6, h

@@ -160,7 +160,7 @@ int main(int argc, char **argv) {
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("rows_h16: %.3f ms for %zu rows\n", ms, N);
   const size_t passes = (N + kH16RowsPerWg - 1) / kH16RowsPerWg;
-  const size_t nb = std::min<size_t>(passes, 512);
+  const size_t nb = std::min<size_t>(passes, getenv("H16_NB") ? (size_t)atoi(getenv("H16_NB")) : 512);
   const size_t rpb = (passes + nb - 1) / nb * kH16RowsPerWg;
   const size_t nblk = (N + rpb - 1) / rpb;
   const size_t lds = dense_h16_lds(H);
@@ -192,6 +192,30 @@ int main(int argc, char **argv) {
       run(k_scan_dense_h16<64, true, 1>, "matrix instructions alone");
       run(k_scan_dense_h16<64, true, 2>, "classification alone");
       run(k_scan_dense_h16<64, true, 3>, "matrix instructions alone, no barrier / tile requests (LDS reads stay)");
+      run(k_scan_dense_h16<64, true, 0>, "filter alone");
+      run(k_scan_dense_h16<64, true, 8>, "filter alone, packed classification (until r05)");
+      auto phases = [&]() {
+        std::vector<unsigned long long> tp((size_t)nblk * 4 * 8);
+        CK(hipMemcpy(tp.data(), d_amb, tp.size() * 8, hipMemcpyDeviceToHost));
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < (size_t)nblk * 4; w++)
+          for (int i = 0; i < 6; i++) sum[i] += (double)tp[w * 8 + i];
+        const double tiles = sum[4];
+        printf("  per tile and wave (shader-clock ticks of s_memtime): barrier %.0f, x fragments from LDS %.0f, 24 matrix instructions issued %.0f, "
+               "results + classification %.0f; tiles per wave %.0f; whole wave %.0f ticks\n",
+               sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, tiles / (nblk * 4.0), sum[5] / (nblk * 4.0));
+      };
+      run(k_scan_dense_h16<64, true, 7>, "filter alone, phase clocks");
+      phases();
+      CK(hipMemset(d_segcnt, 0, 1024 * 4));
+      run(k_scan_dense_h16<64, false, 7>, "with worklist, phase clocks (the clocks' dump overwrites worklist entries)");
+      phases();
+      CK(hipMemset(d_segcnt, 0, 1024 * 4));
+      run(k_scan_dense_h16<64, false, 8>, "with worklist, packed classification (until r05)");
+      CK(hipMemset(d_segcnt, 0, 1024 * 4));
+      run(k_scan_dense_h16<64, false, 0>, "with worklist");
+      CK(hipMemset(d_votes, 0, H * 4));
+      CK(hipMemset(d_segcnt, 0, 1024 * 4));
       CK(hipMemset(d_votes, 0, H * 4));
     }
     if (getenv("H16_SKIP_AMB")) {

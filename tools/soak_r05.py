@@ -1,7 +1,8 @@
 """Differential soak of round 5's new paths (run on the GPU box; exit code 1 on a mismatch):
   * plane phantom minimal solves: LU + inverse iteration (phantom_fast_solve 1) against the Jacobi SVD (0) -- the same
-    hypotheses valid, the 41 parameters within 1e-6 (the null vector's common sign aligned) -- over random uploads
-    (frames, off-plane fraction, pixel noise over four orders of magnitude, translations rescaled);
+    hypotheses valid, the 41 parameters within 1e-6 (the null vector's common sign aligned, angles modulo 2 pi;
+    tests/soak_phantom_lu.py referees anything further apart with the oracle) -- over random uploads (frames,
+    off-plane fraction, pixel noise over four orders of magnitude, translations rescaled);
   * iterative US fits: the persistent kernel with the host's step (lm_persist 3) and with the device's step (2, on the
     smaller sets) against the launch path (0) -- last iterate, info, nfev bit for bit -- over random single / pointer
     uploads, sizes, noise levels, consensus masks and workgroup counts.
@@ -20,13 +21,23 @@ g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 
 
 def align(p, q):
+    """the null vector's sign is arbitrary (tests/soak_phantom_lu.py: align)"""
     q = q.copy()
     blk = list(range(11, 41)) + [2]
     if np.dot(p[blk], q[blk]) < 0:
         q[blk] = -q[blk]
+        if abs(abs(q[0]) - np.pi / 2) > 0.008726535498373935:   # else the reference sets omega_x to zero
+            q[1] = q[1] - np.pi if abs(q[1] - np.pi - p[1]) < abs(q[1] + np.pi - p[1]) else q[1] + np.pi
         q[0] = -q[0]
-        q[1] = q[1] - np.pi if abs(q[1] - np.pi - p[1]) < abs(q[1] + np.pi - p[1]) else q[1] + np.pi
     return q
+
+
+def apart(p, q):
+    q = align(p, q)
+    d = np.abs(q - p)
+    ang = [0, 1, 6, 7, 8]
+    d[ang] = np.minimum(d[ang], np.abs(2 * np.pi - d[ang]))
+    return float(np.max(d / np.maximum(np.abs(p), 1e-3 * np.abs(p).max())))
 
 
 def phantom_round(ctx):
@@ -46,11 +57,7 @@ def phantom_round(ctx):
         res.append(ctx.hypotheses(votes=False))
     (pj, vj, _), (pf, vf, _) = res
     bad = int(np.count_nonzero(vj != vf))
-    worst = 0.0
-    for h in np.flatnonzero(vj & vf):
-        q = align(pj[h], pf[h])
-        scale = np.maximum(np.abs(pj[h]), 1e-3 * np.abs(pj[h]).max())
-        worst = max(worst, float(np.max(np.abs(q - pj[h]) / scale)))
+    worst = max([0.0] + [apart(pj[h], pf[h]) for h in np.flatnonzero(vj & vf)])
     return H, bad, worst
 
 
@@ -81,7 +88,7 @@ def lm_round(ctx):
 
 def main():
     t0 = time.time()
-    ph = {"uploads": 0, "hypotheses": 0, "validity_mismatches": 0, "worst_rel": 0.0, "over_1e-6": 0}
+    ph = {"uploads": 0, "hypotheses": 0, "validity_mismatches": 0, "worst_apart": 0.0}
     lm = {"uploads": 0, "fits": 0, "evaluations": 0, "mismatches": 0}
     with Context(0) as ctx:
         while time.time() - t0 < T:
@@ -90,8 +97,7 @@ def main():
                 ph["uploads"] += 1
                 ph["hypotheses"] += H
                 ph["validity_mismatches"] += bad
-                ph["worst_rel"] = max(ph["worst_rel"], worst)
-                ph["over_1e-6"] += worst >= 1e-6
+                ph["worst_apart"] = max(ph["worst_apart"], worst)
             else:
                 k, ok, nfev = lm_round(ctx)
                 lm["uploads"] += 1
@@ -100,7 +106,7 @@ def main():
                 lm["mismatches"] += not ok
     print("phantom LU vs Jacobi:", ph)
     print("persistent LM vs launch path:", lm)
-    fail = ph["validity_mismatches"] or ph["over_1e-6"] or lm["mismatches"]
+    fail = ph["validity_mismatches"] or ph["worst_apart"] >= 1e-6 or lm["mismatches"]
     print("soak_r05: %s in %.0f s" % ("MISMATCH" if fail else "no difference", time.time() - t0))
     sys.exit(1 if fail else 0)
 
