@@ -87,16 +87,20 @@ __global__ __launch_bounds__(256) void k_dense_rows_h16(const double *__restrict
 }
 
 // Once per batch: per hypothesis 256 B  [x1: 64 fp16 | x2: 64 fp16]  and  thr4 = (-a, band bits, -ph, 0).
+// One wave per hypothesis, lane = unknown (r05; until then one THREAD per hypothesis: 16 waves on the whole device walking
+// 64 unknowns each, 43-48 us per 1024 hypotheses -- a twentieth of a step).
 __global__ __launch_bounds__(256) void k_dense_prep_h16(const double *__restrict__ sp, uint32_t H, int n, int nr,
                                                         double delta, double amax, double bmax, double pa,
                                                         _Float16 *__restrict__ xh, float *__restrict__ thr4) {
-  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= H) return;
-  double l1 = 0.0, xm = 0.0;
-  for (int k = 0; k < n; k++) {
-    const double v = fabs(sp[(size_t)h * nr + k]);
-    l1 += v;
-    xm = v > xm ? v : xm;
+  const uint32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (h >= H) return;  // whole waves
+  const int k = threadIdx.x & 63;
+  const double xk = k < n ? sp[(size_t)h * nr + k] : 0.0;
+  double l1 = fabs(xk), xm = fabs(xk);  // (a NaN unknown: l1 is NaN on every lane after the sum; xm is not used then)
+  for (int o = 32; o > 0; o >>= 1) {
+    l1 += __shfl_xor(l1, o);
+    const double t = __shfl_xor(xm, o);
+    xm = t > xm ? t : xm;
   }
   const double u = 5.9604644775390625e-08;
   // ph is an fp32 number (it is a factor of the fma that subtracts b'' ph): everything below uses the rounded value
@@ -128,18 +132,18 @@ __global__ __launch_bounds__(256) void k_dense_prep_h16(const double *__restrict
   // row, so the hypothesis is never counted and nothing of it is ambiguous (d = r''^2 + inf) -- not a row per
   // observation in the worklist
   if (!(l1 == l1)) a = -INFINITY, band = 0.0f;
-  thr4[4 * (size_t)h] = -a;
-  thr4[4 * (size_t)h + 1] = band;
-  thr4[4 * (size_t)h + 2] = nph;
-  thr4[4 * (size_t)h + 3] = 0.0f;
-  _Float16 *o = xh + (size_t)h * 128;
-  for (int k = 0; k < 64; k++) {
-    const double v = (live && k < n) ? sp[(size_t)h * nr + k] * (double)(-nph) : 0.0;
-    _Float16 x1, x2;
-    h16_split(v, x1, x2);
-    o[k] = x1;
-    o[64 + k] = x2;
+  if (k == 0) {
+    thr4[4 * (size_t)h] = -a;
+    thr4[4 * (size_t)h + 1] = band;
+    thr4[4 * (size_t)h + 2] = nph;
+    thr4[4 * (size_t)h + 3] = 0.0f;
   }
+  const double v = live ? xk * (double)(-nph) : 0.0;
+  _Float16 x1, x2;
+  h16_split(v, x1, x2);
+  _Float16 *o = xh + (size_t)h * 128;
+  o[k] = x1;
+  o[64 + k] = x2;
 }
 
 // LDS atomics as inline assembly: the compiler orders every LDS write or atomic that may alias the destination of a

@@ -1409,7 +1409,7 @@ int run_scan_dense_ee(lsqr_ctx *c, bool *done) {
   bool h16 = false;
   if (c->opt_dense_f32 == 2 && (st = ensure_dense_h16(c, &h16)) != LSQR_OK) return st;
   if (h16)  // the fp16 filter's rows live where the fp32 filter keeps its own (256 B per hypothesis either way)
-    hipLaunchKernelGGL(k_dense_prep_h16, dim3((H + 255) / 256), dim3(256), 0, c->stream, c->d_hparams, H, (int)c->cfg.dim,
+    hipLaunchKernelGGL(k_dense_prep_h16, dim3((H + 3) / 4), dim3(256), 0, c->stream, c->d_hparams, H, (int)c->cfg.dim,
                        64, c->mc.delta, c->mc.absmax_rot, c->mc.absmax, c->h16_pa, (_Float16 *)d_sp32, c->d_h16_thr);
   else
     hipLaunchKernelGGL(k_dense_thresholds32, dim3((H + 255) / 256), dim3(256), 0, c->stream, c->d_hparams, H,
@@ -1607,7 +1607,7 @@ int run_scan(lsqr_ctx *c) {
               if (c->opt_dense_f32 == 2 && (st = ensure_dense_h16(c, &h16)) != LSQR_OK) return st;
               if (h16) {  // fp16 matrix cores on two-way splits (dense_h16.h)
                 ProfScope ps(c, KID_SCAN);
-                hipLaunchKernelGGL(k_dense_prep_h16, dim3((unsigned)((c->H + 255) / 256)), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(k_dense_prep_h16, dim3((unsigned)((c->H + 3) / 4)), dim3(256), 0, c->stream,
                                    c->d_hparams, (uint32_t)c->H, (int)c->cfg.dim, 64, c->mc.delta, c->mc.absmax_rot,
                                    c->mc.absmax, c->h16_pa, (_Float16 *)d_sp32, c->d_h16_thr);
                 HIPCHK(c, hipGetLastError());
@@ -2542,6 +2542,12 @@ int run_fit(lsqr_ctx *c, int use_mask, SolveOut *out, bool have_moments = false)
           if (!lm_advance(s, pin + 64)) break;
         }
         bool ok = s.info >= 1 && s.info <= 4;  // vnl_levenberg_marquardt::minimize -> true
+        {
+          static const bool dbg_on = getenv("LSQR_LM_DEBUG") != nullptr;
+          if (dbg_on)
+            fprintf(stderr, "lm: info %d nfev %d outer iterations %d (accepted steps %d) cost %.17g stall %d par %.3g delta %.3g\n",
+                    s.info, s.nfev, s.iter, s.iter - 1, s.fnorm * s.fnorm, s.stall, s.par, s.delta);
+        }
         out->ok = ok ? 1 : 0;
         out->cont = 0;
         out->lm_info = s.info;

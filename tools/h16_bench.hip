@@ -171,7 +171,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(d_segcnt, 0, 1024 * 4));
     CK(hipMemset(d_total, 0, 8));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_dense_prep_h16, dim3((H + 255) / 256), dim3(256), 0, 0, d_sp, H, n, 64, delta, amax, bmax, pa,
+    hipLaunchKernelGGL(k_dense_prep_h16, dim3((H + 3) / 4), dim3(256), 0, 0, d_sp, H, n, 64, delta, amax, bmax, pa,
                        d_xh, d_thr4);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
