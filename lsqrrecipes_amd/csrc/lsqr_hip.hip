@@ -526,8 +526,9 @@ int run_estimate(lsqr_ctx *c) {
           fprintf(stderr, "phantom_lu: H %zu mean it %.1f max %.0f, correction steps mean %.2f max %.0f, refused %zu converged %zu; mean us: setup+LU %.1f iter %.1f (max %.1f) finish %.1f\n",
                   c->H, sit / c->H, mit, spcg / c->H, mpcg, nref, nconv, slu / c->H / 100, sitr / c->H / 100, mitr / 100, sfin / c->H / 100);
         }
-        hipLaunchKernelGGL(k_estimate_phantom<64>, dim3((unsigned)c->H), dim3(64), 0, c->stream, c->d_data,
-                           c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, (const uint8_t *)d_ref);
+        hipLaunchKernelGGL(k_estimate_phantom<64>, dim3((unsigned)std::min<size_t>(c->H, 512)), dim3(64), 0, c->stream,
+                           c->d_data, c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid,
+                           (const uint8_t *)d_ref);
       } else if (c->opt_block == 256)
         hipLaunchKernelGGL(k_estimate_phantom<256>, dim3((unsigned)c->H), dim3(256), 0, c->stream, c->d_data,
                            c->stride, c->n, c->d_subsets, (uint32_t)c->H, c->d_hparams, c->d_valid, (const uint8_t *)nullptr);

@@ -265,8 +265,11 @@ __global__ __launch_bounds__(T) void k_estimate_phantom(const double *__restrict
   __shared__ double A[N * LDA], V[N * LDA], recs[N][M::ND], x[N];
   __shared__ int s_bad, s_npos;
   const int tid = threadIdx.x;
-  const uint32_t h = blockIdx.x;
-  if (only && !only[h]) return;  // (behind k_estimate_phantom_lu: only what the fast path refused)
+  // behind k_estimate_phantom_lu (`only`): a few hundred workgroups walk the batch and solve what the fast path refused
+  // -- one workgroup per hypothesis, 4096 of them returning at once, took 63 us of the step
+  for (uint32_t h = blockIdx.x; h < H; h += gridDim.x) {
+  if (only && !only[h]) continue;  // (workgroup-uniform)
+  __syncthreads();  // the previous hypothesis of this workgroup is written
   if (tid == 0) s_bad = 0;
   __syncthreads();
   for (int idx = tid; idx < N * M::ND; idx += T) {
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(T) void k_estimate_phantom(const double *__restrict
     const double qnan = __builtin_nan("");
     for (int j = 0; j < M::P; j++) hparams[(size_t)h * M::SP + j] = ok ? par[j] : qnan;
     valid[h] = ok ? 1 : 0;
+  }
   }
 }
 
