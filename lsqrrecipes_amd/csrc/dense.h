@@ -833,7 +833,10 @@ __global__ __launch_bounds__(256) void k_syrk_dense(const double *__restrict__ d
 // through LDS, so the per-block partial is deterministic.
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int VAR>
+// NB = number of 16-column blocks that hold anything (n + 1 <= 16 NB): the plane phantom's 32-column rows need two of
+// the five -- 3 matrix instructions and 2 loads per four rows instead of 15 and 5 (until r05 the three idle blocks
+// were loaded from column 0 and multiplied as zeros: 186 us per 1 M x 32 matrix, 1.4 TB/s), with PF groups in flight.
+template <int VAR, int NB = 5, int PF = 4>
 __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ data, size_t stride,
                                                    size_t begin, size_t end, size_t chunk, int n,
                                                    const uint8_t *__restrict__ mask, int use_mask,
@@ -851,15 +854,14 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
   size_t hi = lo + chunk < end ? lo + chunk : end;
   // software pipeline: the loads of the next 4-row group are issued before the 15 MFMAs of the
   // current one (one wave per SIMD: nothing else would cover the HBM latency)
-  constexpr int PF = 4;  // groups in flight
-  double z[PF][5];
+  double z[PF][NB];  // PF groups in flight
   unsigned char mk[PF];
   // Loop-invariant column offsets (columns past the row are read from column 0 and zeroed below);
   // loads never depend on the mask byte (a dependent load would drain the whole ring with vmcnt(0)).
-  int off[5];
-  bool colok[5];
+  int off[NB];
+  bool colok[NB];
 #pragma unroll
-  for (int b = 0; b < 5; b++) {
+  for (int b = 0; b < NB; b++) {
     colok[b] = 16 * b + c16 < nz;
     off[b] = colok[b] ? 16 * b + c16 : 0;
   }
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
     const double *rp = data + (in ? row : last) * stride;
     m = in ? (use_mask ? mask[row] : (unsigned char)1) : (unsigned char)0;
 #pragma unroll
-    for (int b = 0; b < 5; b++) zz[b] = rp[off[b]];
+    for (int b = 0; b < NB; b++) zz[b] = rp[off[b]];
   };
   size_t g = lo + (size_t)wave * 4;
 #pragma unroll
@@ -878,22 +880,23 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(const double *__restrict__ da
   for (; g < hi; g += 16 * PF) {
 #pragma unroll
     for (int p = 0; p < PF; p++) {
-      double zc[5];
+      double zc[NB];
       bool vc = mk[p] != 0;
 #pragma unroll
-      for (int b = 0; b < 5; b++) zc[b] = (vc && colok[b]) ? z[p][b] : 0.0;
+      for (int b = 0; b < NB; b++) zc[b] = (vc && colok[b]) ? z[p][b] : 0.0;
       if (VAR != 2) fetch(g + (size_t)(p + PF) * 16, z[p], mk[p]);  // refill this slot for the next round
       rows_used += (unsigned)__builtin_popcountll(__ballot(vc && c16 == 0));
       if (VAR == 1) {  // diagnostic: loads only
 #pragma unroll
-        for (int b = 0; b < 5; b++) acc[b][0] += zc[b];
+        for (int b = 0; b < NB; b++) acc[b][0] += zc[b];
       } else {
         int t = 0;
 #pragma unroll
         for (int bi = 0; bi < 5; bi++)
 #pragma unroll
           for (int bj = bi; bj < 5; bj++, t++)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[bi], zc[bj], acc[t], 0, 0, 0);
+            if (bi < NB && bj < NB)
+              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[bi < NB ? bi : 0], zc[bj < NB ? bj : 0], acc[t], 0, 0, 0);
       }
     }
   }

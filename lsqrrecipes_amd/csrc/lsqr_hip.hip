@@ -1907,6 +1907,9 @@ int launch_syrk(lsqr_ctx *c, const double *data, size_t stride, int n, int use_m
       else if (c->opt_syrk_diag == 2)
         hipLaunchKernelGGL(k_syrk_mfma<2>, dim3(nb), dim3(256), 0, c->stream, data, stride,
                            begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
+      else if (n + 1 <= 32)  // the plane phantom's 31 + 1 columns: two of the five column blocks
+        hipLaunchKernelGGL((k_syrk_mfma<0, 2, 10>), dim3(nb), dim3(256), 0, c->stream, data, stride,
+                           begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
       else
         hipLaunchKernelGGL(k_syrk_mfma<0>, dim3(nb), dim3(256), 0, c->stream, data, stride,
                            begin, end, chunk, n, c->d_mask, use_mask, ps, c->d_partials);
