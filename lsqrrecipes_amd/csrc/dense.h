@@ -726,9 +726,15 @@ __global__ __launch_bounds__(256) void k_dense_recheck_seg(const double *__restr
                                                            uint32_t seg_cap, uint32_t *__restrict__ votes,
                                                            unsigned int *__restrict__ out_max) {
   typedef DenseModel<NR> M;
+  // votes per workgroup first (us_h16.h: k_us_recheck_seg -- device-wide atomics on the few counters of the good
+  // hypotheses are served one at a time), in a direct-mapped LDS table keyed by the hypothesis index
+  constexpr unsigned kSlots = 1024;
+  __shared__ uint32_t s_tag[kSlots], s_votes[kSlots];
   const unsigned filled = amb_counts[blockIdx.x];
-  if (filled == 0) return;
+  if (filled == 0) return;  // workgroup-uniform
+  for (unsigned i = threadIdx.x; i < kSlots; i += 256) s_tag[i] = 0xFFFFFFFFu, s_votes[i] = 0;
   if (threadIdx.x == 0) atomicMax(out_max, filled);
+  __syncthreads();
   const unsigned total = filled < seg_cap ? filled : seg_cap;
   for (unsigned e = threadIdx.x; e < total; e += 256) {
     unsigned long long v = amb_list[(size_t)blockIdx.x * seg_cap + e];
@@ -736,9 +742,18 @@ __global__ __launch_bounds__(256) void k_dense_recheck_seg(const double *__restr
     uint32_t h = (uint32_t)(v & 0xffffffffu);
     double x[M::REC];
     M::load(data + row * stride, mc, x);
-    if (M::agree(sp + (size_t)h * NR, x, mc)) atomicAdd(&votes[h], 1u);
+    if (M::agree(sp + (size_t)h * NR, x, mc)) {
+      const unsigned slot = h & (kSlots - 1);
+      const uint32_t was = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, h);
+      if (was == 0xFFFFFFFFu || was == h)
+        atomicAdd(&s_votes[slot], 1u);
+      else
+        atomicAdd(&votes[h], 1u);
+    }
   }
   __syncthreads();  // every thread has read `filled`
+  for (unsigned i = threadIdx.x; i < kSlots; i += 256)
+    if (s_votes[i]) atomicAdd(&votes[s_tag[i]], s_votes[i]);
   if (threadIdx.x == 0) amb_counts[blockIdx.x] = 0;  // decided: the segment is free for the next chunk's appends
 }
 

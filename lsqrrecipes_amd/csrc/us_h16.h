@@ -366,9 +366,18 @@ __global__ __launch_bounds__(1024) void k_us_recheck_seg(const double *__restric
                                                         const unsigned long long *__restrict__ amb_list,
                                                         unsigned int *__restrict__ amb_counts, uint32_t seg_cap,
                                                         uint32_t *__restrict__ votes, unsigned int *__restrict__ out_max) {
+  // The band's pairs belong to few hypotheses (the good ones: every frame near their threshold), and a device-wide
+  // atomic on one address is served by the memory side, one at a time, for all eight XCDs: 150 k votes on a few dozen
+  // counters were most of this kernel's 59 us (plane phantom, r05).  Votes are first added up per workgroup in a
+  // direct-mapped LDS table keyed by the hypothesis index (a launch's 1024 consecutive hypotheses never collide; a
+  // key whose slot is taken by another goes to the global counter as before), one global atomic per used slot at the end.
+  constexpr unsigned kSlots = 4096;
+  __shared__ uint32_t s_tag[kSlots], s_votes[kSlots];
   const unsigned filled = amb_counts[blockIdx.x];
-  if (filled == 0) return;
+  if (filled == 0) return;  // workgroup-uniform
+  for (unsigned i = threadIdx.x; i < kSlots; i += blockDim.x) s_tag[i] = 0xFFFFFFFFu, s_votes[i] = 0;
   if (threadIdx.x == 0) atomicMax(out_max, filled);
+  __syncthreads();
   const unsigned total = filled < seg_cap ? filled : seg_cap;
   for (unsigned e = threadIdx.x; e < total; e += blockDim.x) {  // (dependent loads: one entry per thread where it fits)
     const unsigned long long v = amb_list[(size_t)blockIdx.x * seg_cap + e];
@@ -376,9 +385,18 @@ __global__ __launch_bounds__(1024) void k_us_recheck_seg(const double *__restric
     const uint32_t h = (uint32_t)(v & 0xffffffffu);
     double x[M::REC];
     M::load(data + row * stride, mc, x);
-    if (M::agree(sp + (size_t)h * sp_stride, x, mc)) atomicAdd(&votes[h], 1u);
+    if (M::agree(sp + (size_t)h * sp_stride, x, mc)) {
+      const unsigned slot = h & (kSlots - 1);
+      const uint32_t was = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, h);
+      if (was == 0xFFFFFFFFu || was == h)
+        atomicAdd(&s_votes[slot], 1u);
+      else
+        atomicAdd(&votes[h], 1u);
+    }
   }
   __syncthreads();
+  for (unsigned i = threadIdx.x; i < kSlots; i += blockDim.x)
+    if (s_votes[i]) atomicAdd(&votes[s_tag[i]], s_votes[i]);
   if (threadIdx.x == 0) amb_counts[blockIdx.x] = 0;
 }
 
