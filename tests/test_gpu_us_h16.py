@@ -185,3 +185,32 @@ def test_us_minimal_solves_elimination_against_svd(kind):
     scale = np.maximum(np.abs(p0[ok]).max(axis=0), 1e-300)
     assert (np.abs(p1[ok] - p0[ok]) / scale).max() < 1e-9
     assert np.abs(c1.astype(np.int64) - c0.astype(np.int64)).max() <= 2   # (a frame within 1e-10 of delta may flip)
+
+
+@pytest.mark.parametrize("kind", ["single", "dense"])
+def test_votes_of_a_batch_larger_than_the_rechecks_vote_table(kind):
+    """the exact re-check adds its votes up per workgroup in a direct-mapped LDS table keyed by the hypothesis index
+    (4096 slots for the calibrations, 1024 for the dense system: r05); with more hypotheses than slots keys collide and
+    the colliding ones go to the global counters -- every vote must still equal the exact kernel's"""
+    with Context(0) as ctx:
+        if kind == "single":
+            data = synth.us_single_fast(40_000, 0.3, seed=15)[0]
+            _, valid, v16 = _votes(ctx, L.US_SINGLE, data, 3.0, 99, 9000, 1)
+            _, v2, vex = _votes(ctx, L.US_SINGLE, data, 3.0, 99, 9000, 0, filt=0)
+            ctx.set_option("us_mfma", 1)
+            ctx.set_option("scan_filter", 1)
+        else:
+            data = synth.dense(30_000, 64, 0.05, seed=16)[0]
+            out = []
+            for f32, filt in ((2, 1), (0, 0)):
+                ctx.set_option("dense_f32", f32)
+                ctx.set_option("scan_filter", filt)
+                ctx.set_model(L.DENSE, 64, 0.1, L.LS_ALGEBRAIC).upload(data)
+                ctx.hypotheses_sample(98, 0, 2500)
+                ctx.scan()
+                out.append(ctx.hypotheses())
+            (_, valid, v16), (_, v2, vex) = out
+            ctx.set_option("dense_f32", 2)
+            ctx.set_option("scan_filter", 1)
+        assert np.array_equal(valid, v2) and valid.sum() > 0
+        assert np.array_equal(v16, vex)
