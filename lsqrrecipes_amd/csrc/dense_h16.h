@@ -21,7 +21,9 @@
 //                       k_dense_h16_probe below): the products of one instruction and its addend are aligned to the largest of
 //                       them with two guard bits and truncated -- fifteen terms just below an ulp of a 2^20 term lose
 //                       3.8 ulp of it, a quarter ulp = 0.5 u of the largest magnitude each.  ASSUMED: twice that, 1 u
-//                       of the largest magnitude involved per product and addend.  The eight instructions of the small
+//                       of the largest magnitude involved per product and addend (r05: 65 536 sums of RANDOM
+//                       operands per context, k_dense_h16_probe_random: worst 4 u of the largest magnitude, 6 u over
+//                       4 M sums -- the assumption allows 17).  The eight instructions of the small
 //                       terms come first (partial sums <= 2^-10 S):  136 2^-10 u S <= 0.14 u S;  the four of a1 x1:
 //                       68 (1 + 2^-9) u S <= 68.2 u S.   (tests/test_gpu_dense_h16.py measures the whole chain on every
 //                       run: the largest deviation seen is below 1.5 u S.)
@@ -211,6 +213,75 @@ inline double dense_h16_probe_worst(const float *res) {
 }
 // the assumption is 1 u per product and addend of the largest magnitude: 17 u for a full instruction
 constexpr double kH16ProbeLimit = 12.0;
+
+// The same question on RANDOM operands (r05): `rounds` instructions, each 32 x 32 outputs whose 16 products and addend
+// have random signs, random 11- / 24-bit significands and exponents spread over 13 (the fp16 factors) and 32 (the
+// addend) binades -- every alignment the eight hand-made patterns above do not think of.  Every lane rebuilds the
+// operands of its 16 outputs from the same hash, adds the 17 terms in fp64 (the products of two fp16 numbers are exact
+// there, the sum is good to 2^-53 of the largest term) and compares: out[0] = the worst |result - exact| in u of the
+// largest magnitude among the products, the addend and the exact result (the result's own rounding is half an ulp
+// = up to 1 u of it).  65 536 cases per context at 64 rounds, a few microseconds.
+__device__ __forceinline__ uint32_t h16_probe_hash(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  h *= 0x297A2D39u;
+  h ^= h >> 15;
+  return h;
+}
+// a random fp16 number: sign, 10 random fraction bits, exponent -8 .. +4
+__device__ __forceinline__ _Float16 h16_probe_f16(uint32_t h) {
+  const int e = (int)((h >> 11) % 13u) - 8;
+  const float m = 1.0f + (float)(h & 1023u) * (1.0f / 1024.0f);
+  const float v = __builtin_ldexpf(m, e);
+  return (_Float16)((h >> 31) ? -v : v);
+}
+// a random fp32 addend: sign, 23 random fraction bits, exponent -20 .. +11
+__device__ __forceinline__ float h16_probe_f32(uint32_t h, uint32_t h2) {
+  const int e = (int)((h2 >> 8) % 32u) - 20;
+  const float m = 1.0f + (float)(h & 0x7FFFFFu) * (1.0f / 8388608.0f);
+  return __builtin_ldexpf((h >> 31) ? -m : m, e);
+}
+__global__ __launch_bounds__(64) void k_dense_h16_probe_random(float *__restrict__ out, int rounds) {
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+  double worst = 0.0;
+  for (int r = 0; r < rounds; r++) {
+    // operand element A[row][k] = f16(hash(r, row, k)), B[k][col] = f16(hash(r, 64 + col, k)), C[row][col]
+    h16x8 a, b;
+    for (int i = 0; i < 8; i++) {
+      const int k = 8 * half + i;
+      a[i] = h16_probe_f16(h16_probe_hash((uint32_t)r, (uint32_t)col, (uint32_t)k));        // my A row is `col`
+      b[i] = h16_probe_f16(h16_probe_hash((uint32_t)r, 64u + (uint32_t)col, (uint32_t)k));
+    }
+    f32x16 acc;
+    for (int i = 0; i < 16; i++) {
+      const int row = 8 * (i / 4) + 4 * half + i % 4;
+      const uint32_t hc = h16_probe_hash((uint32_t)r, 128u + (uint32_t)row, (uint32_t)col);
+      acc[i] = h16_probe_f32(hc, h16_probe_hash(hc, 7u, 9u));
+    }
+    const f32x16 c0 = acc;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    for (int i = 0; i < 16; i++) {
+      const int row = 8 * (i / 4) + 4 * half + i % 4;
+      double exact = (double)c0[i], big = fabs((double)c0[i]);
+      for (int k = 0; k < 16; k++) {
+        const double p = (double)(float)h16_probe_f16(h16_probe_hash((uint32_t)r, (uint32_t)row, (uint32_t)k)) *
+                         (double)(float)h16_probe_f16(h16_probe_hash((uint32_t)r, 64u + (uint32_t)col, (uint32_t)k));
+        exact += p;
+        big = fabs(p) > big ? fabs(p) : big;
+      }
+      big = fabs(exact) > big ? fabs(exact) : big;
+      const double dev = fabs((double)acc[i] - exact) / (5.9604644775390625e-08 * big);
+      if (!(dev <= worst)) worst = dev;  // (a NaN is the worst)
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(worst, o);
+    if (!(t <= worst)) worst = t;
+  }
+  if (lane == 0) out[0] = (float)worst;
+}
 
 // The scan.  One workgroup = four waves; a wave owns 64 rows (two 32-row tiles whose fragments stay in registers
 // for a whole pass over the batch), the workgroup 256.  The hypotheses come through a ring of 32-hypothesis tiles in

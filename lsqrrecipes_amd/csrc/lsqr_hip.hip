@@ -1211,10 +1211,16 @@ int h16_probe_unit(lsqr_ctx *c) {
   if (!c->d_h16_thr) HIPCHK(c, hipMalloc((void **)&c->d_h16_thr, sizeof(float) * 4 * 8192));
   float *d_probe = c->d_h16_thr;  // (the batch's threshold block: not in use yet)
   hipLaunchKernelGGL(k_dense_h16_probe, dim3(1), dim3(64), 0, c->stream, d_probe);
+  // ... and 64 instructions of random operands (65 536 sums of 16 products and an addend against fp64)
+  hipLaunchKernelGGL(k_dense_h16_probe_random, dim3(1), dim3(64), 0, c->stream, d_probe + kH16ProbeVariants, 64);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_pin, d_probe, sizeof(float) * kH16ProbeVariants, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pin, d_probe, sizeof(float) * (kH16ProbeVariants + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, sync_stream(c));
   c->h16_unit_dev = dense_h16_probe_worst((const float *)c->h_pin);
+  {
+    const double rnd = (double)((const float *)c->h_pin)[kH16ProbeVariants];
+    if (!(rnd <= c->h16_unit_dev)) c->h16_unit_dev = rnd;  // (a NaN is the worst)
+  }
   c->h16_unit = c->h16_unit_dev <= kH16ProbeLimit ? 1 : -1;
   if (c->h16_unit < 0)
     (void)fail(c, LSQR_OK, "fp16 matrix-core filters: this device's matrix unit loses %.1f u per instruction (limit %.1f): fp32 filter used",

@@ -97,6 +97,10 @@ def test_h16_standalone_check_and_error_of_the_matrix_unit():
     # the alignment of one instruction's products: the probe's worst case must stay below half of what is assumed
     offs = [abs(float(m)) for m in re.findall(r"= ([+-][0-9.]+) u of the sum of magnitudes", out.stdout)]
     assert len(offs) == 8 and max(offs) < 8.5, offs   # 17 terms x 0.5 u; measured 5.5 - 7.6
+    # the same on random operands (r05): 64 instructions (what the library runs per context) and 4096; measured 4.0 / 6.0
+    rnd = [float(x) for x in re.findall(r"random probe: \d+ instructions x 1024 outputs, worst \|result - exact\| = ([0-9.eE+-]+) u",
+                                        out.stdout)]
+    assert len(rnd) == 2 and max(rnd) < 8.5, rnd
 
 
 def test_refused_minimal_systems_are_never_counted_and_do_not_flood_the_worklist():

@@ -329,6 +329,14 @@ int main(int argc, char **argv) {
     }
     printf("align probe: worst %.2f u of the sum of magnitudes (the library refuses the fp16 filter beyond %.1f)\n",
            dense_h16_probe_worst(al), kH16ProbeLimit);
+    for (int rounds : {64, 4096}) {
+      hipLaunchKernelGGL(k_dense_h16_probe_random, dim3(1), dim3(64), 0, 0, d_al, rounds);
+      CK(hipDeviceSynchronize());
+      float w;
+      CK(hipMemcpy(&w, d_al, 4, hipMemcpyDeviceToHost));
+      printf("random probe: %d instructions x 1024 outputs, worst |result - exact| = %.3f u of the largest magnitude involved\n",
+             rounds, (double)w);
+    }
   }
   return bad ? 1 : 0;
 }
