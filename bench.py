@@ -97,9 +97,9 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="single GPU, pipelined steps: HIP streams (lanes of lsqr_batch_fit_enqueue) the batches "
                          "alternate over; batches of different streams overlap on the device (1 = one stream; 0 = the "
-                         "default: 4, and 12 host threads with a context each for the US workload's iterative fit, whose "
+                         "default: 4, and 8 host threads with a context each for the US workload's iterative fit, whose "
                          "steps are thousands of HBM-bound LM evaluations that overlap each other's host round trips: "
-                         "r05, 66 - 71 k hypotheses/s on twelve, 53 - 71 k on eight depending on the box, 50 - 60 k on four)")
+                         "r05, 67 - 72 k hypotheses/s on eight, 66 - 67 k on twelve, 63 - 65 k on sixteen, 50 - 60 k on four)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single GPU: one blocking lsqr_batch_fit per step instead of pipelined batches")
     ap.add_argument("--no-end-to-end", action="store_true",
@@ -546,7 +546,7 @@ class Run:
         self.data, self.truth, self.lab = data
         self.rec = self.data.shape[1] * 8
         self.ctx = self._new_ctx()
-        a.streams = max(1, min(8, a.streams))      # the library's lanes go up to 4; host-threaded contexts up to 8
+        a.streams = max(1, min(16, a.streams))     # the library's lanes go up to 4; host-threaded contexts up to 16
         self.ctx.set_option("batch_lanes", min(4, a.streams))
         self.comm = Comm(dist, device)
         self.eng = ShardedRansac(self.ctx, self.comm)
@@ -1104,7 +1104,7 @@ def run_legs(a0, local):
         a.steps, a.warmup, a.repeats = 20, 5, 1
         a.streams = a0.streams
         if getattr(a0, "streams_auto", False) and w == "us" and fit == "iterative":
-            a.streams, a.steps, a.warmup = 12, 24, 12    # twelve host threads with a context each (see --streams)
+            a.streams, a.steps, a.warmup = 8, 24, 8      # eight host threads with a context each (see --streams)
         a.no_end_to_end = True
         a.no_cpu_baseline = a0.no_cpu_baseline
         try:
@@ -1448,7 +1448,7 @@ def main():
         a.batch = 1024 if a.workload == "dense" else 4096
     a.streams_auto = a.streams <= 0
     if a.streams_auto:
-        a.streams = 12 if (a.workload == "us" and a.us_fit == "iterative" and a.gpus == 1) else 4
+        a.streams = 8 if (a.workload == "us" and a.us_fit == "iterative" and a.gpus == 1) else 4
     in_launcher_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not in_launcher_env:
         # nothing in this process has touched the GPU yet (numpy and the standard library only)
