@@ -33,6 +33,23 @@ __global__ __launch_bounds__(256) void k_read(const uint4 *__restrict__ p, size_
   if (acc == 0x12345678u) out[0] = acc;  // (never: keeps the loads)
 }
 
+// the same with 8-byte loads (the LM pass's tiles are read field by field, one double per lane and load)
+template <int U>
+__global__ __launch_bounds__(256) void k_read8(const uint2 *__restrict__ p, size_t n, uint32_t *__restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (; i + (U - 1) * stride < n; i += U * stride) {
+    uint2 v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) v[k] = p[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < U; k++) acc ^= v[k].x ^ v[k].y;
+  }
+  for (; i < n; i += stride) acc ^= p[i].x;
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 200;
   uint32_t *d_out;
@@ -62,6 +79,22 @@ int main(int argc, char **argv) {
       printf("  %4d wg %7.0f", g, (double)bytes * r / (ms * 1e-3) * 1e-9);
     }
     printf("\n");
+    if (mb == 56 || mb == 4096) {
+      printf("%5zu MB, 8-byte loads, 16 in flight per thread:", mb);
+      for (int g : grids) {
+        hipLaunchKernelGGL(k_read8<16>, dim3(g), dim3(256), 0, 0, (const uint2 *)d, bytes / 8, d_out);
+        CK(hipDeviceSynchronize());
+        const int r = mb >= 1024 ? reps / 8 + 1 : reps;
+        CK(hipEventRecord(e0));
+        for (int k = 0; k < r; k++) hipLaunchKernelGGL(k_read8<16>, dim3(g), dim3(256), 0, 0, (const uint2 *)d, bytes / 8, d_out);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  %4d wg %7.0f", g, (double)bytes * r / (ms * 1e-3) * 1e-9);
+      }
+      printf("\n");
+    }
     CK(hipFree(d));
   }
   return 0;
