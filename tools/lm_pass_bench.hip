@@ -152,5 +152,35 @@ int main(int argc, char **argv) {
     run(k_pass_parts<M, 4>, nb, "... and two accumulator chains");
     run(k_pass_parts<M, 5>, nb, "everything, two tiles requested ahead");
   }
+  // several passes at once (several fits in flight): the same kernel on S streams, each with its own copy of the tiles
+  for (int S : {2, 4, 8}) {
+    std::vector<hipStream_t> st(S);
+    std::vector<double *> buf(S);
+    for (int i = 0; i < S; i++) {
+      CK(hipStreamCreate(&st[i]));
+      CK(hipMalloc(&buf[i], h.size() * 8));
+      CK(hipMemcpy(buf[i], h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < S; i++)
+      hipLaunchKernelGGL((k_lm_pass_mfma_t<M>), dim3(488), dim3(kBlock), 0, st[i], buf[i], n, coef, d_part + (size_t)i * 512 * 128 % (2048 * 128 - 488 * 128));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < reps; r++)
+      for (int i = 0; i < S; i++)
+        hipLaunchKernelGGL((k_lm_pass_mfma_t<M>), dim3(488), dim3(kBlock), 0, st[i], buf[i], n, coef, d_part);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / (reps * S);
+    printf("the pass on %d streams at once (a set of tiles each): %6.2f us per pass in the aggregate = %5.2f TB/s\n", S, us,
+           (double)n * 14 * 8 / (us * 1e-6) * 1e-12);
+    for (int i = 0; i < S; i++) {
+      CK(hipFree(buf[i]));
+      CK(hipStreamDestroy(st[i]));
+    }
+  }
   return 0;
 }
