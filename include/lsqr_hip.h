@@ -403,6 +403,11 @@ LSQR_API void lsqr_dedup_destroy(void *set);
  *                15 % (plane) to 40 % (sphere) fewer (hypothesis, cell) pairs reach the second level of the scan;
  *                0 = plain Morton runs (A/B knob).  "scan_presorted": 1 = cells are runs of the UPLOAD order (experiments
  *                with other spatial orders: tools/ab_order_kd.py).  Votes are identical whatever the order;
+ * "scan_kd_levels": k-d levels ABOVE those runs, each one radix sort of (segment, coordinate) pairs (default 7: runs of
+ *               1 M records; 0 = the Morton order above the runs, as until r05).  5 - 12 % fewer surviving pairs for
+ *               ~0.6 ms per level and 10 M records; built by the first scan after the upload has been asked to scan
+ * "scan_kd_after" hypotheses (default 16384; 0 = with the first index) -- the first index of an upload keeps the
+ *               cheaper order.  Votes do not depend on either.
  * "batch_lanes": streams (1..4, default 4) the slots of lsqr_batch_fit_enqueue / _wait are spread over (see there);
  * "scan_pairs":  plain (unbounded) scans of an indexed upload: 0 (default) = the model's measured choice (plane, batches
  *                of >= 1024: the statically balanced kernel of the bounded scan, k_scan_pairs; else k_scan_cells),

@@ -259,6 +259,131 @@ __device__ __forceinline__ float ord_u32_inv(uint32_t o) {
   const uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
   return __builtin_bit_cast(float, b);
 }
+
+// ---- pass 2a (r05): k-d levels ABOVE the runs, by segmented sorts ------------------------------------------------------
+// The refinement below re-partitions runs of 8192 records; the Morton order above them still straddles octant
+// boundaries.  Simulated at the bench's 10 M points (tools/kd_order_sim.py, share of (random plane, cell) pairs that
+// survive level 1): Morton runs 11.61 %, + k-d inside runs of 8192 9.86 %, of 65 536 9.53 %, of 262 144 9.37 %, of 1 M
+// 9.28 %, the exact k-d partition 9.32 %.  Medians have to be exact here (regions cut at sampled medians do not align
+// with the 8192-record runs of the stage behind them and come out WORSE than the plain refinement), so a level is a
+// SORT: every segment of S consecutive positions of the current order (S = 2^k, aligned) takes the axis of its widest
+// extent (k_seg_extent), every record gets the key (segment << 16) | its coordinate along that axis in 65 535 steps of
+// the extent (k_seg_keys), one stable radix sort of the (key, index) pairs orders every segment along its axis, and the
+// next level's segments are the halves by position.  `kd_levels` levels from S = 8192 << kd_levels down to 16 384.
+struct SegExtent {
+  uint32_t lo[3], hi[3];  // ord_u32 of the fp32 coordinates
+};
+// (float)double one value at a time: hipcc 7.2 crashes in instruction selection ("AMDGPU DAG->DAG") on the
+// <2 x double> -> <2 x float> conversion the vectoriser forms from two neighbouring ones in these kernels
+__device__ __forceinline__ float seg_f32(double d) {
+  asm("" : "+v"(d));
+  return (float)d;
+}
+// ... and ord_u32_inv likewise (the select on a <2 x i32> formed from two neighbouring extents)
+__device__ __forceinline__ float seg_ord_inv(uint32_t o) {
+  asm("" : "+v"(o));
+  return ord_u32_inv(o);
+}
+__global__ __launch_bounds__(256) void k_seg_extent_init(SegExtent *__restrict__ ext, uint32_t nseg) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nseg) return;
+  for (int d = 0; d < 3; d++) ext[s].lo[d] = 0xFFFFFFFFu, ext[s].hi[d] = 0u;
+}
+// The levels work on a compact copy of the coordinates in MORTON order (xyz: D floats per record, k_seg_gather) and on
+// positions q into it: a segment's records sit in one window of that copy (3 - 12 MB: the L2s hold it), where the
+// original records are 24 B each anywhere in the upload (the first version read them through the permutation: two
+// random gathers of 240 MB per level, 0.44 of a level's 0.8 ms).  k_seg_compose turns the final positions back into
+// record indices.
+template <int D>
+__global__ __launch_bounds__(256) void k_seg_gather(const double *__restrict__ data, size_t stride,
+                                                    const uint32_t *__restrict__ perm, size_t n, size_t ns,
+                                                    float *__restrict__ xyz, uint32_t *__restrict__ q) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  q[i] = (uint32_t)i;
+  if (i >= ns) return;
+  const double *p = data + (size_t)perm[i] * stride;
+  for (int d = 0; d < D; d++) xyz[i * D + d] = seg_f32(p[d]);
+}
+__global__ __launch_bounds__(256) void k_seg_compose(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ q,
+                                                     size_t n, uint32_t *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = perm[q[i]];
+}
+// one workgroup per 1024 consecutive positions (S is a multiple of 1024: all of one segment)
+template <int D>
+__global__ __launch_bounds__(256) void k_seg_extent(const float *__restrict__ xyz, const uint32_t *__restrict__ q, size_t ns,
+                                                    uint32_t seg_shift, SegExtent *__restrict__ ext) {
+  __shared__ uint32_t s_lo[D], s_hi[D];
+  if (threadIdx.x < D) s_lo[threadIdx.x] = 0xFFFFFFFFu, s_hi[threadIdx.x] = 0u;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * 1024;
+  uint32_t lo[D], hi[D];
+  for (int d = 0; d < D; d++) lo[d] = 0xFFFFFFFFu, hi[d] = 0u;
+  for (int u = 0; u < 4; u++) {
+    const size_t i = base + (size_t)u * 256 + threadIdx.x;
+    if (i < ns) {
+      const float *p = xyz + (size_t)q[i] * D;
+      for (int d = 0; d < D; d++) {
+        const uint32_t o = ord_u32(p[d]);
+        lo[d] = o < lo[d] ? o : lo[d];
+        hi[d] = o > hi[d] ? o : hi[d];
+      }
+    }
+  }
+  for (int d = 0; d < D; d++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t a = __shfl_xor(lo[d], off), b = __shfl_xor(hi[d], off);
+      lo[d] = a < lo[d] ? a : lo[d];
+      hi[d] = b > hi[d] ? b : hi[d];
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&s_lo[d], lo[d]);
+      atomicMax(&s_hi[d], hi[d]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < D && base < ns) {
+    SegExtent *e = ext + (base >> seg_shift);
+    atomicMin(&e->lo[threadIdx.x], s_lo[threadIdx.x]);
+    atomicMax(&e->hi[threadIdx.x], s_hi[threadIdx.x]);
+  }
+}
+// key = (segment << 16) | coordinate along the segment's widest axis; positions past the finite records keep their
+// place behind everything (segment number nseg)
+template <int D>
+__global__ __launch_bounds__(256) void k_seg_keys(const float *__restrict__ xyz, const uint32_t *__restrict__ q, size_t n,
+                                                  size_t ns, uint32_t seg_shift, uint32_t nseg,
+                                                  const SegExtent *__restrict__ ext, uint32_t *__restrict__ keys,
+                                                  uint32_t *__restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t pos = q[i];
+  vals[i] = pos;
+  if (i >= ns) {
+    keys[i] = nseg << 16;
+    return;
+  }
+  const uint32_t seg = (uint32_t)(i >> seg_shift);
+  const SegExtent *e = ext + seg;
+  const float *p = xyz + (size_t)pos * D;
+  // the widest axis (ties: the lowest) and the record's coordinate along it
+  float lo = seg_ord_inv(e->lo[0]), w = seg_ord_inv(e->hi[0]) - lo, x = p[0];
+  {
+    const float l1 = seg_ord_inv(e->lo[1]), w1 = seg_ord_inv(e->hi[1]) - l1, x1 = p[1];
+    const bool take = w1 > w;
+    lo = take ? l1 : lo, x = take ? x1 : x, w = take ? w1 : w;
+  }
+  if (D == 3) {
+    const float l2 = seg_ord_inv(e->lo[2]), w2 = seg_ord_inv(e->hi[2]) - l2, x2 = p[D - 1];
+    const bool take = w2 > w;
+    lo = take ? l2 : lo, x = take ? x2 : x, w = take ? w2 : w;
+  }
+  float t = w > 0.0f ? (x - lo) / w * 65535.0f : 0.0f;
+  t = t > 0.0f ? (t < 65535.0f ? t : 65535.0f) : 0.0f;  // (NaN cannot occur: the records below ns are finite)
+  keys[i] = (seg << 16) | (uint32_t)t;
+}
+
 constexpr uint32_t kRunMaxSeg = 16;  // segments of a level: runs of kRunPts are split down to 512-record segments
 __host__ __device__ inline size_t refine_lds_bytes(int D) {
   return (size_t)kRunPts * (sizeof(float) * D + 2 * sizeof(uint16_t)) + kRunMaxSeg * 256 * sizeof(uint32_t) + 1024;
