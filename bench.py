@@ -768,9 +768,11 @@ class Run:
         if bound is not None:
             self.set_option("scan_bound", bound)
         ctx.profile(True)   # the spatial index is built inside the first large scan of an upload
-        if self.multi_stream:
-            self.run_steps(5 * a.streams, side=True)   # every stream builds its index (the k-d levels above the runs come with
-            #                                            the fourth batch of 4096: "scan_kd_after") and loads its code objects before the W steps
+        # every stream builds its index (the k-d levels above the runs come with the fourth batch of 4096: "scan_kd_after")
+        # and loads its code objects before the W steps
+        if self.multi_stream or a.workload in ("plane", "sphere", "line"):
+            self.run_steps((5 if a.workload in ("plane", "sphere", "line") else 2) *
+                           max(1, a.streams if self.multi_stream else 1), side=True)
         self.run_steps(a.warmup)
         idx_warm = ctx.profile_get("index")
         abs_warm = ctx.profile_get("absmax")
@@ -913,7 +915,8 @@ def report(R, rates, cpu_budget, headline=True):
                    "rccl": ({"bringup_s": RCCL_INFO["bringup_s"], "stream_groups_s": RCCL_INFO["stream_groups_s"],
                              "communicators": RCCL_INFO["communicators"], "fallback": RCCL_INFO["fallback"]}
                             if RCCL_INFO["communicators"] else None),
-                   "stream_priming_steps": 5 * a.streams if R.multi_stream else 0,
+                   "stream_priming_steps": (5 if a.workload in ("plane", "sphere", "line") else 2) *
+                   (a.streams if R.multi_stream else 1) if (R.multi_stream or a.workload in ("plane", "sphere", "line")) else 0,
                    "repeats": max(1, a.repeats),
                    "step": step_text(R) + "; " + what_value},
         "value_is": main_rate["mode"],
