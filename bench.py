@@ -1064,12 +1064,14 @@ def report(R, rates, cpu_budget, headline=True):
 
 
 def rates_for(a):
-    """(mode, scan_bound) pairs in the order measured; the first one is `value`"""
+    """(mode, scan_bound) pairs in the order measured"""
     if a.rates == "full":
         return [("full_count", 0)]
     if a.rates == "early":
         return [("early_exit", 1)]
-    return [("full_count", 0), ("early_exit", 1)]
+    # the early-exit rate first: the plane's bounded scan keeps the index order of a fresh upload, the counting one has
+    # the k-d levels above the runs built (scan_kd_levels; DESIGN 3.1a) -- run_workload puts `value`'s rate back in front
+    return [("early_exit", 1), ("full_count", 0)]
 
 
 def run_workload(a, dist, device, local, backend, force_dist, cpu_budget, headline=True):
@@ -1078,6 +1080,7 @@ def run_workload(a, dist, device, local, backend, force_dist, cpu_budget, headli
         rates = []
         for mode, bound in rates_for(a):
             rates.append(R.measure(mode, bound))
+        rates.sort(key=lambda r: r["mode"] != "full_count")   # (stable: full_count, the unit of `value`, first)
         return report(R, rates, cpu_budget, headline) if R.comm.rank == 0 else None
     finally:
         R.close()
@@ -1335,7 +1338,7 @@ def run_multi(a):
                     step += 1
                 vals.append(H * a.gpus * a.steps / (time.perf_counter() - t0))
             out_rates[mode] = vals
-    first = rates_for(a)[0][0]
+    first = "full_count" if "full_count" in out_rates else rates_for(a)[0][0]   # (`value` counts everything when measured)
     value = float(np.median(out_rates[first]))
     f = last["info"].fit
     out = {"metric": METRIC, "value": value, "unit": "hypotheses/s", "n_gpus": a.gpus, "steps": a.steps,

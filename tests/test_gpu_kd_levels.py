@@ -60,10 +60,10 @@ def test_the_levels_come_with_the_fourth_batch_and_leave_fewer_pairs():
     """default options: the first index of an upload keeps the Morton order above the runs; once the upload has been asked
     to scan 16384 hypotheses the index is built again with the k-d levels -- fewer (hypothesis, cell) pairs survive
     level 1, the batch's results do not change"""
-    data = synth.plane(2_000_000, 0.5, seed=3)[0]
+    data = synth.sphere(2_000_000, 0.5, seed=3)[0]
     H = 4096
     with Context(0) as ctx:
-        ctx.set_model(L.PLANE, 3, 0.5, L.LS_ALGEBRAIC).upload(data)
+        ctx.set_model(L.SPHERE, 3, 0.5, L.LS_ALGEBRAIC).upload(data)
         ctx.profile(True)
         first = ctx.batch_fit(99, 0, H, want_consensus=True)
         assert ctx.profile_get("index")[0] == 1
@@ -81,3 +81,22 @@ def test_the_levels_come_with_the_fourth_batch_and_leave_fewer_pairs():
     assert again["info"].best_index == first["info"].best_index and again["info"].best_votes == first["info"].best_votes
     assert np.array_equal(again["consensus"], first["consensus"])
     assert np.array_equal(again["params"], first["params"])
+
+
+def test_the_planes_bounded_scan_keeps_the_order_of_a_fresh_upload():
+    """the plane's axis bound is tighter on the Morton runs: bounded batches never ask for the levels, a counting batch
+    does, and an index that has them keeps them"""
+    data = synth.plane(2_000_000, 0.5, seed=4)[0]
+    H = 4096
+    with Context(0) as ctx:
+        ctx.set_model(L.PLANE, 3, 0.5, L.LS_ALGEBRAIC).upload(data)
+        ctx.profile(True)
+        for s in range(6):
+            ctx.batch_fit(7, s * H, H)                      # bounded (the default): 24576 hypotheses
+        assert ctx.profile_get("index")[0] == 1
+        ctx.set_option("scan_bound", 0)
+        ctx.batch_fit(7, 6 * H, H)
+        assert ctx.profile_get("index")[0] == 2             # a counting batch: built again with the levels
+        ctx.set_option("scan_bound", 1)
+        ctx.batch_fit(7, 7 * H, H)
+        assert ctx.profile_get("index")[0] == 2             # ... and kept
