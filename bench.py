@@ -1015,8 +1015,10 @@ def report(R, rates, cpu_budget, headline=True):
                     "build_ms": ms_idx / n_idx if n_idx else None,
                     "builds_in_warmup": int(main_rate["idx_warm"][0]),
                     "builds_in_timed_region": int(prof["index"][0]),
-                    "note": "one-time per upload (device radix sort on Morton keys + cell boxes), built inside "
-                            "the scan that first needs it"}
+                    "note": "per upload: device radix sort on Morton keys, k-d refinement of the 8192-record runs, cell "
+                            "boxes -- built inside the scan that first needs it, and built again with seven k-d levels "
+                            "above the runs by the first scan after the upload has been asked for 16384 hypotheses "
+                            "(scan_kd_levels / scan_kd_after; the plane's bounded scan keeps the first order)"}
     single_plain = a.gpus == 1 and R.dist is None
     if headline and single_plain and w in ("plane", "sphere", "line") and not a.no_end_to_end:
         # a second build in the same process (code objects loaded, buffers kept): the build's own device time
