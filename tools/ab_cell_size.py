@@ -1,4 +1,5 @@
 # full-count / bounded scan time per cell size with the refined index:  python3 tools/ab_cell_size.py plane|sphere|line
+# (r05: with the k-d levels above the runs from the first build, as the bench's timed steps have them)
 import sys
 sys.path.insert(0, '.')
 from lsqrrecipes_amd import _lib as L, synth
@@ -14,6 +15,7 @@ for cell in (256, 512):
         ctx.set_model(model, 3, 0.5, L.LS_ALGEBRAIC)
         ctx.set_option('scan_refine', refine)
         ctx.set_option('scan_cell', cell)
+        ctx.set_option('scan_kd_after', 0)
         ctx.upload(data)
         ctx.set_option('scan_index', 2)
         out = []
