@@ -2,7 +2,7 @@
 # For every drawn configuration (model, dimension, size, outlier fraction, threshold, coordinate offset and scale,
 # batch size) the votes of the exhaustive exact fp64 kernel (scan_index 0, scan_filter 0) are the truth; checked
 # against it: the exhaustive fp32-filter kernel, the two-level scan in every arrangement (k_scan_cells / k_scan_pairs,
-# cells of 256 / 512, readlane / LDS broadcast), and the batch entry point with and without the bounded scan (winner,
+# cells of 256 / 512, readlane / LDS broadcast; r05: 0 / 3 / 7 / 12 k-d levels above the index's runs), and the batch entry point with and without the bounded scan (winner,
 # consensus, parameters; counted hypotheses exact, the others 0 and not above the running maximum before them).
 import sys, time, numpy as np
 sys.path.insert(0, '.')
@@ -29,6 +29,10 @@ while time.time() < t_end:
     data = gen(n, out, seed=seed, dim=dim, sigma=sigma, box=box)[0] + off
     ls = L.LS_ALGEBRAIC if model == L.SPHERE else 0
     ctx.set_model(model, dim, delta, ls).upload(data)
+    kd = int(g.choice([0, 3, 7, 12]))            # k-d levels above the index's runs (r05), built with the first index
+    cfg["kd_levels"] = kd
+    ctx.set_option("scan_kd_levels", kd)
+    ctx.set_option("scan_kd_after", 0)
     ctx.hypotheses_sample(seed, 0, H)
 
     def votes(index, filt, pairs=0, cell=0, block=0):
